@@ -1,0 +1,68 @@
+"""Build recipe for the gfx950 HIP extension (C-ABI shared library, in-tree).
+
+    python -m desed_task_amd.build          # -> desed_task_amd/libsed_hip.so
+
+hipcc cross-compiles for gfx950 without a GPU.  One object per .hip source, compiled in parallel and
+cached by mtime, then linked into ONE shared library whose exported symbols are exactly the
+`extern "C"` entry points declared in include/sed_hip.h.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsed_hip.so")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I", CSRC]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(verbose=True, force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    jobs = []
+    objs = []
+    for src in sources():
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr[-6000:]))
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr[-2000:])
+        return obj
+
+    if jobs:
+        if verbose:
+            print("[build] hipcc gfx950:", ", ".join(os.path.basename(s) for s, _ in jobs), flush=True)
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(cc, jobs))
+    if jobs or force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,89 @@
+// Common device helpers for the MI355X (gfx950 / CDNA4) SED kernels.
+// Wave = 64 lanes.  All kernels are launched through SED_LAUNCH on the caller's stream and
+// never allocate: the host (PyTorch) owns every buffer.
+#pragma once
+
+#ifdef SED_EMU
+#include "hip_emu.h"   // tests/emu: CPU fiber emulator, test infrastructure only
+#else
+#include <hip/hip_runtime.h>
+#define SED_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define SED_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#endif
+
+#include <stdint.h>
+
+#define SED_OK 0
+#define SED_ERR_ARG (-1)
+#define SED_ERR_LAUNCH (-2)
+#define SED_ERR_UNSUPPORTED (-3)
+
+static inline int sed_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SED_OK : SED_ERR_LAUNCH;
+}
+
+// ---- MFMA wrappers (exact f32: a k-ordered fmaf chain, guide section 3) ---------------------
+// 32x32x2: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31];
+//          acc[r] is D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+#ifdef SED_EMU
+    return emu_mfma_32x32x2(a, b, c);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// 16x16x4: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; acc[r] is D[row=(l>>4)*4+r][col=l&15].
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+#ifdef SED_EMU
+    return emu_mfma_16x16x4(a, b, c);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ f32x16 f32x16_zero() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// ---- wave / block reductions -------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// ---- counter-based dropout RNG ------------------------------------------------------------------
+// keep(idx) is a pure function of (seed, idx): the backward pass regenerates the forward mask.
+// murmur3 finaliser over idx mixed with the seed; the tests replicate it in numpy.
+__device__ __forceinline__ uint32_t sed_hash(uint32_t idx, uint32_t seed) {
+    uint32_t x = idx * 0x9E3779B1u + seed;
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+// threshold = round(p * 2^24): keep when the top 24 bits are >= threshold.
+__device__ __forceinline__ bool sed_keep(uint32_t idx, uint32_t seed, uint32_t threshold24) {
+    return (sed_hash(idx, seed) >> 8) >= threshold24;
+}
+
+__device__ __forceinline__ float sed_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -1,0 +1,144 @@
+// K2-K5: spectrogram-domain elementwise ops, all on (B, L) row-major clips (L = T * n_mels).
+//  * sed_logscale_fwd  : take_log (sed_trainer.py:253-264) + TorchScaler instance/minmax
+//                        (desed_task/utils/scaler.py:114-120): two launches, deterministic
+//                        (per-chunk partial min/max, no atomics).
+//  * sed_mixup         : desed_task/data_augm.py:31-51 on a group of n clips (soft/hard labels too).
+//  * sed_specaug       : the two torchaudio axis masks of desed_task/nnet/CRNN.py:207-219, given
+//                        per-clip [f0,f1,t0,t1) bounds.
+// All are HBM-bound streaming kernels: float4 per lane, grid-stride.
+#include "sed_common.h"
+
+#define FEAT_CHUNKS 32
+
+__device__ __forceinline__ float logdb(float v) {
+    v = 20.0f * log10f(fmaxf(v, 1e-5f));
+    return fminf(fmaxf(v, -50.0f), 80.0f);
+}
+
+// pass 1: y = LOG ? logdb(x) : x ; partial[b][chunk] = (min, max) of y over the chunk
+template <bool LOG>
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             float* __restrict__ partial, int L) {
+    __shared__ float smin[4], smax[4];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int per = (L + FEAT_CHUNKS - 1) / FEAT_CHUNKS;
+    const int lo = chunk * per, hi = min(L, lo + per);
+    const float* xi = x + (size_t)b * L;
+    float* yo = y + (size_t)b * L;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        float v = xi[i];
+        if (LOG) v = logdb(v);
+        if (LOG || yo != xi) yo[i] = v;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[((size_t)b * FEAT_CHUNKS + chunk) * 2 + 0] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+        partial[((size_t)b * FEAT_CHUNKS + chunk) * 2 + 1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    }
+}
+
+// pass 2: out = (y - mn) / (mx - mn + eps) * 2 - 1 (same op order as the reference); also emits (mn, mx)
+__global__ __launch_bounds__(256) void minmax_apply_kernel(const float* __restrict__ y, float* __restrict__ out,
+                                                           const float* __restrict__ partial, float* __restrict__ minmax,
+                                                           int L, float eps) {
+    __shared__ float s_mn, s_mx;
+    const int b = blockIdx.y;
+    if (threadIdx.x < 64) {
+        float mn = INFINITY, mx = -INFINITY;
+        if (threadIdx.x < FEAT_CHUNKS) {
+            mn = partial[((size_t)b * FEAT_CHUNKS + threadIdx.x) * 2 + 0];
+            mx = partial[((size_t)b * FEAT_CHUNKS + threadIdx.x) * 2 + 1];
+        }
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        if (threadIdx.x == 0) { s_mn = mn; s_mx = mx; }
+    }
+    __syncthreads();
+    const float mn = s_mn, den = s_mx - s_mn + eps;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && minmax) { minmax[2 * b] = s_mn; minmax[2 * b + 1] = s_mx; }
+    const float* yi = y + (size_t)b * L;
+    float* oo = out + (size_t)b * L;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) oo[i] = (yi[i] - mn) / den * 2.0f - 1.0f;
+}
+
+// x: (B, L) linear mel (apply_log=1) or any tensor (apply_log=0).  logbuf: (B, L) scratch for the log values
+// (may alias out).  partial: B*32*2 floats.  minmax: optional (B,2) output.  out may alias x when apply_log=0.
+extern "C" int sed_logscale_fwd(const float* x, float* logbuf, float* out, float* partial, float* minmax, int B, int L,
+                                int apply_log, float eps, void* stream) {
+    if (B <= 0 || L <= 0) return B < 0 || L < 0 ? SED_ERR_ARG : SED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (apply_log)
+        SED_LAUNCH((minmax_partial_kernel<true>), dim3(FEAT_CHUNKS, B), dim3(256), 0, s, x, logbuf, partial, L);
+    else
+        SED_LAUNCH((minmax_partial_kernel<false>), dim3(FEAT_CHUNKS, B), dim3(256), 0, s, x, (float*)x, partial, L);
+    const float* src = apply_log ? logbuf : x;
+    int gx = (L + 256 * 8 - 1) / (256 * 8);
+    SED_LAUNCH(minmax_apply_kernel, dim3(gx, B), dim3(256), 0, s, src, out, partial, minmax, L, eps);
+    return sed_check_launch();
+}
+
+// log only (take_log as a standalone op)
+__global__ __launch_bounds__(256) void logdb_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = logdb(x[i]);
+}
+extern "C" int sed_take_log(const float* x, float* y, long long n, void* stream) {
+    if (n <= 0) return SED_OK;
+    int grid = (int)min((long long)4096, (n + 255) / 256);
+    SED_LAUNCH(logdb_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n);
+    return sed_check_launch();
+}
+
+// ---- mixup ------------------------------------------------------------------------------------
+// data[i] = c*src[i] + omc*src[perm[i]]   (src = snapshot of the group; mode 1/2 = soft/hard label clamp)
+__global__ __launch_bounds__(256) void mixup_kernel(float* __restrict__ data, const float* __restrict__ src,
+                                                    const int* __restrict__ perm, float c, float omc, int L, int mode) {
+    const int i = blockIdx.y;
+    const int j = perm[i];
+    const float* a = src + (size_t)i * L;
+    const float* p = src + (size_t)j * L;
+    float* o = data + (size_t)i * L;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < L; e += gridDim.x * 256) {
+        float v;
+        if (mode == 2) v = a[e] + p[e];
+        else v = c * a[e] + omc * p[e];
+        if (mode != 0) v = fminf(fmaxf(v, 0.0f), 1.0f);
+        o[e] = v;
+    }
+}
+// data: (n, L) in place; tmp: (n, L) scratch; perm: n int32 on device.  mode 0 = features, 1 = soft labels, 2 = hard labels.
+extern "C" int sed_mixup(float* data, float* tmp, const int* perm, float c, float one_minus_c, int n, int L, int mode, void* stream) {
+    if (n <= 0 || L <= 0) return SED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(tmp, data, (size_t)n * L * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return SED_ERR_LAUNCH;
+    int gx = min(64, (L + 255) / 256);
+    SED_LAUNCH(mixup_kernel, dim3(gx, n), dim3(256), 0, s, data, (const float*)tmp, perm, c, one_minus_c, L, mode);
+    return sed_check_launch();
+}
+
+// ---- SpecAugment ------------------------------------------------------------------------------
+// x, y: (B, T, F); bounds: (B, 4) int32 = [f0, f1, t0, t1): y = 0 inside either band else x
+__global__ __launch_bounds__(256) void specaug_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      const int* __restrict__ bounds, int T, int Fq) {
+    const int b = blockIdx.y;
+    const int f0 = bounds[4 * b], f1 = bounds[4 * b + 1], t0 = bounds[4 * b + 2], t1 = bounds[4 * b + 3];
+    const int L = T * Fq;
+    const float* xi = x + (size_t)b * L;
+    float* yo = y + (size_t)b * L;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < L; e += gridDim.x * 256) {
+        const int t = e / Fq, f = e - t * Fq;
+        const bool masked = (f >= f0 && f < f1) || (t >= t0 && t < t1);
+        yo[e] = masked ? 0.0f : xi[e];
+    }
+}
+extern "C" int sed_specaug(const float* x, float* y, const int* bounds, int B, int T, int Fq, void* stream) {
+    if (B <= 0) return SED_OK;
+    int gx = min(64, (T * Fq + 255) / 256);
+    SED_LAUNCH(specaug_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, y, bounds, T, Fq);
+    return sed_check_launch();
+}

@@ -1,0 +1,139 @@
+// K1: fused reflect-pad -> Hamming window -> 2048-point real FFT (LDS Stockham radix-4 on the
+// packed 1024-point complex transform) -> magnitude -> sparse HTK mel (-> optional 20*log10 / clamp).
+// Replaces torchaudio MelSpectrogram(n_fft=2048, hop=256, power=1, center=True, reflect) as built at
+// recipes/dcase2023_task4_baseline/local/sed_trainer.py:80-91 and called at :282.
+//
+// Layout: audio (B, N) fp32 row-major; out (B, T, n_mels) fp32 -- frame-major ("NHWC with C=1"),
+// so one frame's 128 mel values are one coalesced 512-byte store and conv0 reads rows directly.
+// The Python side hands the reference's (B, n_mels, T) shape out as a transposed view.
+//
+// One 256-thread workgroup per frame (grid-stride over B*T frames).  LDS: two 8 KB ping-pong
+// buffers + 8 KB twiddles + 4.1 KB magnitudes.  HBM: 4*N bytes in (each sample is re-read 8x by
+// overlapping frames, served by L2) + 4*T*n_mels out per clip = 960,512 B/clip at the 2023 config.
+#include "sed_common.h"
+
+#define MEL_NFFT 2048
+#define MEL_M 1024   // packed complex length
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+template <bool LOG>
+__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audio, float* __restrict__ out,
+                                                  int B, int N, int T, int hop, int n_mels,
+                                                  const float* __restrict__ window, const float2* __restrict__ tw1024,
+                                                  const float2* __restrict__ tw2048, const int* __restrict__ fb_start,
+                                                  const int* __restrict__ fb_len, const float* __restrict__ fb_w, int fb_stride) {
+    __shared__ float2 buf0[MEL_M];
+    __shared__ float2 buf1[MEL_M];
+    __shared__ float2 stw[MEL_M];
+    __shared__ float mag[MEL_M + 8];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stw[tid + 256 * q] = tw1024[tid + 256 * q];
+    __syncthreads();
+
+    const int n_frames = B * T;
+    for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
+        const int b = frame / T, t = frame - b * T;
+        const float* clip = audio + (size_t)b * N;
+        const int base = t * hop - MEL_NFFT / 2;
+        // ---- load, reflect-pad, window, pack z[n] = x[2n] + i x[2n+1] ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = tid + 256 * q;
+            int s0 = base + 2 * n, s1 = s0 + 1;
+            if (s0 < 0) s0 = -s0;
+            if (s1 < 0) s1 = -s1;
+            if (s0 >= N) s0 = 2 * (N - 1) - s0;
+            if (s1 >= N) s1 = 2 * (N - 1) - s1;
+            buf0[n] = make_float2(clip[s0] * window[2 * n], clip[s1] * window[2 * n + 1]);
+        }
+        __syncthreads();
+        // ---- 5 Stockham radix-4 passes, Ns = 1,4,16,64,256; result lands in buf1 ----
+        float2* src = buf0;
+        float2* dst = buf1;
+#pragma unroll
+        for (int pass = 0; pass < 5; ++pass) {
+            const int Ns = 1 << (2 * pass);
+            const int k = tid & (Ns - 1);
+            const int tstep = (256 / Ns) * k;           // twiddle index of exp(-2 pi i k / (4 Ns))
+            float2 v0 = src[tid], v1 = src[tid + 256], v2 = src[tid + 512], v3 = src[tid + 768];
+            if (pass > 0) {
+                v1 = cmul(v1, stw[tstep]);
+                v2 = cmul(v2, stw[2 * tstep]);
+                v3 = cmul(v3, stw[3 * tstep]);
+            }
+            // DFT-4 (forward, e^{-i pi/2} = -i)
+            const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
+            const float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+            const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
+            const float2 a3 = make_float2(v1.x - v3.x, v1.y - v3.y);   // (v1 - v3)
+            const int d = ((tid - k) << 2) + k;
+            dst[d] = make_float2(a0.x + a2.x, a0.y + a2.y);
+            dst[d + Ns] = make_float2(a1.x + a3.y, a1.y - a3.x);      // a1 - i a3
+            dst[d + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
+            dst[d + 3 * Ns] = make_float2(a1.x - a3.y, a1.y + a3.x);  // a1 + i a3
+            __syncthreads();
+            float2* tmp = src; src = dst; dst = tmp;
+        }
+        const float2* Z = src;   // == buf1 after an odd number of swaps
+        // ---- real-FFT post-processing + magnitude: bins 0..1024 ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = tid + 256 * q;
+            float m;
+            if (k == 0) {
+                const float2 z0 = Z[0];
+                m = fabsf(z0.x + z0.y);
+                mag[MEL_M] = fabsf(z0.x - z0.y);
+            } else {
+                const float2 zk = Z[k], zm = Z[MEL_M - k];
+                const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                const float dr = zk.x - zm.x, di = zk.y + zm.y;            // zk - conj(zm)
+                const float2 xo = make_float2(0.5f * di, -0.5f * dr);       // -i/2 * (zk - conj(zm))
+                const float2 wx = cmul(tw2048[k], xo);
+                const float re = xe.x + wx.x, im = xe.y + wx.y;
+                m = sqrtf(re * re + im * im);
+            }
+            mag[k] = m;
+        }
+        __syncthreads();
+        // ---- sparse triangular mel: two threads per mel band (even/odd taps) ----
+        {
+            const int m = tid >> 1, half = tid & 1;
+            float acc = 0.f;
+            if (m < n_mels) {
+                const int st = fb_start[m], ln = fb_len[m];
+                const float* w = fb_w + (size_t)m * fb_stride;
+                for (int i = half; i < ln; i += 2) acc = fmaf(w[i], mag[st + i], acc);
+            }
+            acc += __shfl_xor(acc, 1);
+            if (m < n_mels && half == 0) {
+                float v = acc;
+                if (LOG) {
+                    v = 20.0f * log10f(fmaxf(v, 1e-5f));
+                    v = fminf(fmaxf(v, -50.0f), 80.0f);
+                }
+                out[((size_t)b * T + t) * n_mels + m] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int sed_mel_fwd(const float* audio, float* out, int B, int N, int T, int n_fft, int hop, int n_mels,
+                           const float* window, const float* tw1024, const float* tw2048, const int* fb_start,
+                           const int* fb_len, const float* fb_w, int fb_stride, int apply_log, void* stream) {
+    if (n_fft != MEL_NFFT || n_mels > 128 || n_mels < 1 || N < n_fft / 2 + 1 || T != 1 + N / hop) return SED_ERR_UNSUPPORTED;
+    if (B <= 0) return SED_OK;
+    int grid = B * T < 4096 ? B * T : 4096;
+    if (apply_log)
+        SED_LAUNCH((mel_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, audio, out, B, N, T, hop, n_mels, window,
+                   (const float2*)tw1024, (const float2*)tw2048, fb_start, fb_len, fb_w, fb_stride);
+    else
+        SED_LAUNCH((mel_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, audio, out, B, N, T, hop, n_mels, window,
+                   (const float2*)tw1024, (const float2*)tw2048, fb_start, fb_len, fb_w, fb_stride);
+    return sed_check_launch();
+}

@@ -1,0 +1,187 @@
+"""Mel front-end and spectrogram-domain ops on the MI355X kernels (K1-K5).
+
+Mirrors what recipes/dcase2023_task4_baseline/local/sed_trainer.py builds from torchaudio:
+`MelSpectrogram(...)` (:80-91), `take_log` (:253-264), and the TorchScaler instance/minmax call
+inside `detect` (:266-267).  Shapes at the API are the reference's (B, n_mels, T); in HBM the data
+is frame-major (B, T, n_mels) and handed out as a transposed view, so every kernel streams whole
+frames and conv0 consumes it without a permute.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def as_btf(x):
+    """(B, F, T) reference-shaped tensor -> contiguous (B, T, F) tensor (no copy when x is our view)."""
+    xt = x.transpose(1, 2)
+    return xt if xt.is_contiguous() else xt.contiguous()
+
+
+def hz_to_mel_htk(f):
+    return 2595.0 * math.log10(1.0 + f / 700.0)
+
+
+def melscale_fbanks_htk(n_freqs, f_min, f_max, n_mels, sample_rate):
+    """HTK triangular filters, norm=None, fp32 like torchaudio.functional.melscale_fbanks -> (n_freqs, n_mels)."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_pts = torch.linspace(hz_to_mel_htk(f_min), hz_to_mel_htk(f_max), n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.min(down, up), min=0.0)
+
+
+class MelSpectrogram(torch.nn.Module):
+    """Drop-in for torchaudio.transforms.MelSpectrogram as configured by the DCASE recipes.
+
+    Supported configuration (the one every recipe uses): n_fft == win_length == 2048, power == 1,
+    center=True/reflect, HTK mel scale, norm=None, n_mels <= 128.  Anything else raises."""
+
+    def __init__(self, sample_rate=16000, n_fft=2048, win_length=None, hop_length=256, f_min=0.0, f_max=None,
+                 n_mels=128, window_fn=torch.hamming_window, wkwargs=None, power=1, **unsupported):
+        super().__init__()
+        if unsupported:
+            raise NotImplementedError("MelSpectrogram options not supported by the HIP kernel: %s" % sorted(unsupported))
+        win_length = n_fft if win_length is None else win_length
+        if n_fft != 2048 or win_length != n_fft or power != 1 or n_mels > 128:
+            raise NotImplementedError("HIP mel kernel supports n_fft=win_length=2048, power=1, n_mels<=128")
+        self.sample_rate, self.n_fft, self.hop_length, self.n_mels = sample_rate, n_fft, hop_length, n_mels
+        f_max = float(sample_rate // 2) if f_max is None else float(f_max)
+        window = window_fn(n_fft, **(wkwargs or {})).float()
+        n = np.arange(1024, dtype=np.float64)
+        tw1024 = np.stack([np.cos(2 * np.pi * n / 1024), -np.sin(2 * np.pi * n / 1024)], 1).astype(np.float32)
+        tw2048 = np.stack([np.cos(2 * np.pi * n / 2048), -np.sin(2 * np.pi * n / 2048)], 1).astype(np.float32)
+        fb = melscale_fbanks_htk(n_fft // 2 + 1, float(f_min), f_max, n_mels, sample_rate)     # (1025, n_mels)
+        nz = fb != 0
+        start = torch.zeros(n_mels, dtype=torch.int32)
+        length = torch.zeros(n_mels, dtype=torch.int32)
+        for m in range(n_mels):
+            idx = torch.nonzero(nz[:, m]).flatten()
+            if idx.numel():
+                start[m] = int(idx[0])
+                length[m] = int(idx[-1]) - int(idx[0]) + 1
+        stride = max(8, int(length.max()))
+        w = torch.zeros(n_mels, stride)
+        for m in range(n_mels):
+            w[m, : int(length[m])] = fb[int(start[m]): int(start[m]) + int(length[m]), m]
+        self.fb_stride = stride
+        self.register_buffer("window", window, persistent=False)
+        self.register_buffer("tw1024", torch.from_numpy(tw1024).contiguous(), persistent=False)
+        self.register_buffer("tw2048", torch.from_numpy(tw2048).contiguous(), persistent=False)
+        self.register_buffer("fb_start", start, persistent=False)
+        self.register_buffer("fb_len", length, persistent=False)
+        self.register_buffer("fb_w", w.contiguous(), persistent=False)
+
+    def _tables_to(self, device):
+        if self.window.device != device:
+            self.to(device)
+
+    def frames_major(self, audio, apply_log=False):
+        """audio (B, N) -> (B, T, n_mels) contiguous."""
+        if audio.dim() != 2:
+            raise ValueError("audio must be (batch, samples)")
+        audio = audio.float()
+        if not audio.is_contiguous():
+            audio = audio.contiguous()
+        _lib.check_tensor(audio, "audio")
+        self._tables_to(audio.device)
+        B, N = audio.shape
+        T = 1 + N // self.hop_length
+        out = torch.empty(B, T, self.n_mels, device=audio.device, dtype=torch.float32)
+        _lib.get().call("sed_mel_fwd", audio.data_ptr(), out.data_ptr(), B, N, T, self.n_fft, self.hop_length, self.n_mels,
+                        self.window.data_ptr(), self.tw1024.data_ptr(), self.tw2048.data_ptr(), self.fb_start.data_ptr(),
+                        self.fb_len.data_ptr(), self.fb_w.data_ptr(), self.fb_stride, int(apply_log), _lib.stream_ptr(audio))
+        return out
+
+    def forward(self, audio):
+        return self.frames_major(audio).transpose(1, 2)          # (B, n_mels, T) view
+
+
+def take_log(mels):
+    """SEDTask4.take_log: 20*log10(clamp(x, 1e-5)).clamp(-50, 80)."""
+    if mels.dim() == 3 and not mels.is_contiguous():
+        xt = as_btf(mels)
+        _lib.check_tensor(xt, "mels")
+        y = torch.empty_like(xt)
+        _lib.get().call("sed_take_log", xt.data_ptr(), y.data_ptr(), xt.numel(), _lib.stream_ptr(xt))
+        return y.transpose(1, 2)
+    x = mels.contiguous()
+    _lib.check_tensor(x, "mels")
+    y = torch.empty_like(x)
+    _lib.get().call("sed_take_log", x.data_ptr(), y.data_ptr(), x.numel(), _lib.stream_ptr(x))
+    return y
+
+
+def minmax_scale(x, eps=1e-8, apply_log=False, return_minmax=False):
+    """Instance min-max scaling over all non-batch dims to [-1, 1]; optionally fused with take_log.
+    Works on any layout whose clips are contiguous blocks (our (B,F,T) views included)."""
+    if x.dim() == 3 and not x.is_contiguous():
+        xt = as_btf(x)
+        view_back = True
+    else:
+        xt = x.contiguous()
+        view_back = False
+    _lib.check_tensor(xt, "features")
+    B = xt.shape[0]
+    L = xt.numel() // max(B, 1)
+    out = torch.empty_like(xt)
+    partial = torch.empty(B * 64, device=xt.device, dtype=torch.float32)
+    mm = torch.empty(B, 2, device=xt.device, dtype=torch.float32) if return_minmax else None
+    _lib.get().call("sed_logscale_fwd", xt.data_ptr(), out.data_ptr(), out.data_ptr(), partial.data_ptr(),
+                    mm.data_ptr() if mm is not None else None, B, L, int(apply_log), float(eps), _lib.stream_ptr(xt))
+    res = out.transpose(1, 2) if view_back else out
+    return (res, mm) if return_minmax else res
+
+
+def mixup_(data, perm, c, mode=0):
+    """In-place mixup of a group: data[i] <- c*data[i] + (1-c)*data[perm[i]] (perm: int tensor on any device).
+    `data` must be a batch-major slice whose clips are contiguous blocks."""
+    n = data.shape[0]
+    if n == 0:
+        return data
+    base = data
+    if not data.is_contiguous():
+        if data.dim() == 3 and data.transpose(1, 2).is_contiguous():
+            base = data.transpose(1, 2)
+        else:
+            raise RuntimeError("mixup_: clips must be contiguous blocks")
+    _lib.check_tensor(base, "mixup data")
+    L = base.numel() // n
+    tmp = torch.empty_like(base)
+    perm_d = perm.to(device=base.device, dtype=torch.int32, non_blocking=True)
+    _lib.get().call("sed_mixup", base.data_ptr(), tmp.data_ptr(), perm_d.data_ptr(), float(np.float32(c)),
+                    float(np.float32(1.0 - c)), n, L, int(mode), _lib.stream_ptr(base))
+    return data
+
+
+def specaug_bounds(batch, n_freq, n_time, f_l, f_p, t_l, t_p, device, iid_masks=True, generator=None):
+    """Draws of torchaudio's mask_along_axis(_iid) for CRNN.apply_specaugment -> (B,4) int32 [f0,f1,t0,t1)."""
+    out = torch.zeros(batch, 4, dtype=torch.int32, device=device)
+    n = batch if iid_masks else 1
+    for col, (cap, p, axis_len) in enumerate(((f_l, f_p, n_freq), (t_l, t_p, n_time))):
+        mask_param = min(cap, int(axis_len * p))
+        if mask_param < 1:
+            continue
+        u = torch.rand(2, n, device=device, generator=generator)
+        value = u[0] * mask_param
+        min_value = u[1] * (axis_len - value)
+        start = min_value.long()
+        end = start + value.long()
+        out[:, 2 * col] = start.to(torch.int32)
+        out[:, 2 * col + 1] = end.to(torch.int32)
+    return out
+
+
+def specaug_apply(x, bounds):
+    """x (B, F, T) reference-shaped -> masked copy (same view convention)."""
+    xt = as_btf(x)
+    _lib.check_tensor(xt, "specaug input")
+    y = torch.empty_like(xt)
+    B, T, Fq = xt.shape
+    _lib.get().call("sed_specaug", xt.data_ptr(), y.data_ptr(), bounds.data_ptr(), B, T, Fq, _lib.stream_ptr(xt))
+    return y.transpose(1, 2)

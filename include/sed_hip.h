@@ -1,0 +1,52 @@
+/* C ABI of libsed_hip.so -- the MI355X (gfx950) kernels behind the DESED_task mel + CRNN
+ * mean-teacher training step.
+ *
+ * The reference (DCASE-REPO/DESED_task) is pure Python with no FFI of its own; the boundary a
+ * maintainer binds is therefore this header (ctypes stub: INTEGRATION.md).  Each entry point names
+ * the reference call site it replaces (paths relative to the reference repository).
+ *
+ * Conventions: every function returns 0 (SED_OK) or a negative error code, never throws, never
+ * allocates or frees -- the caller (PyTorch) owns all buffers, including workspaces -- and is
+ * asynchronous on `stream` (a hipStream_t passed as void*).  Pointers are device pointers.
+ * Re-entrant across streams; no global mutable state.
+ * Activation layout is channels-last: (B, T, F, C) fp32, T = time frames, F = mel bins.
+ */
+#ifndef SED_HIP_H
+#define SED_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* K1: torchaudio MelSpectrogram(n_fft=2048, hop=256, hamming(periodic=False), power=1, center, reflect)
+ * built at recipes/dcase2023_task4_baseline/local/sed_trainer.py:80-91, called :282.
+ * audio (B,N) -> out (B,T,n_mels), T = 1 + N/hop.  Tables are host-built once: window[2048],
+ * tw1024[1024] complex exp(-2 pi i n/1024), tw2048[1024] complex exp(-2 pi i k/2048), sparse filterbank
+ * (start bin, length, weights[n_mels][fb_stride]).  apply_log=1 fuses take_log (:253-264). */
+int sed_mel_fwd(const float* audio, float* out, int B, int N, int T, int n_fft, int hop, int n_mels,
+                const float* window, const float* tw1024, const float* tw2048, const int* fb_start,
+                const int* fb_len, const float* fb_w, int fb_stride, int apply_log, void* stream);
+
+/* K3+K4: SEDTask4.take_log (sed_trainer.py:253-264) + TorchScaler("instance","minmax") forward
+ * (desed_task/utils/scaler.py:114-120) on (B, L) clips.  partial: B*64 floats scratch; minmax: optional (B,2). */
+int sed_logscale_fwd(const float* x, float* logbuf, float* out, float* partial, float* minmax, int B, int L,
+                     int apply_log, float eps, void* stream);
+
+/* K3 alone: amp_to_db(mels).clamp(-50, 80) with amin = 1e-5 (sed_trainer.py:262-264). */
+int sed_take_log(const float* x, float* y, long long n, void* stream);
+
+/* K2: desed_task/data_augm.py:31-51 mixup on a group of n clips of L floats, in place (tmp = scratch copy).
+ * mode 0 = features, 1 = soft labels (clamp 0..1), 2 = hard labels. */
+int sed_mixup(float* data, float* tmp, const int* perm, float c, float one_minus_c, int n, int L, int mode, void* stream);
+
+/* K5: the two axis masks of CRNN.apply_specaugment (desed_task/nnet/CRNN.py:207-219) on (B,T,F);
+ * bounds (B,4) int32 = [f0,f1,t0,t1). */
+int sed_specaug(const float* x, float* y, const int* bounds, int B, int T, int Fq, void* stream);
+
+/* Hardware self-test of the MFMA lane maps (no reference counterpart): C = A[M][K] * B[K][M], M = shape (32|16). */
+int sed_selftest_mfma(const float* A, const float* Bm, float* C, int K, int shape, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,19 @@
+"""CPU (fiber-emulator) runs of the K1-K5 parity cases.  Same cases run on the GPU in test_gpu_parity.py."""
+from tests import parity_cases as P
+from tests.emu_support import emu  # noqa: F401
+
+
+def test_mfma_maps(emu):
+    P.case_mfma_selftest("cpu")
+
+
+def test_mel_matches_oracle(emu):
+    P.case_mel("cpu")
+
+
+def test_logscale_generic(emu):
+    P.case_logscale_generic("cpu")
+
+
+def test_mixup_and_specaug(emu):
+    P.case_mixup_specaug("cpu")

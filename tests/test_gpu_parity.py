@@ -1,0 +1,43 @@
+"""GPU parity tests (`pytest -m gpu`): HIP kernels through the real C-ABI library vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests import parity_cases as P
+from desed_task_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    _lib.use_library(None)
+    lib = _lib.get()
+    assert not lib.is_emulator
+    return lib
+
+
+def test_mfma_maps():
+    P.case_mfma_selftest("cuda")
+
+
+def test_mel_small():
+    P.case_mel("cuda")
+
+
+def test_mel_full_clip_and_golden():
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden.npz"))
+    got = P.case_mel("cuda", batch=2, n_samples=160000)
+    assert tuple(got.shape) == (2, 128, 626)
+    ref = G["g1_mel_lin"]
+    np.testing.assert_allclose(got[:, :, ::25].cpu().numpy(), ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max())
+
+
+def test_logscale_generic():
+    P.case_logscale_generic("cuda")
+
+
+def test_mixup_and_specaug():
+    P.case_mixup_specaug("cuda")
