@@ -50,6 +50,10 @@ class _Lib:
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
 
+    def value(self, name, *args):
+        """For the few entry points that return a count instead of a status."""
+        return getattr(self._dll, name)(*args)
+
     def call(self, name, *args):
         rc = getattr(self._dll, name)(*args)
         if rc != 0:

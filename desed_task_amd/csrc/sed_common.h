@@ -16,6 +16,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #include <stdint.h>
 
+#define SED_MAX_SMEM(kern, bytes) \
+    (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+
 #define SED_OK 0
 #define SED_ERR_ARG (-1)
 #define SED_ERR_LAUNCH (-2)

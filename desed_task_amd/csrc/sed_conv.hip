@@ -1,0 +1,526 @@
+// K6 (convolution half): 3x3 / stride 1 / pad 1 convolutions of the CNN encoder
+// (desed_task/nnet/CNN.py:66-76: nn.Conv2d + the batch statistics nn.BatchNorm2d needs), forward,
+// data-gradient and weight-gradient, as implicit GEMMs on the exact-f32 MFMA
+// (v_mfma_f32_32x32x2_f32: bitwise a k-ordered fmaf chain, so parity with the fp32 reference is
+// rounding-order only).
+//
+// Layouts: activations channels-last (B, T, F, C) fp32; packed weights Wp[tap][cin][cout] (K-major for
+// the MFMA B operand).  The forward kernel also emits per-workgroup partial (sum, sum-of-squares) per
+// output channel; bn_finalize reduces them in double and produces mean / invstd / scale / shift and
+// the running-stat update (BatchNorm2d eps=1e-3, momentum=0.99, CNN.py:76).
+//
+// Workgroup = 256 threads = 4 waves; block tile = 128 output pixels (TR x TF patch) x all COUT;
+// each wave owns 32 pixels x COUT (COUT/32 accumulators of 16 VGPRs).  K loop = (cin chunk of <=32)
+// x 9 taps: the halo patch of the chunk sits in LDS (row stride CK+1 dwords: conflict-free A reads),
+// the tap's CK x COUT weight slab is double-buffered in LDS and prefetched through registers while
+// the previous tap's MFMAs run; one barrier per tap.
+#include "sed_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: W (COUT, CIN, 3, 3) -> Wf[tap][ci][co] ; Wd[tap'][co][ci] = W[co][ci][2-a'][2-b']
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ W, float* __restrict__ Wf,
+                                                           float* __restrict__ Wd, int COUT, int CIN) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= COUT * CIN * 9) return;
+    const int b = i % 3, a = (i / 3) % 3, ci = (i / 9) % CIN, co = i / (9 * CIN);
+    const float w = W[i];
+    Wf[((a * 3 + b) * CIN + ci) * COUT + co] = w;
+    if (Wd) Wd[(((2 - a) * 3 + (2 - b)) * COUT + co) * CIN + ci] = w;
+}
+extern "C" int sed_conv_pack_weights(const float* W, float* Wf, float* Wd, int COUT, int CIN, void* stream) {
+    const int n = COUT * CIN * 9;
+    SED_LAUNCH(pack_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, Wf, Wd, COUT, CIN);
+    return sed_check_launch();
+}
+// dWp[tap][ci][co] (packed) -> dW (COUT, CIN, 3, 3)
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dWp, float* __restrict__ dW, int COUT, int CIN) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= COUT * CIN * 9) return;
+    const int b = i % 3, a = (i / 3) % 3, ci = (i / 9) % CIN, co = i / (9 * CIN);
+    dW[i] = dWp[((a * 3 + b) * CIN + ci) * COUT + co];
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic 3x3 conv, implicit GEMM (also used for dgrad with flipped/transposed weights)
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int TF>
+struct ConvCfg {
+    static constexpr int TR = 128 / TF;
+    static constexpr int PW = TF + 2, PH = TR + 2, PP = PW * PH;
+    static constexpr int CK = CIN < 32 ? CIN : 32;
+    static constexpr int CKP = CK + 1;
+    static constexpr int NCH = CIN / CK;
+    static constexpr int NT = (COUT + 31) / 32;
+    static constexpr int WCH = CK * COUT;
+    static constexpr int PATCH_F = (PP * CKP + 3) & ~3;
+    static constexpr int SMEM = (PATCH_F + 2 * WCH) * 4;
+};
+
+template <int CIN, int COUT, int TF, bool STATS>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      float* __restrict__ partial, int B, int T, int F) {
+    using Cfg = ConvCfg<CIN, COUT, TF>;
+    constexpr int TR = Cfg::TR, PW = Cfg::PW, PP = Cfg::PP, CK = Cfg::CK, CKP = Cfg::CKP, NCH = Cfg::NCH, NT = Cfg::NT,
+                  WCH = Cfg::WCH;
+    SED_DYN_SMEM(smem);
+    float* patch = (float*)smem;
+    float* wbuf = patch + Cfg::PATCH_F;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int ftiles = F / TF, ttiles = (T + TR - 1) / TR;
+    const int bid = blockIdx.x;
+    const int ft = bid % ftiles, tt = (bid / ftiles) % ttiles, b = bid / (ftiles * ttiles);
+    const int t0 = tt * TR, f0 = ft * TF;
+    const int p = 32 * w + lo;
+    const int abase = ((p / TF) * PW + (p % TF)) * CKP + hi;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x16_zero();
+
+    constexpr int WV = (WCH / 4 + 255) / 256;
+    float4 wreg[WV];
+
+    for (int cc = 0; cc < NCH; ++cc) {
+        // ---- stage the halo patch of this cin chunk ----
+        constexpr int V = CK / 4;
+        for (int idx = tid; idx < PP * V; idx += 256) {
+            const int pix = idx / V, v = idx - pix * V;
+            const int i = pix / PW, j = pix - i * PW;
+            const int t = t0 - 1 + i, f = f0 - 1 + j;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < T && f >= 0 && f < F)
+                val = *(const float4*)(x + (((size_t)b * T + t) * F + f) * CIN + cc * CK + 4 * v);
+            float* d = patch + pix * CKP + 4 * v;
+            d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+        }
+        // ---- tap 0 weights straight to LDS buffer 0 ----
+        {
+            const float4* src = (const float4*)(Wp + ((size_t)0 * CIN + cc * CK) * COUT);
+#pragma unroll
+            for (int i = 0; i < WV; ++i) {
+                const int idx = tid + 256 * i;
+                if (idx < WCH / 4) ((float4*)wbuf)[idx] = src[idx];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) {
+                const float4* src = (const float4*)(Wp + ((size_t)(tap + 1) * CIN + cc * CK) * COUT);
+#pragma unroll
+                for (int i = 0; i < WV; ++i) {
+                    const int idx = tid + 256 * i;
+                    if (idx < WCH / 4) wreg[i] = src[idx];
+                }
+            }
+            const float* wb = wbuf + (tap & 1) * WCH;
+            const float* ap = patch + abase + ((tap / 3) * PW + (tap % 3)) * CKP;
+#pragma unroll
+            for (int k = 0; k < CK; k += 2) {
+                const float av = ap[k];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float bv = (COUT >= 32 || lo < COUT) ? wb[(k + hi) * COUT + nt * 32 + lo] : 0.f;
+                    acc[nt] = mfma32(av, bv, acc[nt]);
+                }
+            }
+            if (tap + 1 < 9) {
+                float4* dst = (float4*)(wbuf + ((tap + 1) & 1) * WCH);
+#pragma unroll
+                for (int i = 0; i < WV; ++i) {
+                    const int idx = tid + 256 * i;
+                    if (idx < WCH / 4) dst[idx] = wreg[i];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: bias, store, per-channel partial statistics ----
+    float* red = wbuf;   // free after the last barrier: [4 waves][2][NT*32]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nt * 32 + lo;
+        const float bv = (bias != nullptr && co < COUT) ? bias[co] : 0.f;
+        float s = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pp = 32 * w + mfma32_row(r, lane);
+            const int t = t0 + pp / TF, f = f0 + pp % TF;
+            if (t < T && co < COUT) {
+                const float v = acc[nt][r] + bv;
+                y[(((size_t)b * T + t) * F + f) * COUT + co] = v;
+                s += v;
+                s2 += v * v;
+            }
+        }
+        if (STATS) {
+            s += __shfl_xor(s, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (hi == 0) {
+                red[(w * 2 + 0) * (NT * 32) + co] = s;
+                red[(w * 2 + 1) * (NT * 32) + co] = s2;
+            }
+        }
+    }
+    if (STATS) {
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const int which = tid / COUT, co = tid - which * COUT;
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) v += red[(ww * 2 + which) * (NT * 32) + co];
+            partial[(size_t)bid * 2 * COUT + tid] = v;
+        }
+    }
+}
+
+template <int CIN, int COUT, int TF>
+static int launch_conv(const float* x, const float* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
+                       hipStream_t s) {
+    using Cfg = ConvCfg<CIN, COUT, TF>;
+    const int nblk = B * ((T + Cfg::TR - 1) / Cfg::TR) * (F / TF);
+    if (partial) {
+        SED_MAX_SMEM((conv3x3_kernel<CIN, COUT, TF, true>), Cfg::SMEM);
+        SED_LAUNCH((conv3x3_kernel<CIN, COUT, TF, true>), dim3(nblk), dim3(256), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
+    } else {
+        SED_MAX_SMEM((conv3x3_kernel<CIN, COUT, TF, false>), Cfg::SMEM);
+        SED_LAUNCH((conv3x3_kernel<CIN, COUT, TF, false>), dim3(nblk), dim3(256), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
+    }
+    return sed_check_launch();
+}
+
+static inline int conv_tf(int F) { return F >= 32 ? 32 : F; }
+
+// number of workgroups (= rows of `partial`, each 2*COUT floats) the forward launch uses
+extern "C" int sed_conv_fwd_blocks(int B, int T, int F, int CIN) {
+    if (CIN == 1) return B * ((T + 15) / 16);
+    const int TF = conv_tf(F);
+    return B * ((T + 128 / TF - 1) / (128 / TF)) * (F / TF);
+}
+
+// x (B,T,F,CIN), Wp packed [9][CIN][COUT], bias [COUT] or null, y (B,T,F,COUT), partial: null or
+// [sed_conv_fwd_blocks][2*COUT] floats.
+extern "C" int sed_conv3x3(const float* x, const float* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
+                           int CIN, int COUT, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0 || T <= 0) return SED_OK;
+    const int TF = conv_tf(F);
+    if (F % TF != 0 || (F & (F - 1)) != 0 || F < 2) return SED_ERR_UNSUPPORTED;
+#define CONV_CASE(ci, co, tf) \
+    if (CIN == ci && COUT == co && TF == tf) return launch_conv<ci, co, tf>(x, Wp, bias, y, partial, B, T, F, s);
+    CONV_CASE(16, 32, 32) CONV_CASE(32, 64, 32) CONV_CASE(64, 128, 16)
+    CONV_CASE(128, 128, 8) CONV_CASE(128, 128, 4) CONV_CASE(128, 128, 2)
+    CONV_CASE(32, 16, 32) CONV_CASE(64, 32, 32) CONV_CASE(128, 64, 16)
+    // small-shape variants used by the unit tests / other n_mels
+    CONV_CASE(16, 32, 16) CONV_CASE(32, 64, 8) CONV_CASE(64, 128, 4) CONV_CASE(128, 128, 16) CONV_CASE(128, 128, 32)
+    CONV_CASE(32, 16, 16) CONV_CASE(64, 32, 8) CONV_CASE(128, 64, 4) CONV_CASE(64, 128, 32) CONV_CASE(64, 128, 8)
+    CONV_CASE(32, 64, 16) CONV_CASE(64, 32, 16) CONV_CASE(128, 64, 8) CONV_CASE(128, 64, 32)
+#undef CONV_CASE
+    return SED_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// layer 0: CIN = 1 -> COUT = 16, direct VALU (K = 9 is not a dense contraction).  Fuses the SpecAugment
+// predicate (CRNN.py:207-219) into the load.  Tile = 16 frames x F mel bins.
+// ---------------------------------------------------------------------------------------------
+#define C0_TR 16
+template <int COUT>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                    const float* __restrict__ bias, const int* __restrict__ bounds,
+                                                    float* __restrict__ y, float* __restrict__ partial, int B, int T, int F) {
+    __shared__ float tile[(C0_TR + 2) * (128 + 2)];
+    __shared__ float sw[COUT * 9], sb[COUT];
+    __shared__ float red[4][2 * COUT];
+    const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * C0_TR, PW = F + 2;
+    if (tid < COUT * 9) sw[tid] = W[tid];
+    if (tid < COUT) sb[tid] = bias ? bias[tid] : 0.f;
+    int mf0 = 0, mf1 = 0, mt0 = 0, mt1 = 0;
+    if (bounds) { mf0 = bounds[4 * b]; mf1 = bounds[4 * b + 1]; mt0 = bounds[4 * b + 2]; mt1 = bounds[4 * b + 3]; }
+    for (int idx = tid; idx < (C0_TR + 2) * PW; idx += 256) {
+        const int i = idx / PW, j = idx - i * PW;
+        const int t = t0 - 1 + i, f = j - 1;
+        float v = 0.f;
+        if (t >= 0 && t < T && f >= 0 && f < F) {
+            v = x[((size_t)b * T + t) * F + f];
+            if ((f >= mf0 && f < mf1) || (t >= mt0 && t < mt1)) v = 0.f;
+        }
+        tile[idx] = v;
+    }
+    __syncthreads();
+    float s[COUT], s2[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) { s[c] = 0.f; s2[c] = 0.f; }
+    for (int p = tid; p < C0_TR * F; p += 256) {
+        const int pr = p / F, pc = p - pr * F, t = t0 + pr;
+        if (t < T) {
+            float in[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) in[a * 3 + bb] = tile[(pr + a) * PW + pc + bb];
+            float o[COUT];
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc = fmaf(in[k], sw[c * 9 + k], acc);
+                acc += sb[c];
+                o[c] = acc;
+                s[c] += acc;
+                s2[c] += acc * acc;
+            }
+            float4* dst = (float4*)(y + (((size_t)b * T + t) * F + pc) * COUT);
+#pragma unroll
+            for (int c = 0; c < COUT; c += 4) dst[c / 4] = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+        }
+    }
+    if (partial) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+            const float a = wave_sum(s[c]), q = wave_sum(s2[c]);
+            if ((tid & 63) == 0) { red[tid >> 6][c] = a; red[tid >> 6][COUT + c] = q; }
+        }
+        __syncthreads();
+        if (tid < 2 * COUT)
+            partial[((size_t)b * gridDim.x + blockIdx.x) * 2 * COUT + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    }
+}
+// x (B,T,F) scaled log-mel; W (16,1,3,3) PyTorch layout; bounds (B,4) int32 or null.
+extern "C" int sed_conv0_fwd(const float* x, const float* W, const float* bias, const int* bounds, float* y, float* partial,
+                             int B, int T, int F, int COUT, void* stream) {
+    if (COUT != 16 || F > 128 || F < 1) return SED_ERR_UNSUPPORTED;
+    if (B <= 0 || T <= 0) return SED_OK;
+    SED_LAUNCH((conv0_kernel<16>), dim3((T + C0_TR - 1) / C0_TR, B), dim3(256), 0, (hipStream_t)stream, x, W, bias, bounds, y,
+               partial, B, T, F);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm statistics finalisation (one workgroup per channel; double accumulation)
+// stats layout: [mean | invstd | scale = gamma*invstd | shift = beta - mean*scale], 4*C floats
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float momentum, float eps, float* __restrict__ stats, int training,
+                                                          int update_running) {
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    float mean, invstd;
+    if (training) {
+        double a = 0.0, q = 0.0;
+        for (int i = tid; i < nblocks; i += 256) {
+            a += (double)partial[(size_t)i * 2 * C + c];
+            q += (double)partial[(size_t)i * 2 * C + C + c];
+        }
+        r1[tid] = a; r2[tid] = q;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) { r1[tid] += r1[tid + st]; r2[tid] += r2[tid + st]; }
+            __syncthreads();
+        }
+        if (tid != 0) return;
+        const double m = r1[0] / (double)count;
+        double var = r2[0] / (double)count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (update_running) {
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+            const float unbiased = (float)(var * ((double)count / ((double)count - 1.0)));
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+        }
+    } else {
+        if (tid != 0) return;
+        mean = running_mean[c];
+        invstd = 1.0f / sqrtf(running_var[c] + eps);
+    }
+    const float sc = gamma[c] * invstd;
+    stats[c] = mean;
+    stats[C + c] = invstd;
+    stats[2 * C + c] = sc;
+    stats[3 * C + c] = beta[c] - mean * sc;
+}
+extern "C" int sed_bn_finalize(const float* partial, int nblocks, int C, float count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, float* stats, int training,
+                               int update_running, void* stream) {
+    if (C <= 0) return SED_ERR_ARG;
+    SED_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nblocks, C, count, gamma, beta,
+               running_mean, running_var, momentum, eps, stats, training, update_running);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: dWp[tap][ci][co] = sum_p x[p + tap][ci] * dy[p][co]   (K = pixels)
+// grid = (splits, 9 taps).  Each workgroup walks its share of 64-pixel K-tiles; A = shifted x tile
+// [64][CIN], B = dy tile [64][COUT] in LDS; waves split the COUT tiles (and K when few tiles).
+// Partial results are added with fp32 atomics into dWp (zeroed by the caller).
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+struct WgCfg {
+    static constexpr int KT = 64;                       // pixels per K tile
+    static constexpr int MT = (CIN + 31) / 32, NT = (COUT + 31) / 32;
+    static constexpr int WN = NT >= 4 ? 4 : NT;         // waves along N
+    static constexpr int WK = 4 / WN;                   // waves along K
+    static constexpr int NTW = NT / WN;                 // N tiles per wave
+    static constexpr int CIP = CIN + 1, COP = COUT + 1; // padded LDS strides (reads are along the channel: contiguous)
+    static constexpr int SMEM = KT * (CIN + COUT) * 4;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ dWp, int B, int T, int F) {
+    using Cfg = WgCfg<CIN, COUT>;
+    constexpr int KT = Cfg::KT, MT = Cfg::MT, WN = Cfg::WN, WK = Cfg::WK, NTW = Cfg::NTW;
+    SED_DYN_SMEM(smem);
+    float* xs = (float*)smem;            // [KT][CIN]
+    float* ds = xs + KT * CIN;           // [KT][COUT]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int wn = w % WN, wk = w / WN;
+    const int tap = blockIdx.y, da = tap / 3 - 1, db = tap % 3 - 1;
+    const int npix = B * T * F;
+    const int ntiles = (npix + KT - 1) / KT;
+
+    f32x16 acc[MT][NTW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[m][n] = f32x16_zero();
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int p0 = tile * KT;
+        __syncthreads();
+        // stage shifted x and dy for pixels p0 .. p0+KT-1 (zero outside the image / beyond npix)
+        for (int idx = tid; idx < KT * (CIN / 4); idx += 256) {
+            const int r = idx / (CIN / 4), v = idx - r * (CIN / 4);
+            const int p = p0 + r;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < npix) {
+                const int f = p % F, t = (p / F) % T, bb = p / (F * T);
+                const int t2 = t + da, f2 = f + db;
+                if (t2 >= 0 && t2 < T && f2 >= 0 && f2 < F)
+                    val = *(const float4*)(x + (((size_t)bb * T + t2) * F + f2) * CIN + 4 * v);
+            }
+            *(float4*)(xs + r * CIN + 4 * v) = val;
+        }
+        for (int idx = tid; idx < KT * (COUT / 4); idx += 256) {
+            const int r = idx / (COUT / 4), v = idx - r * (COUT / 4);
+            const int p = p0 + r;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < npix) val = *(const float4*)(dy + (size_t)p * COUT + 4 * v);
+            *(float4*)(ds + r * COUT + 4 * v) = val;
+        }
+        __syncthreads();
+        // this wave's K slice: rows [wk*KT/WK, (wk+1)*KT/WK)
+        constexpr int KS = KT / WK;
+#pragma unroll 4
+        for (int k = wk * KS; k < (wk + 1) * KS; k += 2) {
+            float av[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[m] = (CIN >= 32 || lo < CIN) ? xs[(k + hi) * CIN + m * 32 + lo] : 0.f;
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int co = (wn * NTW + n) * 32 + lo;
+                const float bv = (COUT >= 32 || lo < COUT) ? ds[(k + hi) * COUT + co] : 0.f;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][n] = mfma32(av[m], bv, acc[m][n]);
+            }
+        }
+    }
+    // ---- accumulate into global dWp[tap][ci][co] ----
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int co = (wn * NTW + n) * 32 + lo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = m * 32 + mfma32_row(r, lane);
+                if (ci < CIN && co < COUT) atomicAdd(dWp + ((size_t)tap * CIN + ci) * COUT + co, acc[m][n][r]);
+            }
+        }
+}
+
+template <int CIN, int COUT>
+static int launch_wgrad(const float* x, const float* dy, float* dWp, int B, int T, int F, hipStream_t s) {
+    using Cfg = WgCfg<CIN, COUT>;
+    const int ntiles = (B * T * F + Cfg::KT - 1) / Cfg::KT;
+    int splits = ntiles < 56 ? ntiles : 56;          // 56 x 9 taps = 504 workgroups ~ 2 per CU
+    SED_MAX_SMEM((conv_wgrad_kernel<CIN, COUT>), Cfg::SMEM);
+    SED_LAUNCH((conv_wgrad_kernel<CIN, COUT>), dim3(splits, 9), dim3(256), Cfg::SMEM, s, x, dy, dWp, B, T, F);
+    return sed_check_launch();
+}
+
+// x (B,T,F,CIN), dy (B,T,F,COUT) -> dW (COUT,CIN,3,3).  dWp: scratch 9*CIN*COUT floats.
+extern "C" int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
+                              void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(dWp, 0, (size_t)9 * CIN * COUT * sizeof(float), s) != hipSuccess) return SED_ERR_LAUNCH;
+    int rc = SED_ERR_UNSUPPORTED;
+#define WG_CASE(ci, co) if (CIN == ci && COUT == co) rc = launch_wgrad<ci, co>(x, dy, dWp, B, T, F, s);
+    WG_CASE(16, 32) WG_CASE(32, 64) WG_CASE(64, 128) WG_CASE(128, 128)
+#undef WG_CASE
+    if (rc != SED_OK) return rc;
+    const int n = COUT * CIN * 9;
+    SED_LAUNCH(unpack_wgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)dWp, dW, COUT, CIN);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// layer-0 weight gradient: dW[co][tap] = sum_p x[p + tap] * dy[p][co], CIN = 1, COUT = 16.
+// MFMA form: A[i = tap (9 of 32)][k = pixel], B[k = pixel][j = co (16 of 32)]; one wave per K slice.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const int* __restrict__ bounds,
+                                                          const float* __restrict__ dy, float* __restrict__ dW, int B, int T, int F) {
+    const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+    const int npix = B * T * F;
+    const int wave_global = blockIdx.x * 4 + (tid >> 6), nwaves = gridDim.x * 4;
+    const int da = lo / 3 - 1, db = lo % 3 - 1;            // tap of this lane's A row (valid for lo < 9)
+    f32x16 acc = f32x16_zero();
+    // 8 pixels (4 MFMA k-steps) per iteration: issue all loads, then the MFMAs
+    for (int p0 = wave_global * 8; p0 < npix; p0 += nwaves * 8) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + 2 * u + hi;
+            av[u] = 0.f; bv[u] = 0.f;
+            if (p < npix) {
+                const int f = p % F, t = (p / F) % T, bb = p / (F * T);
+                if (lo < 9) {
+                    const int t2 = t + da, f2 = f + db;
+                    if (t2 >= 0 && t2 < T && f2 >= 0 && f2 < F) {
+                        float v = x[((size_t)bb * T + t2) * F + f2];
+                        if (bounds) {
+                            const int* bd = bounds + 4 * bb;
+                            if ((f2 >= bd[0] && f2 < bd[1]) || (t2 >= bd[2] && t2 < bd[3])) v = 0.f;
+                        }
+                        av[u] = v;
+                    }
+                }
+                if (lo < 16) bv[u] = dy[(size_t)p * 16 + lo];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = mfma32(av[u], bv[u], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int tap = mfma32_row(r, lane);
+        if (tap < 9 && lo < 16) atomicAdd(dW + lo * 9 + tap, acc[r]);
+    }
+}
+// dW (16,1,3,3) PyTorch layout, accumulated with atomics (zeroed here).
+extern "C" int sed_conv0_wgrad(const float* x, const int* bounds, const float* dy, float* dW, int B, int T, int F, int COUT,
+                               void* stream) {
+    if (COUT != 16) return SED_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(dW, 0, 16 * 9 * sizeof(float), s) != hipSuccess) return SED_ERR_LAUNCH;
+    const int npix = B * T * F;
+    int grid = (npix + 8191) / 8192;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    SED_LAUNCH(conv0_wgrad_kernel, dim3(grid), dim3(256), 0, s, x, bounds, dy, dW, B, T, F);
+    return sed_check_launch();
+}

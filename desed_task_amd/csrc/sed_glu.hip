@@ -1,0 +1,414 @@
+// K6 (activation half): BatchNorm-apply + GLU + Dropout + AvgPool of one CNN block, fused, forward and
+// backward.  Reference: desed_task/nnet/CNN.py:11-16 (GLU = Linear_CxC(x) * sigmoid(x), both branches on
+// the BN output), :76 (BatchNorm2d eps 1e-3), :90-91 (Dropout), :96-98 (AvgPool2d, floor mode).
+//
+// Forward : y (B,T,F,C) pre-BN conv output -> out (B,T/PT,F/PF,C).  One read of y, one (4x or 2x
+//           smaller) write; the CxC GLU linear runs on the exact-f32 MFMA with the weight resident in LDS.
+// Backward: g_out -> dz = dL/d(xhat) (B,T,F,C) plus the reductions dgamma, dbeta (BatchNorm), dWg, dbg
+//           (GLU linear): three MFMA GEMMs per tile sharing one LDS image of xhat; nothing but y was saved
+//           by the forward (xn, lin, sigmoid and the dropout mask are recomputed).
+// bn_bwd_apply then turns dz into dy = dL/d(conv output) in place (training-mode BN backward).
+//
+// M tile rows are ordered by pooling window (row = window*WIN + q), so that the MFMA accumulator groups
+// of 4 consecutive rows held by one lane are exactly one 2x2 window (or two 1x2 windows): pooling and
+// un-pooling are lane-local.
+#include "sed_common.h"
+
+template <int C, int PT, int PF>
+struct GluGeom {
+    static constexpr int WIN = PT * PF;
+    static constexpr int CP = C + 1;
+    static constexpr int NT = C >= 32 ? C / 32 : 1;
+};
+
+// map row m of a tile starting at window o0 to the input pixel; returns false when the window is out of range
+template <int PT, int PF>
+__device__ __forceinline__ bool row_pixel(int m, int o0, int NWC, int Fo, int& o, int& t, int& f) {
+    constexpr int WIN = PT * PF;
+    const int q = m % WIN;
+    o = o0 + m / WIN;
+    const int to = o / Fo, fo = o - to * Fo;
+    t = to * PT + q / PF;
+    f = fo * PF + q % PF;
+    return o < NWC;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int C, int PT, int PF>
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                      const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                      float* __restrict__ out, int B, int T, int F, uint32_t seed,
+                                                      uint32_t thr24, float dscale) {
+    using G = GluGeom<C, PT, PF>;
+    constexpr int WIN = G::WIN, CP = G::CP, NT = G::NT, ROWS = 128, NW = ROWS / WIN;
+    SED_DYN_SMEM(smem);
+    float* wg = (float*)smem;           // [C][CP]
+    float* xs = wg + C * CP;            // [ROWS][CP]  BN output xn
+    float* sc = xs + ROWS * CP;         // scale[C], shift[C], bg[C]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int To = T / PT, Fo = F / PF, NWC = To * Fo;
+    const int tiles_per_clip = (NWC + NW - 1) / NW, ntiles = B * tiles_per_clip;
+
+    for (int i = tid; i < C * C; i += 256) wg[(i / C) * CP + (i % C)] = Wg[i];
+    if (tid < C) { sc[tid] = stats[2 * C + tid]; sc[C + tid] = stats[3 * C + tid]; sc[2 * C + tid] = bg[tid]; }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
+        __syncthreads();
+        for (int idx = tid; idx < ROWS * (C / 4); idx += 256) {
+            const int m = idx / (C / 4), v = idx - m * (C / 4);
+            int o, t, f;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f)) {
+                val = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
+                const float* s = sc + 4 * v;
+                val.x = fmaf(val.x, s[0], s[C + 0]); val.y = fmaf(val.y, s[1], s[C + 1]);
+                val.z = fmaf(val.z, s[2], s[C + 2]); val.w = fmaf(val.w, s[3], s[C + 3]);
+            }
+            float* d = xs + m * CP + 4 * v;
+            d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+        }
+        __syncthreads();
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x16_zero();
+        const float* ap = xs + (32 * w + lo) * CP + hi;
+#pragma unroll 8
+        for (int k = 0; k < C; k += 2) {
+            const float av = ap[k];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float bv = (C >= 32 || lo < C) ? wg[(nt * 32 + lo) * CP + k + hi] : 0.f;
+                acc[nt] = mfma32(av, bv, acc[nt]);
+            }
+        }
+        // ---- epilogue: gate, dropout, pool ----
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + lo;
+            if (n < C) {
+                const float bias = sc[2 * C + n];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int m = 32 * w + 8 * j + 4 * hi + q;
+                        int o, t, f;
+                        const bool ok = row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f);
+                        const float xn = xs[m * CP + n];
+                        float r = (acc[nt][4 * j + q] + bias) * sed_sigmoid(xn);
+                        const uint32_t e = (uint32_t)((((size_t)b * T + t) * F + f) * C + n);
+                        r = (ok && sed_keep(e, seed, thr24)) ? r * dscale : 0.f;
+                        v[q] = r;
+                    }
+                    const int mbase = 32 * w + 8 * j + 4 * hi;
+                    if (WIN == 4) {
+                        const int o = o0 + mbase / 4;
+                        if (o < NWC) out[((size_t)b * NWC + o) * C + n] = 0.25f * ((v[0] + v[1]) + (v[2] + v[3]));
+                    } else {
+                        const int o = o0 + mbase / 2;
+                        if (o < NWC) out[((size_t)b * NWC + o) * C + n] = 0.5f * (v[0] + v[1]);
+                        if (o + 1 < NWC) out[((size_t)b * NWC + o + 1) * C + n] = 0.5f * (v[2] + v[3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int C, int PT, int PF>
+static int launch_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
+                          uint32_t seed, uint32_t thr24, float dscale, hipStream_t s) {
+    using G = GluGeom<C, PT, PF>;
+    constexpr int SMEM = (C * G::CP + 128 * G::CP + 3 * C) * 4;
+    const int NWC = (T / PT) * (F / PF);
+    const int ntiles = B * ((NWC + 128 / G::WIN - 1) / (128 / G::WIN));
+    const int per_cu = SMEM > 80 * 1024 ? 1 : (SMEM > 40 * 1024 ? 2 : 4);
+    int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+    if (grid < 1) return SED_OK;
+    SED_MAX_SMEM((glu_fwd_kernel<C, PT, PF>), SMEM);
+    SED_LAUNCH((glu_fwd_kernel<C, PT, PF>), dim3(grid), dim3(256), SMEM, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale);
+    return sed_check_launch();
+}
+
+// y (B,T,F,C); stats 4*C (mean, invstd, scale, shift); Wg (C,C) [out][in]; out (B,T/PT,F/PF,C).
+// dropout: keep element e when hash(e, seed) >> 8 >= thr24 (thr24 = round(p * 2^24)); dscale = 1/(1-p).
+extern "C" int sed_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
+                           int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (F % PF != 0) return SED_ERR_UNSUPPORTED;
+#define GLU_CASE(c, pt, pf) \
+    if (C == c && PT == pt && PF == pf) return launch_glu_fwd<c, pt, pf>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, s);
+    GLU_CASE(16, 2, 2) GLU_CASE(32, 2, 2) GLU_CASE(64, 1, 2) GLU_CASE(128, 1, 2)
+#undef GLU_CASE
+    return SED_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+template <int C, int PT, int PF>
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                      const float* __restrict__ gout, float* __restrict__ dz,
+                                                      float* __restrict__ dWg, float* __restrict__ dbg,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int T, int F,
+                                                      uint32_t seed, uint32_t thr24, float dscale) {
+    using G = GluGeom<C, PT, PF>;
+    constexpr int WIN = G::WIN, CP = G::CP, NT = G::NT;
+    constexpr int ROWS = C >= 64 ? 64 : 128, WM = ROWS / 32, WN = 4 / WM, NTW = NT / WN, NW = ROWS / WIN;
+    constexpr int NTILES3 = NT * NT, TPW = NTILES3 >= 4 ? NTILES3 / 4 : 1;
+    SED_DYN_SMEM(smem);
+    float* wg = (float*)smem;           // [C][CP]
+    float* xh = wg + C * CP;            // [ROWS][CP]  xhat
+    float* dl = xh + ROWS * CP;         // [ROWS][CP]  d lin
+    float* sc = dl + ROWS * CP;         // mean[C], invstd[C], gamma[C], beta[C], bg[C]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int wm = w % WM, wn = w / WM;
+    const int To = T / PT, Fo = F / PF, NWC = To * Fo;
+    const int tiles_per_clip = (NWC + NW - 1) / NW, ntiles = B * tiles_per_clip;
+
+    for (int i = tid; i < C * C; i += 256) wg[(i / C) * CP + (i % C)] = Wg[i];
+    if (tid < C) {
+        sc[tid] = stats[tid]; sc[C + tid] = stats[C + tid];
+        sc[2 * C + tid] = gamma[tid]; sc[3 * C + tid] = beta[tid]; sc[4 * C + tid] = bg[tid];
+    }
+    const float* gam = sc + 2 * C;
+    const float* bet = sc + 3 * C;
+
+    f32x16 P[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) P[i] = f32x16_zero();
+    float a_dbg[NTW], a_dgam[NTW], a_dbet[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) { a_dbg[i] = 0.f; a_dgam[i] = 0.f; a_dbet[i] = 0.f; }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
+        __syncthreads();
+        for (int idx = tid; idx < ROWS * (C / 4); idx += 256) {
+            const int m = idx / (C / 4), v = idx - m * (C / 4);
+            int o, t, f;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f)) {
+                val = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
+                const float* mu = sc + 4 * v;
+                val.x = (val.x - mu[0]) * mu[C + 0]; val.y = (val.y - mu[1]) * mu[C + 1];
+                val.z = (val.z - mu[2]) * mu[C + 2]; val.w = (val.w - mu[3]) * mu[C + 3];
+            }
+            float* d = xh + m * CP + 4 * v;
+            d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+        }
+        __syncthreads();
+        // ---- GEMM1: lin = xn . Wg^T ----
+        f32x16 acc[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[nt] = f32x16_zero();
+        {
+            const float* ap = xh + (32 * wm + lo) * CP + hi;
+#pragma unroll 8
+            for (int k = 0; k < C; k += 2) {
+                const float av = fmaf(ap[k], gam[k + hi], bet[k + hi]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int n = (wn * NTW + nt) * 32 + lo;
+                    const float bv = (C >= 32 || lo < C) ? wg[n * CP + k + hi] : 0.f;
+                    acc[nt] = mfma32(av, bv, acc[nt]);
+                }
+            }
+        }
+        // ---- epilogue 1: dlin -> LDS, e -> acc (seed of GEMM2) ----
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int n = (wn * NTW + nt) * 32 + lo;
+            const bool nok = n < C;
+            const float bias = nok ? sc[4 * C + n] : 0.f, gn = nok ? gam[n] : 0.f, bn = nok ? bet[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 32 * wm + mfma32_row(r, lane);
+                int o, t, f;
+                const bool ok = row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f) && nok;
+                float dlin = 0.f, e = 0.f;
+                if (ok) {
+                    const float xn = fmaf(xh[m * CP + n], gn, bn);
+                    const float sg = sed_sigmoid(xn);
+                    const float lin = acc[nt][r] + bias;
+                    const uint32_t ei = (uint32_t)((((size_t)b * T + t) * F + f) * C + n);
+                    float g = gout[((size_t)b * NWC + o) * C + n] * (1.0f / WIN);
+                    g = sed_keep(ei, seed, thr24) ? g * dscale : 0.f;
+                    dlin = g * sg;
+                    e = g * lin * sg * (1.0f - sg);
+                }
+                if (nok) dl[m * CP + n] = dlin;
+                acc[nt][r] = e;
+                a_dbg[nt] += dlin;
+            }
+        }
+        __syncthreads();
+        // ---- GEMM2: dxn = dlin . Wg + e ----
+        {
+            const float* ap = dl + (32 * wm + lo) * CP + hi;
+#pragma unroll 8
+            for (int k = 0; k < C; k += 2) {
+                const float av = ap[k];
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int c = (wn * NTW + nt) * 32 + lo;
+                    const float bv = (C >= 32 || lo < C) ? wg[(k + hi) * CP + c] : 0.f;
+                    acc[nt] = mfma32(av, bv, acc[nt]);
+                }
+            }
+        }
+        // ---- epilogue 2: dz = dxn * gamma, BN reductions ----
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int c = (wn * NTW + nt) * 32 + lo;
+            const bool cok = c < C;
+            const float gc = cok ? gam[c] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 32 * wm + mfma32_row(r, lane);
+                int o, t, f;
+                if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f) && cok) {
+                    const float dxn = acc[nt][r];
+                    a_dgam[nt] += dxn * xh[m * CP + c];
+                    a_dbet[nt] += dxn;
+                    dz[(((size_t)b * T + t) * F + f) * C + c] = dxn * gc;
+                }
+            }
+        }
+        // ---- GEMM3: P[n'][c] += sum_rows dlin[row][n'] * xn[row][c] ----
+        if (NTILES3 >= 4) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int id = w * TPW + i, mt = id / NT, ct = id % NT;
+                const int c = ct * 32 + lo;
+                const float gc = gam[c], bc = bet[c];
+#pragma unroll 8
+                for (int k = 0; k < ROWS; k += 2) {
+                    const float av = dl[(k + hi) * CP + mt * 32 + lo];
+                    const float bv = fmaf(xh[(k + hi) * CP + c], gc, bc);
+                    P[i] = mfma32(av, bv, P[i]);
+                }
+            }
+        } else {   // single 32x32 output tile: the 4 waves split K (rows)
+            const bool cok = lo < C;
+            const float gc = cok ? gam[lo] : 0.f, bc = cok ? bet[lo] : 0.f;
+#pragma unroll 8
+            for (int k = 32 * w; k < 32 * w + 32; k += 2) {
+                const float av = cok ? dl[(k + hi) * CP + lo] : 0.f;
+                const float bv = cok ? fmaf(xh[(k + hi) * CP + lo], gc, bc) : 0.f;
+                P[0] = mfma32(av, bv, P[0]);
+            }
+        }
+    }
+    // ---- flush the per-workgroup reductions ----
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int id = NTILES3 >= 4 ? w * TPW + i : 0;
+        const int mt = id / NT, ct = id % NT, c = ct * 32 + lo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = mt * 32 + mfma32_row(r, lane);
+            if (n < C && c < C) atomicAdd(dWg + (size_t)n * C + c, P[i][r]);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int c = (wn * NTW + nt) * 32 + lo;
+        float v0 = a_dbg[nt], v1 = a_dgam[nt], v2 = a_dbet[nt];
+        v0 += __shfl_xor(v0, 32); v1 += __shfl_xor(v1, 32); v2 += __shfl_xor(v2, 32);
+        if (hi == 0 && c < C) { atomicAdd(dbg + c, v0); atomicAdd(dgamma + c, v1); atomicAdd(dbeta + c, v2); }
+    }
+}
+
+template <int C, int PT, int PF>
+static int launch_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
+                          const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
+                          int B, int T, int F, uint32_t seed, uint32_t thr24, float dscale, hipStream_t s) {
+    using G = GluGeom<C, PT, PF>;
+    constexpr int ROWS = C >= 64 ? 64 : 128;
+    constexpr int SMEM = (C * G::CP + 2 * ROWS * G::CP + 5 * C) * 4;
+    const int NWC = (T / PT) * (F / PF);
+    const int NW = ROWS / G::WIN;
+    const int ntiles = B * ((NWC + NW - 1) / NW);
+    const int per_cu = SMEM > 80 * 1024 ? 1 : (SMEM > 40 * 1024 ? 2 : 4);
+    int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+    if (grid < 1) return SED_OK;
+    SED_MAX_SMEM((glu_bwd_kernel<C, PT, PF>), SMEM);
+    SED_LAUNCH((glu_bwd_kernel<C, PT, PF>), dim3(grid), dim3(256), SMEM, s, y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg,
+               dgamma, dbeta, B, T, F, seed, thr24, dscale);
+    return sed_check_launch();
+}
+
+// gout (B,T/PT,F/PF,C) -> dz (B,T,F,C) = dL/d xhat; dWg (C,C), dbg, dgamma, dbeta (C) are ZEROED here and
+// accumulated with fp32 atomics.  When T % PT != 0 the dropped frames of dz are zeroed too.
+extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
+                           const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
+                           int B, int T, int F, int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (F % PF != 0) return SED_ERR_UNSUPPORTED;
+    if (hipMemsetAsync(dWg, 0, (size_t)C * C * 4, s) != hipSuccess) return SED_ERR_LAUNCH;
+    (void)hipMemsetAsync(dbg, 0, (size_t)C * 4, s);
+    (void)hipMemsetAsync(dgamma, 0, (size_t)C * 4, s);
+    (void)hipMemsetAsync(dbeta, 0, (size_t)C * 4, s);
+    if (T % PT != 0) (void)hipMemsetAsync(dz, 0, (size_t)B * T * F * C * 4, s);
+#define GLU_CASE(c, pt, pf)                                                                                              \
+    if (C == c && PT == pt && PF == pf)                                                                                  \
+        return launch_glu_bwd<c, pt, pf>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B, T, F, seed, thr24, \
+                                         dscale, s);
+    GLU_CASE(16, 2, 2) GLU_CASE(32, 2, 2) GLU_CASE(64, 1, 2) GLU_CASE(128, 1, 2)
+#undef GLU_CASE
+    return SED_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm backward apply, in place: dz (= dL/d xhat) -> dy = dL/d(conv output)
+//   training: dy = invstd * (dz - mean(dz) - xhat * mean(dz * xhat));  eval: dy = invstd * dz
+// with sum(dz) = gamma*dbeta and sum(dz*xhat) = gamma*dgamma.  Also emits the conv-bias gradient
+// (= sum dy: analytically 0 in training mode, invstd*gamma*dbeta in eval mode).
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, float* __restrict__ dz,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                           float* __restrict__ dbias, size_t npix, float inv_count, int training) {
+    constexpr int V = C / 4, RPI = 256 / V;
+    const int tid = threadIdx.x, v = tid % V, r0 = tid / V;
+    float mean[4], istd[4], m1[4], m2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = 4 * v + i;
+        mean[i] = stats[c];
+        istd[i] = stats[C + c];
+        m1[i] = training ? gamma[c] * dbeta[c] * inv_count : 0.f;
+        m2[i] = training ? gamma[c] * dgamma[c] * inv_count : 0.f;
+    }
+    if (blockIdx.x == 0 && tid < C) dbias[tid] = training ? 0.f : stats[C + tid] * gamma[tid] * dbeta[tid];
+    for (size_t p = (size_t)blockIdx.x * RPI + r0; p < npix; p += (size_t)gridDim.x * RPI) {
+        const float4 yv = *(const float4*)(y + p * C + 4 * v);
+        float4 g = *(const float4*)(dz + p * C + 4 * v);
+        g.x = istd[0] * (g.x - m1[0] - (yv.x - mean[0]) * istd[0] * m2[0]);
+        g.y = istd[1] * (g.y - m1[1] - (yv.y - mean[1]) * istd[1] * m2[1]);
+        g.z = istd[2] * (g.z - m1[2] - (yv.z - mean[2]) * istd[2] * m2[2]);
+        g.w = istd[3] * (g.w - m1[3] - (yv.w - mean[3]) * istd[3] * m2[3]);
+        *(float4*)(dz + p * C + 4 * v) = g;
+    }
+}
+extern "C" int sed_bn_bwd_apply(const float* y, float* dz, const float* stats, const float* gamma, const float* dgamma,
+                                const float* dbeta, float* dbias, long long npix, int C, int training, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (npix <= 0) return SED_OK;
+    const float inv = 1.0f / (float)npix;
+    int grid = (int)((npix * (C / 4) + 255) / 256);
+    if (grid > 4096) grid = 4096;
+#define BN_CASE(c) \
+    if (C == c) { SED_LAUNCH((bn_bwd_apply_kernel<c>), dim3(grid), dim3(256), 0, s, y, dz, stats, gamma, dgamma, dbeta, dbias, (size_t)npix, inv, training); return sed_check_launch(); }
+    BN_CASE(16) BN_CASE(32) BN_CASE(64) BN_CASE(128)
+#undef BN_CASE
+    return SED_ERR_UNSUPPORTED;
+}

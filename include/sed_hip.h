@@ -43,6 +43,54 @@ int sed_mixup(float* data, float* tmp, const int* perm, float c, float one_minus
  * bounds (B,4) int32 = [f0,f1,t0,t1). */
 int sed_specaug(const float* x, float* y, const int* bounds, int B, int T, int Fq, void* stream);
 
+/* ---- K6: CNN block (desed_task/nnet/CNN.py:66-98), channels-last (B,T,F,C) ---------------------------------- */
+
+/* nn.Conv2d weight (COUT,CIN,3,3) -> packed Wf[9][CIN][COUT] (forward) and Wd[9][COUT][CIN] (data gradient:
+ * flipped taps, transposed channels); Wd may be null. */
+int sed_conv_pack_weights(const float* W, float* Wf, float* Wd, int COUT, int CIN, void* stream);
+
+/* Number of workgroups (= rows of `partial`, 2*COUT floats each) a forward conv launch writes. */
+int sed_conv_fwd_blocks(int B, int T, int F, int CIN);
+
+/* Conv2d(k=3,s=1,p=1) (CNN.py:69-72) as implicit GEMM on f32 MFMA.  x (B,T,F,CIN), Wp packed, bias or null,
+ * y (B,T,F,COUT); partial (or null) receives per-workgroup (sum, sumsq) per channel for BatchNorm.
+ * The same entry computes the data gradient when given Wd and the output gradient as x. */
+int sed_conv3x3(const float* x, const float* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
+                int CIN, int COUT, void* stream);
+
+/* Layer 0 (CIN=1): direct conv with the SpecAugment predicate (CRNN.py:207-219) fused into the load.
+ * x (B,T,F) scaled log-mel; W (16,1,3,3) PyTorch layout; bounds (B,4) int32 [f0,f1,t0,t1) or null. */
+int sed_conv0_fwd(const float* x, const float* W, const float* bias, const int* bounds, float* y, float* partial,
+                  int B, int T, int F, int COUT, void* stream);
+
+/* BatchNorm2d(eps=1e-3, momentum=0.99) statistics (CNN.py:76): reduce the partials (training) or read the
+ * running stats (eval); stats = [mean | invstd | scale | shift] (4*C); updates running stats when asked. */
+int sed_bn_finalize(const float* partial, int nblocks, int C, float count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* stats, int training,
+                    int update_running, void* stream);
+
+/* BN-apply + GLU (CNN.py:11-16) + Dropout (:90-91) + AvgPool2d (:96-98), fused.  y (B,T,F,C) -> out (B,T/PT,F/PF,C).
+ * Dropout keeps element e iff (hash(e,seed)>>8) >= thr24; dscale = 1/(1-p). */
+int sed_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
+                int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, void* stream);
+
+/* Backward of the above: gout -> dz = dL/d(xhat) (B,T,F,C) and dWg (C,C), dbg, dgamma, dbeta (C) (zeroed inside). */
+int sed_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
+                const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
+                int B, int T, int F, int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, void* stream);
+
+/* BatchNorm backward apply in place: dz -> dy = dL/d(conv output); dbias (C) = conv-bias gradient. */
+int sed_bn_bwd_apply(const float* y, float* dz, const float* stats, const float* gamma, const float* dgamma,
+                     const float* dbeta, float* dbias, long long npix, int C, int training, void* stream);
+
+/* Conv weight gradient: x (B,T,F,CIN), dy (B,T,F,COUT) -> dW (COUT,CIN,3,3); dWp = scratch 9*CIN*COUT floats. */
+int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
+                   void* stream);
+
+/* Layer-0 weight gradient: x (B,T,F) (+ SpecAugment bounds or null), dy (B,T,F,16) -> dW (16,1,3,3). */
+int sed_conv0_wgrad(const float* x, const int* bounds, const float* dy, float* dW, int B, int T, int F, int COUT,
+                    void* stream);
+
 /* Hardware self-test of the MFMA lane maps (no reference counterpart): C = A[M][K] * B[K][M], M = shape (32|16). */
 int sed_selftest_mfma(const float* A, const float* Bm, float* C, int K, int shape, void* stream);
 

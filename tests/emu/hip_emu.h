@@ -40,6 +40,8 @@ static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 #define hipMemcpyDeviceToDevice 3
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+template <typename F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return 0; }
 
 struct EmuFiber {
     dim3 tid;

@@ -72,3 +72,82 @@ def case_mixup_specaug(dev):
     ref = O.specaug_apply(xin, (bounds[:, 0].long(), bounds[:, 1].long()), (bounds[:, 2].long(), bounds[:, 3].long()))
     got = Fh.specaug_apply(to(dev, xin), to(dev, bounds))
     assert torch.equal(got.cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# CNN block (K6)
+# ------------------------------------------------------------------------------------------------
+def np_keep_mask(shape, seed, p):
+    """numpy replica of sed_keep() over a (B,T,F,C) channels-last element index."""
+    n = int(np.prod(shape))
+    thr = int(round(p * (1 << 24))) if p > 0 else 0
+    x = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B1) + np.uint64(seed)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(13); x = (x * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    return torch.from_numpy(((x >> np.uint64(8)) >= thr).astype(np.float32)).reshape(shape)
+
+
+def case_cnn_block(dev, layer, B, T, F, training=True, dropout_p=0.5, seed=1234, tol=2e-5):
+    import torch.nn.functional as TF
+    from desed_task_amd.ops import ConvBlockFn
+    filt = (1,) + O.NB_FILTERS
+    CIN, COUT = filt[layer], filt[layer + 1]
+    PT, PF = O.POOLING[layer]
+    k = 100 * layer
+    x = O.lcg_fill((B, T, F, CIN), k + 1, 1.0)
+    w = O.lcg_fill((COUT, CIN, 3, 3), k + 2, 1.0 / np.sqrt(9 * CIN))
+    bias = O.lcg_fill((COUT,), k + 3, 0.3)
+    gam = O.lcg_fill((COUT,), k + 4, 0.25, 1.0)
+    bet = O.lcg_fill((COUT,), k + 5, 0.2)
+    wg = O.lcg_fill((COUT, COUT), k + 6, 1.0 / np.sqrt(COUT))
+    bg = O.lcg_fill((COUT,), k + 7, 0.2)
+    rm = O.lcg_fill((COUT,), k + 8, 0.2)
+    rv = O.lcg_fill((COUT,), k + 9, 0.3, 1.0)
+    gout = O.lcg_fill((B, T // PT, F // PF, COUT), k + 10, 1.0)
+    bounds = torch.tensor([[1, 3, 2, 4]] * B, dtype=torch.int32) if layer == 0 else None
+
+    # ---- oracle (NCHW, torch autograd on CPU) ----
+    params = [t.clone().requires_grad_(True) for t in (w, bias, gam, bet, wg, bg)]
+    xo = x.clone()
+    if layer == 0:
+        xo = O.specaug_apply(xo[..., 0].transpose(1, 2), (bounds[:, 0].long(), bounds[:, 1].long()),
+                             (bounds[:, 2].long(), bounds[:, 3].long())).transpose(1, 2).unsqueeze(-1)
+    xo = xo.permute(0, 3, 1, 2).contiguous().requires_grad_(layer > 0)
+    rm_o, rv_o = rm.clone(), rv.clone()
+    h = TF.conv2d(xo, params[0], params[1], padding=1)
+    h = TF.batch_norm(h, rm_o, rv_o, params[2], params[3], training=training, momentum=O.BN_MOMENTUM, eps=O.BN_EPS)
+    lin = TF.linear(h.permute(0, 2, 3, 1), params[4], params[5]).permute(0, 3, 1, 2)
+    h = lin * torch.sigmoid(h)
+    if dropout_p > 0:
+        keep = np_keep_mask((B, T, F, COUT), seed, dropout_p).permute(0, 3, 1, 2)
+        h = h * keep / (1 - dropout_p)
+    ref = TF.avg_pool2d(h, (PT, PF))
+    ref.backward(gout.permute(0, 3, 1, 2))
+
+    # ---- HIP ----
+    xd = to(dev, x[..., 0].contiguous() if layer == 0 else x).requires_grad_(layer > 0)
+    pd = [to(dev, t).requires_grad_(True) for t in (w, bias, gam, bet, wg, bg)]
+    rm_d, rv_d = to(dev, rm.clone()), to(dev, rv.clone())
+    cfg = dict(pool=(PT, PF), bn_training=training, dropout_p=dropout_p, apply_dropout=dropout_p > 0, seed=seed,
+               bounds=to(dev, bounds) if bounds is not None else None, update_running=True)
+    out = ConvBlockFn.apply(xd, *pd, rm_d, rv_d, cfg)
+    out.backward(to(dev, gout))
+
+    def cmp(name, a, b, scale=None):
+        a, b = a.detach().cpu(), b.detach().cpu()
+        s = scale if scale is not None else max(1.0, b.abs().max().item())
+        err = (a - b).abs().max().item() / s
+        assert err < tol, "%s layer %d: rel err %.3e (max ref %.3e)" % (name, layer, err, b.abs().max().item())
+
+    cmp("out", out, ref.permute(0, 2, 3, 1))
+    cmp("running_mean", rm_d, rm_o)
+    cmp("running_var", rv_d, rv_o)
+    names = ("conv_w", "conv_b", "bn_w", "bn_b", "glu_w", "glu_b")
+    for nm, a, b in zip(names, pd, params):
+        if nm == "conv_b" and training:
+            assert a.grad.abs().max().item() < 1e-3 * max(1.0, pd[0].grad.abs().max().item())   # analytically zero
+            continue
+        cmp("d_" + nm, a.grad, b.grad)
+    if layer > 0:
+        cmp("dx", xd.grad, xo.grad.permute(0, 2, 3, 1))

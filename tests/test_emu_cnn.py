@@ -1,0 +1,19 @@
+"""CPU (fiber-emulator) runs of the CNN-block parity cases (K6): forward, BN running stats, and every gradient,
+against torch autograd on the CPU oracle graph.  Small shapes; the GPU tests run the production shapes."""
+import pytest
+
+from tests import parity_cases as P
+from tests.emu_support import emu  # noqa: F401
+
+# (layer, B, T, F): F follows the 2023 recipe's per-layer mel width where cheap enough
+CASES = [(0, 2, 6, 16), (1, 2, 5, 64), (2, 2, 6, 32), (3, 1, 10, 16), (4, 2, 9, 8), (5, 2, 20, 4), (6, 2, 35, 2)]
+
+
+@pytest.mark.parametrize("layer,B,T,F", CASES)
+def test_block_train(emu, layer, B, T, F):
+    P.case_cnn_block("cpu", layer, B, T, F, training=True, dropout_p=0.5)
+
+
+@pytest.mark.parametrize("layer,B,T,F", [(0, 1, 5, 8), (2, 1, 4, 32), (6, 1, 70, 2)])
+def test_block_eval_nodrop(emu, layer, B, T, F):
+    P.case_cnn_block("cpu", layer, B, T, F, training=False, dropout_p=0.0)

@@ -41,3 +41,17 @@ def test_logscale_generic():
 
 def test_mixup_and_specaug():
     P.case_mixup_specaug("cuda")
+
+
+# production spatial shapes of the 2023 recipe (T, F per layer), small batch so the CPU oracle stays fast
+CNN_SHAPES = [(0, 626, 128), (1, 313, 64), (2, 156, 32), (3, 156, 16), (4, 156, 8), (5, 156, 4), (6, 156, 2)]
+
+
+@pytest.mark.parametrize("layer,T,F", CNN_SHAPES)
+def test_cnn_block_train(layer, T, F):
+    P.case_cnn_block("cuda", layer, 3, T, F, training=True, dropout_p=0.5, tol=5e-5)
+
+
+@pytest.mark.parametrize("layer,T,F", [(0, 626, 128), (3, 156, 16)])
+def test_cnn_block_eval(layer, T, F):
+    P.case_cnn_block("cuda", layer, 2, T, F, training=False, dropout_p=0.0, tol=5e-5)
