@@ -1,0 +1,269 @@
+// K7: bidirectional GRU (desed_task/nnet/RNN.py:19-30 = nn.GRU(batch_first, bidirectional); gate order
+// r,z,n; n = tanh(W_in x + b_in + r * (W_hn h + b_hn)); h0 = 0), forward and backward.
+//
+// The input projections (all time steps at once) and every weight gradient are plain f32-MFMA GEMMs
+// (sed_gemm below).  The recurrence itself is latency-bound: 156 dependent steps of a 128 -> 384 matvec.
+// It runs as one persistent workgroup per (clip, direction) -- 96 workgroups at batch 48 -- with the
+// W_hh rows of three gates held in VGPRs (192 floats per thread: thread (j, half) owns hidden unit j and
+// half of the K range), the hidden state double-buffered in LDS (broadcast reads), the two K halves
+// combined with one lane shuffle, and ONE barrier per step.  Exact fp32 (VALU fmaf), state never
+// leaves the CU.  Forward saves r, z, n and (W_hn h + b_hn) for the backward recurrence, which mirrors
+// the structure with W_hh^T in registers.
+#include "sed_common.h"
+
+#define GRU_H 128
+
+// ---------------------------------------------------------------------------------------------
+// generic GEMM  C[M][N] (+)= opA(A) * opB(B) (+ bias[N]),  f32 MFMA 32x32x2, 128 x (32*NTN) x 32 tiles
+//   TA = 0: A is [M][K] (lda)      TA = 1: A is [K][M] (lda)
+//   TB = 0: B is [K][N] (ldb)      TB = 1: B is [N][K] (ldb)
+// grid.z = split-K slices; with more than one slice (or accumulate=1) results are atomically added to C.
+// ---------------------------------------------------------------------------------------------
+template <int TA, int TB, int NTN>
+__global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                   const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K,
+                                                   int lda, int ldb, int ldc, int k_per_slice, int atomic) {
+    constexpr int BM = 128, BN = 32 * NTN, BK = 32, AP = BK + 1, BNP = BN + 1;
+    __shared__ float As[BM * AP];
+    __shared__ float Bs[BK * BNP];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * k_per_slice, kend = min(K, kbeg + k_per_slice);
+    f32x16 acc[NTN];
+#pragma unroll
+    for (int i = 0; i < NTN; ++i) acc[i] = f32x16_zero();
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();
+        // ---- stage A tile -> As[m][k] ----
+        if (TA == 0) {
+            for (int idx = tid; idx < BM * BK; idx += 256) {
+                const int m = idx / BK, k = idx - m * BK;
+                const int gm = m0 + m, gk = k0 + k;
+                As[m * AP + k] = (gm < M && gk < kend) ? A[(size_t)gm * lda + gk] : 0.f;
+            }
+        } else {
+            for (int idx = tid; idx < BM * BK; idx += 256) {
+                const int k = idx / BM, m = idx - k * BM;
+                const int gm = m0 + m, gk = k0 + k;
+                As[m * AP + k] = (gm < M && gk < kend) ? A[(size_t)gk * lda + gm] : 0.f;
+            }
+        }
+        // ---- stage B tile -> Bs[k][n] ----
+        if (TB == 0) {
+            for (int idx = tid; idx < BK * BN; idx += 256) {
+                const int k = idx / BN, n = idx - k * BN;
+                const int gn = n0 + n, gk = k0 + k;
+                Bs[k * BNP + n] = (gn < N && gk < kend) ? Bm[(size_t)gk * ldb + gn] : 0.f;
+            }
+        } else {
+            for (int idx = tid; idx < BK * BN; idx += 256) {
+                const int n = idx / BK, k = idx - n * BK;
+                const int gn = n0 + n, gk = k0 + k;
+                Bs[k * BNP + n] = (gn < N && gk < kend) ? Bm[(size_t)gn * ldb + gk] : 0.f;
+            }
+        }
+        __syncthreads();
+        const float* ap = As + (32 * w + lo) * AP + hi;
+#pragma unroll
+        for (int k = 0; k < BK; k += 2) {
+            const float av = ap[k];
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) acc[nt] = mfma32(av, Bs[(k + hi) * BNP + nt * 32 + lo], acc[nt]);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int gn = n0 + nt * 32 + lo;
+        if (gn < N) {
+            const float bv = (bias != nullptr && blockIdx.z == 0) ? bias[gn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + 32 * w + mfma32_row(r, lane);
+                if (gm < M) {
+                    float* dst = Cm + (size_t)gm * ldc + gn;
+                    const float v = acc[nt][r] + bv;
+                    if (atomic) atomicAdd(dst, v); else *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// C[M][N] = opA(A)[M][K] * opB(B)[K][N] + bias.  accumulate != 0 adds into C (atomics); split_k > 1 requires
+// the caller to have zeroed C (or accumulate).  Leading dimensions are in floats.
+extern "C" int sed_gemm(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
+                        int ldc, int transA, int transB, int split_k, int accumulate, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return SED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (split_k < 1) split_k = 1;
+    int kps = ((K + split_k - 1) / split_k + 31) / 32 * 32;
+    split_k = (K + kps - 1) / kps;
+    const int atomic = (split_k > 1 || accumulate) ? 1 : 0;
+    const int ntn = N > 64 ? 4 : 2;
+    dim3 grid((N + 32 * ntn - 1) / (32 * ntn), (M + 127) / 128, split_k);
+#define GEMM_CASE(ta, tb, nn) \
+    if (transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic); return sed_check_launch(); }
+    GEMM_CASE(0, 0, 2) GEMM_CASE(0, 0, 4) GEMM_CASE(0, 1, 2) GEMM_CASE(0, 1, 4) GEMM_CASE(1, 0, 2) GEMM_CASE(1, 0, 4)
+#undef GEMM_CASE
+    return SED_ERR_UNSUPPORTED;
+}
+
+// column sums: out[n] = sum_m X[m*ld + n], n < N  (bias gradients); out is zeroed here, atomics across row chunks
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ out, int M, int N, int ld,
+                                                     int rows_per_block) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += X[(size_t)r * ld + n];
+    atomicAdd(out + n, acc);
+}
+extern "C" int sed_colsum(const float* X, float* out, int M, int N, int ld, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, (size_t)N * 4, s) != hipSuccess) return SED_ERR_LAUNCH;
+    if (M <= 0 || N <= 0) return SED_OK;
+    const int rpb = 64;
+    SED_LAUNCH(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, s, X, out, M, N, ld, rpb);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward recurrence.  gi: (B, T, 2, 3H) input projections incl. b_ih; whh0/whh1: (3H, H) per direction; bhh0/bhh1: (3H)
+// out: (B, T, 2H) ([fwd | bwd]); saved: (B, T, 2, 4, H) = r, z, n, hn   (null in inference)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh0,
+                                                      const float* __restrict__ whh1, const float* __restrict__ bhh0,
+                                                      const float* __restrict__ bhh1, float* __restrict__ out,
+                                                      float* __restrict__ saved, int B, int T) {
+    constexpr int H = GRU_H, KH = H / 2;
+    __shared__ __attribute__((aligned(16))) float hbuf[2][H];
+    const int tid = threadIdx.x, j = tid >> 1, half = tid & 1;
+    const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const float* W = dir ? whh1 : whh0;
+    const float* bhh = dir ? bhh1 : bhh0;
+    float wr[KH], wz[KH], wn[KH];
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+        wr[k] = W[(size_t)(0 * H + j) * H + half * KH + k];
+        wz[k] = W[(size_t)(1 * H + j) * H + half * KH + k];
+        wn[k] = W[(size_t)(2 * H + j) * H + half * KH + k];
+    }
+    const float br = bhh[j], bz = bhh[H + j], bn = bhh[2 * H + j];
+    if (tid < H) hbuf[0][tid] = 0.f;
+    float hprev = 0.f;
+    __syncthreads();
+    int cur = 0;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? T - 1 - step : step;
+        const float* g = gi + (((size_t)b * T + t) * 2 + dir) * 3 * H;
+        const float gr = g[j], gz = g[H + j], gn = g[2 * H + j];
+        const float* hv = hbuf[cur] + half * KH;
+        float ar = 0.f, az = 0.f, an = 0.f;
+#pragma unroll
+        for (int k = 0; k < KH; k += 4) {
+            const float4 h4 = *(const float4*)(hv + k);
+            ar = fmaf(wr[k], h4.x, ar); az = fmaf(wz[k], h4.x, az); an = fmaf(wn[k], h4.x, an);
+            ar = fmaf(wr[k + 1], h4.y, ar); az = fmaf(wz[k + 1], h4.y, az); an = fmaf(wn[k + 1], h4.y, an);
+            ar = fmaf(wr[k + 2], h4.z, ar); az = fmaf(wz[k + 2], h4.z, az); an = fmaf(wn[k + 2], h4.z, an);
+            ar = fmaf(wr[k + 3], h4.w, ar); az = fmaf(wz[k + 3], h4.w, az); an = fmaf(wn[k + 3], h4.w, an);
+        }
+        ar += __shfl_xor(ar, 1); az += __shfl_xor(az, 1); an += __shfl_xor(an, 1);
+        const float r = sed_sigmoid(gr + ar + br);
+        const float z = sed_sigmoid(gz + az + bz);
+        const float hn = an + bn;
+        const float n = tanhf(gn + r * hn);
+        const float hnew = (1.0f - z) * n + z * hprev;
+        hprev = hnew;
+        if (half == 0) {
+            hbuf[cur ^ 1][j] = hnew;
+            out[((size_t)b * T + t) * 2 * H + dir * H + j] = hnew;
+            if (saved) {
+                float* sv = saved + (((size_t)b * T + t) * 2 + dir) * 4 * H;
+                sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = hn;
+            }
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+}
+extern "C" int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
+                           float* out, float* saved, int B, int T, int H, void* stream) {
+    if (H != GRU_H) return SED_ERR_UNSUPPORTED;
+    if (B <= 0 || T <= 0) return SED_OK;
+    SED_LAUNCH(gru_fwd_kernel, dim3(2 * B), dim3(256), 0, (hipStream_t)stream, gi, whh0, whh1, bhh0, bhh1, out, saved, B, T);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward recurrence.  dout: (B,T,2H) upstream gradient of the layer output; out/saved from the forward.
+// Produces dgi (B,T,2,3H) = dL/d(W_ih x + b_ih), dgh (B,T,2,3H) = dL/d(W_hh h + b_hh) and
+// hprev (B,T,2,H) = the hidden state each step consumed (for dW_hh = dgh^T hprev).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                      const float* __restrict__ saved, const float* __restrict__ whh0,
+                                                      const float* __restrict__ whh1, float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ hprev_out,
+                                                      int B, int T) {
+    constexpr int H = GRU_H, KH = H / 2;
+    __shared__ __attribute__((aligned(16))) float gbuf[2][3 * H];
+    const int tid = threadIdx.x, k = tid >> 1, half = tid & 1;
+    const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const float* W = dir ? whh1 : whh0;
+    // W^T slices: for hidden unit k, the contributions of gate rows j in this thread's half
+    float wr[KH], wz[KH], wn[KH];
+#pragma unroll
+    for (int jj = 0; jj < KH; ++jj) {
+        const int j = half * KH + jj;
+        wr[jj] = W[(size_t)(0 * H + j) * H + k];
+        wz[jj] = W[(size_t)(1 * H + j) * H + k];
+        wn[jj] = W[(size_t)(2 * H + j) * H + k];
+    }
+    float dh_carry = 0.f;
+    int cur = 0;
+    for (int step = T - 1; step >= 0; --step) {
+        const int t = dir ? T - 1 - step : step;           // time index processed at forward step `step`
+        const int tp = dir ? t + 1 : t - 1;                // time index of the previous hidden state
+        const size_t bt = (size_t)b * T + t;
+        const float* sv = saved + (bt * 2 + dir) * 4 * H;
+        const float r = sv[k], z = sv[H + k], n = sv[2 * H + k], hn = sv[3 * H + k];
+        const float hp = step > 0 ? out[((size_t)b * T + tp) * 2 * H + dir * H + k] : 0.f;
+        const float dh = dout[bt * 2 * H + dir * H + k] + dh_carry;
+        const float dn = dh * (1.0f - z);
+        const float dzg = dh * (hp - n);
+        const float da_n = dn * (1.0f - n * n);
+        const float da_z = dzg * z * (1.0f - z);
+        const float da_r = da_n * hn * r * (1.0f - r);
+        const float dhn = da_n * r;
+        if (half == 0) {
+            gbuf[cur][k] = da_r; gbuf[cur][H + k] = da_z; gbuf[cur][2 * H + k] = dhn;
+            float* gi_o = dgi + (bt * 2 + dir) * 3 * H;
+            float* gh_o = dgh + (bt * 2 + dir) * 3 * H;
+            gi_o[k] = da_r; gi_o[H + k] = da_z; gi_o[2 * H + k] = da_n;
+            gh_o[k] = da_r; gh_o[H + k] = da_z; gh_o[2 * H + k] = dhn;
+            hprev_out[(bt * 2 + dir) * H + k] = hp;
+        }
+        __syncthreads();
+        const float* gv = gbuf[cur] + half * KH;
+        float acc = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < KH; jj += 4) {
+            const float4 a = *(const float4*)(gv + jj);
+            const float4 c = *(const float4*)(gv + H + jj);
+            const float4 d = *(const float4*)(gv + 2 * H + jj);
+            acc = fmaf(wr[jj], a.x, acc); acc = fmaf(wz[jj], c.x, acc); acc = fmaf(wn[jj], d.x, acc);
+            acc = fmaf(wr[jj + 1], a.y, acc); acc = fmaf(wz[jj + 1], c.y, acc); acc = fmaf(wn[jj + 1], d.y, acc);
+            acc = fmaf(wr[jj + 2], a.z, acc); acc = fmaf(wz[jj + 2], c.z, acc); acc = fmaf(wn[jj + 2], d.z, acc);
+            acc = fmaf(wr[jj + 3], a.w, acc); acc = fmaf(wz[jj + 3], c.w, acc); acc = fmaf(wn[jj + 3], d.w, acc);
+        }
+        acc += __shfl_xor(acc, 1);
+        dh_carry = dh * z + acc;
+        cur ^= 1;
+    }
+}
+extern "C" int sed_gru_bwd(const float* dout, const float* out, const float* saved, const float* whh0, const float* whh1,
+                           float* dgi, float* dgh, float* hprev, int B, int T, int H, void* stream) {
+    if (H != GRU_H) return SED_ERR_UNSUPPORTED;
+    if (B <= 0 || T <= 0) return SED_OK;
+    SED_LAUNCH(gru_bwd_kernel, dim3(2 * B), dim3(256), 0, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh, hprev, B, T);
+    return sed_check_launch();
+}

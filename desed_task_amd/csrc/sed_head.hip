@@ -1,0 +1,273 @@
+// K8 + K9: attention-pooling head and the mean-teacher losses, fp32.
+//  head : desed_task/nnet/CRNN.py:152-178 -- Dropout (CRNN.py:304) -> strong = sigmoid(dense(x)),
+//         sof = clamp(softmax_over_CLASSES(dense_softmax(x)), 1e-7, 1), weak = sum_t(strong*sof) / sum_t(sof).
+//  loss : recipes/dcase2023_task4_baseline/local/sed_trainer.py:309-342 -- BCE (strong on the first n_strong
+//         clips, weak on the next n_weak), the two teacher BCEs (logging), MSE student-vs-teacher on all clips;
+//         emits the scalars and the gradient seeds d(total)/d(strong_s), d(total)/d(weak_s).
+// Layout: x (B,T,D=256); strong/sof (B,T,NC) (the Python side returns the (B,NC,T) transposed view);
+// labels stay in the reference layout (B,NC,T).  One workgroup per clip; one thread per frame.
+#include "sed_common.h"
+
+#define HEAD_D 256
+
+template <int NC>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W1,
+                                                       const float* __restrict__ b1, const float* __restrict__ W2,
+                                                       const float* __restrict__ b2, float* __restrict__ strong,
+                                                       float* __restrict__ psoft, float* __restrict__ weak,
+                                                       float* __restrict__ den, int T, uint32_t seed, uint32_t thr24,
+                                                       float dscale) {
+    constexpr int D = HEAD_D;
+    __shared__ float w1[NC * D], w2[NC * D];
+    __shared__ float red[4][2 * NC];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int i = tid; i < NC * D; i += 256) { w1[i] = W1[i]; w2[i] = W2[i]; }
+    __syncthreads();
+    float num[NC], dn[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { num[c] = 0.f; dn[c] = 0.f; }
+    for (int t = tid; t < T; t += 256) {
+        const float* xr = x + ((size_t)b * T + t) * D;
+        float l1[NC], l2[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { l1[c] = b1[c]; l2[c] = b2[c]; }
+        for (int k = 0; k < D; k += 4) {
+            float4 v = *(const float4*)(xr + k);
+            const uint32_t e = (uint32_t)(((size_t)b * T + t) * D + k);
+            v.x = sed_keep(e, seed, thr24) ? v.x * dscale : 0.f;
+            v.y = sed_keep(e + 1, seed, thr24) ? v.y * dscale : 0.f;
+            v.z = sed_keep(e + 2, seed, thr24) ? v.z * dscale : 0.f;
+            v.w = sed_keep(e + 3, seed, thr24) ? v.w * dscale : 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float* a = w1 + c * D + k;
+                const float* q = w2 + c * D + k;
+                l1[c] = fmaf(v.x, a[0], fmaf(v.y, a[1], fmaf(v.z, a[2], fmaf(v.w, a[3], l1[c]))));
+                l2[c] = fmaf(v.x, q[0], fmaf(v.y, q[1], fmaf(v.z, q[2], fmaf(v.w, q[3], l2[c]))));
+            }
+        }
+        float mx = l2[0];
+#pragma unroll
+        for (int c = 1; c < NC; ++c) mx = fmaxf(mx, l2[c]);
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { l2[c] = expf(l2[c] - mx); se += l2[c]; }
+        const float inv = 1.0f / se;
+        float* so = strong + ((size_t)b * T + t) * NC;
+        float* po = psoft + ((size_t)b * T + t) * NC;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float s = sed_sigmoid(l1[c]);
+            const float p = l2[c] * inv;
+            const float a = fminf(fmaxf(p, 1e-7f), 1.0f);
+            so[c] = s;
+            po[c] = p;
+            num[c] += s * a;
+            dn[c] += a;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float a = wave_sum(num[c]), q = wave_sum(dn[c]);
+        if ((tid & 63) == 0) { red[tid >> 6][c] = a; red[tid >> 6][NC + c] = q; }
+    }
+    __syncthreads();
+    if (tid < NC) {
+        const float n = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        const float d = red[0][NC + tid] + red[1][NC + tid] + red[2][NC + tid] + red[3][NC + tid];
+        weak[b * NC + tid] = n / d;
+        den[b * NC + tid] = d;
+    }
+}
+
+// backward: d_strong (B,T,NC), d_weak (B,NC) -> dx (B,T,D), dW1,dW2 (NC,D), db1,db2 (NC) (atomics; zeroed by caller)
+template <int NC>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W1,
+                                                       const float* __restrict__ W2, const float* __restrict__ strong,
+                                                       const float* __restrict__ psoft, const float* __restrict__ weak,
+                                                       const float* __restrict__ den, const float* __restrict__ d_strong,
+                                                       const float* __restrict__ d_weak, float* __restrict__ dx,
+                                                       float* __restrict__ dW1, float* __restrict__ dW2, float* __restrict__ db1,
+                                                       float* __restrict__ db2, int T, uint32_t seed, uint32_t thr24, float dscale) {
+    constexpr int D = HEAD_D;
+    SED_DYN_SMEM(smem);
+    float* w1 = (float*)smem;            // NC*D
+    float* w2 = w1 + NC * D;             // NC*D
+    float* dl = w2 + NC * D;             // T * 2*NC  (d logit1 | d logit2 per frame)
+    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int i = tid; i < NC * D; i += 256) { w1[i] = W1[i]; w2[i] = W2[i]; }
+    __syncthreads();
+    // ---- phase 1: per-frame logit gradients and dx rows ----
+    for (int t = tid; t < T; t += 256) {
+        const size_t bt = (size_t)b * T + t;
+        float g1[NC], g2[NC];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float s = strong[bt * NC + c], p = psoft[bt * NC + c];
+            const float a = fminf(fmaxf(p, 1e-7f), 1.0f);
+            const float dw = d_weak[b * NC + c], dd = den[b * NC + c], wk = weak[b * NC + c];
+            const float ds = d_strong[bt * NC + c] + dw * a / dd;
+            g1[c] = ds * s * (1.0f - s);
+            const float da = dw * (s - wk) / dd;
+            const float dp = (p >= 1e-7f && p <= 1.0f) ? da : 0.f;
+            g2[c] = dp;
+            dot += p * dp;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            g2[c] = psoft[bt * NC + c] * (g2[c] - dot);
+            dl[t * 2 * NC + c] = g1[c];
+            dl[t * 2 * NC + NC + c] = g2[c];
+        }
+        float* dr = dx + bt * D;
+        for (int k = 0; k < D; k += 4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float* a = w1 + c * D + k;
+                const float* q = w2 + c * D + k;
+                acc.x = fmaf(g1[c], a[0], fmaf(g2[c], q[0], acc.x));
+                acc.y = fmaf(g1[c], a[1], fmaf(g2[c], q[1], acc.y));
+                acc.z = fmaf(g1[c], a[2], fmaf(g2[c], q[2], acc.z));
+                acc.w = fmaf(g1[c], a[3], fmaf(g2[c], q[3], acc.w));
+            }
+            const uint32_t e = (uint32_t)(bt * D + k);
+            acc.x = sed_keep(e, seed, thr24) ? acc.x * dscale : 0.f;
+            acc.y = sed_keep(e + 1, seed, thr24) ? acc.y * dscale : 0.f;
+            acc.z = sed_keep(e + 2, seed, thr24) ? acc.z * dscale : 0.f;
+            acc.w = sed_keep(e + 3, seed, thr24) ? acc.w * dscale : 0.f;
+            *(float4*)(dr + k) = acc;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: weight gradients, thread k owns input feature k (D == 256 threads) ----
+    {
+        const int k = tid;
+        float a1[NC], a2[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { a1[c] = 0.f; a2[c] = 0.f; }
+        for (int t = 0; t < T; ++t) {
+            const size_t bt = (size_t)b * T + t;
+            float v = x[bt * D + k];
+            v = sed_keep((uint32_t)(bt * D + k), seed, thr24) ? v * dscale : 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                a1[c] = fmaf(dl[t * 2 * NC + c], v, a1[c]);
+                a2[c] = fmaf(dl[t * 2 * NC + NC + c], v, a2[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { atomicAdd(dW1 + c * D + k, a1[c]); atomicAdd(dW2 + c * D + k, a2[c]); }
+        if (tid < 2 * NC) {
+            float s = 0.f;
+            for (int t = 0; t < T; ++t) s += dl[t * 2 * NC + tid];
+            atomicAdd(tid < NC ? db1 + tid : db2 + (tid - NC), s);
+        }
+    }
+}
+
+extern "C" int sed_head_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, float* strong,
+                            float* psoft, float* weak, float* den, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
+                            float dscale, void* stream) {
+    if (D != HEAD_D) return SED_ERR_UNSUPPORTED;
+    if (B <= 0 || T <= 0) return SED_OK;
+    hipStream_t s = (hipStream_t)stream;
+#define HEAD_CASE(nc) \
+    if (NC == nc) { SED_LAUNCH((head_fwd_kernel<nc>), dim3(B), dim3(256), 0, s, x, W1, b1, W2, b2, strong, psoft, weak, den, T, seed, thr24, dscale); return sed_check_launch(); }
+    HEAD_CASE(10) HEAD_CASE(27)
+#undef HEAD_CASE
+    return SED_ERR_UNSUPPORTED;
+}
+
+extern "C" int sed_head_bwd(const float* x, const float* W1, const float* W2, const float* strong, const float* psoft,
+                            const float* weak, const float* den, const float* d_strong, const float* d_weak, float* dx, float* dW1,
+                            float* dW2, float* db1, float* db2, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
+                            float dscale, void* stream) {
+    if (D != HEAD_D) return SED_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(dW1, 0, (size_t)NC * D * 4, s);
+    (void)hipMemsetAsync(dW2, 0, (size_t)NC * D * 4, s);
+    (void)hipMemsetAsync(db1, 0, (size_t)NC * 4, s);
+    (void)hipMemsetAsync(db2, 0, (size_t)NC * 4, s);
+    if (B <= 0 || T <= 0) return SED_OK;
+    const int smem = (2 * NC * D + T * 2 * NC) * 4;
+#define HEAD_CASE(nc) \
+    if (NC == nc) { SED_MAX_SMEM((head_bwd_kernel<nc>), smem); SED_LAUNCH((head_bwd_kernel<nc>), dim3(B), dim3(256), smem, s, x, W1, W2, strong, psoft, weak, den, d_strong, d_weak, dx, dW1, dW2, db1, db2, T, seed, thr24, dscale); return sed_check_launch(); }
+    HEAD_CASE(10) HEAD_CASE(27)
+#undef HEAD_CASE
+    return SED_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mean-teacher losses + gradient seeds.  Single workgroup (the tensors are ~75k elements).
+// scalars[0..5] = BCE strong (student), BCE weak (student), BCE strong (teacher), BCE weak (teacher),
+//                 MSE strong, MSE weak.  g_strong (B,T,NC), g_weak (B,NC) = d(total)/d(student outputs) with
+// total = BCE_s + BCE_w + weight * (MSE_s + MSE_w).  torch.nn.BCELoss semantics: log clamped at -100,
+// gradient (s - y) / max(s (1-s), 1e-12).  labels (B,NC,T) reference layout; labels_weak (n_weak, NC).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bce_term(float s, float y) {
+    return -(y * fmaxf(logf(s), -100.0f) + (1.0f - y) * fmaxf(logf(1.0f - s), -100.0f));
+}
+__global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ strong_s, const float* __restrict__ weak_s,
+                                                    const float* __restrict__ strong_t, const float* __restrict__ weak_t,
+                                                    const float* __restrict__ labels, const float* __restrict__ labels_weak,
+                                                    float* __restrict__ scalars, float* __restrict__ g_strong,
+                                                    float* __restrict__ g_weak, int B, int T, int NC, int n_strong, int n_weak,
+                                                    float weight) {
+    __shared__ float red[16][6];
+    const int tid = threadIdx.x;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int ns_el = n_strong * T * NC, all_el = B * T * NC;
+    const float inv_bs = ns_el > 0 ? 1.0f / (float)ns_el : 0.f, inv_all = 1.0f / (float)all_el;
+    for (int i = tid; i < all_el; i += 1024) {
+        const int c = i % NC, t = (i / NC) % T, b = i / (NC * T);
+        const float s = strong_s[i], q = strong_t[i];
+        float g = weight * 2.0f * (s - q) * inv_all;
+        const float d = s - q;
+        acc[4] += d * d;
+        if (b < n_strong) {
+            const float y = labels[((size_t)b * NC + c) * T + t];
+            acc[0] += bce_term(s, y);
+            acc[2] += bce_term(q, y);
+            g += (s - y) / fmaxf(s * (1.0f - s), 1e-12f) * inv_bs;
+        }
+        g_strong[i] = g;
+    }
+    const int nw_el = n_weak * NC, allw = B * NC;
+    const float inv_bw = nw_el > 0 ? 1.0f / (float)nw_el : 0.f, inv_allw = 1.0f / (float)allw;
+    for (int i = tid; i < allw; i += 1024) {
+        const int c = i % NC, b = i / NC;
+        const float s = weak_s[i], q = weak_t[i];
+        float g = weight * 2.0f * (s - q) * inv_allw;
+        const float d = s - q;
+        acc[5] += d * d;
+        if (b >= n_strong && b < n_strong + n_weak) {
+            const float y = labels_weak[(b - n_strong) * NC + c];
+            acc[1] += bce_term(s, y);
+            acc[3] += bce_term(q, y);
+            g += (s - y) / fmaxf(s * (1.0f - s), 1e-12f) * inv_bw;
+        }
+        g_weak[i] = g;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float v = wave_sum(acc[k]);
+        if ((tid & 63) == 0) red[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid < 6) {
+        float v = 0.f;
+        for (int w = 0; w < 16; ++w) v += red[w][tid];
+        const float sc = tid == 0 || tid == 2 ? inv_bs : (tid == 1 || tid == 3 ? inv_bw : (tid == 4 ? inv_all : inv_allw));
+        scalars[tid] = v * sc;
+    }
+}
+extern "C" int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
+                           const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
+                           int T, int NC, int n_strong, int n_weak, float weight, void* stream) {
+    if (B <= 0 || T <= 0 || NC <= 0 || n_strong + n_weak > B) return SED_ERR_ARG;
+    SED_LAUNCH(loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, strong_s, weak_s, strong_t, weak_t, labels, labels_weak,
+               scalars, g_strong, g_weak, B, T, NC, n_strong, n_weak, weight);
+    return sed_check_launch();
+}

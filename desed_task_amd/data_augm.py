@@ -1,0 +1,37 @@
+"""mixup with the reference's call signature (desed_task/data_augm.py:19-53) on the HIP kernel.
+Random draws follow the reference exactly: c ~ np.random.beta(alpha, beta), perm = torch.randperm(n) on the CPU."""
+import numpy as np
+import torch
+
+from . import features
+
+
+def mixup(data, target=None, alpha=0.2, beta=0.2, mixup_label_type="soft"):
+    if mixup_label_type not in ("soft", "hard"):
+        raise NotImplementedError(
+            f"mixup_label_type: {mixup_label_type} not implemented. choice in {'soft', 'hard'}")
+    with torch.no_grad():
+        batch_size = data.size(0)
+        c = np.random.beta(alpha, beta)
+        perm = torch.randperm(batch_size)
+        mixed = features.mixup_(_owned(data), perm, c, mode=0)
+        if target is None:
+            return mixed
+        mixed_t = features.mixup_(_owned(target).float(), perm, c, mode=1 if mixup_label_type == "soft" else 2)
+        return mixed, mixed_t
+
+
+def mixup_inplace_(data, target, alpha=0.2, beta=0.2, mixup_label_type="soft"):
+    """Same draws, but mixes `data` and `target` (batch-major slices) in place: no gather/scatter copies."""
+    c = np.random.beta(alpha, beta)
+    perm = torch.randperm(data.size(0))
+    features.mixup_(data, perm, c, mode=0)
+    features.mixup_(target, perm, c, mode=1 if mixup_label_type == "soft" else 2)
+    return c, perm
+
+
+def _owned(t):
+    """A private copy whose clips are contiguous blocks (keeps our frame-major (B,F,T) views cheap)."""
+    if t.dim() == 3 and not t.is_contiguous() and t.transpose(1, 2).is_contiguous():
+        return t.transpose(1, 2).clone().transpose(1, 2)
+    return t.contiguous().clone()

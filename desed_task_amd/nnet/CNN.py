@@ -1,0 +1,70 @@
+"""Parameter containers of the CNN encoder (state-dict layout of desed_task/nnet/CNN.py:5-114).
+
+These modules only HOLD parameters/buffers under the reference's names (`cnn.conv{i}`, `cnn.batchnorm{i}`,
+`cnn.glu{i}.linear`) and in the reference's construction order, so (a) published checkpoints load unchanged
+and (b) a given torch seed yields the reference's initial weights.  They never run torch arithmetic: the
+forward of every block is desed_task_amd.ops.ConvBlockFn (HIP kernels).
+"""
+import torch
+import torch.nn as nn
+
+from ..ops import ConvBlockFn, new_seed
+
+
+class GLU(nn.Module):
+    """Holds Linear(C, C) of the gated unit `linear(x) * sigmoid(x)` (CNN.py:5-16)."""
+
+    def __init__(self, input_num):
+        super().__init__()
+        self.sigmoid = nn.Sigmoid()
+        self.linear = nn.Linear(input_num, input_num)
+
+    def forward(self, x):  # pragma: no cover
+        raise RuntimeError("GLU is fused into the HIP CNN block; call CNN.forward")
+
+
+class CNN(nn.Module):
+    SUPPORTED = "activation='glu', normalization='batch', 3x3/stride 1/pad 1 convs, 1 input channel"
+
+    def __init__(self, n_in_channel, activation="Relu", conv_dropout=0, kernel_size=[3, 3, 3], padding=[1, 1, 1],
+                 stride=[1, 1, 1], nb_filters=[64, 64, 64], pooling=[(1, 4), (1, 4), (1, 4)], normalization="batch",
+                 **transformer_kwargs):
+        super().__init__()
+        self.nb_filters = nb_filters
+        self.n_in_channel = n_in_channel
+        self.conv_dropout = conv_dropout
+        self.pooling = [tuple(p) for p in pooling]
+        n_layers = len(nb_filters)
+        ok = (str(activation).lower() == "glu" and normalization == "batch" and n_in_channel == 1
+              and all(int(k) == 3 for k in kernel_size[:n_layers]) and all(int(p) == 1 for p in padding[:n_layers])
+              and all(int(s) == 1 for s in stride[:n_layers]) and all(p in ((2, 2), (1, 2)) for p in self.pooling))
+        if not ok:
+            raise NotImplementedError("HIP CNN encoder supports only: " + self.SUPPORTED)
+        layers = nn.Sequential()
+        chans = [n_in_channel] + list(nb_filters)
+        for i in range(n_layers):
+            layers.add_module("conv%d" % i, nn.Conv2d(chans[i], chans[i + 1], 3, 1, 1))
+            layers.add_module("batchnorm%d" % i, nn.BatchNorm2d(chans[i + 1], eps=0.001, momentum=0.99))
+            layers.add_module("glu%d" % i, GLU(chans[i + 1]))
+            if conv_dropout is not None:
+                layers.add_module("dropout%d" % i, nn.Dropout(conv_dropout))
+            layers.add_module("pooling%d" % i, nn.AvgPool2d(self.pooling[i]))
+        self.cnn = layers
+
+    def forward(self, x, bounds=None, arena=None):
+        """x: (B, T, F) scaled log-mel (channels-last with C = 1).  Returns (B, T', F', C_last) channels-last.
+        bounds: optional (B,4) int32 SpecAugment bands fused into the first conv's load."""
+        mods = self.cnn._modules
+        p_drop = float(self.conv_dropout or 0.0)
+        for i in range(len(self.nb_filters)):
+            conv, bn, glu = mods["conv%d" % i], mods["batchnorm%d" % i], mods["glu%d" % i]
+            drop = mods.get("dropout%d" % i)
+            apply_drop = drop is not None and drop.training and p_drop > 0
+            cfg = dict(pool=self.pooling[i], bn_training=bn.training, dropout_p=p_drop, apply_dropout=apply_drop,
+                       seed=new_seed() if apply_drop else 0, bounds=bounds if i == 0 else None, update_running=True,
+                       arena=arena)
+            x = ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, glu.linear.weight, glu.linear.bias,
+                                  bn.running_mean, bn.running_var, cfg)
+            if bn.training and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+        return x

@@ -1,0 +1,137 @@
+"""Drop-in for desed_task.nnet.CRNN.CRNN (desed_task/nnet/CRNN.py:11-323) on the MI355X kernels.
+
+Same constructor keywords, same `forward(x, pad_mask=None, embeddings=None, classes_mask=None) ->
+(strong (B,nclass,T//4), weak (B,nclass))`, same state-dict keys (62 parameter tensors + 21 BN buffers), same
+`train()` quirk (returns None).  Differences, all internal: activations are channels-last in HBM, the
+parameters are views into one flat arena (arena.py), SpecAugment is folded into the first conv's load, and the
+whole forward/backward is a chain of HIP kernels (ops.py).
+
+Not built yet (SURVEY 8f "next" rows; they raise NotImplementedError): use_embeddings / aggregation, pad_mask,
+classes_mask, dropstep_recurrent, cnn_integration, multi-head nclass lists.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from .. import features
+from ..arena import ParamArena
+from ..ops import HeadFn, new_seed
+from .CNN import CNN
+from .RNN import BidirectionalGRU
+
+
+class CRNN(nn.Module):
+    def __init__(self, n_in_channel=1, nclass=10, attention=True, activation="glu", dropout=0.5, train_cnn=True,
+                 rnn_type="BGRU", n_RNN_cell=128, n_layers_RNN=2, dropout_recurrent=0, cnn_integration=False,
+                 freeze_bn=False, use_embeddings=False, embedding_size=527, embedding_type="global",
+                 frame_emb_enc_dim=512, aggregation_type="global", specaugm_t_p=0.2, specaugm_t_l=5, specaugm_f_p=0.2,
+                 specaugm_f_l=10, dropstep_recurrent=0.0, dropstep_recurrent_len=5, specaugm_iid_masks=True, **kwargs):
+        super().__init__()
+        if cnn_integration or use_embeddings or dropstep_recurrent:
+            raise NotImplementedError("cnn_integration / use_embeddings / dropstep_recurrent: next rows (SURVEY 8f)")
+        if rnn_type != "BGRU":
+            raise NotImplementedError("Only BGRU supported for CRNN for now")
+        if isinstance(nclass, (tuple, list)):
+            if len(nclass) > 1:
+                raise NotImplementedError("multi-head nclass lists are not supported")
+            nclass = nclass[0]
+        if attention not in (True, "legacy"):
+            raise NotImplementedError("the HIP head implements the attention-pooling variant (attention=True)")
+        self.n_in_channel, self.attention, self.cnn_integration = n_in_channel, attention, cnn_integration
+        self.freeze_bn, self.use_embeddings = freeze_bn, use_embeddings
+        self.embedding_type, self.aggregation_type = embedding_type, aggregation_type
+        self.nclass = nclass
+        self.dropstep_recurrent, self.dropstep_recurrent_len = dropstep_recurrent, dropstep_recurrent_len
+        self.specaugm_t_p, self.specaugm_t_l = specaugm_t_p, specaugm_t_l
+        self.specaugm_f_p, self.specaugm_f_l = specaugm_f_p, specaugm_f_l
+        # torchaudio >= 2.1 draws one SpecAugment mask per clip for this call; <= 2.0.x shared one mask per batch
+        self.specaugm_iid_masks = specaugm_iid_masks
+        self.dropout_p = float(dropout)
+
+        # construction order == reference (same RNG consumption -> same default initialisation)
+        self.cnn = CNN(n_in_channel=n_in_channel, activation=activation, conv_dropout=dropout, **kwargs)
+        self.train_cnn = train_cnn
+        if not train_cnn:
+            for p in self.cnn.parameters():
+                p.requires_grad = False
+        self.rnn = BidirectionalGRU(n_in=self.cnn.nb_filters[-1], n_hidden=n_RNN_cell, dropout=dropout_recurrent,
+                                    num_layers=n_layers_RNN)
+        self.dropout = nn.Dropout(dropout)
+        self.dense = nn.Linear(n_RNN_cell * 2, nclass)
+        self.sigmoid = nn.Sigmoid()
+        self.dense_softmax = nn.Linear(n_RNN_cell * 2, nclass)
+        self.softmax = nn.Softmax(dim=-1)
+        self._arena = None
+        self._build_arena()
+
+    # ---- flat parameter arena -------------------------------------------------------------------
+    def _build_arena(self):
+        self._arena = ParamArena(list(self.parameters()))
+
+    @property
+    def arena(self):
+        if self._arena is None or not self._arena.is_intact():
+            self._build_arena()
+        return self._arena
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._build_arena()
+        return out
+
+    def __deepcopy__(self, memo):
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_arena":
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new._arena = None
+        new._build_arena()
+        return new
+
+    # ---- reference surface ----------------------------------------------------------------------
+    def apply_specaugment(self, x):
+        """Reference semantics on a (B, n_mels, T) tensor (CRNN.py:207-219); the forward() path fuses it instead."""
+        if not self.training:
+            return x
+        b = self._specaug_bounds(x.shape[0], x.shape[1], x.shape[2], x.device)
+        return features.specaug_apply(x, b) if b is not None else x
+
+    def _specaug_bounds(self, B, n_freq, n_time, device):
+        if min(self.specaugm_f_l, int(n_freq * self.specaugm_f_p)) < 1 and min(self.specaugm_t_l, int(n_time * self.specaugm_t_p)) < 1:
+            return None
+        return features.specaug_bounds(B, n_freq, n_time, self.specaugm_f_l, self.specaugm_f_p, self.specaugm_t_l,
+                                       self.specaugm_t_p, device, iid_masks=self.specaugm_iid_masks)
+
+    def forward(self, x, pad_mask=None, embeddings=None, classes_mask=None):
+        if pad_mask is not None or embeddings is not None or classes_mask is not None:
+            raise NotImplementedError("pad_mask / embeddings / classes_mask: next rows (SURVEY 8f)")
+        if x.dim() != 3:
+            raise ValueError("expected (batch, n_mels, frames)")
+        xt = features.as_btf(x)                                           # (B, T, F), no copy for our own views
+        arena = self.arena
+        bounds = self._specaug_bounds(xt.shape[0], xt.shape[2], xt.shape[1], xt.device) if self.training else None
+        h = self.cnn(xt, bounds=bounds, arena=arena)                      # (B, T', F', C)
+        bs, frames, freq, chan = h.shape
+        if freq != 1:
+            raise NotImplementedError("CNN output keeps %d frequency bins; the recurrent stage expects 1" % freq)
+        h = h.view(bs, frames, chan)
+        h = self.rnn(h, arena=arena)                                      # (B, T', 256)
+        drop = self.dropout.training and self.dropout_p > 0
+        cfg = dict(dropout_p=self.dropout_p, apply_dropout=drop, seed=new_seed() if drop else 0, arena=arena)
+        strong, weak = HeadFn.apply(h, self.dense.weight, self.dense.bias, self.dense_softmax.weight,
+                                    self.dense_softmax.bias, cfg)
+        return strong.transpose(1, 2), weak
+
+    def train(self, mode=True):
+        """Mirrors CRNN.train (CRNN.py:308-323), including that it returns None."""
+        super().train(mode)
+        if self.freeze_bn:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+                    m.weight.requires_grad = False
+                    m.bias.requires_grad = False

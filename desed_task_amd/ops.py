@@ -29,6 +29,17 @@ def new_seed(generator=None):
     return int(torch.randint(0, 2 ** 31 - 1, (1,), generator=generator).item())
 
 
+def _grad_buf(cfg, param):
+    """Gradient output buffer for `param`: a view into the parameter arena's flat gradient buffer when the
+    parameter lives in one (so the optimizer / all-reduce see ONE contiguous tensor), else a fresh tensor."""
+    arena = cfg.get("arena") if cfg else None
+    if arena is not None:
+        g = arena.grad_view_for(param)
+        if g is not None:
+            return g
+    return torch.empty_like(param)
+
+
 class ConvBlockFn(torch.autograd.Function):
     """One CNN block: Conv2d(3x3,p1) -> BatchNorm2d -> GLU -> Dropout -> AvgPool2d  (CNN.py:66-98).
 
@@ -69,32 +80,34 @@ class ConvBlockFn(torch.autograd.Function):
         glu_w = glu_w.contiguous()
         lib.call("sed_glu_fwd", y.data_ptr(), stats.data_ptr(), glu_w.data_ptr(), glu_b.data_ptr(), out.data_ptr(), B, T, F, COUT,
                  PT, PF, seed, thr24, dscale, st)
-        ctx.save_for_backward(x, y, stats, conv_w, bn_w, bn_b, glu_w, glu_b)
+        ctx.save_for_backward(x, y, stats, conv_w, bn_w, bn_b, glu_w, glu_b, conv_b)
         ctx.meta = (first, B, T, F, CIN, COUT, PT, PF, training, seed, thr24, dscale, bounds)
+        ctx.cfg = cfg
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = _lib.get()
-        x, y, stats, conv_w, bn_w, bn_b, glu_w, glu_b = ctx.saved_tensors
+        x, y, stats, conv_w, bn_w, bn_b, glu_w, glu_b, conv_b = ctx.saved_tensors
         first, B, T, F, CIN, COUT, PT, PF, training, seed, thr24, dscale, bounds = ctx.meta
         gout = gout.contiguous()
         dev = y.device
         st = _lib.stream_ptr(y)
         f32 = dict(device=dev, dtype=torch.float32)
         dz = torch.empty_like(y)
-        d_glu_w = torch.empty(COUT, COUT, **f32)
-        d_glu_b = torch.empty(COUT, **f32)
-        d_gamma = torch.empty(COUT, **f32)
-        d_beta = torch.empty(COUT, **f32)
+        cfg = ctx.cfg
+        d_glu_w = _grad_buf(cfg, glu_w)
+        d_glu_b = _grad_buf(cfg, glu_b)
+        d_gamma = _grad_buf(cfg, bn_w)
+        d_beta = _grad_buf(cfg, bn_b)
         lib.call("sed_glu_bwd", y.data_ptr(), stats.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(), glu_w.data_ptr(), glu_b.data_ptr(),
                  gout.data_ptr(), dz.data_ptr(), d_glu_w.data_ptr(), d_glu_b.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(),
                  B, T, F, COUT, PT, PF, seed, thr24, dscale, st)
-        d_bias = torch.empty(COUT, **f32)
+        d_bias = _grad_buf(cfg, conv_b)
         lib.call("sed_bn_bwd_apply", y.data_ptr(), dz.data_ptr(), stats.data_ptr(), bn_w.data_ptr(), d_gamma.data_ptr(),
                  d_beta.data_ptr(), d_bias.data_ptr(), B * T * F, COUT, int(training), st)
         dy = dz
-        d_w = torch.empty_like(conv_w)
+        d_w = _grad_buf(cfg, conv_w)
         dx = None
         if first:
             lib.call("sed_conv0_wgrad", x.data_ptr(), _p(bounds), dy.data_ptr(), d_w.data_ptr(), B, T, F, COUT, st)
@@ -107,3 +120,147 @@ class ConvBlockFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 lib.call("sed_conv3x3", dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, B, T, F, COUT, CIN, st)
         return dx, d_w, d_bias, d_gamma, d_beta, d_glu_w, d_glu_b, None, None, None
+
+
+def _gemm(lib, A, Bm, bias, C, M, N, K, lda, ldb, ldc, ta, tb, split_k, accumulate, st):
+    lib.call("sed_gemm", A, Bm, bias, C, M, N, K, lda, ldb, ldc, ta, tb, split_k, accumulate, st)
+
+
+class BiGRULayerFn(torch.autograd.Function):
+    """One bidirectional GRU layer (nn.GRU semantics, RNN.py:19-30).  x (B,T,I) -> (B,T,2H), H = 128.
+    Input projections and all weight gradients are MFMA GEMMs; the recurrence is the persistent kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r, cfg=None):
+        lib = _lib.get()
+        x = x.contiguous()
+        _lib.check_tensor(x, "gru input")
+        B, T, I = x.shape
+        H = w_hh_f.shape[1]
+        st = _lib.stream_ptr(x)
+        f32 = dict(device=x.device, dtype=torch.float32)
+        gi = torch.empty(B, T, 2, 3 * H, **f32)
+        w_ih = [w_ih_f.contiguous(), w_ih_r.contiguous()]
+        w_hh = [w_hh_f.contiguous(), w_hh_r.contiguous()]
+        for d, (w, b) in enumerate(zip(w_ih, (b_ih_f, b_ih_r))):
+            _gemm(lib, x.data_ptr(), w.data_ptr(), b.data_ptr(), gi.data_ptr() + d * 3 * H * 4, B * T, 3 * H, I, I, I, 6 * H,
+                  0, 1, 1, 0, st)
+        out = torch.empty(B, T, 2 * H, **f32)
+        need = any(ctx.needs_input_grad)
+        saved = torch.empty(B, T, 2, 4, H, **f32) if need else None
+        lib.call("sed_gru_fwd", gi.data_ptr(), w_hh[0].data_ptr(), w_hh[1].data_ptr(), b_hh_f.data_ptr(), b_hh_r.data_ptr(),
+                 out.data_ptr(), _p(saved), B, T, H, st)
+        if need:
+            ctx.save_for_backward(x, out, saved, w_ih[0], w_ih[1], w_hh[0], w_hh[1], b_ih_f, b_hh_f, b_ih_r, b_hh_r)
+        ctx.dims = (B, T, I, H)
+        ctx.cfg = cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.get()
+        x, out, saved, w_ih_f, w_ih_r, w_hh_f, w_hh_r, b_ih_f, b_hh_f, b_ih_r, b_hh_r = ctx.saved_tensors
+        B, T, I, H = ctx.dims
+        cfg = ctx.cfg
+        dout = dout.contiguous()
+        st = _lib.stream_ptr(x)
+        f32 = dict(device=x.device, dtype=torch.float32)
+        dgi = torch.empty(B, T, 2, 3 * H, **f32)
+        dgh = torch.empty(B, T, 2, 3 * H, **f32)
+        hprev = torch.empty(B, T, 2, H, **f32)
+        lib.call("sed_gru_bwd", dout.data_ptr(), out.data_ptr(), saved.data_ptr(), w_hh_f.data_ptr(), w_hh_r.data_ptr(),
+                 dgi.data_ptr(), dgh.data_ptr(), hprev.data_ptr(), B, T, H, st)
+        BT = B * T
+        split = max(1, min(32, BT // 256))
+        d_w_ih, d_w_hh, d_b_ih, d_b_hh = [], [], [], []
+        for d, (wi, wh, bi, bh) in enumerate(((w_ih_f, w_hh_f, b_ih_f, b_hh_f), (w_ih_r, w_hh_r, b_ih_r, b_hh_r))):
+            dwi = _grad_buf(cfg, wi).zero_()
+            _gemm(lib, dgi.data_ptr() + d * 3 * H * 4, x.data_ptr(), None, dwi.data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, 0, st)
+            dwh = _grad_buf(cfg, wh).zero_()
+            _gemm(lib, dgh.data_ptr() + d * 3 * H * 4, hprev.data_ptr() + d * H * 4, None, dwh.data_ptr(), 3 * H, H, BT, 6 * H, 2 * H,
+                  H, 1, 0, split, 0, st)
+            dbi, dbh = _grad_buf(cfg, bi), _grad_buf(cfg, bh)
+            lib.call("sed_colsum", dgi.data_ptr() + d * 3 * H * 4, dbi.data_ptr(), BT, 3 * H, 6 * H, st)
+            lib.call("sed_colsum", dgh.data_ptr() + d * 3 * H * 4, dbh.data_ptr(), BT, 3 * H, 6 * H, st)
+            d_w_ih.append(dwi); d_w_hh.append(dwh); d_b_ih.append(dbi); d_b_hh.append(dbh)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, T, I, **f32)
+            for d, w in enumerate((w_ih_f, w_ih_r)):
+                _gemm(lib, dgi.data_ptr() + d * 3 * H * 4, w.data_ptr(), None, dx.data_ptr(), BT, I, 3 * H, 6 * H, I, I, 0, 0, 1, d, st)
+        return (dx, d_w_ih[0], d_w_hh[0], d_b_ih[0], d_b_hh[0], d_w_ih[1], d_w_hh[1], d_b_ih[1], d_b_hh[1], None)
+
+
+class HeadFn(torch.autograd.Function):
+    """Dropout + the two dense layers + class-softmax attention pooling (CRNN.py:152-178, :304).
+    x (B,T,256) -> strong (B,T,NC) [caller exposes the (B,NC,T) view], weak (B,NC)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, cfg):
+        lib = _lib.get()
+        x = x.contiguous()
+        _lib.check_tensor(x, "head input")
+        B, T, D = x.shape
+        NC = w1.shape[0]
+        thr24, dscale = dropout_params(cfg.get("dropout_p", 0.0) if cfg.get("apply_dropout", False) else 0.0)
+        seed = int(cfg.get("seed", 0))
+        f32 = dict(device=x.device, dtype=torch.float32)
+        strong = torch.empty(B, T, NC, **f32)
+        psoft = torch.empty(B, T, NC, **f32)
+        weak = torch.empty(B, NC, **f32)
+        den = torch.empty(B, NC, **f32)
+        w1, w2 = w1.contiguous(), w2.contiguous()
+        lib.call("sed_head_fwd", x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), strong.data_ptr(),
+                 psoft.data_ptr(), weak.data_ptr(), den.data_ptr(), B, T, D, NC, seed, thr24, dscale, _lib.stream_ptr(x))
+        ctx.save_for_backward(x, w1, w2, strong, psoft, weak, den, b1, b2)
+        ctx.meta = (B, T, D, NC, seed, thr24, dscale)
+        ctx.cfg = cfg
+        return strong, weak
+
+    @staticmethod
+    def backward(ctx, d_strong, d_weak):
+        lib = _lib.get()
+        x, w1, w2, strong, psoft, weak, den, b1, b2 = ctx.saved_tensors
+        B, T, D, NC, seed, thr24, dscale = ctx.meta
+        cfg = ctx.cfg
+        f32 = dict(device=x.device, dtype=torch.float32)
+        d_strong = torch.zeros(B, T, NC, **f32) if d_strong is None else d_strong.contiguous()
+        d_weak = torch.zeros(B, NC, **f32) if d_weak is None else d_weak.contiguous()
+        dx = torch.empty_like(x)
+        dw1, dw2 = _grad_buf(cfg, w1), _grad_buf(cfg, w2)
+        db1, db2 = _grad_buf(cfg, b1), _grad_buf(cfg, b2)
+        lib.call("sed_head_bwd", x.data_ptr(), w1.data_ptr(), w2.data_ptr(), strong.data_ptr(), psoft.data_ptr(), weak.data_ptr(),
+                 den.data_ptr(), d_strong.data_ptr(), d_weak.data_ptr(), dx.data_ptr(), dw1.data_ptr(), dw2.data_ptr(),
+                 db1.data_ptr(), db2.data_ptr(), B, T, D, NC, seed, thr24, dscale, _lib.stream_ptr(x))
+        return dx, dw1, db1, dw2, db2, None
+
+
+class MeanTeacherLossFn(torch.autograd.Function):
+    """Fused losses of SEDTask4.training_step (sed_trainer.py:309-342).
+    Returns a (7,) tensor: [bce_strong, bce_weak, bce_strong_teacher, bce_weak_teacher, mse_strong, mse_weak, total]
+    with total = bce_strong + bce_weak + weight * (mse_strong + mse_weak).  Only `total` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, strong_s, weak_s, strong_t, weak_t, labels, labels_weak, n_strong, n_weak, weight):
+        lib = _lib.get()
+        strong_s, weak_s = strong_s.contiguous(), weak_s.contiguous()
+        strong_t, weak_t = strong_t.contiguous(), weak_t.contiguous()
+        labels, labels_weak = labels.contiguous().float(), labels_weak.contiguous().float()
+        _lib.check_tensor(strong_s, "strong preds")
+        B, T, NC = strong_s.shape
+        f32 = dict(device=strong_s.device, dtype=torch.float32)
+        scalars = torch.empty(6, **f32)
+        g_strong = torch.empty(B, T, NC, **f32)
+        g_weak = torch.empty(B, NC, **f32)
+        lib.call("sed_mt_loss", strong_s.data_ptr(), weak_s.data_ptr(), strong_t.data_ptr(), weak_t.data_ptr(), labels.data_ptr(),
+                 labels_weak.data_ptr(), scalars.data_ptr(), g_strong.data_ptr(), g_weak.data_ptr(), B, T, NC, int(n_strong),
+                 int(n_weak), float(weight), _lib.stream_ptr(strong_s))
+        total = scalars[0] + scalars[1] + float(weight) * (scalars[4] + scalars[5])
+        ctx.save_for_backward(g_strong, g_weak)
+        return torch.cat([scalars, total.reshape(1)])
+
+    @staticmethod
+    def backward(ctx, g):
+        g_strong, g_weak = ctx.saved_tensors
+        gt = g[6]
+        return g_strong * gt, g_weak * gt, None, None, None, None, None, None, None

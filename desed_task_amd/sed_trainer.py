@@ -1,0 +1,169 @@
+"""SEDTask4 with the training-step surface of recipes/dcase2023_task4_baseline/local/sed_trainer.py:24-365,
+running on the MI355X kernels.
+
+Kept from the reference: constructor signature, `mel_spec`, `scaler`, `take_log`, `detect`, `training_step`
+(batch tuple in, 0-d loss tensor with grad out, the same 11 logged keys, in-place mutation of features/labels
+by mixup, python/numpy/torch-CPU RNG consumption order), `on_before_zero_grad` -> `update_ema`,
+`lr_scheduler_step`, `configure_optimizers`, `on_save_checkpoint`, `train_dataloader`.
+Validation/test/metric code (sed_trainer.py:367-975) is outside this path: those hooks raise.
+
+It subclasses pytorch_lightning.LightningModule when Lightning is importable, else a minimal stand-in with
+`hparams`/`log` so the step can be driven by desed_task_amd.launcher (one process per GPU).
+"""
+import random
+from copy import deepcopy
+
+import torch
+
+from . import features
+from .arena import ema_update_
+from .data_augm import mixup_inplace_
+from .ops import MeanTeacherLossFn
+from .utils.scaler import TorchScaler
+
+try:  # pragma: no cover - Lightning is not installed in the build image
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    class _Base(torch.nn.Module):
+        """Stand-in for LightningModule: `hparams` dict + `log` sink (values stay on the device, no sync)."""
+
+        def __init__(self):
+            super().__init__()
+            self.hparams = {}
+            self.logged = {}
+
+        def log(self, name, value, **kwargs):
+            self.logged[name] = value
+
+
+class SEDTask4(_Base):
+    def __init__(self, hparams, encoder, sed_student, opt=None, train_data=None, valid_data=None, test_data=None,
+                 train_sampler=None, scheduler=None, fast_dev_run=False, evaluation=False, sed_teacher=None):
+        super().__init__()
+        self.hparams.update(hparams)
+        self.encoder = encoder
+        self.sed_student = sed_student
+        self.sed_teacher = deepcopy(sed_student) if sed_teacher is None else sed_teacher
+        self.opt = opt
+        self.train_data, self.valid_data, self.test_data = train_data, valid_data, test_data
+        self.train_sampler = train_sampler
+        self.scheduler = scheduler
+        self.fast_dev_run = fast_dev_run
+        self.evaluation = evaluation
+        self.num_workers = 1 if fast_dev_run else self.hparams["training"]["num_workers"]
+
+        feat = self.hparams["feats"]
+        self.mel_spec = features.MelSpectrogram(
+            sample_rate=feat["sample_rate"], n_fft=feat["n_window"], win_length=feat["n_window"],
+            hop_length=feat["hop_length"], f_min=feat["f_min"], f_max=feat["f_max"], n_mels=feat["n_mels"],
+            window_fn=torch.hamming_window, wkwargs={"periodic": False}, power=1)
+
+        for p in self.sed_teacher.parameters():
+            p.detach_()
+
+        sup = self.hparams["training"]["self_sup_loss"]
+        if sup == "bce":
+            raise NotImplementedError("self_sup_loss: bce is not built on the HIP loss kernel (the 2023 recipe uses mse)")
+        if sup != "mse":
+            raise NotImplementedError
+        self.scaler = self._init_scaler()
+
+    # ---- feature pipeline ------------------------------------------------------------------------
+    def _init_scaler(self):
+        sc = self.hparams["scaler"]
+        if sc["statistic"] == "instance":
+            return TorchScaler("instance", sc["normtype"], sc["dims"])
+        raise NotImplementedError("dataset-wide scaler statistics need the data loaders (outside the hot path)")
+
+    def take_log(self, mels):
+        return features.take_log(mels)
+
+    def _fused_scaler(self):
+        s = self.scaler
+        return isinstance(s, TorchScaler) and s.statistic == "instance" and s.normtype == "minmax" and tuple(s.dims) == (1, 2)
+
+    def scaled_logmel(self, mel_feats):
+        """scaler(take_log(mels)) -- one fused log + per-clip min/max + affine pass when the scaler is instance/minmax."""
+        if self._fused_scaler():
+            return features.minmax_scale(mel_feats, eps=self.scaler.eps, apply_log=True)
+        return self.scaler(self.take_log(mel_feats))
+
+    def detect(self, mel_feats, model):
+        return model(self.scaled_logmel(mel_feats))
+
+    # ---- optimisation hooks -----------------------------------------------------------------------
+    def lr_scheduler_step(self, scheduler, optimizer_idx=None, metric=None):
+        scheduler.step()
+
+    def update_ema(self, alpha, global_step, model, ema_model):
+        alpha = min(1 - 1 / (global_step + 1), alpha)
+        ema_update_(list(ema_model.parameters()), list(model.parameters()), alpha,
+                    getattr(ema_model, "arena", None), getattr(model, "arena", None))
+
+    def on_before_zero_grad(self, *args, **kwargs):
+        self.update_ema(self.hparams["training"]["ema_factor"], self.scheduler["scheduler"].step_num,
+                        self.sed_student, self.sed_teacher)
+
+    def configure_optimizers(self):
+        return [self.opt], [self.scheduler]
+
+    def on_save_checkpoint(self, checkpoint):
+        checkpoint["sed_student"] = self.sed_student.state_dict()
+        checkpoint["sed_teacher"] = self.sed_teacher.state_dict()
+        return checkpoint
+
+    def train_dataloader(self):
+        self.train_loader = torch.utils.data.DataLoader(self.train_data, batch_sampler=self.train_sampler,
+                                                        num_workers=self.num_workers)
+        return self.train_loader
+
+    # ---- the hot path -----------------------------------------------------------------------------
+    def training_step(self, batch, batch_indx):
+        audio, labels = batch[0], batch[1]
+        indx_synth, indx_weak, indx_unlabelled = self.hparams["training"]["batch_size"]
+        features_ = self.mel_spec(audio)                                  # (B, n_mels, T) view of frame-major HBM
+
+        batch_num = features_.shape[0]
+        if indx_synth + indx_weak > batch_num:
+            raise ValueError("batch smaller than the configured strong+weak sizes")
+        weak_sl = slice(indx_synth, indx_synth + indx_weak)
+        strong_sl = slice(0, indx_synth)
+        labels_weak = (torch.sum(labels[weak_sl], -1) > 0).float()
+
+        mixup_type = self.hparams["training"].get("mixup")
+        if mixup_type is not None and 0.5 > random.random():
+            mixup_inplace_(features_[weak_sl], labels_weak, mixup_label_type=mixup_type)
+            mixup_inplace_(features_[strong_sl], labels[strong_sl], mixup_label_type=mixup_type)
+
+        x = self.scaled_logmel(features_)                                 # shared by student and teacher
+        strong_s, weak_s = self.sed_student(x)
+        with torch.no_grad():
+            strong_t, weak_t = self.sed_teacher(x)
+
+        sched = self.scheduler["scheduler"]
+        weight = self.hparams["training"]["const_max"] * sched._get_scaling_factor()
+        out = MeanTeacherLossFn.apply(strong_s.transpose(1, 2), weak_s, strong_t.transpose(1, 2), weak_t, labels, labels_weak,
+                                      indx_synth, indx_weak, weight)
+        loss_strong, loss_weak, loss_strong_t, loss_weak_t, strong_self, weak_self, tot_loss = out.unbind(0)
+        tot_self_loss = (strong_self + weak_self).detach() * weight
+
+        self.log("train/student/loss_strong", loss_strong.detach())
+        self.log("train/student/loss_weak", loss_weak.detach())
+        self.log("train/teacher/loss_strong", loss_strong_t.detach())
+        self.log("train/teacher/loss_weak", loss_weak_t.detach())
+        self.log("train/step", sched.step_num, prog_bar=True)
+        self.log("train/student/tot_self_loss", tot_self_loss, prog_bar=True)
+        self.log("train/weight", weight)
+        self.log("train/student/tot_supervised", strong_self.detach(), prog_bar=True)      # sic (reference :351)
+        self.log("train/student/weak_self_sup_loss", weak_self.detach())
+        self.log("train/student/strong_self_sup_loss", strong_self.detach())
+        self.log("train/lr", self.opt.param_groups[-1]["lr"] if self.opt is not None else 0.0, prog_bar=True)
+        self.last_outputs = (strong_s, weak_s, strong_t, weak_t)
+        return tot_loss
+
+    # ---- outside the hot path -----------------------------------------------------------
+    def validation_step(self, batch, batch_indx):
+        raise NotImplementedError("validation/test scoring is a 'next' row (SURVEY 8f rank 1-2)")
+
+    test_step = validation_step

@@ -91,6 +91,54 @@ int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float* dW, int B
 int sed_conv0_wgrad(const float* x, const int* bounds, const float* dy, float* dW, int B, int T, int F, int COUT,
                     void* stream);
 
+/* ---- K7: bidirectional GRU (desed_task/nnet/RNN.py:19-30) ---------------------------------------------------- */
+
+/* Plain GEMM on f32 MFMA: C[M][N] = opA(A) * opB(B) + bias[N].  transA: A stored [K][M]; transB: B stored [N][K].
+ * split_k > 1 or accumulate != 0 adds atomically into C (caller zeroes C for split_k).  ld* in floats. */
+int sed_gemm(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
+             int ldc, int transA, int transB, int split_k, int accumulate, void* stream);
+
+/* out[n] = sum_m X[m*ld + n] (bias gradients). */
+int sed_colsum(const float* X, float* out, int M, int N, int ld, void* stream);
+
+/* GRU recurrence of one layer, both directions: gi (B,T,2,3H) = W_ih x + b_ih per direction; whh0/whh1 (3H,H),
+ * bhh0/bhh1 (3H) = forward / reverse direction; out (B,T,2H); saved (B,T,2,4,H) = r,z,n,hn or null. */
+int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
+                float* out, float* saved, int B, int T, int H, void* stream);
+
+/* Backward recurrence: dout (B,T,2H) -> dgi, dgh (B,T,2,3H) and hprev (B,T,2,H). */
+int sed_gru_bwd(const float* dout, const float* out, const float* saved, const float* whh0, const float* whh1,
+                float* dgi, float* dgh, float* hprev, int B, int T, int H, void* stream);
+
+/* ---- K8 + K9: attention-pooling head (desed_task/nnet/CRNN.py:152-178, dropout :304) and losses ---------------- */
+
+/* x (B,T,256) -> strong (B,T,NC) = sigmoid(dense), psoft (B,T,NC) = softmax over classes of dense_softmax,
+ * weak (B,NC) = sum_t(strong*clamp(psoft)) / sum_t(clamp(psoft)), den (B,NC) = the denominators. */
+int sed_head_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, float* strong,
+                 float* psoft, float* weak, float* den, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
+                 float dscale, void* stream);
+
+int sed_head_bwd(const float* x, const float* W1, const float* W2, const float* strong, const float* psoft,
+                 const float* weak, const float* den, const float* d_strong, const float* d_weak, float* dx, float* dW1,
+                 float* dW2, float* db1, float* db2, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
+                 float dscale, void* stream);
+
+/* Mean-teacher losses of SEDTask4.training_step (recipes/dcase2023_task4_baseline/local/sed_trainer.py:309-342):
+ * scalars[6] = BCE strong/weak (student), BCE strong/weak (teacher), MSE strong/weak; g_strong (B,T,NC), g_weak (B,NC)
+ * = d(BCE_s + BCE_w + weight*(MSE_s + MSE_w)) / d(student outputs).  labels (B,NC,T); labels_weak (n_weak,NC). */
+int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
+                const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
+                int T, int NC, int n_strong, int n_weak, float weight, void* stream);
+
+/* ---- K10 + K11: flat parameter arena ------------------------------------------------------------------------- */
+
+/* SEDTask4.update_ema (sed_trainer.py:187-199) over the whole arena: teacher = alpha*teacher + (1-alpha)*student. */
+int sed_ema_update(float* teacher, const float* student, long long n, float alpha, float one_minus_alpha, void* stream);
+
+/* torch.optim.Adam step (train_sed.py:199-201) over the whole arena; grad_scale folds in 1/world_size. */
+int sed_adam_step(float* p, const float* g, float* m, float* v, long long n, float b1, float b2, float eps,
+                  float step_size, float inv_bc2_sqrt, float grad_scale, void* stream);
+
 /* Hardware self-test of the MFMA lane maps (no reference counterpart): C = A[M][K] * B[K][M], M = shape (32|16). */
 int sed_selftest_mfma(const float* A, const float* Bm, float* C, int K, int shape, void* stream);
 

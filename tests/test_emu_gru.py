@@ -1,0 +1,15 @@
+"""CPU (fiber-emulator) runs of the GEMM and BiGRU parity cases (K7)."""
+from tests import parity_cases as P
+from tests.emu_support import emu  # noqa: F401
+
+
+def test_gemm(emu):
+    P.case_gemm("cpu")
+
+
+def test_bigru_layer0(emu):
+    P.case_bigru("cpu", B=2, T=7, I=128)
+
+
+def test_bigru_layer1(emu):
+    P.case_bigru("cpu", B=1, T=5, I=256)

@@ -1,0 +1,27 @@
+"""CPU (fiber-emulator) run of the whole mean-teacher step: drop-in CRNN + SEDTask4 + StepDriver against the
+oracle trainer on identical mixup draws (dropout / SpecAugment off).  Also state-dict compatibility."""
+import torch
+
+from oracle import sed_oracle as O
+from tests import parity_cases as P
+from tests.emu_support import emu  # noqa: F401
+
+
+def test_state_dict_layout(emu):
+    from desed_task_amd.nnet.CRNN import CRNN
+    net = CRNN(**P.recipe_config()["net"])
+    sd = net.state_dict()
+    shapes = O.crnn_param_shapes()
+    assert [n for n, _ in net.named_parameters()] == O.PARAM_KEYS            # reference parameters() order
+    assert sum(p.numel() for p in net.parameters()) == 1112420
+    for k, shp in shapes.items():
+        assert tuple(sd[k].shape) == tuple(shp), k
+    buffers = [k for k in sd if k not in shapes]
+    assert len(buffers) == 21 and all("batchnorm" in k for k in buffers)
+    net.load_state_dict(O.make_state_dict(seed=7), strict=True)
+    assert net.arena.is_intact()
+    assert net.eval() is None                                                # reference quirk Q5
+
+
+def test_training_steps_match_oracle(emu):
+    P.case_training_step("cpu", small=True)

@@ -55,3 +55,21 @@ def test_cnn_block_train(layer, T, F):
 @pytest.mark.parametrize("layer,T,F", [(0, 626, 128), (3, 156, 16)])
 def test_cnn_block_eval(layer, T, F):
     P.case_cnn_block("cuda", layer, 2, T, F, training=False, dropout_p=0.0, tol=5e-5)
+
+
+def test_gemm():
+    P.case_gemm("cuda")
+
+
+def test_bigru_production_shape():
+    P.case_bigru("cuda", B=4, T=156, I=128, tol=5e-5)
+    P.case_bigru("cuda", B=3, T=156, I=256, tol=5e-5)
+
+
+def test_training_steps_vs_oracle_and_reference_golden():
+    """3 full mean-teacher steps (mel -> mixup -> student/teacher CRNN -> losses -> EMA -> backward -> Adam ->
+    warm-up) on the GPU against the oracle trainer AND the scalars recorded from the reference's own
+    SEDTask4.training_step (fixture G6)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden.npz"))
+    P.case_training_step("cuda", small=False, golden=G)
