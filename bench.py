@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Throughput of the mel + CRNN mean-teacher TRAINING step on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = SEDTask4.training_step (mel -> mixup -> log/min-max -> student CRNN + teacher CRNN, both in train mode
+with dropout + SpecAugment -> BCE/MSE losses) + EMA + backward + [gradient all-reduce] + Adam + warm-up scheduler
+on one batch of 48 synthetic 10 s / 16 kHz clips per GPU (12 strong / 12 weak / 24 unlabelled), already resident in
+HBM.  Weak scaling: every rank runs the reference's single-GPU step on its own clips; gradients are averaged.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel that dominates the step (the 3x3 convolution as
+implicit GEMM on the f32 MFMA): algorithmic FLOPs per launch / the mean launch time measured with HIP events inside
+the timed region.  `cpu_baseline` times the CPU oracle (oracle/sed_oracle.py, the unfused torch restatement of the
+reference step) on this host's cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BATCH = (12, 12, 24)
+N_SAMPLES = 160000
+N_FRAMES_OUT = 156
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: exact-f32 MFMA = f32 vector peak
+
+
+def recipe_config():
+    return {
+        "training": {"batch_size": list(BATCH), "const_max": 2, "num_workers": 0, "ema_factor": 0.999,
+                     "self_sup_loss": "mse", "mixup": "soft", "n_epochs_warmup": 50},
+        "scaler": {"statistic": "instance", "normtype": "minmax", "dims": [1, 2], "savepath": None},
+        "opt": {"lr": 0.001},
+        "feats": {"n_mels": 128, "n_filters": 2048, "hop_length": 256, "n_window": 2048, "sample_rate": 16000,
+                  "f_min": 0, "f_max": 8000},
+        "net": {"dropout": 0.5, "rnn_layers": 2, "n_in_channel": 1, "nclass": 10, "attention": True, "n_RNN_cell": 128,
+                "activation": "glu", "rnn_type": "BGRU", "kernel_size": [3] * 7, "padding": [1] * 7, "stride": [1] * 7,
+                "nb_filters": [16, 32, 64, 128, 128, 128, 128],
+                "pooling": [[2, 2], [2, 2], [1, 2], [1, 2], [1, 2], [1, 2], [1, 2]], "dropout_recurrent": 0,
+                "use_embeddings": False},
+    }
+
+
+def synthetic_batch(device, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(N_SAMPLES, dtype=torch.float32) / 16000.0
+    audio = 0.1 * torch.randn(sum(BATCH), N_SAMPLES, generator=g)
+    f0 = 200.0 + 40.0 * torch.arange(sum(BATCH), dtype=torch.float32).unsqueeze(1)
+    audio += 0.3 * torch.sin(2 * np.pi * (f0 * t + 150.0 * t * t)) + 0.2 * torch.sin(2 * np.pi * (3000.0 * t - 120.0 * t * t))
+    labels = torch.zeros(sum(BATCH), 10, N_FRAMES_OUT)
+    labels[:BATCH[0]] = (torch.rand(BATCH[0], 10, N_FRAMES_OUT, generator=g) < 0.1).float()
+    labels[BATCH[0]:BATCH[0] + BATCH[1], :, 0] = (torch.rand(BATCH[1], 10, generator=g) < 0.2).float()
+    return audio.to(device), labels.to(device)
+
+
+class KernelTimer:
+    """HIP-event timing of selected C-ABI entry points on torch's current stream (the stream they launch on)."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = {}
+
+    def wrap(self, lib):
+        orig = lib.call
+        timer = self
+
+        def timed_call(name, *args):
+            if name not in timer.names:
+                return orig(name, *args)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(name, *args)
+            e1.record()
+            key = (name,) + tuple(a for a in args if isinstance(a, int) and 0 < a < 100000 and not isinstance(a, bool))[:6]
+            timer.records.setdefault(key, []).append((e0, e1))
+        lib.call = timed_call
+        self._undo = lambda: setattr(lib, "call", orig)
+
+    def unwrap(self):
+        self._undo()
+
+    def summary(self):
+        out = {}
+        for key, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[key] = (len(ms), float(np.mean(ms)), float(np.sum(ms)))
+        return out
+
+
+def conv_flops(key):
+    """Algorithmic FLOPs of one sed_conv3x3 launch: 2 * B*T*F * 9*CIN * COUT (key = (name, B, T, F, CIN, COUT))."""
+    _, B, T, F, CIN, COUT = key[:6]
+    return 2.0 * B * T * F * 9 * CIN * COUT
+
+
+def cpu_baseline():
+    """One full oracle training step (training_step + EMA + backward + Adam) on a 12-clip batch of 10 s clips."""
+    from oracle import sed_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    bs = (3, 3, 6)
+    B = sum(bs)
+    sd = O.make_state_dict(seed=7)
+    g = torch.Generator().manual_seed(0)
+    audio = 0.1 * torch.randn(B, N_SAMPLES, generator=g)
+    labels = O.synth_labels(bs, 10, N_FRAMES_OUT, seed=5)
+    tr = O.OracleTrainer(sd, batch_sizes=bs)
+
+    def draws():
+        mix = dict(c_weak=float(np.random.beta(0.2, 0.2)), perm_weak=torch.randperm(bs[1]),
+                   c_strong=float(np.random.beta(0.2, 0.2)), perm_strong=torch.randperm(bs[0]))
+        augs, drops = [], []
+        for _ in range(2):
+            fb = O.specaug_bounds(torch.rand(B), torch.rand(B), 10, 128)
+            tb = O.specaug_bounds(torch.rand(B), torch.rand(B), 5, 626)
+            augs.append(dict(f=fb, t=tb))
+            shapes = [(B, 16, 626, 128), (B, 32, 313, 64), (B, 64, 156, 32), (B, 128, 156, 16), (B, 128, 156, 8),
+                      (B, 128, 156, 4), (B, 128, 156, 2), (B, 156, 256)]
+            drops.append([(torch.rand(s) >= 0.5).float() for s in shapes])
+        return mix, augs, drops
+
+    # tiny warm-up (thread pool, allocator), not timed
+    warm = O.OracleTrainer(sd, batch_sizes=(1, 1, 2))
+    tot, _ = warm.training_step(audio[:4, :16000], O.synth_labels((1, 1, 2), 10, 15, seed=1))
+    warm.optimizer_step(tot)
+    t0 = time.perf_counter()
+    mix, augs, drops = draws()
+    tot, _ = tr.training_step(audio, labels, mix=mix, aug_s=augs[0], aug_t=augs[1], drop_s=drops[0], drop_t=drops[1])
+    tr.optimizer_step(tot)
+    dt = time.perf_counter() - t0
+    return {"value": B / dt, "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "1 full oracle training step (mel+mixup+student/teacher fwd+losses+EMA+bwd+Adam), batch 12 (3/3/6) of "
+                      "10 s clips, dropout+SpecAugment on, fp32 torch CPU, %.2f s wall" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from desed_task_amd import _lib
+    from desed_task_amd.arena import FusedAdam
+    from desed_task_amd.launcher import StepDriver, init_distributed
+    from desed_task_amd.nnet.CRNN import CRNN
+    from desed_task_amd.sed_trainer import SEDTask4
+    from desed_task_amd.utils.schedulers import ExponentialWarmup
+
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    dev = torch.device("cuda", local)
+    torch.manual_seed(1234 + rank); np.random.seed(1234 + rank); random.seed(1234 + rank)
+
+    config = recipe_config()
+    student = CRNN(**config["net"]).to(dev)
+    if world > 1:                                   # identical initial weights on every rank
+        dist.broadcast(student.arena.flat, src=0)
+    opt = FusedAdam(student.parameters(), lr=1e-3, betas=(0.9, 0.999), arena=student.arena)
+    sched = {"scheduler": ExponentialWarmup(opt, 1e-3, 50 * 118), "interval": "step"}
+
+    class Enc:
+        labels = list(range(10))
+    task = SEDTask4(config, Enc(), student, opt=opt, scheduler=sched).to(dev)
+    opt.arena = task.sed_student.arena
+    task.train()
+    driver = StepDriver(task, world_size=world)
+    audio, labels = synthetic_batch(dev, 1234 + rank)
+
+    def one_step(i):
+        driver.run_step((audio, labels.clone(), None, None), i)
+
+    for i in range(args.warmup):
+        one_step(i)
+    timer = KernelTimer({"sed_conv3x3"})
+    timer.wrap(_lib.get())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.unwrap()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(task.logged["train/student/loss_strong"])
+    if rank != 0:
+        return
+
+    summ = timer.summary()
+    dom_key, dom = None, None
+    for key, (n, mean_ms, tot_ms) in summ.items():
+        if dom is None or tot_ms > dom[2]:
+            dom_key, dom = key, (n, mean_ms, tot_ms)
+    roofline = None
+    if dom_key is not None:
+        fl = conv_flops(dom_key)
+        achieved = fl / (dom[1] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv3x3_kernel<CIN=%d,COUT=%d> (B,T,F)=(%d,%d,%d) f32 MFMA 32x32x2" %
+                    (dom_key[4], dom_key[5], dom_key[1], dom_key[2], dom_key[3]),
+                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_timed": dom[0], "avg_launch_ms": round(dom[1], 4),
+                    "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
+                    "conv_share_of_step": round(sum(v[2] for v in summ.values()) / (dt * 1e3), 3)}
+    clips = sum(BATCH) * world * args.steps
+    out = {
+        "metric": "10s-clips/sec CRNN mean-teacher train @batch48",
+        "value": round(clips / dt, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "dcase2023 CRNN mean-teacher train step, 128-mel 10s@16kHz, batch 48/GPU (12 strong/12 weak/24 "
+                               "unlabelled), dropout+SpecAugment+mixup on, fp32 (exact-f32 MFMA)",
+                   "global_batch": sum(BATCH) * world, "parallelism": "dp%d" % world, "last_loss_strong": round(loss_val, 5)},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
