@@ -90,3 +90,5 @@ __device__ __forceinline__ bool sed_keep(uint32_t idx, uint32_t seed, uint32_t t
 }
 
 __device__ __forceinline__ float sed_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh via one exp: 1 - 2/(e^{2x}+1); abs error < 1e-7 (saturates correctly at +-1)
+__device__ __forceinline__ float sed_tanh(float x) { return 1.0f - 2.0f / (expf(2.0f * x) + 1.0f); }

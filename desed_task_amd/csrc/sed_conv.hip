@@ -9,8 +9,9 @@
 // output channel; bn_finalize reduces them in double and produces mean / invstd / scale / shift and
 // the running-stat update (BatchNorm2d eps=1e-3, momentum=0.99, CNN.py:76).
 //
-// Workgroup = 256 threads = 4 waves; block tile = 128 output pixels (TR x TF patch) x all COUT;
-// each wave owns 32 pixels x COUT (COUT/32 accumulators of 16 VGPRs).  K loop = (cin chunk of <=32)
+// Workgroup = 4 (M) x WN (N) waves; block tile = 128 output pixels (TR x TF patch) x all COUT; WN = 2 for
+// COUT >= 64 (8 waves = 2 per SIMD, so one wave's LDS operand reads hide under the other's 64-cycle MFMAs);
+// each wave owns 32 pixels x COUT/WN (accumulators of 16 VGPRs per 32 channels).  K loop = (cin chunk of <=32)
 // x 9 taps: the halo patch of the chunk sits in LDS (row stride CK+1 dwords: conflict-free A reads),
 // the tap's CK x COUT weight slab is double-buffered in LDS and prefetched through registers while
 // the previous tap's MFMAs run; one barrier per tap.
@@ -44,6 +45,8 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // generic 3x3 conv, implicit GEMM (also used for dgrad with flipped/transposed weights)
 // ---------------------------------------------------------------------------------------------
+#define CONV_THREADS(COUT) ((COUT) >= 64 ? 512 : 256)
+
 template <int CIN, int COUT, int TF>
 struct ConvCfg {
     static constexpr int TR = 128 / TF;
@@ -52,22 +55,26 @@ struct ConvCfg {
     static constexpr int CKP = CK + 1;
     static constexpr int NCH = CIN / CK;
     static constexpr int NT = (COUT + 31) / 32;
+    static constexpr int WN = NT >= 2 ? 2 : 1;          // waves along N: 8-wave workgroups for COUT >= 64
+    static constexpr int NTW = NT / WN;                 // accumulator tiles per wave
+    static constexpr int THREADS = 256 * WN;
+    static_assert(THREADS == CONV_THREADS(COUT), "launch bounds");
     static constexpr int WCH = CK * COUT;
     static constexpr int PATCH_F = (PP * CKP + 3) & ~3;
     static constexpr int SMEM = (PATCH_F + 2 * WCH) * 4;
 };
 
 template <int CIN, int COUT, int TF, bool STATS>
-__global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
+__global__ __launch_bounds__(CONV_THREADS(COUT)) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       float* __restrict__ partial, int B, int T, int F) {
     using Cfg = ConvCfg<CIN, COUT, TF>;
     constexpr int TR = Cfg::TR, PW = Cfg::PW, PP = Cfg::PP, CK = Cfg::CK, CKP = Cfg::CKP, NCH = Cfg::NCH, NT = Cfg::NT,
-                  WCH = Cfg::WCH;
+                  WCH = Cfg::WCH, NTW = Cfg::NTW, THREADS = Cfg::THREADS;
     SED_DYN_SMEM(smem);
     float* patch = (float*)smem;
     float* wbuf = patch + Cfg::PATCH_F;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3, wn = tid >> 8, lo = lane & 31, hi = lane >> 5;
     const int ftiles = F / TF, ttiles = (T + TR - 1) / TR;
     const int bid = blockIdx.x;
     const int ft = bid % ftiles, tt = (bid / ftiles) % ttiles, b = bid / (ftiles * ttiles);
@@ -75,17 +82,17 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     const int p = 32 * w + lo;
     const int abase = ((p / TF) * PW + (p % TF)) * CKP + hi;
 
-    f32x16 acc[NT];
+    f32x16 acc[NTW];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x16_zero();
+    for (int nt = 0; nt < NTW; ++nt) acc[nt] = f32x16_zero();
 
-    constexpr int WV = (WCH / 4 + 255) / 256;
+    constexpr int WV = (WCH / 4 + THREADS - 1) / THREADS;
     float4 wreg[WV];
 
     for (int cc = 0; cc < NCH; ++cc) {
         // ---- stage the halo patch of this cin chunk ----
         constexpr int V = CK / 4;
-        for (int idx = tid; idx < PP * V; idx += 256) {
+        for (int idx = tid; idx < PP * V; idx += THREADS) {
             const int pix = idx / V, v = idx - pix * V;
             const int i = pix / PW, j = pix - i * PW;
             const int t = t0 - 1 + i, f = f0 - 1 + j;
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
             const float4* src = (const float4*)(Wp + ((size_t)0 * CIN + cc * CK) * COUT);
 #pragma unroll
             for (int i = 0; i < WV; ++i) {
-                const int idx = tid + 256 * i;
+                const int idx = tid + THREADS * i;
                 if (idx < WCH / 4) ((float4*)wbuf)[idx] = src[idx];
             }
         }
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
                 const float4* src = (const float4*)(Wp + ((size_t)(tap + 1) * CIN + cc * CK) * COUT);
 #pragma unroll
                 for (int i = 0; i < WV; ++i) {
-                    const int idx = tid + 256 * i;
+                    const int idx = tid + THREADS * i;
                     if (idx < WCH / 4) wreg[i] = src[idx];
                 }
             }
@@ -121,8 +128,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
             for (int k = 0; k < CK; k += 2) {
                 const float av = ap[k];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float bv = (COUT >= 32 || lo < COUT) ? wb[(k + hi) * COUT + nt * 32 + lo] : 0.f;
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const float bv = (COUT >= 32 || lo < COUT) ? wb[(k + hi) * COUT + (wn * NTW + nt) * 32 + lo] : 0.f;
                     acc[nt] = mfma32(av, bv, acc[nt]);
                 }
             }
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
                 float4* dst = (float4*)(wbuf + ((tap + 1) & 1) * WCH);
 #pragma unroll
                 for (int i = 0; i < WV; ++i) {
-                    const int idx = tid + 256 * i;
+                    const int idx = tid + THREADS * i;
                     if (idx < WCH / 4) dst[idx] = wreg[i];
                 }
             }
@@ -140,8 +147,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     // ---- epilogue: bias, store, per-channel partial statistics ----
     float* red = wbuf;   // free after the last barrier: [4 waves][2][NT*32]
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int co = nt * 32 + lo;
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int co = (wn * NTW + nt) * 32 + lo;
         const float bv = (bias != nullptr && co < COUT) ? bias[co] : 0.f;
         float s = 0.f, s2 = 0.f;
 #pragma unroll
@@ -183,10 +190,10 @@ static int launch_conv(const float* x, const float* Wp, const float* bias, float
     const int nblk = B * ((T + Cfg::TR - 1) / Cfg::TR) * (F / TF);
     if (partial) {
         SED_MAX_SMEM((conv3x3_kernel<CIN, COUT, TF, true>), Cfg::SMEM);
-        SED_LAUNCH((conv3x3_kernel<CIN, COUT, TF, true>), dim3(nblk), dim3(256), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
+        SED_LAUNCH((conv3x3_kernel<CIN, COUT, TF, true>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
     } else {
         SED_MAX_SMEM((conv3x3_kernel<CIN, COUT, TF, false>), Cfg::SMEM);
-        SED_LAUNCH((conv3x3_kernel<CIN, COUT, TF, false>), dim3(nblk), dim3(256), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
+        SED_LAUNCH((conv3x3_kernel<CIN, COUT, TF, false>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
     }
     return sed_check_launch();
 }
@@ -470,57 +477,72 @@ extern "C" int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float
 
 // ---------------------------------------------------------------------------------------------
 // layer-0 weight gradient: dW[co][tap] = sum_p x[p + tap] * dy[p][co], CIN = 1, COUT = 16.
-// MFMA form: A[i = tap (9 of 32)][k = pixel], B[k = pixel][j = co (16 of 32)]; one wave per K slice.
+// K = 9 taps x 16 channels is no dense contraction: direct VALU, 144 accumulators per thread.  Same 16 x F
+// LDS tile as the forward (SpecAugment predicate fused); each thread walks pixels of its tile, dy is read
+// once (64 B per pixel, coalesced across lanes); one wave-shuffle reduction + 144 atomics per workgroup.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const int* __restrict__ bounds,
-                                                          const float* __restrict__ dy, float* __restrict__ dW, int B, int T, int F) {
-    const int tid = threadIdx.x, lane = tid & 63, lo = lane & 31, hi = lane >> 5;
-    const int npix = B * T * F;
-    const int wave_global = blockIdx.x * 4 + (tid >> 6), nwaves = gridDim.x * 4;
-    const int da = lo / 3 - 1, db = lo % 3 - 1;            // tap of this lane's A row (valid for lo < 9)
-    f32x16 acc = f32x16_zero();
-    // 8 pixels (4 MFMA k-steps) per iteration: issue all loads, then the MFMAs
-    for (int p0 = wave_global * 8; p0 < npix; p0 += nwaves * 8) {
-        float av[4], bv[4];
+                                                          const float* __restrict__ dy, float* __restrict__ dW, int B, int T, int F,
+                                                          int tiles_t) {
+    __shared__ float tile[(C0_TR + 2) * (128 + 2)];
+    __shared__ float red[4][144];
+    const int tid = threadIdx.x, PW = F + 2;
+    float acc[144];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int p = p0 + 2 * u + hi;
-            av[u] = 0.f; bv[u] = 0.f;
-            if (p < npix) {
-                const int f = p % F, t = (p / F) % T, bb = p / (F * T);
-                if (lo < 9) {
-                    const int t2 = t + da, f2 = f + db;
-                    if (t2 >= 0 && t2 < T && f2 >= 0 && f2 < F) {
-                        float v = x[((size_t)bb * T + t2) * F + f2];
-                        if (bounds) {
-                            const int* bd = bounds + 4 * bb;
-                            if ((f2 >= bd[0] && f2 < bd[1]) || (t2 >= bd[2] && t2 < bd[3])) v = 0.f;
-                        }
-                        av[u] = v;
+    for (int i = 0; i < 144; ++i) acc[i] = 0.f;
+    const int ntiles = B * tiles_t;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int b = tl / tiles_t, t0 = (tl - b * tiles_t) * C0_TR;
+        int mf0 = 0, mf1 = 0, mt0 = 0, mt1 = 0;
+        if (bounds) { mf0 = bounds[4 * b]; mf1 = bounds[4 * b + 1]; mt0 = bounds[4 * b + 2]; mt1 = bounds[4 * b + 3]; }
+        __syncthreads();
+        for (int idx = tid; idx < (C0_TR + 2) * PW; idx += 256) {
+            const int i = idx / PW, j = idx - i * PW;
+            const int t = t0 - 1 + i, f = j - 1;
+            float v = 0.f;
+            if (t >= 0 && t < T && f >= 0 && f < F) {
+                v = x[((size_t)b * T + t) * F + f];
+                if ((f >= mf0 && f < mf1) || (t >= mt0 && t < mt1)) v = 0.f;
+            }
+            tile[idx] = v;
+        }
+        __syncthreads();
+        for (int p = tid; p < C0_TR * F; p += 256) {
+            const int pr = p / F, pc = p - pr * F, t = t0 + pr;
+            if (t < T) {
+                const float4* g4 = (const float4*)(dy + (((size_t)b * T + t) * F + pc) * 16);
+                float g[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float4 v = g4[q]; g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w; }
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 3; ++bb) {
+                        const float xv = tile[(pr + a) * PW + pc + bb];
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) acc[c * 9 + a * 3 + bb] = fmaf(xv, g[c], acc[c * 9 + a * 3 + bb]);
                     }
-                }
-                if (lo < 16) bv[u] = dy[(size_t)p * 16 + lo];
             }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = mfma32(av[u], bv[u], acc);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int tap = mfma32_row(r, lane);
-        if (tap < 9 && lo < 16) atomicAdd(dW + lo * 9 + tap, acc[r]);
+    for (int i = 0; i < 144; ++i) {
+        const float v = wave_sum(acc[i]);
+        if ((tid & 63) == 0) red[tid >> 6][i] = v;
     }
+    __syncthreads();
+    if (tid < 144) atomicAdd(dW + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
 }
 // dW (16,1,3,3) PyTorch layout, accumulated with atomics (zeroed here).
 extern "C" int sed_conv0_wgrad(const float* x, const int* bounds, const float* dy, float* dW, int B, int T, int F, int COUT,
                                void* stream) {
-    if (COUT != 16) return SED_ERR_UNSUPPORTED;
+    if (COUT != 16 || F > 128 || F < 1) return SED_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(dW, 0, 16 * 9 * sizeof(float), s) != hipSuccess) return SED_ERR_LAUNCH;
-    const int npix = B * T * F;
-    int grid = (npix + 8191) / 8192;
-    if (grid > 2048) grid = 2048;
-    if (grid < 1) grid = 1;
-    SED_LAUNCH(conv0_wgrad_kernel, dim3(grid), dim3(256), 0, s, x, bounds, dy, dW, B, T, F);
+    if (B <= 0 || T <= 0) return SED_OK;
+    const int tiles_t = (T + C0_TR - 1) / C0_TR;
+    int grid = B * tiles_t;
+    if (grid > 1024) grid = 1024;
+    SED_LAUNCH(conv0_wgrad_kernel, dim3(grid), dim3(256), 0, s, x, bounds, dy, dW, B, T, F, tiles_t);
     return sed_check_launch();
 }

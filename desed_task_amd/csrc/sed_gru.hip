@@ -90,6 +90,113 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     }
 }
 
+// Vectorised variant (16-byte global loads, next K tile prefetched into registers under the MFMAs).
+// Requires 16-byte aligned bases, lda/ldb % 4 == 0 and the contiguous extent of each operand % 4 == 0.
+template <int TA, int TB, int NTN>
+__global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                       const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K,
+                                                       int lda, int ldb, int ldc, int k_per_slice, int atomic) {
+    constexpr int BM = 128, BN = 32 * NTN, BK = 32, AP = BK + 1, BNS = BN + 4;
+    constexpr int AV = BM * BK / 4 / 256, BV = BK * BN / 4 / 256;     // float4 per thread per tile
+    __shared__ float As[BM * AP];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BNS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * k_per_slice, kend = min(K, kbeg + k_per_slice);
+    f32x16 acc[NTN];
+#pragma unroll
+    for (int i = 0; i < NTN; ++i) acc[i] = f32x16_zero();
+    float4 ra[AV], rb[BV];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < AV; ++u) {
+            const int i = tid + 256 * u;
+            if (TA == 0) {
+                const int m = i / (BK / 4), kq = i % (BK / 4);
+                const int gm = m0 + m, gk = k0 + 4 * kq;
+                ra[u] = (gm < M && gk < kend) ? *(const float4*)(A + (size_t)gm * lda + gk) : zero4;
+            } else {
+                const int k = i / (BM / 4), mq = i % (BM / 4);
+                const int gm = m0 + 4 * mq, gk = k0 + k;
+                ra[u] = (gm < M && gk < kend) ? *(const float4*)(A + (size_t)gk * lda + gm) : zero4;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BV; ++u) {
+            const int i = tid + 256 * u;
+            if (TB == 0) {
+                const int k = i / (BN / 4), nq = i % (BN / 4);
+                const int gn = n0 + 4 * nq, gk = k0 + k;
+                rb[u] = (gn < N && gk < kend) ? *(const float4*)(Bm + (size_t)gk * ldb + gn) : zero4;
+            } else {
+                const int n = i / (BK / 4), kq = i % (BK / 4);
+                const int gn = n0 + n, gk = k0 + 4 * kq;
+                rb[u] = (gn < N && gk < kend) ? *(const float4*)(Bm + (size_t)gn * ldb + gk) : zero4;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < AV; ++u) {
+            const int i = tid + 256 * u;
+            if (TA == 0) {
+                const int m = i / (BK / 4), kq = i % (BK / 4);
+                float* d = As + m * AP + 4 * kq;
+                d[0] = ra[u].x; d[1] = ra[u].y; d[2] = ra[u].z; d[3] = ra[u].w;
+            } else {
+                const int k = i / (BM / 4), mq = i % (BM / 4);
+                float* d = As + (4 * mq) * AP + k;
+                d[0] = ra[u].x; d[AP] = ra[u].y; d[2 * AP] = ra[u].z; d[3 * AP] = ra[u].w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BV; ++u) {
+            const int i = tid + 256 * u;
+            if (TB == 0) {
+                const int k = i / (BN / 4), nq = i % (BN / 4);
+                *(float4*)(Bs + k * BNS + 4 * nq) = rb[u];
+            } else {
+                const int n = i / (BK / 4), kq = i % (BK / 4);
+                float* d = Bs + (4 * kq) * BNS + n;
+                d[0] = rb[u].x; d[BNS] = rb[u].y; d[2 * BNS] = rb[u].z; d[3 * BNS] = rb[u].w;
+            }
+        }
+    };
+
+    if (kbeg < kend) load_tile(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();                 // everyone finished reading the previous tile
+        store_tile();
+        __syncthreads();
+        if (k0 + BK < kend) load_tile(k0 + BK);
+        const float* ap = As + (32 * w + lo) * AP + hi;
+#pragma unroll
+        for (int k = 0; k < BK; k += 2) {
+            const float av = ap[k];
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) acc[nt] = mfma32(av, Bs[(k + hi) * BNS + nt * 32 + lo], acc[nt]);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int gn = n0 + nt * 32 + lo;
+        if (gn < N) {
+            const float bv = (bias != nullptr && blockIdx.z == 0) ? bias[gn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + 32 * w + mfma32_row(r, lane);
+                if (gm < M) {
+                    float* dst = Cm + (size_t)gm * ldc + gn;
+                    const float v = acc[nt][r] + bv;
+                    if (atomic) atomicAdd(dst, v); else *dst = v;
+                }
+            }
+        }
+    }
+}
+
 // C[M][N] = opA(A)[M][K] * opB(B)[K][N] + bias.  accumulate != 0 adds into C (atomics); split_k > 1 requires
 // the caller to have zeroed C (or accumulate).  Leading dimensions are in floats.
 extern "C" int sed_gemm(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
@@ -102,6 +209,12 @@ extern "C" int sed_gemm(const float* A, const float* Bm, const float* bias, floa
     const int atomic = (split_k > 1 || accumulate) ? 1 : 0;
     const int ntn = N > 64 ? 4 : 2;
     dim3 grid((N + 32 * ntn - 1) / (32 * ntn), (M + 127) / 128, split_k);
+    const bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)Bm % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 &&
+                     ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0) && kps % 4 == 0;
+#define GEMMV_CASE(ta, tb, nn) \
+    if (vec && transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_vec_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic); return sed_check_launch(); }
+    GEMMV_CASE(0, 0, 2) GEMMV_CASE(0, 0, 4) GEMMV_CASE(0, 1, 2) GEMMV_CASE(0, 1, 4) GEMMV_CASE(1, 0, 2) GEMMV_CASE(1, 0, 4)
+#undef GEMMV_CASE
 #define GEMM_CASE(ta, tb, nn) \
     if (transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic); return sed_check_launch(); }
     GEMM_CASE(0, 0, 2) GEMM_CASE(0, 0, 4) GEMM_CASE(0, 1, 2) GEMM_CASE(0, 1, 4) GEMM_CASE(1, 0, 2) GEMM_CASE(1, 0, 4)
@@ -154,10 +267,21 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
     float hprev = 0.f;
     __syncthreads();
     int cur = 0;
+    // software prefetch: the next step's input projections are loaded one step ahead (HBM latency off the chain)
+    float gr, gz, gn;
+    {
+        const int t = dir ? T - 1 : 0;
+        const float* g = gi + (((size_t)b * T + t) * 2 + dir) * 3 * H;
+        gr = g[j]; gz = g[H + j]; gn = g[2 * H + j];
+    }
     for (int step = 0; step < T; ++step) {
         const int t = dir ? T - 1 - step : step;
-        const float* g = gi + (((size_t)b * T + t) * 2 + dir) * 3 * H;
-        const float gr = g[j], gz = g[H + j], gn = g[2 * H + j];
+        float ngr = 0.f, ngz = 0.f, ngn = 0.f;
+        if (step + 1 < T) {
+            const int tn = dir ? t - 1 : t + 1;
+            const float* g = gi + (((size_t)b * T + tn) * 2 + dir) * 3 * H;
+            ngr = g[j]; ngz = g[H + j]; ngn = g[2 * H + j];
+        }
         const float* hv = hbuf[cur] + half * KH;
         float ar = 0.f, az = 0.f, an = 0.f;
 #pragma unroll
@@ -172,9 +296,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
         const float r = sed_sigmoid(gr + ar + br);
         const float z = sed_sigmoid(gz + az + bz);
         const float hn = an + bn;
-        const float n = tanhf(gn + r * hn);
+        const float n = sed_tanh(gn + r * hn);
         const float hnew = (1.0f - z) * n + z * hprev;
         hprev = hnew;
+        gr = ngr; gz = ngz; gn = ngn;
         if (half == 0) {
             hbuf[cur ^ 1][j] = hnew;
             out[((size_t)b * T + t) * 2 * H + dir * H + j] = hnew;
@@ -220,14 +345,31 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
     }
     float dh_carry = 0.f;
     int cur = 0;
-    for (int step = T - 1; step >= 0; --step) {
-        const int t = dir ? T - 1 - step : step;           // time index processed at forward step `step`
-        const int tp = dir ? t + 1 : t - 1;                // time index of the previous hidden state
+    // software prefetch of the next (earlier) step's operands
+    float r, z, n, hn, hp, dout_v;
+    {
+        const int step = T - 1;
+        const int t = dir ? T - 1 - step : step, tp = dir ? t + 1 : t - 1;
         const size_t bt = (size_t)b * T + t;
         const float* sv = saved + (bt * 2 + dir) * 4 * H;
-        const float r = sv[k], z = sv[H + k], n = sv[2 * H + k], hn = sv[3 * H + k];
-        const float hp = step > 0 ? out[((size_t)b * T + tp) * 2 * H + dir * H + k] : 0.f;
-        const float dh = dout[bt * 2 * H + dir * H + k] + dh_carry;
+        r = sv[k]; z = sv[H + k]; n = sv[2 * H + k]; hn = sv[3 * H + k];
+        hp = step > 0 ? out[((size_t)b * T + tp) * 2 * H + dir * H + k] : 0.f;
+        dout_v = dout[bt * 2 * H + dir * H + k];
+    }
+    for (int step = T - 1; step >= 0; --step) {
+        const int t = dir ? T - 1 - step : step;           // time index processed at forward step `step`
+        const size_t bt = (size_t)b * T + t;
+        float nr = 0.f, nz = 0.f, nn = 0.f, nhn = 0.f, nhp = 0.f, ndout = 0.f;
+        if (step > 0) {
+            const int s2 = step - 1;
+            const int t2 = dir ? T - 1 - s2 : s2, tp2 = dir ? t2 + 1 : t2 - 1;
+            const size_t bt2 = (size_t)b * T + t2;
+            const float* sv = saved + (bt2 * 2 + dir) * 4 * H;
+            nr = sv[k]; nz = sv[H + k]; nn = sv[2 * H + k]; nhn = sv[3 * H + k];
+            nhp = s2 > 0 ? out[((size_t)b * T + tp2) * 2 * H + dir * H + k] : 0.f;
+            ndout = dout[bt2 * 2 * H + dir * H + k];
+        }
+        const float dh = dout_v + dh_carry;
         const float dn = dh * (1.0f - z);
         const float dzg = dh * (hp - n);
         const float da_n = dn * (1.0f - n * n);
@@ -244,20 +386,22 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
         }
         __syncthreads();
         const float* gv = gbuf[cur] + half * KH;
-        float acc = 0.f;
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;     // three independent chains (FMA latency)
 #pragma unroll
         for (int jj = 0; jj < KH; jj += 4) {
             const float4 a = *(const float4*)(gv + jj);
             const float4 c = *(const float4*)(gv + H + jj);
             const float4 d = *(const float4*)(gv + 2 * H + jj);
-            acc = fmaf(wr[jj], a.x, acc); acc = fmaf(wz[jj], c.x, acc); acc = fmaf(wn[jj], d.x, acc);
-            acc = fmaf(wr[jj + 1], a.y, acc); acc = fmaf(wz[jj + 1], c.y, acc); acc = fmaf(wn[jj + 1], d.y, acc);
-            acc = fmaf(wr[jj + 2], a.z, acc); acc = fmaf(wz[jj + 2], c.z, acc); acc = fmaf(wn[jj + 2], d.z, acc);
-            acc = fmaf(wr[jj + 3], a.w, acc); acc = fmaf(wz[jj + 3], c.w, acc); acc = fmaf(wn[jj + 3], d.w, acc);
+            acc0 = fmaf(wr[jj], a.x, acc0); acc1 = fmaf(wz[jj], c.x, acc1); acc2 = fmaf(wn[jj], d.x, acc2);
+            acc0 = fmaf(wr[jj + 1], a.y, acc0); acc1 = fmaf(wz[jj + 1], c.y, acc1); acc2 = fmaf(wn[jj + 1], d.y, acc2);
+            acc0 = fmaf(wr[jj + 2], a.z, acc0); acc1 = fmaf(wz[jj + 2], c.z, acc1); acc2 = fmaf(wn[jj + 2], d.z, acc2);
+            acc0 = fmaf(wr[jj + 3], a.w, acc0); acc1 = fmaf(wz[jj + 3], c.w, acc1); acc2 = fmaf(wn[jj + 3], d.w, acc2);
         }
+        float acc = (acc0 + acc1) + acc2;
         acc += __shfl_xor(acc, 1);
         dh_carry = dh * z + acc;
         cur ^= 1;
+        r = nr; z = nz; n = nn; hn = nhn; hp = nhp; dout_v = ndout;
     }
 }
 extern "C" int sed_gru_bwd(const float* dout, const float* out, const float* saved, const float* whh0, const float* whh1,

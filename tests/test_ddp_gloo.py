@@ -1,0 +1,83 @@
+"""Data-parallel path on CPU: world_size 2, gloo, kernels through the fiber emulator.
+Checks the StepDriver contract: each rank runs the single-GPU step on its own clips, the flat gradient arena is
+summed with ONE all-reduce, the 1/world factor is folded into Adam, and the student stays bit-identical
+across ranks while BN statistics stay rank-local."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from tests.emu_support import bind_emulator
+    bind_emulator()
+    from oracle import sed_oracle as O
+    from tests import parity_cases as P
+    from desed_task_amd.launcher import StepDriver, init_distributed
+    r, _, w = init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    bs, n_samp = (1, 1, 1), 8192 + 1024
+    sd = O.make_state_dict(seed=7)
+    task = P.build_task("cpu", bs, sd, dropout=0.0, specaug=False, rampup=100)
+    driver = StepDriver(task, world_size=world)
+    audio = O.synth_audio(3, n_samp, seed=100 + rank)           # different clips per rank
+    n_out = (1 + n_samp // 256) // 4
+    labels = O.synth_labels(bs, 10, n_out, seed=5 + rank)
+    import random
+    random.seed(4); np.random.seed(7); torch.manual_seed(7)     # same mixup gate everywhere, draws rank-local anyway
+    # local gradient (before the exchange), for the averaging check
+    loss = task.training_step((audio.clone(), labels.clone(), None, None), 0)
+    task.opt.zero_grad(set_to_none=True)
+    loss.backward()
+    local = task.sed_student.arena.gather_grads().clone()
+    task.opt.zero_grad(set_to_none=True)
+    # the real step
+    random.seed(4); np.random.seed(7); torch.manual_seed(7)
+    task2 = P.build_task("cpu", bs, sd, dropout=0.0, specaug=False, rampup=100)
+    driver = StepDriver(task2, world_size=world)
+    driver.run_step((audio.clone(), labels.clone(), None, None), 0)
+    arena = task2.sed_student.arena
+    summed = arena.flat_grad.clone()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    flats = [torch.zeros_like(arena.flat) for _ in range(world)]
+    dist.all_gather(flats, arena.flat.clone())
+    rm = task2.sed_student.cnn.cnn.batchnorm0.running_mean.clone()
+    rms = [torch.zeros_like(rm) for _ in range(world)]
+    dist.all_gather(rms, rm)
+    if rank == 0:
+        torch.save(dict(summed=summed, gathered=gathered, flats=flats, rms=rms, init=None), os.path.join(out_dir, "r0.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_gradient_average(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    d = torch.load(os.path.join(str(tmp_path), "r0.pt"))
+    g0, g1 = d["gathered"]
+    assert (g0 - g1).abs().max() > 1e-6                                    # ranks really saw different data
+    ref_sum = g0 + g1
+    assert (d["summed"] - ref_sum).abs().max().item() <= 1e-6 * ref_sum.abs().max().item() + 1e-9
+    f0, f1 = d["flats"]
+    assert torch.equal(f0, f1)                                             # student bit-identical across ranks
+    assert not torch.equal(d["rms"][0], d["rms"][1])                       # BN running stats stay rank-local

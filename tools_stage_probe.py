@@ -1,0 +1,51 @@
+"""Per-stage wall-clock probe of the training step on the GPU (diagnostics; prints progressively)."""
+import sys, time, os
+sys.path.insert(0, '.')
+import torch, numpy as np, random
+import bench
+from desed_task_amd import _lib
+from desed_task_amd.arena import FusedAdam
+from desed_task_amd.launcher import StepDriver
+from desed_task_amd.nnet.CRNN import CRNN
+from desed_task_amd.sed_trainer import SEDTask4
+from desed_task_amd.utils.schedulers import ExponentialWarmup
+
+def log(*a):
+    print(*a, flush=True)
+
+dev = torch.device("cuda", 0)
+config = bench.recipe_config()
+t0 = time.time()
+student = CRNN(**config["net"]).to(dev)
+opt = FusedAdam(student.parameters(), lr=1e-3, arena=student.arena)
+sched = {"scheduler": ExponentialWarmup(opt, 1e-3, 5900), "interval": "step"}
+class Enc: labels = list(range(10))
+task = SEDTask4(config, Enc(), student, opt=opt, scheduler=sched).to(dev)
+opt.arena = task.sed_student.arena
+task.train()
+audio, labels = bench.synthetic_batch(dev, 1)
+torch.cuda.synchronize(); log("setup %.2fs" % (time.time() - t0))
+
+# wrap every C call with sync timing
+lib = _lib.get()
+orig = lib.call
+acc = {}
+def timed(name, *args):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    orig(name, *args)
+    torch.cuda.synchronize(); d = time.perf_counter() - t
+    ints = tuple(a for a in args if isinstance(a, int) and 0 < a < 100000)[:6]
+    acc.setdefault((name,) + ints, []).append(d)
+    if d > 0.05: log("SLOW %s %s %.3fs" % (name, ints, d))
+lib.call = timed
+driver = StepDriver(task, 1, ema_side_stream=False)
+for i in range(3):
+    t = time.perf_counter()
+    driver.run_step((audio, labels.clone(), None, None), i)
+    torch.cuda.synchronize()
+    log("step %d: %.3f s" % (i, time.perf_counter() - t))
+rows = sorted(((np.mean(v[1:]) if len(v) > 1 else v[0]) * 1e3 * (len(v) / 3.0), k, len(v) // 3, np.mean(v[1:] if len(v) > 1 else v) * 1e3) for k, v in acc.items())
+tot = sum(r[0] for r in rows)
+log("per-step sum of synchronous kernel-call times: %.2f ms" % tot)
+for ms, k, n, each in reversed(rows):
+    log("%8.3f ms/step  x%-2d  %8.3f ms each  %s" % (ms, n, each, k))
