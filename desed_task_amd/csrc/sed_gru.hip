@@ -244,13 +244,23 @@ extern "C" int sed_colsum(const float* X, float* out, int M, int N, int ld, void
 // ---------------------------------------------------------------------------------------------
 // forward recurrence.  gi: (B, T, 2, 3H) input projections incl. b_ih; whh0/whh1: (3H, H) per direction; bhh0/bhh1: (3H)
 // out: (B, T, 2H) ([fwd | bwd]); saved: (B, T, 2, 4, H) = r, z, n, hn   (null in inference)
+//
+// No global memory operation sits inside the step loop: the input projections of the NEXT chunk of 8 steps are
+// fetched into registers at the start of a chunk and parked in LDS at its end, and the per-step results (h and
+// the four saved gate tensors) are collected in an LDS buffer that is flushed, coalesced, one chunk later.
+// (CDNA4's vmcnt counts stores too, so a single store in the loop would put HBM write latency on the chain.)
 // ---------------------------------------------------------------------------------------------
+#define GRU_CH 8
 __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh0,
                                                       const float* __restrict__ whh1, const float* __restrict__ bhh0,
                                                       const float* __restrict__ bhh1, float* __restrict__ out,
                                                       float* __restrict__ saved, int B, int T) {
-    constexpr int H = GRU_H, KH = H / 2;
+    constexpr int H = GRU_H, KH = H / 2, CH = GRU_CH;
+    constexpr int GI_F = CH * 3 * H, OB_F = CH * 5 * H;            // floats per chunk buffer
     __shared__ __attribute__((aligned(16))) float hbuf[2][H];
+    SED_DYN_SMEM(smem);
+    float* gis = (float*)smem;                 // [2][CH][3H]
+    float* obuf = gis + 2 * GI_F;              // [2][CH][5H] = h | r | z | n | hn
     const int tid = threadIdx.x, j = tid >> 1, half = tid & 1;
     const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const float* W = dir ? whh1 : whh0;
@@ -265,58 +275,87 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
     const float br = bhh[j], bz = bhh[H + j], bn = bhh[2 * H + j];
     if (tid < H) hbuf[0][tid] = 0.f;
     float hprev = 0.f;
-    __syncthreads();
-    int cur = 0;
-    // software prefetch: the next step's input projections are loaded one step ahead (HBM latency off the chain)
-    float gr, gz, gn;
-    {
-        const int t = dir ? T - 1 : 0;
-        const float* g = gi + (((size_t)b * T + t) * 2 + dir) * 3 * H;
-        gr = g[j]; gz = g[H + j]; gn = g[2 * H + j];
-    }
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? T - 1 - step : step;
-        float ngr = 0.f, ngz = 0.f, ngn = 0.f;
-        if (step + 1 < T) {
-            const int tn = dir ? t - 1 : t + 1;
-            const float* g = gi + (((size_t)b * T + tn) * 2 + dir) * 3 * H;
-            ngr = g[j]; ngz = g[H + j]; ngn = g[2 * H + j];
-        }
-        const float* hv = hbuf[cur] + half * KH;
-        float ar = 0.f, az = 0.f, an = 0.f;
+    const int nchunks = (T + CH - 1) / CH;
+    constexpr int GV = GI_F / 4 / 256;         // float4 of gi per thread per chunk (= 3)
+    float4 greg[GV];
+    auto load_chunk = [&](int c) {
 #pragma unroll
-        for (int k = 0; k < KH; k += 4) {
-            const float4 h4 = *(const float4*)(hv + k);
-            ar = fmaf(wr[k], h4.x, ar); az = fmaf(wz[k], h4.x, az); an = fmaf(wn[k], h4.x, an);
-            ar = fmaf(wr[k + 1], h4.y, ar); az = fmaf(wz[k + 1], h4.y, az); an = fmaf(wn[k + 1], h4.y, an);
-            ar = fmaf(wr[k + 2], h4.z, ar); az = fmaf(wz[k + 2], h4.z, az); an = fmaf(wn[k + 2], h4.z, an);
-            ar = fmaf(wr[k + 3], h4.w, ar); az = fmaf(wz[k + 3], h4.w, az); an = fmaf(wn[k + 3], h4.w, an);
-        }
-        ar += __shfl_xor(ar, 1); az += __shfl_xor(az, 1); an += __shfl_xor(an, 1);
-        const float r = sed_sigmoid(gr + ar + br);
-        const float z = sed_sigmoid(gz + az + bz);
-        const float hn = an + bn;
-        const float n = sed_tanh(gn + r * hn);
-        const float hnew = (1.0f - z) * n + z * hprev;
-        hprev = hnew;
-        gr = ngr; gz = ngz; gn = ngn;
-        if (half == 0) {
-            hbuf[cur ^ 1][j] = hnew;
-            out[((size_t)b * T + t) * 2 * H + dir * H + j] = hnew;
-            if (saved) {
-                float* sv = saved + (((size_t)b * T + t) * 2 + dir) * 4 * H;
-                sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = hn;
+        for (int u = 0; u < GV; ++u) {
+            const int e4 = tid + 256 * u, s = e4 / (3 * H / 4), q = e4 - s * (3 * H / 4);
+            const int step = c * CH + s;
+            greg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (step < T) {
+                const int t = dir ? T - 1 - step : step;
+                greg[u] = *(const float4*)(gi + (((size_t)b * T + t) * 2 + dir) * 3 * H + 4 * q);
             }
         }
-        cur ^= 1;
+    };
+    auto park_chunk = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < GV; ++u) *(float4*)(gis + (c & 1) * GI_F + 4 * (tid + 256 * u)) = greg[u];
+    };
+    auto flush_chunk = [&](int c) {
+        constexpr int PER = 5 * H / 4;         // float4 per step: 32 of h + 128 of saved
+        const float* ob = obuf + (c & 1) * OB_F;
+        for (int e4 = tid; e4 < CH * PER; e4 += 256) {
+            const int s = e4 / PER, q = e4 - s * PER;
+            const int step = c * CH + s;
+            if (step >= T) break;
+            const int t = dir ? T - 1 - step : step;
+            const float4 v = *(const float4*)(ob + s * 5 * H + 4 * q);
+            if (q < H / 4) *(float4*)(out + ((size_t)b * T + t) * 2 * H + dir * H + 4 * q) = v;
+            else if (saved) *(float4*)(saved + (((size_t)b * T + t) * 2 + dir) * 4 * H + 4 * (q - H / 4)) = v;
+        }
+    };
+    load_chunk(0);
+    park_chunk(0);
+    __syncthreads();
+    int cur = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        if (c > 0) flush_chunk(c - 1);
+        const float* gch = gis + (c & 1) * GI_F;
+        float* och = obuf + (c & 1) * OB_F;
+        const int nsteps = min(CH, T - c * CH);
+        for (int s = 0; s < nsteps; ++s) {
+            const float gr = gch[s * 3 * H + j], gz = gch[s * 3 * H + H + j], gn = gch[s * 3 * H + 2 * H + j];
+            const float* hv = hbuf[cur] + half * KH;
+            float ar = 0.f, az = 0.f, an = 0.f;
+#pragma unroll
+            for (int k = 0; k < KH; k += 4) {
+                const float4 h4 = *(const float4*)(hv + k);
+                ar = fmaf(wr[k], h4.x, ar); az = fmaf(wz[k], h4.x, az); an = fmaf(wn[k], h4.x, an);
+                ar = fmaf(wr[k + 1], h4.y, ar); az = fmaf(wz[k + 1], h4.y, az); an = fmaf(wn[k + 1], h4.y, an);
+                ar = fmaf(wr[k + 2], h4.z, ar); az = fmaf(wz[k + 2], h4.z, az); an = fmaf(wn[k + 2], h4.z, an);
+                ar = fmaf(wr[k + 3], h4.w, ar); az = fmaf(wz[k + 3], h4.w, az); an = fmaf(wn[k + 3], h4.w, an);
+            }
+            ar += __shfl_xor(ar, 1); az += __shfl_xor(az, 1); an += __shfl_xor(an, 1);
+            const float r = sed_sigmoid(gr + ar + br);
+            const float z = sed_sigmoid(gz + az + bz);
+            const float hn = an + bn;
+            const float n = sed_tanh(gn + r * hn);
+            const float hnew = (1.0f - z) * n + z * hprev;
+            hprev = hnew;
+            if (half == 0) {
+                hbuf[cur ^ 1][j] = hnew;
+                float* o = och + s * 5 * H;
+                o[j] = hnew; o[H + j] = r; o[2 * H + j] = z; o[3 * H + j] = n; o[4 * H + j] = hn;
+            }
+            cur ^= 1;
+            __syncthreads();
+        }
+        if (c + 1 < nchunks) park_chunk(c + 1);
         __syncthreads();
     }
+    flush_chunk(nchunks - 1);
 }
 extern "C" int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
                            float* out, float* saved, int B, int T, int H, void* stream) {
     if (H != GRU_H) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
-    SED_LAUNCH(gru_fwd_kernel, dim3(2 * B), dim3(256), 0, (hipStream_t)stream, gi, whh0, whh1, bhh0, bhh1, out, saved, B, T);
+    const int smem = (2 * GRU_CH * 3 * GRU_H + 2 * GRU_CH * 5 * GRU_H) * 4;
+    SED_MAX_SMEM(gru_fwd_kernel, smem);
+    SED_LAUNCH(gru_fwd_kernel, dim3(2 * B), dim3(256), smem, (hipStream_t)stream, gi, whh0, whh1, bhh0, bhh1, out, saved, B, T);
     return sed_check_launch();
 }
 
@@ -324,18 +363,22 @@ extern "C" int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1
 // backward recurrence.  dout: (B,T,2H) upstream gradient of the layer output; out/saved from the forward.
 // Produces dgi (B,T,2,3H) = dL/d(W_ih x + b_ih), dgh (B,T,2,3H) = dL/d(W_hh h + b_hh) and
 // hprev (B,T,2,H) = the hidden state each step consumed (for dW_hh = dgh^T hprev).
+// Same chunked LDS staging as the forward: nothing touches global memory inside the step loop.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                       const float* __restrict__ saved, const float* __restrict__ whh0,
-                                                      const float* __restrict__ whh1, float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ hprev_out,
-                                                      int B, int T) {
-    constexpr int H = GRU_H, KH = H / 2;
+                                                      const float* __restrict__ whh1, float* __restrict__ dgi,
+                                                      float* __restrict__ dgh, float* __restrict__ hprev_out, int B, int T) {
+    constexpr int H = GRU_H, KH = H / 2, CH = GRU_CH;
+    constexpr int IB_F = CH * 6 * H, OB_F = CH * 7 * H;
     __shared__ __attribute__((aligned(16))) float gbuf[2][3 * H];
+    SED_DYN_SMEM(smem);
+    float* ibuf = (float*)smem;                // [2][CH][6H] = r | z | n | hn | hprev | dout
+    float* obuf = ibuf + 2 * IB_F;             // [2][CH][7H] = dgi(3H) | dgh(3H) | hprev(H)
     const int tid = threadIdx.x, k = tid >> 1, half = tid & 1;
     const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const float* W = dir ? whh1 : whh0;
-    // W^T slices: for hidden unit k, the contributions of gate rows j in this thread's half
-    float wr[KH], wz[KH], wn[KH];
+    float wr[KH], wz[KH], wn[KH];              // W^T slices: contributions of gate rows j in this thread's half to unit k
 #pragma unroll
     for (int jj = 0; jj < KH; ++jj) {
         const int j = half * KH + jj;
@@ -343,71 +386,104 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
         wz[jj] = W[(size_t)(1 * H + j) * H + k];
         wn[jj] = W[(size_t)(2 * H + j) * H + k];
     }
+    const int nchunks = (T + CH - 1) / CH;
+    constexpr int IV = IB_F / 4 / 256;         // = 6 float4 per thread per chunk
+    float4 ireg[IV];
+    // chunk c covers reverse-order positions rs = c*CH .. c*CH+CH-1, forward step index = T-1-rs
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < IV; ++u) {
+            const int e4 = tid + 256 * u, s = e4 / (6 * H / 4), q = e4 - s * (6 * H / 4);
+            const int rs = c * CH + s;
+            ireg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rs < T) {
+                const int step = T - 1 - rs;
+                const int t = dir ? T - 1 - step : step, tp = dir ? t + 1 : t - 1;
+                const size_t bt = (size_t)b * T + t;
+                if (q < H) ireg[u] = *(const float4*)(saved + (bt * 2 + dir) * 4 * H + 4 * q);
+                else if (q < H + H / 4) { if (step > 0) ireg[u] = *(const float4*)(out + ((size_t)b * T + tp) * 2 * H + dir * H + 4 * (q - H)); }
+                else ireg[u] = *(const float4*)(dout + bt * 2 * H + dir * H + 4 * (q - H - H / 4));
+            }
+        }
+    };
+    auto park_chunk = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < IV; ++u) *(float4*)(ibuf + (c & 1) * IB_F + 4 * (tid + 256 * u)) = ireg[u];
+    };
+    auto flush_chunk = [&](int c) {
+        constexpr int PER = 7 * H / 4;
+        const float* ob = obuf + (c & 1) * OB_F;
+        for (int e4 = tid; e4 < CH * PER; e4 += 256) {
+            const int s = e4 / PER, q = e4 - s * PER;
+            const int rs = c * CH + s;
+            if (rs >= T) break;
+            const int step = T - 1 - rs;
+            const int t = dir ? T - 1 - step : step;
+            const size_t bt = (size_t)b * T + t;
+            const float4 v = *(const float4*)(ob + s * 7 * H + 4 * q);
+            if (q < 3 * H / 4) *(float4*)(dgi + (bt * 2 + dir) * 3 * H + 4 * q) = v;
+            else if (q < 6 * H / 4) *(float4*)(dgh + (bt * 2 + dir) * 3 * H + 4 * (q - 3 * H / 4)) = v;
+            else *(float4*)(hprev_out + (bt * 2 + dir) * H + 4 * (q - 6 * H / 4)) = v;
+        }
+    };
+    load_chunk(0);
+    park_chunk(0);
+    __syncthreads();
     float dh_carry = 0.f;
     int cur = 0;
-    // software prefetch of the next (earlier) step's operands
-    float r, z, n, hn, hp, dout_v;
-    {
-        const int step = T - 1;
-        const int t = dir ? T - 1 - step : step, tp = dir ? t + 1 : t - 1;
-        const size_t bt = (size_t)b * T + t;
-        const float* sv = saved + (bt * 2 + dir) * 4 * H;
-        r = sv[k]; z = sv[H + k]; n = sv[2 * H + k]; hn = sv[3 * H + k];
-        hp = step > 0 ? out[((size_t)b * T + tp) * 2 * H + dir * H + k] : 0.f;
-        dout_v = dout[bt * 2 * H + dir * H + k];
-    }
-    for (int step = T - 1; step >= 0; --step) {
-        const int t = dir ? T - 1 - step : step;           // time index processed at forward step `step`
-        const size_t bt = (size_t)b * T + t;
-        float nr = 0.f, nz = 0.f, nn = 0.f, nhn = 0.f, nhp = 0.f, ndout = 0.f;
-        if (step > 0) {
-            const int s2 = step - 1;
-            const int t2 = dir ? T - 1 - s2 : s2, tp2 = dir ? t2 + 1 : t2 - 1;
-            const size_t bt2 = (size_t)b * T + t2;
-            const float* sv = saved + (bt2 * 2 + dir) * 4 * H;
-            nr = sv[k]; nz = sv[H + k]; nn = sv[2 * H + k]; nhn = sv[3 * H + k];
-            nhp = s2 > 0 ? out[((size_t)b * T + tp2) * 2 * H + dir * H + k] : 0.f;
-            ndout = dout[bt2 * 2 * H + dir * H + k];
-        }
-        const float dh = dout_v + dh_carry;
-        const float dn = dh * (1.0f - z);
-        const float dzg = dh * (hp - n);
-        const float da_n = dn * (1.0f - n * n);
-        const float da_z = dzg * z * (1.0f - z);
-        const float da_r = da_n * hn * r * (1.0f - r);
-        const float dhn = da_n * r;
-        if (half == 0) {
-            gbuf[cur][k] = da_r; gbuf[cur][H + k] = da_z; gbuf[cur][2 * H + k] = dhn;
-            float* gi_o = dgi + (bt * 2 + dir) * 3 * H;
-            float* gh_o = dgh + (bt * 2 + dir) * 3 * H;
-            gi_o[k] = da_r; gi_o[H + k] = da_z; gi_o[2 * H + k] = da_n;
-            gh_o[k] = da_r; gh_o[H + k] = da_z; gh_o[2 * H + k] = dhn;
-            hprev_out[(bt * 2 + dir) * H + k] = hp;
-        }
-        __syncthreads();
-        const float* gv = gbuf[cur] + half * KH;
-        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;     // three independent chains (FMA latency)
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        if (c > 0) flush_chunk(c - 1);
+        const float* ich = ibuf + (c & 1) * IB_F;
+        float* och = obuf + (c & 1) * OB_F;
+        const int nsteps = min(CH, T - c * CH);
+        for (int s = 0; s < nsteps; ++s) {
+            const float* in = ich + s * 6 * H;
+            const float r = in[k], z = in[H + k], n = in[2 * H + k], hn = in[3 * H + k], hp = in[4 * H + k];
+            const float dh = in[5 * H + k] + dh_carry;
+            const float dn = dh * (1.0f - z);
+            const float dzg = dh * (hp - n);
+            const float da_n = dn * (1.0f - n * n);
+            const float da_z = dzg * z * (1.0f - z);
+            const float da_r = da_n * hn * r * (1.0f - r);
+            const float dhn = da_n * r;
+            if (half == 0) {
+                gbuf[cur][k] = da_r; gbuf[cur][H + k] = da_z; gbuf[cur][2 * H + k] = dhn;
+                float* o = och + s * 7 * H;
+                o[k] = da_r; o[H + k] = da_z; o[2 * H + k] = da_n;
+                o[3 * H + k] = da_r; o[4 * H + k] = da_z; o[5 * H + k] = dhn;
+                o[6 * H + k] = hp;
+            }
+            __syncthreads();
+            const float* gv = gbuf[cur] + half * KH;
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;     // three independent chains (FMA latency)
 #pragma unroll
-        for (int jj = 0; jj < KH; jj += 4) {
-            const float4 a = *(const float4*)(gv + jj);
-            const float4 c = *(const float4*)(gv + H + jj);
-            const float4 d = *(const float4*)(gv + 2 * H + jj);
-            acc0 = fmaf(wr[jj], a.x, acc0); acc1 = fmaf(wz[jj], c.x, acc1); acc2 = fmaf(wn[jj], d.x, acc2);
-            acc0 = fmaf(wr[jj + 1], a.y, acc0); acc1 = fmaf(wz[jj + 1], c.y, acc1); acc2 = fmaf(wn[jj + 1], d.y, acc2);
-            acc0 = fmaf(wr[jj + 2], a.z, acc0); acc1 = fmaf(wz[jj + 2], c.z, acc1); acc2 = fmaf(wn[jj + 2], d.z, acc2);
-            acc0 = fmaf(wr[jj + 3], a.w, acc0); acc1 = fmaf(wz[jj + 3], c.w, acc1); acc2 = fmaf(wn[jj + 3], d.w, acc2);
+            for (int jj = 0; jj < KH; jj += 4) {
+                const float4 a = *(const float4*)(gv + jj);
+                const float4 cc = *(const float4*)(gv + H + jj);
+                const float4 d = *(const float4*)(gv + 2 * H + jj);
+                acc0 = fmaf(wr[jj], a.x, acc0); acc1 = fmaf(wz[jj], cc.x, acc1); acc2 = fmaf(wn[jj], d.x, acc2);
+                acc0 = fmaf(wr[jj + 1], a.y, acc0); acc1 = fmaf(wz[jj + 1], cc.y, acc1); acc2 = fmaf(wn[jj + 1], d.y, acc2);
+                acc0 = fmaf(wr[jj + 2], a.z, acc0); acc1 = fmaf(wz[jj + 2], cc.z, acc1); acc2 = fmaf(wn[jj + 2], d.z, acc2);
+                acc0 = fmaf(wr[jj + 3], a.w, acc0); acc1 = fmaf(wz[jj + 3], cc.w, acc1); acc2 = fmaf(wn[jj + 3], d.w, acc2);
+            }
+            float acc = (acc0 + acc1) + acc2;
+            acc += __shfl_xor(acc, 1);
+            dh_carry = dh * z + acc;
+            cur ^= 1;
         }
-        float acc = (acc0 + acc1) + acc2;
-        acc += __shfl_xor(acc, 1);
-        dh_carry = dh * z + acc;
-        cur ^= 1;
-        r = nr; z = nz; n = nn; hn = nhn; hp = nhp; dout_v = ndout;
+        __syncthreads();                       // all steps of the chunk done (gbuf/obuf/ibuf reads retired)
+        if (c + 1 < nchunks) park_chunk(c + 1);
+        __syncthreads();
     }
+    flush_chunk(nchunks - 1);
 }
 extern "C" int sed_gru_bwd(const float* dout, const float* out, const float* saved, const float* whh0, const float* whh1,
                            float* dgi, float* dgh, float* hprev, int B, int T, int H, void* stream) {
     if (H != GRU_H) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
-    SED_LAUNCH(gru_bwd_kernel, dim3(2 * B), dim3(256), 0, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh, hprev, B, T);
+    const int smem = (2 * GRU_CH * 6 * GRU_H + 2 * GRU_CH * 7 * GRU_H) * 4;
+    SED_MAX_SMEM(gru_bwd_kernel, smem);
+    SED_LAUNCH(gru_bwd_kernel, dim3(2 * B), dim3(256), smem, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh, hprev, B, T);
     return sed_check_launch();
 }

@@ -13,3 +13,7 @@ def test_bigru_layer0(emu):
 
 def test_bigru_layer1(emu):
     P.case_bigru("cpu", B=1, T=5, I=256)
+
+
+def test_bigru_multi_chunk(emu):
+    P.case_bigru("cpu", B=1, T=19, I=128)        # 2 full chunks of 8 steps + a partial one
