@@ -92,3 +92,27 @@ __device__ __forceinline__ bool sed_keep(uint32_t idx, uint32_t seed, uint32_t t
 __device__ __forceinline__ float sed_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 // tanh via one exp: 1 - 2/(e^{2x}+1); abs error < 1e-7 (saturates correctly at +-1)
 __device__ __forceinline__ float sed_tanh(float x) { return 1.0f - 2.0f / (expf(2.0f * x) + 1.0f); }
+
+// Hardware-rate transcendentals for the latency-bound GRU chain: v_exp_f32 / v_rcp_f32 (1 ulp each), i.e.
+// sigmoid/tanh to ~3e-7 absolute -- far inside the parity tolerance, ~10x fewer dependent instructions than
+// the IEEE expf + division sequences.
+__device__ __forceinline__ float sed_fast_exp(float x) {
+#ifdef SED_EMU
+    return exp2f(x * 1.44269504088896341f);
+#else
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+#endif
+}
+__device__ __forceinline__ float sed_fast_rcp(float x) {
+#ifdef SED_EMU
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+__device__ __forceinline__ float sed_fast_sigmoid(float x) { return sed_fast_rcp(1.0f + sed_fast_exp(-x)); }
+__device__ __forceinline__ float sed_fast_tanh(float x) { return 1.0f - 2.0f * sed_fast_rcp(sed_fast_exp(2.0f * x) + 1.0f); }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// packed fp32 FMA (v_pk_fma_f32): two lanes-worth of FMAs per VALU issue slot
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }

@@ -134,12 +134,152 @@ static int launch_glu_fwd(const float* y, const float* stats, const float* Wg, c
     return sed_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// C = 16 (first block, 2x2 pooling): no LDS, one wave per 16-pixel tile (4 pooling windows along F) on the
+// 16x16x4 f32 MFMA.  Lane (i = l&15, g = l>>4) loads ONE float4 = pixel i, channels 4g..4g+3, and that same
+// register quad is the MFMA operand with the contraction index ordered (k-step q, lane group g) -> channel 4g+q.
+// The GEMM is computed transposed (lin^T = Wg . xn^T) so that the result lands on the lane that already holds
+// xn for the same (pixel, channels): the gate is lane-local, the 2x2 pooling is two DPP adds inside a lane quad.
+// HBM-bound: reads y once (64 B/pixel), writes 16 B/pixel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void glu16_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                        const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                        float* __restrict__ out, int B, int T, int F, uint32_t seed,
+                                                        uint32_t thr24, float dscale) {
+    constexpr int C = 16;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    float wa[4], sc[4], sh[4], bgr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        wa[q] = Wg[i * C + 4 * g + q];
+        sc[q] = stats[2 * C + 4 * g + q];
+        sh[q] = stats[3 * C + 4 * g + q];
+        bgr[q] = bg[4 * g + q];
+    }
+    const int To = T / 2, Fo = F / 2, tpr = Fo / 4, ntiles = B * To * tpr;
+    const int nwaves = gridDim.x * 4;
+    for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += nwaves) {
+        const int tr = tile % tpr, to = (tile / tpr) % To, b = tile / (tpr * To);
+        const int w = i >> 2, q = i & 3;
+        const int t = 2 * to + (q >> 1), f = 2 * (4 * tr + w) + (q & 1);
+        const size_t pix = ((size_t)b * T + t) * F + f;
+        const float4 yv = *(const float4*)(y + pix * C + 4 * g);
+        float xn[4] = {fmaf(yv.x, sc[0], sh[0]), fmaf(yv.y, sc[1], sh[1]), fmaf(yv.z, sc[2], sh[2]), fmaf(yv.w, sc[3], sh[3])};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = mfma16(wa[k], xn[k], acc);      // D[n = 4g+r][pixel i]
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float o = (acc[r] + bgr[r]) * sed_sigmoid(xn[r]);
+            const uint32_t e = (uint32_t)(pix * C + 4 * g + r);
+            o = sed_keep(e, seed, thr24) ? o * dscale : 0.f;
+            o += __shfl_xor(o, 1);
+            o += __shfl_xor(o, 2);
+            v[r] = 0.25f * o;
+        }
+        if (q == 0)
+            *(float4*)(out + (((size_t)b * To + to) * Fo + 4 * tr + w) * C + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// backward of the above: 24 MFMA 16x16x4 per 16-pixel tile (GEMM1^T, GEMM2 with e folded in through an identity
+// operand, two identity "transposes" into accumulator layout, and dWg accumulation straight from accumulator
+// registers: the accumulator layout of X is the A-operand layout of X^T with k = pixel).
+__global__ __launch_bounds__(256) void glu16_bwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                        const float* __restrict__ gout, float* __restrict__ dz,
+                                                        float* __restrict__ dWg, float* __restrict__ dbg,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int T, int F,
+                                                        uint32_t seed, uint32_t thr24, float dscale) {
+    constexpr int C = 16;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    float wa1[4], wb2[4], idb[4], mu[4], istd[4], gam4[4], bet4[4], bgr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = 4 * g + q;
+        wa1[q] = Wg[i * C + c];
+        wb2[q] = Wg[c * C + i];
+        idb[q] = (c == i) ? 1.0f : 0.0f;
+        mu[q] = stats[c]; istd[q] = stats[C + c];
+        gam4[q] = gamma[c]; bet4[q] = beta[c];
+        bgr[q] = bg[c];
+    }
+    const float gam_i = gamma[i], bet_i = beta[i];
+    f32x4 P = {0.f, 0.f, 0.f, 0.f};
+    float a_dgam = 0.f, a_dbet = 0.f, a_dbg = 0.f;
+    const int To = T / 2, Fo = F / 2, tpr = Fo / 4, ntiles = B * To * tpr;
+    const int nwaves = gridDim.x * 4;
+    for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += nwaves) {
+        const int tr = tile % tpr, to = (tile / tpr) % To, b = tile / (tpr * To);
+        const int w = i >> 2, q = i & 3;
+        const int t = 2 * to + (q >> 1), f = 2 * (4 * tr + w) + (q & 1);
+        const size_t pix = ((size_t)b * T + t) * F + f;
+        const float4 yv = *(const float4*)(y + pix * C + 4 * g);
+        const float4 go = *(const float4*)(gout + (((size_t)b * To + to) * Fo + 4 * tr + w) * C + 4 * g);
+        float xh[4] = {(yv.x - mu[0]) * istd[0], (yv.y - mu[1]) * istd[1], (yv.z - mu[2]) * istd[2], (yv.w - mu[3]) * istd[3]};
+        float xn[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xn[k] = fmaf(xh[k], gam4[k], bet4[k]);
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc1 = mfma16(wa1[k], xn[k], acc1);   // lin^T: D[n = 4g+r][pixel i]
+        const float gv[4] = {go.x, go.y, go.z, go.w};
+        float dlin[4], e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lin = acc1[r] + bgr[r];
+            const float sg = sed_sigmoid(xn[r]);
+            const uint32_t ei = (uint32_t)(pix * C + 4 * g + r);
+            const float gr = sed_keep(ei, seed, thr24) ? gv[r] * 0.25f * dscale : 0.f;
+            dlin[r] = gr * sg;
+            e[r] = gr * lin * sg * (1.0f - sg);
+        }
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, accx = {0.f, 0.f, 0.f, 0.f}, accd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc2 = mfma16(dlin[k], wb2[k], acc2);       // dxn[pixel 4g+r][c = i] = dlin . Wg
+            acc2 = mfma16(e[k], idb[k], acc2);          //                         + e
+            accx = mfma16(xh[k], idb[k], accx);         // xhat  in accumulator layout
+            accd = mfma16(dlin[k], idb[k], accd);       // dlin  in accumulator layout  [pixel 4g+r][n' = i]
+        }
+        float xnD[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tp = 2 * to + (r >> 1), fp = 2 * (4 * tr + g) + (r & 1);       // pixel of accumulator row 4g+r
+            const float dxn = acc2[r];
+            a_dgam += dxn * accx[r];
+            a_dbet += dxn;
+            a_dbg += accd[r];
+            dz[(((size_t)b * T + tp) * F + fp) * C + i] = dxn * gam_i;
+            xnD[r] = fmaf(accx[r], gam_i, bet_i);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) P = mfma16(accd[k], xnD[k], P);     // P[n' = 4g+r][c = i] += sum_pixels dlin[p][n'] xn[p][c]
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dWg + (4 * g + r) * C + i, P[r]);
+    a_dgam += __shfl_xor(a_dgam, 16); a_dgam += __shfl_xor(a_dgam, 32);
+    a_dbet += __shfl_xor(a_dbet, 16); a_dbet += __shfl_xor(a_dbet, 32);
+    a_dbg += __shfl_xor(a_dbg, 16); a_dbg += __shfl_xor(a_dbg, 32);
+    if (g == 0) { atomicAdd(dgamma + i, a_dgam); atomicAdd(dbeta + i, a_dbet); atomicAdd(dbg + i, a_dbg); }
+}
+
 // y (B,T,F,C); stats 4*C (mean, invstd, scale, shift); Wg (C,C) [out][in]; out (B,T/PT,F/PF,C).
 // dropout: keep element e when hash(e, seed) >> 8 >= thr24 (thr24 = round(p * 2^24)); dscale = 1/(1-p).
 extern "C" int sed_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
                            int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (F % PF != 0) return SED_ERR_UNSUPPORTED;
+    if (C == 16 && PT == 2 && PF == 2 && F % 8 == 0) {
+        const int ntiles = B * (T / 2) * (F / 8);
+        if (ntiles <= 0) return SED_OK;
+        int grid = (ntiles + 3) / 4;
+        if (grid > 2048) grid = 2048;
+        SED_LAUNCH(glu16_fwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale);
+        return sed_check_launch();
+    }
 #define GLU_CASE(c, pt, pf) \
     if (C == c && PT == pt && PF == pf) return launch_glu_fwd<c, pt, pf>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, s);
     GLU_CASE(16, 2, 2) GLU_CASE(32, 2, 2) GLU_CASE(64, 1, 2) GLU_CASE(128, 1, 2)
@@ -357,6 +497,15 @@ extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamm
     (void)hipMemsetAsync(dgamma, 0, (size_t)C * 4, s);
     (void)hipMemsetAsync(dbeta, 0, (size_t)C * 4, s);
     if (T % PT != 0) (void)hipMemsetAsync(dz, 0, (size_t)B * T * F * C * 4, s);
+    if (C == 16 && PT == 2 && PF == 2 && F % 8 == 0) {
+        const int ntiles = B * (T / 2) * (F / 8);
+        if (ntiles <= 0) return SED_OK;
+        int grid = (ntiles + 3) / 4;
+        if (grid > 1024) grid = 1024;
+        SED_LAUNCH(glu16_bwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B,
+                   T, F, seed, thr24, dscale);
+        return sed_check_launch();
+    }
 #define GLU_CASE(c, pt, pf)                                                                                              \
     if (C == c && PT == pt && PF == pf)                                                                                  \
         return launch_glu_bwd<c, pt, pf>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B, T, F, seed, thr24, \

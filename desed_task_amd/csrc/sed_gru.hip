@@ -251,40 +251,41 @@ extern "C" int sed_colsum(const float* X, float* out, int M, int N, int ld, void
 // (CDNA4's vmcnt counts stores too, so a single store in the loop would put HBM write latency on the chain.)
 // ---------------------------------------------------------------------------------------------
 #define GRU_CH 8
-__global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh0,
+#define GRU_THREADS 512
+__global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh0,
                                                       const float* __restrict__ whh1, const float* __restrict__ bhh0,
                                                       const float* __restrict__ bhh1, float* __restrict__ out,
                                                       float* __restrict__ saved, int B, int T) {
-    constexpr int H = GRU_H, KH = H / 2, CH = GRU_CH;
+    constexpr int H = GRU_H, KH = H / 4, CH = GRU_CH, NT_ = GRU_THREADS;   // KH: K quarter per thread
     constexpr int GI_F = CH * 3 * H, OB_F = CH * 5 * H;            // floats per chunk buffer
     __shared__ __attribute__((aligned(16))) float hbuf[2][H];
     SED_DYN_SMEM(smem);
     float* gis = (float*)smem;                 // [2][CH][3H]
     float* obuf = gis + 2 * GI_F;              // [2][CH][5H] = h | r | z | n | hn
-    const int tid = threadIdx.x, j = tid >> 1, half = tid & 1;
+    const int tid = threadIdx.x, j = tid >> 2, half = tid & 3;    // `half` = which K quarter
     const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const float* W = dir ? whh1 : whh0;
     const float* bhh = dir ? bhh1 : bhh0;
-    float wr[KH], wz[KH], wn[KH];
+    f32x2 wr[KH / 2], wz[KH / 2], wn[KH / 2];
 #pragma unroll
-    for (int k = 0; k < KH; ++k) {
-        wr[k] = W[(size_t)(0 * H + j) * H + half * KH + k];
-        wz[k] = W[(size_t)(1 * H + j) * H + half * KH + k];
-        wn[k] = W[(size_t)(2 * H + j) * H + half * KH + k];
+    for (int k = 0; k < KH / 2; ++k) {
+        wr[k] = *(const f32x2*)(W + (size_t)(0 * H + j) * H + half * KH + 2 * k);
+        wz[k] = *(const f32x2*)(W + (size_t)(1 * H + j) * H + half * KH + 2 * k);
+        wn[k] = *(const f32x2*)(W + (size_t)(2 * H + j) * H + half * KH + 2 * k);
     }
     const float br = bhh[j], bz = bhh[H + j], bn = bhh[2 * H + j];
     if (tid < H) hbuf[0][tid] = 0.f;
     float hprev = 0.f;
     const int nchunks = (T + CH - 1) / CH;
-    constexpr int GV = GI_F / 4 / 256;         // float4 of gi per thread per chunk (= 3)
+    constexpr int GV = (GI_F / 4 + NT_ - 1) / NT_;         // float4 of gi per thread per chunk
     float4 greg[GV];
     auto load_chunk = [&](int c) {
 #pragma unroll
         for (int u = 0; u < GV; ++u) {
-            const int e4 = tid + 256 * u, s = e4 / (3 * H / 4), q = e4 - s * (3 * H / 4);
+            const int e4 = tid + NT_ * u, s = e4 / (3 * H / 4), q = e4 - s * (3 * H / 4);
             const int step = c * CH + s;
             greg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (step < T) {
+            if (e4 < GI_F / 4 && step < T) {
                 const int t = dir ? T - 1 - step : step;
                 greg[u] = *(const float4*)(gi + (((size_t)b * T + t) * 2 + dir) * 3 * H + 4 * q);
             }
@@ -292,12 +293,13 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
     };
     auto park_chunk = [&](int c) {
 #pragma unroll
-        for (int u = 0; u < GV; ++u) *(float4*)(gis + (c & 1) * GI_F + 4 * (tid + 256 * u)) = greg[u];
+        for (int u = 0; u < GV; ++u)
+            if (tid + NT_ * u < GI_F / 4) *(float4*)(gis + (c & 1) * GI_F + 4 * (tid + NT_ * u)) = greg[u];
     };
     auto flush_chunk = [&](int c) {
         constexpr int PER = 5 * H / 4;         // float4 per step: 32 of h + 128 of saved
         const float* ob = obuf + (c & 1) * OB_F;
-        for (int e4 = tid; e4 < CH * PER; e4 += 256) {
+        for (int e4 = tid; e4 < CH * PER; e4 += NT_) {
             const int s = e4 / PER, q = e4 - s * PER;
             const int step = c * CH + s;
             if (step >= T) break;
@@ -319,21 +321,24 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
         const int nsteps = min(CH, T - c * CH);
         for (int s = 0; s < nsteps; ++s) {
             const float gr = gch[s * 3 * H + j], gz = gch[s * 3 * H + H + j], gn = gch[s * 3 * H + 2 * H + j];
-            const float* hv = hbuf[cur] + half * KH;
-            float ar = 0.f, az = 0.f, an = 0.f;
+            // all of this thread's h slice first (one LDS latency, not one per read), then the FMAs
+            float4 hq[KH / 4];
 #pragma unroll
-            for (int k = 0; k < KH; k += 4) {
-                const float4 h4 = *(const float4*)(hv + k);
-                ar = fmaf(wr[k], h4.x, ar); az = fmaf(wz[k], h4.x, az); an = fmaf(wn[k], h4.x, an);
-                ar = fmaf(wr[k + 1], h4.y, ar); az = fmaf(wz[k + 1], h4.y, az); an = fmaf(wn[k + 1], h4.y, an);
-                ar = fmaf(wr[k + 2], h4.z, ar); az = fmaf(wz[k + 2], h4.z, az); an = fmaf(wn[k + 2], h4.z, an);
-                ar = fmaf(wr[k + 3], h4.w, ar); az = fmaf(wz[k + 3], h4.w, az); an = fmaf(wn[k + 3], h4.w, an);
+            for (int k = 0; k < KH / 4; ++k) hq[k] = *(const float4*)(hbuf[cur] + half * KH + 4 * k);
+            f32x2 pr = {0.f, 0.f}, pz = {0.f, 0.f}, pn = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KH / 4; ++k) {
+                const f32x2 lo2 = {hq[k].x, hq[k].y}, hi2 = {hq[k].z, hq[k].w};
+                pr = pk_fma(wr[2 * k], lo2, pr); pz = pk_fma(wz[2 * k], lo2, pz); pn = pk_fma(wn[2 * k], lo2, pn);
+                pr = pk_fma(wr[2 * k + 1], hi2, pr); pz = pk_fma(wz[2 * k + 1], hi2, pz); pn = pk_fma(wn[2 * k + 1], hi2, pn);
             }
+            float ar = pr.x + pr.y, az = pz.x + pz.y, an = pn.x + pn.y;
             ar += __shfl_xor(ar, 1); az += __shfl_xor(az, 1); an += __shfl_xor(an, 1);
-            const float r = sed_sigmoid(gr + ar + br);
-            const float z = sed_sigmoid(gz + az + bz);
+            ar += __shfl_xor(ar, 2); az += __shfl_xor(az, 2); an += __shfl_xor(an, 2);
+            const float r = sed_fast_sigmoid(gr + ar + br);
+            const float z = sed_fast_sigmoid(gz + az + bz);
             const float hn = an + bn;
-            const float n = sed_tanh(gn + r * hn);
+            const float n = sed_fast_tanh(gn + r * hn);
             const float hnew = (1.0f - z) * n + z * hprev;
             hprev = hnew;
             if (half == 0) {
@@ -355,7 +360,7 @@ extern "C" int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1
     if (B <= 0 || T <= 0) return SED_OK;
     const int smem = (2 * GRU_CH * 3 * GRU_H + 2 * GRU_CH * 5 * GRU_H) * 4;
     SED_MAX_SMEM(gru_fwd_kernel, smem);
-    SED_LAUNCH(gru_fwd_kernel, dim3(2 * B), dim3(256), smem, (hipStream_t)stream, gi, whh0, whh1, bhh0, bhh1, out, saved, B, T);
+    SED_LAUNCH(gru_fwd_kernel, dim3(2 * B), dim3(GRU_THREADS), smem, (hipStream_t)stream, gi, whh0, whh1, bhh0, bhh1, out, saved, B, T);
     return sed_check_launch();
 }
 
@@ -365,35 +370,35 @@ extern "C" int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1
 // hprev (B,T,2,H) = the hidden state each step consumed (for dW_hh = dgh^T hprev).
 // Same chunked LDS staging as the forward: nothing touches global memory inside the step loop.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+__global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                       const float* __restrict__ saved, const float* __restrict__ whh0,
                                                       const float* __restrict__ whh1, float* __restrict__ dgi,
                                                       float* __restrict__ dgh, float* __restrict__ hprev_out, int B, int T) {
-    constexpr int H = GRU_H, KH = H / 2, CH = GRU_CH;
+    constexpr int H = GRU_H, KH = H / 4, CH = GRU_CH, NT_ = GRU_THREADS;
     constexpr int IB_F = CH * 6 * H, OB_F = CH * 7 * H;
     __shared__ __attribute__((aligned(16))) float gbuf[2][3 * H];
     SED_DYN_SMEM(smem);
     float* ibuf = (float*)smem;                // [2][CH][6H] = r | z | n | hn | hprev | dout
     float* obuf = ibuf + 2 * IB_F;             // [2][CH][7H] = dgi(3H) | dgh(3H) | hprev(H)
-    const int tid = threadIdx.x, k = tid >> 1, half = tid & 1;
+    const int tid = threadIdx.x, k = tid >> 2, half = tid & 3;    // `half` = which quarter of the gate rows
     const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const float* W = dir ? whh1 : whh0;
-    float wr[KH], wz[KH], wn[KH];              // W^T slices: contributions of gate rows j in this thread's half to unit k
+    f32x2 wr[KH / 2], wz[KH / 2], wn[KH / 2];  // W^T slices: contributions of gate rows j in this thread's quarter to unit k
 #pragma unroll
-    for (int jj = 0; jj < KH; ++jj) {
-        const int j = half * KH + jj;
-        wr[jj] = W[(size_t)(0 * H + j) * H + k];
-        wz[jj] = W[(size_t)(1 * H + j) * H + k];
-        wn[jj] = W[(size_t)(2 * H + j) * H + k];
+    for (int jj = 0; jj < KH / 2; ++jj) {
+        const int j = half * KH + 2 * jj;
+        wr[jj] = f32x2{W[(size_t)(0 * H + j) * H + k], W[(size_t)(0 * H + j + 1) * H + k]};
+        wz[jj] = f32x2{W[(size_t)(1 * H + j) * H + k], W[(size_t)(1 * H + j + 1) * H + k]};
+        wn[jj] = f32x2{W[(size_t)(2 * H + j) * H + k], W[(size_t)(2 * H + j + 1) * H + k]};
     }
     const int nchunks = (T + CH - 1) / CH;
-    constexpr int IV = IB_F / 4 / 256;         // = 6 float4 per thread per chunk
+    constexpr int IV = IB_F / 4 / NT_;         // = 3 float4 per thread per chunk
     float4 ireg[IV];
     // chunk c covers reverse-order positions rs = c*CH .. c*CH+CH-1, forward step index = T-1-rs
     auto load_chunk = [&](int c) {
 #pragma unroll
         for (int u = 0; u < IV; ++u) {
-            const int e4 = tid + 256 * u, s = e4 / (6 * H / 4), q = e4 - s * (6 * H / 4);
+            const int e4 = tid + NT_ * u, s = e4 / (6 * H / 4), q = e4 - s * (6 * H / 4);
             const int rs = c * CH + s;
             ireg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rs < T) {
@@ -408,12 +413,12 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
     };
     auto park_chunk = [&](int c) {
 #pragma unroll
-        for (int u = 0; u < IV; ++u) *(float4*)(ibuf + (c & 1) * IB_F + 4 * (tid + 256 * u)) = ireg[u];
+        for (int u = 0; u < IV; ++u) *(float4*)(ibuf + (c & 1) * IB_F + 4 * (tid + NT_ * u)) = ireg[u];
     };
     auto flush_chunk = [&](int c) {
         constexpr int PER = 7 * H / 4;
         const float* ob = obuf + (c & 1) * OB_F;
-        for (int e4 = tid; e4 < CH * PER; e4 += 256) {
+        for (int e4 = tid; e4 < CH * PER; e4 += NT_) {
             const int s = e4 / PER, q = e4 - s * PER;
             const int rs = c * CH + s;
             if (rs >= T) break;
@@ -456,19 +461,25 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
             }
             __syncthreads();
             const float* gv = gbuf[cur] + half * KH;
-            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;     // three independent chains (FMA latency)
+            float4 ga[KH / 4], gc[KH / 4], gd[KH / 4];
 #pragma unroll
-            for (int jj = 0; jj < KH; jj += 4) {
-                const float4 a = *(const float4*)(gv + jj);
-                const float4 cc = *(const float4*)(gv + H + jj);
-                const float4 d = *(const float4*)(gv + 2 * H + jj);
-                acc0 = fmaf(wr[jj], a.x, acc0); acc1 = fmaf(wz[jj], cc.x, acc1); acc2 = fmaf(wn[jj], d.x, acc2);
-                acc0 = fmaf(wr[jj + 1], a.y, acc0); acc1 = fmaf(wz[jj + 1], cc.y, acc1); acc2 = fmaf(wn[jj + 1], d.y, acc2);
-                acc0 = fmaf(wr[jj + 2], a.z, acc0); acc1 = fmaf(wz[jj + 2], cc.z, acc1); acc2 = fmaf(wn[jj + 2], d.z, acc2);
-                acc0 = fmaf(wr[jj + 3], a.w, acc0); acc1 = fmaf(wz[jj + 3], cc.w, acc1); acc2 = fmaf(wn[jj + 3], d.w, acc2);
+            for (int q4 = 0; q4 < KH / 4; ++q4) {
+                ga[q4] = *(const float4*)(gv + 4 * q4);
+                gc[q4] = *(const float4*)(gv + H + 4 * q4);
+                gd[q4] = *(const float4*)(gv + 2 * H + 4 * q4);
             }
-            float acc = (acc0 + acc1) + acc2;
+            f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f};     // three independent packed chains
+#pragma unroll
+            for (int q4 = 0; q4 < KH / 4; ++q4) {
+                const f32x2 a0 = {ga[q4].x, ga[q4].y}, a1 = {ga[q4].z, ga[q4].w};
+                const f32x2 c0 = {gc[q4].x, gc[q4].y}, c1 = {gc[q4].z, gc[q4].w};
+                const f32x2 d0 = {gd[q4].x, gd[q4].y}, d1 = {gd[q4].z, gd[q4].w};
+                p0 = pk_fma(wr[2 * q4], a0, p0); p1 = pk_fma(wz[2 * q4], c0, p1); p2 = pk_fma(wn[2 * q4], d0, p2);
+                p0 = pk_fma(wr[2 * q4 + 1], a1, p0); p1 = pk_fma(wz[2 * q4 + 1], c1, p1); p2 = pk_fma(wn[2 * q4 + 1], d1, p2);
+            }
+            float acc = ((p0.x + p0.y) + (p1.x + p1.y)) + (p2.x + p2.y);
             acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
             dh_carry = dh * z + acc;
             cur ^= 1;
         }
@@ -484,6 +495,6 @@ extern "C" int sed_gru_bwd(const float* dout, const float* out, const float* sav
     if (B <= 0 || T <= 0) return SED_OK;
     const int smem = (2 * GRU_CH * 6 * GRU_H + 2 * GRU_CH * 7 * GRU_H) * 4;
     SED_MAX_SMEM(gru_bwd_kernel, smem);
-    SED_LAUNCH(gru_bwd_kernel, dim3(2 * B), dim3(256), smem, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh, hprev, B, T);
+    SED_LAUNCH(gru_bwd_kernel, dim3(2 * B), dim3(GRU_THREADS), smem, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh, hprev, B, T);
     return sed_check_launch();
 }

@@ -50,6 +50,20 @@ class CNN(nn.Module):
                 layers.add_module("dropout%d" % i, nn.Dropout(conv_dropout))
             layers.add_module("pooling%d" % i, nn.AvgPool2d(self.pooling[i]))
         self.cnn = layers
+        # BatchNorm2d.num_batches_tracked is unused by the arithmetic (momentum is not None); it is kept exact for
+        # checkpoints but bumped on the host and only written to the buffers when a state dict is requested
+        # (7 tiny device launches per forward otherwise).
+        self._pending_batches = [0] * n_layers
+        self.register_state_dict_pre_hook(CNN._flush_batch_counters)
+
+    @staticmethod
+    def _flush_batch_counters(module, prefix, keep_vars):
+        for i, n in enumerate(module._pending_batches):
+            if n:
+                bn = module.cnn._modules["batchnorm%d" % i]
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += n
+                module._pending_batches[i] = 0
 
     def forward(self, x, bounds=None, arena=None):
         """x: (B, T, F) scaled log-mel (channels-last with C = 1).  Returns (B, T', F', C_last) channels-last.
@@ -65,6 +79,6 @@ class CNN(nn.Module):
                        arena=arena)
             x = ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, glu.linear.weight, glu.linear.bias,
                                   bn.running_mean, bn.running_var, cfg)
-            if bn.training and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+            if bn.training:
+                self._pending_batches[i] += 1
         return x

@@ -119,6 +119,16 @@ class SEDTask4(_Base):
         return self.train_loader
 
     # ---- the hot path -----------------------------------------------------------------------------
+    overlap_teacher = False         # teacher forward on a side stream (GPU only): measured no gain on MI355X (queues did not overlap), off by default
+    _tstream = None
+
+    def _teacher_stream(self, device):
+        if device.type != "cuda" or not self.overlap_teacher:
+            return None
+        if self._tstream is None:
+            self._tstream = torch.cuda.Stream(device=device)
+        return self._tstream
+
     def training_step(self, batch, batch_indx):
         audio, labels = batch[0], batch[1]
         indx_synth, indx_weak, indx_unlabelled = self.hparams["training"]["batch_size"]
@@ -138,8 +148,21 @@ class SEDTask4(_Base):
 
         x = self.scaled_logmel(features_)                                 # shared by student and teacher
         strong_s, weak_s = self.sed_student(x)
-        with torch.no_grad():
-            strong_t, weak_t = self.sed_teacher(x)
+        tstream = self._teacher_stream(x.device)
+        if tstream is None:
+            with torch.no_grad():
+                strong_t, weak_t = self.sed_teacher(x)
+        else:
+            # The teacher forward is independent of the student's: run it on a second HIP stream so its
+            # latency-bound phases (GRU recurrence, the small late-layer grids) fill CUs the student leaves idle.
+            main = torch.cuda.current_stream(x.device)
+            tstream.wait_stream(main)                                     # x is ready (student kernels are only queued)
+            with torch.cuda.stream(tstream), torch.no_grad():
+                strong_t, weak_t = self.sed_teacher(x)
+            main.wait_stream(tstream)
+            x.record_stream(tstream)
+            strong_t.record_stream(main)
+            weak_t.record_stream(main)
 
         sched = self.scheduler["scheduler"]
         weight = self.hparams["training"]["const_max"] * sched._get_scaling_factor()

@@ -1,0 +1,36 @@
+"""Timing ablation of the GRU forward recurrence (diagnostics).  Builds sed_gru.hip with -DGRU_VARIANT=n into
+tools/_gru_v{n}.so and times sed_gru_fwd at B=48, T=156."""
+import ctypes, os, subprocess, sys, time
+import torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(ROOT, "desed_task_amd", "csrc")
+variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3]
+if "--build" in os.environ.get("GRU_MODE", "--build"):
+    for v in variants:
+        so = os.path.join(HERE, "_gru_v%d.so" % v)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC,
+                               "-DGRU_VARIANT=%d" % v, os.path.join(CSRC, "sed_gru.hip"), "-o", so])
+if not torch.cuda.is_available():
+    sys.exit(0)
+B, T, H = 48, 156, 128
+gi = torch.randn(B, T, 2, 3 * H, device="cuda")
+whh = [torch.randn(3 * H, H, device="cuda") * 0.08 for _ in range(2)]
+bhh = [torch.randn(3 * H, device="cuda") * 0.08 for _ in range(2)]
+out = torch.empty(B, T, 2 * H, device="cuda")
+saved = torch.empty(B, T, 2, 4, H, device="cuda")
+for v in variants:
+    lib = ctypes.CDLL(os.path.join(HERE, "_gru_v%d.so" % v))
+    f = lib.sed_gru_fwd
+    f.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    args = (gi.data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), bhh[0].data_ptr(), bhh[1].data_ptr(), out.data_ptr(),
+            saved.data_ptr(), B, T, H, torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        f(*args)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        f(*args)
+    e1.record(); torch.cuda.synchronize()
+    print("variant %d: %.1f us per launch  (%.0f ns/step)" % (v, e0.elapsed_time(e1) / 20 * 1e3, e0.elapsed_time(e1) / 20 * 1e6 / T), flush=True)
