@@ -47,34 +47,38 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 #define CONV_THREADS(COUT) ((COUT) >= 64 ? 512 : 256)
 
-template <int CIN, int COUT, int TF>
+// MP = output pixels per workgroup: 128, or 64 for the late 128-channel layers whose 128-pixel grids would leave
+// most of the 256 CUs without a second workgroup (F <= 4: 117 / 234 tiles).  Waves: WM = MP/32 along pixels,
+// WN along COUT, WM*WN = 8 for COUT >= 64 (4 otherwise).
+template <int CIN, int COUT, int TF, int MP = 128>
 struct ConvCfg {
-    static constexpr int TR = 128 / TF;
+    static constexpr int TR = MP / TF;
     static constexpr int PW = TF + 2, PH = TR + 2, PP = PW * PH;
     static constexpr int CK = CIN < 32 ? CIN : 32;
     static constexpr int CKP = CK + 1;
     static constexpr int NCH = CIN / CK;
     static constexpr int NT = (COUT + 31) / 32;
-    static constexpr int WN = NT >= 2 ? 2 : 1;          // waves along N: 8-wave workgroups for COUT >= 64
+    static constexpr int WM = MP / 32;
+    static constexpr int THREADS = CONV_THREADS(COUT);
+    static constexpr int WN = THREADS / 64 / WM;        // waves along N
     static constexpr int NTW = NT / WN;                 // accumulator tiles per wave
-    static constexpr int THREADS = 256 * WN;
-    static_assert(THREADS == CONV_THREADS(COUT), "launch bounds");
+    static_assert(NTW >= 1 && NTW * WN == NT, "wave split must tile COUT");
     static constexpr int WCH = CK * COUT;
     static constexpr int PATCH_F = (PP * CKP + 3) & ~3;
     static constexpr int SMEM = (PATCH_F + 2 * WCH) * 4;
 };
 
-template <int CIN, int COUT, int TF, bool STATS>
+template <int CIN, int COUT, int TF, bool STATS, int MP = 128>
 __global__ __launch_bounds__(CONV_THREADS(COUT)) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ Wp,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       float* __restrict__ partial, int B, int T, int F) {
-    using Cfg = ConvCfg<CIN, COUT, TF>;
+    using Cfg = ConvCfg<CIN, COUT, TF, MP>;
     constexpr int TR = Cfg::TR, PW = Cfg::PW, PP = Cfg::PP, CK = Cfg::CK, CKP = Cfg::CKP, NCH = Cfg::NCH, NT = Cfg::NT,
-                  WCH = Cfg::WCH, NTW = Cfg::NTW, THREADS = Cfg::THREADS;
+                  WCH = Cfg::WCH, NTW = Cfg::NTW, THREADS = Cfg::THREADS, WM = Cfg::WM;
     SED_DYN_SMEM(smem);
     float* patch = (float*)smem;
     float* wbuf = patch + Cfg::PATCH_F;
-    const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3, wn = tid >> 8, lo = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) % WM, wn = (tid >> 6) / WM, lo = lane & 31, hi = lane >> 5;
     const int ftiles = F / TF, ttiles = (T + TR - 1) / TR;
     const int bid = blockIdx.x;
     const int ft = bid % ftiles, tt = (bid / ftiles) % ttiles, b = bid / (ftiles * ttiles);
@@ -177,34 +181,36 @@ __global__ __launch_bounds__(CONV_THREADS(COUT)) void conv3x3_kernel(const float
             const int which = tid / COUT, co = tid - which * COUT;
             float v = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) v += red[(ww * 2 + which) * (NT * 32) + co];
+            for (int ww = 0; ww < WM; ++ww) v += red[(ww * 2 + which) * (NT * 32) + co];
             partial[(size_t)bid * 2 * COUT + tid] = v;
         }
     }
 }
 
-template <int CIN, int COUT, int TF>
+template <int CIN, int COUT, int TF, int MP = 128>
 static int launch_conv(const float* x, const float* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
                        hipStream_t s) {
-    using Cfg = ConvCfg<CIN, COUT, TF>;
+    using Cfg = ConvCfg<CIN, COUT, TF, MP>;
     const int nblk = B * ((T + Cfg::TR - 1) / Cfg::TR) * (F / TF);
     if (partial) {
-        SED_MAX_SMEM((conv3x3_kernel<CIN, COUT, TF, true>), Cfg::SMEM);
-        SED_LAUNCH((conv3x3_kernel<CIN, COUT, TF, true>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
+        SED_MAX_SMEM((conv3x3_kernel<CIN, COUT, TF, true, MP>), Cfg::SMEM);
+        SED_LAUNCH((conv3x3_kernel<CIN, COUT, TF, true, MP>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
     } else {
-        SED_MAX_SMEM((conv3x3_kernel<CIN, COUT, TF, false>), Cfg::SMEM);
-        SED_LAUNCH((conv3x3_kernel<CIN, COUT, TF, false>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
+        SED_MAX_SMEM((conv3x3_kernel<CIN, COUT, TF, false, MP>), Cfg::SMEM);
+        SED_LAUNCH((conv3x3_kernel<CIN, COUT, TF, false, MP>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
     }
     return sed_check_launch();
 }
 
 static inline int conv_tf(int F) { return F >= 32 ? 32 : F; }
+static inline int conv_mp(int F, int CIN, int COUT) { return (CIN == 128 && COUT == 128 && F <= 4) ? 64 : 128; }
 
 // number of workgroups (= rows of `partial`, each 2*COUT floats) the forward launch uses
-extern "C" int sed_conv_fwd_blocks(int B, int T, int F, int CIN) {
+extern "C" int sed_conv_fwd_blocks(int B, int T, int F, int CIN, int COUT) {
     if (CIN == 1) return B * ((T + 15) / 16);
     const int TF = conv_tf(F);
-    return B * ((T + 128 / TF - 1) / (128 / TF)) * (F / TF);
+    const int TR = conv_mp(F, CIN, COUT) / TF;
+    return B * ((T + TR - 1) / TR) * (F / TF);
 }
 
 // x (B,T,F,CIN), Wp packed [9][CIN][COUT], bias [COUT] or null, y (B,T,F,COUT), partial: null or
@@ -215,10 +221,12 @@ extern "C" int sed_conv3x3(const float* x, const float* Wp, const float* bias, f
     if (B <= 0 || T <= 0) return SED_OK;
     const int TF = conv_tf(F);
     if (F % TF != 0 || (F & (F - 1)) != 0 || F < 2) return SED_ERR_UNSUPPORTED;
+    if (CIN == 128 && COUT == 128 && TF == 4) return launch_conv<128, 128, 4, 64>(x, Wp, bias, y, partial, B, T, F, s);
+    if (CIN == 128 && COUT == 128 && TF == 2) return launch_conv<128, 128, 2, 64>(x, Wp, bias, y, partial, B, T, F, s);
 #define CONV_CASE(ci, co, tf) \
     if (CIN == ci && COUT == co && TF == tf) return launch_conv<ci, co, tf>(x, Wp, bias, y, partial, B, T, F, s);
     CONV_CASE(16, 32, 32) CONV_CASE(32, 64, 32) CONV_CASE(64, 128, 16)
-    CONV_CASE(128, 128, 8) CONV_CASE(128, 128, 4) CONV_CASE(128, 128, 2)
+    CONV_CASE(128, 128, 8)
     CONV_CASE(32, 16, 32) CONV_CASE(64, 32, 32) CONV_CASE(128, 64, 16)
     // small-shape variants used by the unit tests / other n_mels
     CONV_CASE(16, 32, 16) CONV_CASE(32, 64, 8) CONV_CASE(64, 128, 4) CONV_CASE(128, 128, 16) CONV_CASE(128, 128, 32)
@@ -460,13 +468,106 @@ static int launch_wgrad(const float* x, const float* dy, float* dWp, int B, int 
     return sed_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// weight gradient, narrow layers (CIN <= 32): ALL 9 taps in one workgroup, so x and dy are read from HBM once
+// instead of once per tap.  Tile = the forward's 128-pixel TR x TF patch: halo patch of x [PP][CIN] and the dy
+// tile [128][COUT] in LDS; K = pixels of the tile, split across waves (WK) with the COUT tiles (WN); each wave
+// keeps 9 x (COUT/32/WN) accumulators across all its tiles and adds them to dWp with atomics at the end.
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int TF>
+struct WgaCfg {
+    static constexpr int TR = 128 / TF, PW = TF + 2, PH = TR + 2, PP = PW * PH;
+    static constexpr int NT = COUT / 32, WN = NT >= 2 ? 2 : 1, WK = 4 / WN, NTW = NT / WN;
+    static constexpr int SMEM = (PP * CIN + 128 * COUT) * 4;
+};
+template <int CIN, int COUT, int TF>
+__global__ __launch_bounds__(256) void conv_wgrad_alltaps_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 float* __restrict__ dWp, int B, int T, int F) {
+    using Cfg = WgaCfg<CIN, COUT, TF>;
+    constexpr int TR = Cfg::TR, PW = Cfg::PW, PP = Cfg::PP, WN = Cfg::WN, WK = Cfg::WK, NTW = Cfg::NTW;
+    static_assert(CIN <= 32, "narrow layers only");
+    SED_DYN_SMEM(smem);
+    float* xs = (float*)smem;            // [PP][CIN]
+    float* ds = xs + PP * CIN;           // [128][COUT]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int wn = w % WN, wk = w / WN;
+    const int ftiles = F / TF, ttiles = (T + TR - 1) / TR, ntiles = B * ttiles * ftiles;
+    f32x16 acc[9][NTW];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[tp][n] = f32x16_zero();
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int ft = tile % ftiles, tt = (tile / ftiles) % ttiles, b = tile / (ftiles * ttiles);
+        const int t0 = tt * TR, f0 = ft * TF;
+        __syncthreads();
+        for (int idx = tid; idx < PP * (CIN / 4); idx += 256) {
+            const int pix = idx / (CIN / 4), v = idx - pix * (CIN / 4);
+            const int i = pix / PW, j = pix - i * PW;
+            const int t = t0 - 1 + i, f = f0 - 1 + j;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < T && f >= 0 && f < F) val = *(const float4*)(x + (((size_t)b * T + t) * F + f) * CIN + 4 * v);
+            *(float4*)(xs + pix * CIN + 4 * v) = val;
+        }
+        for (int idx = tid; idx < 128 * (COUT / 4); idx += 256) {
+            const int p = idx / (COUT / 4), v = idx - p * (COUT / 4);
+            const int t = t0 + p / TF, f = f0 + p % TF;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < T) val = *(const float4*)(dy + (((size_t)b * T + t) * F + f) * COUT + 4 * v);
+            *(float4*)(ds + p * COUT + 4 * v) = val;
+        }
+        __syncthreads();
+        constexpr int KS = 128 / WK;
+#pragma unroll 2
+        for (int k = wk * KS; k < (wk + 1) * KS; k += 2) {
+            const int p = k + hi;
+            const int pb = (p / TF) * PW + (p % TF);
+            float bv[NTW];
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) bv[n] = ds[p * COUT + (wn * NTW + n) * 32 + lo];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const float av = (CIN >= 32 || lo < CIN) ? xs[(pb + (tp / 3) * PW + (tp % 3)) * CIN + lo] : 0.f;
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) acc[tp][n] = mfma32(av, bv[n], acc[tp][n]);
+            }
+        }
+    }
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int co = (wn * NTW + n) * 32 + lo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = mfma32_row(r, lane);
+                if (ci < CIN) atomicAdd(dWp + ((size_t)tp * CIN + ci) * COUT + co, acc[tp][n][r]);
+            }
+        }
+}
+template <int CIN, int COUT, int TF>
+static int launch_wgrad_alltaps(const float* x, const float* dy, float* dWp, int B, int T, int F, hipStream_t s) {
+    using Cfg = WgaCfg<CIN, COUT, TF>;
+    const int ntiles = B * ((T + Cfg::TR - 1) / Cfg::TR) * (F / TF);
+    int grid = ntiles < 512 ? ntiles : 512;
+    SED_MAX_SMEM((conv_wgrad_alltaps_kernel<CIN, COUT, TF>), Cfg::SMEM);
+    SED_LAUNCH((conv_wgrad_alltaps_kernel<CIN, COUT, TF>), dim3(grid), dim3(256), Cfg::SMEM, s, x, dy, dWp, B, T, F);
+    return sed_check_launch();
+}
+
 // x (B,T,F,CIN), dy (B,T,F,COUT) -> dW (COUT,CIN,3,3).  dWp: scratch 9*CIN*COUT floats.
 extern "C" int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
                               void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(dWp, 0, (size_t)9 * CIN * COUT * sizeof(float), s) != hipSuccess) return SED_ERR_LAUNCH;
     int rc = SED_ERR_UNSUPPORTED;
-#define WG_CASE(ci, co) if (CIN == ci && COUT == co) rc = launch_wgrad<ci, co>(x, dy, dWp, B, T, F, s);
+    const int TF = conv_tf(F);
+    if (F % TF != 0 || (F & (F - 1)) != 0) return SED_ERR_UNSUPPORTED;
+#define WGA_CASE(ci, co, tf) if (rc != SED_OK && CIN == ci && COUT == co && TF == tf) rc = launch_wgrad_alltaps<ci, co, tf>(x, dy, dWp, B, T, F, s);
+    WGA_CASE(16, 32, 32) WGA_CASE(16, 32, 16) WGA_CASE(32, 64, 32) WGA_CASE(32, 64, 16) WGA_CASE(32, 64, 8)
+#undef WGA_CASE
+#define WG_CASE(ci, co) if (rc != SED_OK && CIN == ci && COUT == co) rc = launch_wgrad<ci, co>(x, dy, dWp, B, T, F, s);
     WG_CASE(16, 32) WG_CASE(32, 64) WG_CASE(64, 128) WG_CASE(128, 128)
 #undef WG_CASE
     if (rc != SED_OK) return rc;

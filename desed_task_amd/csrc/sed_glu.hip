@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ 
                         int o, t, f;
                         const bool ok = row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f);
                         const float xn = xs[m * CP + n];
-                        float r = (acc[nt][4 * j + q] + bias) * sed_sigmoid(xn);
+                        float r = (acc[nt][4 * j + q] + bias) * sed_fast_sigmoid(xn);
                         const uint32_t e = (uint32_t)((((size_t)b * T + t) * F + f) * C + n);
                         r = (ok && sed_keep(e, seed, thr24)) ? r * dscale : 0.f;
                         v[q] = r;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void glu16_fwd_kernel(const float* __restrict_
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float o = (acc[r] + bgr[r]) * sed_sigmoid(xn[r]);
+            float o = (acc[r] + bgr[r]) * sed_fast_sigmoid(xn[r]);
             const uint32_t e = (uint32_t)(pix * C + 4 * g + r);
             o = sed_keep(e, seed, thr24) ? o * dscale : 0.f;
             o += __shfl_xor(o, 1);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void glu16_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float lin = acc1[r] + bgr[r];
-            const float sg = sed_sigmoid(xn[r]);
+            const float sg = sed_fast_sigmoid(xn[r]);
             const uint32_t ei = (uint32_t)(pix * C + 4 * g + r);
             const float gr = sed_keep(ei, seed, thr24) ? gv[r] * 0.25f * dscale : 0.f;
             dlin[r] = gr * sg;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
                 float dlin = 0.f, e = 0.f;
                 if (ok) {
                     const float xn = fmaf(xh[m * CP + n], gn, bn);
-                    const float sg = sed_sigmoid(xn);
+                    const float sg = sed_fast_sigmoid(xn);
                     const float lin = acc[nt][r] + bias;
                     const uint32_t ei = (uint32_t)((((size_t)b * T + t) * F + f) * C + n);
                     float g = gout[((size_t)b * NWC + o) * C + n] * (1.0f / WIN);

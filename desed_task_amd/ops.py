@@ -62,7 +62,7 @@ class ConvBlockFn(torch.autograd.Function):
         st = _lib.stream_ptr(x)
         dev = x.device
         y = torch.empty(B, T, F, COUT, device=dev, dtype=torch.float32)
-        nblk = lib.value("sed_conv_fwd_blocks", B, T, F, CIN)
+        nblk = lib.value("sed_conv_fwd_blocks", B, T, F, CIN, COUT)
         partial = torch.empty(nblk * 2 * COUT, device=dev, dtype=torch.float32) if training else None
         conv_w = conv_w.contiguous()
         if first:

@@ -50,7 +50,7 @@ int sed_specaug(const float* x, float* y, const int* bounds, int B, int T, int F
 int sed_conv_pack_weights(const float* W, float* Wf, float* Wd, int COUT, int CIN, void* stream);
 
 /* Number of workgroups (= rows of `partial`, 2*COUT floats each) a forward conv launch writes. */
-int sed_conv_fwd_blocks(int B, int T, int F, int CIN);
+int sed_conv_fwd_blocks(int B, int T, int F, int CIN, int COUT);
 
 /* Conv2d(k=3,s=1,p=1) (CNN.py:69-72) as implicit GEMM on f32 MFMA.  x (B,T,F,CIN), Wp packed, bias or null,
  * y (B,T,F,COUT); partial (or null) receives per-workgroup (sum, sumsq) per channel for BatchNorm.
