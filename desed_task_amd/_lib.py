@@ -25,7 +25,7 @@ def parse_header(path=_HEADER):
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\bint\s+(sed_\w+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"\b(?:int|long long)\s+(sed_\w+)\s*\(([^)]*)\)\s*;", text):
         args = []
         for a in m.group(2).split(","):
             a = a.strip()
@@ -48,7 +48,7 @@ class _Lib:
         for name, argtypes in self.protos.items():
             fn = getattr(self._dll, name)      # AttributeError if the library misses a declared symbol
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_longlong if name.endswith("_floats") else ctypes.c_int
 
     def value(self, name, *args):
         """For the few entry points that return a count instead of a status."""

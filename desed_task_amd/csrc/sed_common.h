@@ -19,6 +19,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SED_MAX_SMEM(kern, bytes) \
     (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
 
+// zero up to four small buffers in ONE launch (gradient accumulators that the kernels fill with atomics)
+__global__ __launch_bounds__(256) static void sed_zero4_kernel(float* p0, int n0, float* p1, int n1, float* p2, int n2, float* p3, int n3) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n0) p0[i] = 0.f;
+    if (i < n1) p1[i] = 0.f;
+    if (i < n2) p2[i] = 0.f;
+    if (i < n3) p3[i] = 0.f;
+}
+static inline void sed_zero4(hipStream_t s, float* p0, int n0, float* p1, int n1, float* p2, int n2, float* p3, int n3) {
+    int n = n0 > n1 ? n0 : n1;
+    n = n > n2 ? n : n2;
+    n = n > n3 ? n : n3;
+    if (n <= 0) return;
+    SED_LAUNCH(sed_zero4_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p0, n0, p1, n1, p2, n2, p3, n3);
+}
+
 #define SED_OK 0
 #define SED_ERR_ARG (-1)
 #define SED_ERR_LAUNCH (-2)

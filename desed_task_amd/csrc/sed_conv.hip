@@ -34,12 +34,29 @@ extern "C" int sed_conv_pack_weights(const float* W, float* Wf, float* Wd, int C
     SED_LAUNCH(pack_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, Wf, Wd, COUT, CIN);
     return sed_check_launch();
 }
-// dWp[tap][ci][co] (packed) -> dW (COUT, CIN, 3, 3)
-__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dWp, float* __restrict__ dW, int COUT, int CIN) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= COUT * CIN * 9) return;
-    const int b = i % 3, a = (i / 3) % 3, ci = (i / 9) % CIN, co = i / (9 * CIN);
-    dW[i] = dWp[((a * 3 + b) * CIN + ci) * COUT + co];
+// partials[part][tap][ci][co] -> dW (COUT, CIN, 3, 3): fixed-order (deterministic) sum over the workgroup partials
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ parts, float* __restrict__ dW, int nparts,
+                                                           int COUT, int CIN) {
+    const int j = blockIdx.x * 256 + threadIdx.x;          // packed index (tap, ci, co): coalesced reads
+    const int n = 9 * CIN * COUT;
+    if (j >= n) return;
+    float acc = 0.f;
+    for (int p = 0; p < nparts; ++p) acc += parts[(size_t)p * n + j];
+    const int co = j % COUT, ci = (j / COUT) % CIN, tap = j / (COUT * CIN);
+    dW[((size_t)co * CIN + ci) * 9 + tap] = acc;
+}
+// number of workgroup partials the weight-gradient launch writes (each 9*CIN*COUT floats)
+static inline int wgrad_parts(int CIN, int COUT, int B, int T, int F) {
+    if (CIN <= 32) {                                    // all-taps kernel: one partial per workgroup
+        const int TF = F >= 32 ? 32 : F, TR = 128 / TF;
+        const int ntiles = B * ((T + TR - 1) / TR) * (F / TF);
+        return ntiles < 256 ? ntiles : 256;
+    }
+    const int ntiles = (B * T * F + 63) / 64;           // per-tap kernel: `splits` partials
+    return ntiles < 56 ? ntiles : 56;
+}
+extern "C" long long sed_conv_wgrad_scratch_floats(int B, int T, int F, int CIN, int COUT) {
+    return (long long)wgrad_parts(CIN, COUT, B, T, F) * 9 * CIN * COUT;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -444,7 +461,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
             }
         }
     }
-    // ---- accumulate into global dWp[tap][ci][co] ----
+    // ---- this workgroup's partial: dWp[split][tap][ci][co] (deterministic; reduced by wgrad_reduce_kernel) ----
+    static_assert(WK == 1, "wide layers: every wave owns its output tiles");
+    float* part = dWp + ((size_t)blockIdx.x * 9 + tap) * CIN * COUT;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -453,7 +472,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = m * 32 + mfma32_row(r, lane);
-                if (ci < CIN && co < COUT) atomicAdd(dWp + ((size_t)tap * CIN + ci) * COUT + co, acc[m][n][r]);
+                if (ci < CIN && co < COUT) part[(size_t)ci * COUT + co] = acc[m][n][r];
             }
         }
 }
@@ -462,7 +481,7 @@ template <int CIN, int COUT>
 static int launch_wgrad(const float* x, const float* dy, float* dWp, int B, int T, int F, hipStream_t s) {
     using Cfg = WgCfg<CIN, COUT>;
     const int ntiles = (B * T * F + Cfg::KT - 1) / Cfg::KT;
-    int splits = ntiles < 56 ? ntiles : 56;          // 56 x 9 taps = 504 workgroups ~ 2 per CU
+    const int splits = wgrad_parts(CIN, COUT, B, T, F);   // 56 x 9 taps = 504 workgroups ~ 2 per CU
     SED_MAX_SMEM((conv_wgrad_kernel<CIN, COUT>), Cfg::SMEM);
     SED_LAUNCH((conv_wgrad_kernel<CIN, COUT>), dim3(splits, 9), dim3(256), Cfg::SMEM, s, x, dy, dWp, B, T, F);
     return sed_check_launch();
@@ -534,45 +553,63 @@ __global__ __launch_bounds__(256) void conv_wgrad_alltaps_kernel(const float* __
             }
         }
     }
+    // ---- reduce the WK K-slices through LDS (tap groups of <= 5 to fit), then store this workgroup's partial ----
+    float* red = (float*)smem;           // [taps in group][CIN][COUT], reuses the staging area
+    float* part = dWp + (size_t)blockIdx.x * 9 * CIN * COUT;
+    constexpr int TG = 5;
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
+    for (int g0 = 0; g0 < 9; g0 += TG) {
+        for (int round = 0; round < WK; ++round) {
+            __syncthreads();
+            if (wk == round) {
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            const int co = (wn * NTW + n) * 32 + lo;
+                for (int tp = g0; tp < g0 + TG && tp < 9; ++tp)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = mfma32_row(r, lane);
-                if (ci < CIN) atomicAdd(dWp + ((size_t)tp * CIN + ci) * COUT + co, acc[tp][n][r]);
+                    for (int n = 0; n < NTW; ++n) {
+                        const int co = (wn * NTW + n) * 32 + lo;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ci = mfma32_row(r, lane);
+                            if (ci < CIN) {
+                                float* d = red + ((tp - g0) * CIN + ci) * COUT + co;
+                                *d = (round == 0) ? acc[tp][n][r] : *d + acc[tp][n][r];
+                            }
+                        }
+                    }
             }
         }
+        __syncthreads();
+        const int ntp = (9 - g0) < TG ? (9 - g0) : TG;
+        for (int idx = tid; idx < ntp * CIN * COUT; idx += 256) part[(size_t)g0 * CIN * COUT + idx] = red[idx];
+    }
 }
 template <int CIN, int COUT, int TF>
 static int launch_wgrad_alltaps(const float* x, const float* dy, float* dWp, int B, int T, int F, hipStream_t s) {
     using Cfg = WgaCfg<CIN, COUT, TF>;
-    const int ntiles = B * ((T + Cfg::TR - 1) / Cfg::TR) * (F / TF);
-    int grid = ntiles < 512 ? ntiles : 512;
+    const int grid = wgrad_parts(CIN, COUT, B, T, F);
     SED_MAX_SMEM((conv_wgrad_alltaps_kernel<CIN, COUT, TF>), Cfg::SMEM);
     SED_LAUNCH((conv_wgrad_alltaps_kernel<CIN, COUT, TF>), dim3(grid), dim3(256), Cfg::SMEM, s, x, dy, dWp, B, T, F);
     return sed_check_launch();
 }
 
-// x (B,T,F,CIN), dy (B,T,F,COUT) -> dW (COUT,CIN,3,3).  dWp: scratch 9*CIN*COUT floats.
+// x (B,T,F,CIN), dy (B,T,F,COUT) -> dW (COUT,CIN,3,3).  dWp: scratch of sed_conv_wgrad_scratch_floats() floats.
 extern "C" int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
                               void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(dWp, 0, (size_t)9 * CIN * COUT * sizeof(float), s) != hipSuccess) return SED_ERR_LAUNCH;
     int rc = SED_ERR_UNSUPPORTED;
     const int TF = conv_tf(F);
     if (F % TF != 0 || (F & (F - 1)) != 0) return SED_ERR_UNSUPPORTED;
 #define WGA_CASE(ci, co, tf) if (rc != SED_OK && CIN == ci && COUT == co && TF == tf) rc = launch_wgrad_alltaps<ci, co, tf>(x, dy, dWp, B, T, F, s);
-    WGA_CASE(16, 32, 32) WGA_CASE(16, 32, 16) WGA_CASE(32, 64, 32) WGA_CASE(32, 64, 16) WGA_CASE(32, 64, 8)
+    WGA_CASE(16, 32, 32) WGA_CASE(16, 32, 16) WGA_CASE(16, 32, 8) WGA_CASE(32, 64, 32) WGA_CASE(32, 64, 16) WGA_CASE(32, 64, 8)
+    WGA_CASE(32, 64, 4)
 #undef WGA_CASE
 #define WG_CASE(ci, co) if (rc != SED_OK && CIN == ci && COUT == co) rc = launch_wgrad<ci, co>(x, dy, dWp, B, T, F, s);
-    WG_CASE(16, 32) WG_CASE(32, 64) WG_CASE(64, 128) WG_CASE(128, 128)
+    WG_CASE(64, 128) WG_CASE(128, 128)
 #undef WG_CASE
     if (rc != SED_OK) return rc;
     const int n = COUT * CIN * 9;
-    SED_LAUNCH(unpack_wgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)dWp, dW, COUT, CIN);
+    SED_LAUNCH(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)dWp, dW, wgrad_parts(CIN, COUT, B, T, F),
+               COUT, CIN);
     return sed_check_launch();
 }
 

@@ -492,10 +492,7 @@ extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamm
                            int B, int T, int F, int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (F % PF != 0) return SED_ERR_UNSUPPORTED;
-    if (hipMemsetAsync(dWg, 0, (size_t)C * C * 4, s) != hipSuccess) return SED_ERR_LAUNCH;
-    (void)hipMemsetAsync(dbg, 0, (size_t)C * 4, s);
-    (void)hipMemsetAsync(dgamma, 0, (size_t)C * 4, s);
-    (void)hipMemsetAsync(dbeta, 0, (size_t)C * 4, s);
+    sed_zero4(s, dWg, C * C, dbg, C, dgamma, C, dbeta, C);
     if (T % PT != 0) (void)hipMemsetAsync(dz, 0, (size_t)B * T * F * C * 4, s);
     if (C == 16 && PT == 2 && PF == 2 && F % 8 == 0) {
         const int ntiles = B * (T / 2) * (F / 8);

@@ -186,10 +186,7 @@ extern "C" int sed_head_bwd(const float* x, const float* W1, const float* W2, co
                             float dscale, void* stream) {
     if (D != HEAD_D) return SED_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(dW1, 0, (size_t)NC * D * 4, s);
-    (void)hipMemsetAsync(dW2, 0, (size_t)NC * D * 4, s);
-    (void)hipMemsetAsync(db1, 0, (size_t)NC * 4, s);
-    (void)hipMemsetAsync(db2, 0, (size_t)NC * 4, s);
+    sed_zero4(s, dW1, NC * D, dW2, NC * D, db1, NC, db2, NC);
     if (B <= 0 || T <= 0) return SED_OK;
     const int smem = (2 * NC * D + T * 2 * NC) * 4;
 #define HEAD_CASE(nc) \

@@ -112,11 +112,12 @@ class ConvBlockFn(torch.autograd.Function):
         if first:
             lib.call("sed_conv0_wgrad", x.data_ptr(), _p(bounds), dy.data_ptr(), d_w.data_ptr(), B, T, F, COUT, st)
         else:
-            scratch = torch.empty(9 * CIN * COUT, **f32)
+            scratch = torch.empty(int(lib.value("sed_conv_wgrad_scratch_floats", B, T, F, CIN, COUT)), **f32)
             lib.call("sed_conv_wgrad", x.data_ptr(), dy.data_ptr(), scratch.data_ptr(), d_w.data_ptr(), B, T, F, CIN, COUT, st)
             if ctx.needs_input_grad[0]:
                 wd = torch.empty(9 * CIN * COUT, **f32)
-                lib.call("sed_conv_pack_weights", conv_w.data_ptr(), scratch.data_ptr(), wd.data_ptr(), COUT, CIN, st)
+                wf = torch.empty(9 * CIN * COUT, **f32)
+                lib.call("sed_conv_pack_weights", conv_w.data_ptr(), wf.data_ptr(), wd.data_ptr(), COUT, CIN, st)
                 dx = torch.empty_like(x)
                 lib.call("sed_conv3x3", dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, B, T, F, COUT, CIN, st)
         return dx, d_w, d_bias, d_gamma, d_beta, d_glu_w, d_glu_b, None, None, None

@@ -83,7 +83,10 @@ int sed_glu_bwd(const float* y, const float* stats, const float* gamma, const fl
 int sed_bn_bwd_apply(const float* y, float* dz, const float* stats, const float* gamma, const float* dgamma,
                      const float* dbeta, float* dbias, long long npix, int C, int training, void* stream);
 
-/* Conv weight gradient: x (B,T,F,CIN), dy (B,T,F,COUT) -> dW (COUT,CIN,3,3); dWp = scratch 9*CIN*COUT floats. */
+/* Floats of scratch sed_conv_wgrad needs (per-workgroup partial gradients, reduced in a fixed order). */
+long long sed_conv_wgrad_scratch_floats(int B, int T, int F, int CIN, int COUT);
+
+/* Conv weight gradient: x (B,T,F,CIN), dy (B,T,F,COUT) -> dW (COUT,CIN,3,3); dWp = scratch (see above). */
 int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
                    void* stream);
 
