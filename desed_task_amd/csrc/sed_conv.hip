@@ -40,8 +40,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int j = blockIdx.x * 256 + threadIdx.x;          // packed index (tap, ci, co): coalesced reads
     const int n = 9 * CIN * COUT;
     if (j >= n) return;
-    float acc = 0.f;
-    for (int p = 0; p < nparts; ++p) acc += parts[(size_t)p * n + j];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;         // independent chains: the loads overlap
+    int p = 0;
+    for (; p + 4 <= nparts; p += 4) {
+        a0 += parts[(size_t)p * n + j];
+        a1 += parts[(size_t)(p + 1) * n + j];
+        a2 += parts[(size_t)(p + 2) * n + j];
+        a3 += parts[(size_t)(p + 3) * n + j];
+    }
+    for (; p < nparts; ++p) a0 += parts[(size_t)p * n + j];
+    const float acc = (a0 + a1) + (a2 + a3);
     const int co = j % COUT, ci = (j / COUT) % CIN, tap = j / (COUT * CIN);
     dW[((size_t)co * CIN + ci) * 9 + tap] = acc;
 }
@@ -50,7 +58,8 @@ static inline int wgrad_parts(int CIN, int COUT, int B, int T, int F) {
     if (CIN <= 32) {                                    // all-taps kernel: one partial per workgroup
         const int TF = F >= 32 ? 32 : F, TR = 128 / TF;
         const int ntiles = B * ((T + TR - 1) / TR) * (F / TF);
-        return ntiles < 256 ? ntiles : 256;
+        const int cap = CIN <= 16 ? 1024 : 512;       // 4 / 2 resident workgroups per CU: staging of one overlaps MFMAs of another
+        return ntiles < cap ? ntiles : cap;
     }
     const int ntiles = (B * T * F + 63) / 64;           // per-tap kernel: `splits` partials
     return ntiles < 56 ? ntiles : 56;

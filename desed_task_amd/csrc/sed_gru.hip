@@ -95,14 +95,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 template <int TA, int TB, int NTN>
 __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                        const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K,
-                                                       int lda, int ldb, int ldc, int k_per_slice, int atomic) {
+                                                       int lda, int ldb, int ldc, int k_per_slice, int atomic,
+                                                       const float* __restrict__ A1, const float* __restrict__ B1,
+                                                       const float* __restrict__ bias1, float* __restrict__ C1, int nbatch) {
     constexpr int BM = 128, BN = 32 * NTN, BK = 32, AP = BK + 1, BNS = BN + 4;
     constexpr int AV = BM * BK / 4 / 256, BV = BK * BN / 4 / 256;     // float4 per thread per tile
     __shared__ float As[BM * AP];
     __shared__ __attribute__((aligned(16))) float Bs[BK * BNS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * k_per_slice, kend = min(K, kbeg + k_per_slice);
+    const int zb = nbatch == 2 ? (blockIdx.z & 1) : 0, zs = nbatch == 2 ? (blockIdx.z >> 1) : blockIdx.z;
+    if (zb) { A = A1; Bm = B1; bias = bias1; Cm = C1; }          // second problem of a batch of two
+    const int kbeg = zs * k_per_slice, kend = min(K, kbeg + k_per_slice);
     f32x16 acc[NTN];
 #pragma unroll
     for (int i = 0; i < NTN; ++i) acc[i] = f32x16_zero();
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
     for (int nt = 0; nt < NTN; ++nt) {
         const int gn = n0 + nt * 32 + lo;
         if (gn < N) {
-            const float bv = (bias != nullptr && blockIdx.z == 0) ? bias[gn] : 0.f;
+            const float bv = (bias != nullptr && zs == 0) ? bias[gn] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int gm = m0 + 32 * w + mfma32_row(r, lane);
@@ -197,24 +201,28 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
     }
 }
 
-// C[M][N] = opA(A)[M][K] * opB(B)[K][N] + bias.  accumulate != 0 adds into C (atomics); split_k > 1 requires
-// the caller to have zeroed C (or accumulate).  Leading dimensions are in floats.
-extern "C" int sed_gemm(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
-                        int ldc, int transA, int transB, int split_k, int accumulate, void* stream) {
+static int gemm_dispatch(const float* A, const float* Bm, const float* bias, float* Cm, const float* A1, const float* B1,
+                         const float* bias1, float* C1, int nbatch, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                         int transB, int split_k, int accumulate, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0) return SED_OK;
-    hipStream_t s = (hipStream_t)stream;
     if (split_k < 1) split_k = 1;
     int kps = ((K + split_k - 1) / split_k + 31) / 32 * 32;
     split_k = (K + kps - 1) / kps;
     const int atomic = (split_k > 1 || accumulate) ? 1 : 0;
     const int ntn = N > 64 ? 4 : 2;
-    dim3 grid((N + 32 * ntn - 1) / (32 * ntn), (M + 127) / 128, split_k);
-    const bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)Bm % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 &&
-                     ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0) && kps % 4 == 0;
+    dim3 grid((N + 32 * ntn - 1) / (32 * ntn), (M + 127) / 128, split_k * nbatch);
+    bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)Bm % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 &&
+               ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0) && kps % 4 == 0;
+    if (nbatch == 2) vec = vec && ((uintptr_t)A1 % 16 == 0) && ((uintptr_t)B1 % 16 == 0);
 #define GEMMV_CASE(ta, tb, nn) \
-    if (vec && transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_vec_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic); return sed_check_launch(); }
+    if (vec && transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_vec_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic, A1, B1, bias1, C1, nbatch); return sed_check_launch(); }
     GEMMV_CASE(0, 0, 2) GEMMV_CASE(0, 0, 4) GEMMV_CASE(0, 1, 2) GEMMV_CASE(0, 1, 4) GEMMV_CASE(1, 0, 2) GEMMV_CASE(1, 0, 4)
 #undef GEMMV_CASE
+    if (nbatch == 2) {          // scalar fallback: two plain launches
+        int rc = gemm_dispatch(A, Bm, bias, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate, s);
+        if (rc != SED_OK) return rc;
+        return gemm_dispatch(A1, B1, bias1, C1, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate, s);
+    }
 #define GEMM_CASE(ta, tb, nn) \
     if (transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic); return sed_check_launch(); }
     GEMM_CASE(0, 0, 2) GEMM_CASE(0, 0, 4) GEMM_CASE(0, 1, 2) GEMM_CASE(0, 1, 4) GEMM_CASE(1, 0, 2) GEMM_CASE(1, 0, 4)
@@ -222,22 +230,39 @@ extern "C" int sed_gemm(const float* A, const float* Bm, const float* bias, floa
     return SED_ERR_UNSUPPORTED;
 }
 
+// C[M][N] = opA(A)[M][K] * opB(B)[K][N] + bias.  accumulate != 0 adds into C (atomics); split_k > 1 requires
+// the caller to have zeroed C (or accumulate).  Leading dimensions are in floats.
+extern "C" int sed_gemm(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
+                        int ldc, int transA, int transB, int split_k, int accumulate, void* stream) {
+    return gemm_dispatch(A, Bm, bias, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, transA, transB, split_k,
+                         accumulate, (hipStream_t)stream);
+}
+// Two same-shape problems (the two GRU directions) in ONE launch: (A0,B0,bias0 -> C0) and (A1,B1,bias1 -> C1).
+extern "C" int sed_gemm_pair(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
+                             const float* bias1, float* C0, float* C1, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                             int transB, int split_k, int accumulate, void* stream) {
+    return gemm_dispatch(A0, B0, bias0, C0, A1, B1, bias1, C1, 2, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate,
+                         (hipStream_t)stream);
+}
+
 // column sums: out[n] = sum_m X[m*ld + n], n < N  (bias gradients); out is zeroed here, atomics across row chunks
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ out, int M, int N, int ld,
-                                                     int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ out, float* __restrict__ out1,
+                                                     int nsplit, int M, int N, int ld, int rows_per_block) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float acc = 0.f;
     for (int r = r0; r < r1; ++r) acc += X[(size_t)r * ld + n];
-    atomicAdd(out + n, acc);
+    atomicAdd(n < nsplit ? out + n : out1 + (n - nsplit), acc);
 }
-extern "C" int sed_colsum(const float* X, float* out, int M, int N, int ld, void* stream) {
+// out[n] = sum_m X[m*ld + n] for n < nsplit, out1[n - nsplit] for nsplit <= n < N (out1 may be null when nsplit == N).
+extern "C" int sed_colsum(const float* X, float* out, float* out1, int nsplit, int M, int N, int ld, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, (size_t)N * 4, s) != hipSuccess) return SED_ERR_LAUNCH;
+    if (nsplit > N || (nsplit < N && out1 == nullptr)) return SED_ERR_ARG;
+    sed_zero4(s, out, nsplit, out1, N - nsplit, nullptr, 0, nullptr, 0);
     if (M <= 0 || N <= 0) return SED_OK;
-    const int rpb = 64;
-    SED_LAUNCH(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, s, X, out, M, N, ld, rpb);
+    const int rpb = 128;
+    SED_LAUNCH(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, s, X, out, out1, nsplit, M, N, ld, rpb);
     return sed_check_launch();
 }
 

@@ -143,9 +143,9 @@ class BiGRULayerFn(torch.autograd.Function):
         gi = torch.empty(B, T, 2, 3 * H, **f32)
         w_ih = [w_ih_f.contiguous(), w_ih_r.contiguous()]
         w_hh = [w_hh_f.contiguous(), w_hh_r.contiguous()]
-        for d, (w, b) in enumerate(zip(w_ih, (b_ih_f, b_ih_r))):
-            _gemm(lib, x.data_ptr(), w.data_ptr(), b.data_ptr(), gi.data_ptr() + d * 3 * H * 4, B * T, 3 * H, I, I, I, 6 * H,
-                  0, 1, 1, 0, st)
+        # both directions' input projections in one launch: gi[:, :, d, :] = x . W_ih[d]^T + b_ih[d]
+        lib.call("sed_gemm_pair", x.data_ptr(), x.data_ptr(), w_ih[0].data_ptr(), w_ih[1].data_ptr(), b_ih_f.data_ptr(),
+                 b_ih_r.data_ptr(), gi.data_ptr(), gi.data_ptr() + 3 * H * 4, B * T, 3 * H, I, I, I, 6 * H, 0, 1, 1, 0, st)
         out = torch.empty(B, T, 2 * H, **f32)
         need = any(ctx.needs_input_grad)
         saved = torch.empty(B, T, 2, 4, H, **f32) if need else None
@@ -173,22 +173,25 @@ class BiGRULayerFn(torch.autograd.Function):
                  dgi.data_ptr(), dgh.data_ptr(), hprev.data_ptr(), B, T, H, st)
         BT = B * T
         split = max(1, min(32, BT // 256))
-        d_w_ih, d_w_hh, d_b_ih, d_b_hh = [], [], [], []
-        for d, (wi, wh, bi, bh) in enumerate(((w_ih_f, w_hh_f, b_ih_f, b_hh_f), (w_ih_r, w_hh_r, b_ih_r, b_hh_r))):
-            dwi = _grad_buf(cfg, wi).zero_()
-            _gemm(lib, dgi.data_ptr() + d * 3 * H * 4, x.data_ptr(), None, dwi.data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, 0, st)
-            dwh = _grad_buf(cfg, wh).zero_()
-            _gemm(lib, dgh.data_ptr() + d * 3 * H * 4, hprev.data_ptr() + d * H * 4, None, dwh.data_ptr(), 3 * H, H, BT, 6 * H, 2 * H,
-                  H, 1, 0, split, 0, st)
-            dbi, dbh = _grad_buf(cfg, bi), _grad_buf(cfg, bh)
-            lib.call("sed_colsum", dgi.data_ptr() + d * 3 * H * 4, dbi.data_ptr(), BT, 3 * H, 6 * H, st)
-            lib.call("sed_colsum", dgh.data_ptr() + d * 3 * H * 4, dbh.data_ptr(), BT, 3 * H, 6 * H, st)
-            d_w_ih.append(dwi); d_w_hh.append(dwh); d_b_ih.append(dbi); d_b_hh.append(dbh)
+        dwi = [_grad_buf(cfg, w_ih_f).zero_(), _grad_buf(cfg, w_ih_r).zero_()]
+        dwh = [_grad_buf(cfg, w_hh_f).zero_(), _grad_buf(cfg, w_hh_r).zero_()]
+        dbi = [_grad_buf(cfg, b_ih_f), _grad_buf(cfg, b_ih_r)]
+        dbh = [_grad_buf(cfg, b_hh_f), _grad_buf(cfg, b_hh_r)]
+        off = 3 * H * 4
+        # dW_ih[d] = dgi[d]^T . x   and   dW_hh[d] = dgh[d]^T . hprev[d]   (K = B*T, split-K, both directions per launch)
+        lib.call("sed_gemm_pair", dgi.data_ptr(), dgi.data_ptr() + off, x.data_ptr(), x.data_ptr(), None, None,
+                 dwi[0].data_ptr(), dwi[1].data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, 0, st)
+        lib.call("sed_gemm_pair", dgh.data_ptr(), dgh.data_ptr() + off, hprev.data_ptr(), hprev.data_ptr() + H * 4, None, None,
+                 dwh[0].data_ptr(), dwh[1].data_ptr(), 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, 0, st)
+        lib.call("sed_colsum", dgi.data_ptr(), dbi[0].data_ptr(), dbi[1].data_ptr(), 3 * H, BT, 6 * H, 6 * H, st)
+        lib.call("sed_colsum", dgh.data_ptr(), dbh[0].data_ptr(), dbh[1].data_ptr(), 3 * H, BT, 6 * H, 6 * H, st)
+        d_w_ih, d_w_hh, d_b_ih, d_b_hh = dwi, dwh, dbi, dbh
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(B, T, I, **f32)
-            for d, w in enumerate((w_ih_f, w_ih_r)):
-                _gemm(lib, dgi.data_ptr() + d * 3 * H * 4, w.data_ptr(), None, dx.data_ptr(), BT, I, 3 * H, 6 * H, I, I, 0, 0, 1, d, st)
+            # dx = dgi[fwd] . W_ih[fwd] + dgi[rev] . W_ih[rev]: one launch, both products accumulate into dx
+            dx = torch.zeros(B, T, I, **f32)
+            lib.call("sed_gemm_pair", dgi.data_ptr(), dgi.data_ptr() + 3 * H * 4, w_ih_f.data_ptr(), w_ih_r.data_ptr(), None, None,
+                     dx.data_ptr(), dx.data_ptr(), BT, I, 3 * H, 6 * H, I, I, 0, 0, 1, 1, st)
         return (dx, d_w_ih[0], d_w_hh[0], d_b_ih[0], d_b_hh[0], d_w_ih[1], d_w_hh[1], d_b_ih[1], d_b_hh[1], None)
 
 

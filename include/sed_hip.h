@@ -101,8 +101,13 @@ int sed_conv0_wgrad(const float* x, const int* bounds, const float* dy, float* d
 int sed_gemm(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
              int ldc, int transA, int transB, int split_k, int accumulate, void* stream);
 
-/* out[n] = sum_m X[m*ld + n] (bias gradients). */
-int sed_colsum(const float* X, float* out, int M, int N, int ld, void* stream);
+/* Two same-shape GEMMs (the two GRU directions) in one launch: (A0,B0,bias0 -> C0), (A1,B1,bias1 -> C1). */
+int sed_gemm_pair(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
+                  const float* bias1, float* C0, float* C1, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                  int transB, int split_k, int accumulate, void* stream);
+
+/* Column sums (bias gradients): out[n] = sum_m X[m*ld + n] for n < nsplit, out1[n-nsplit] for nsplit <= n < N. */
+int sed_colsum(const float* X, float* out, float* out1, int nsplit, int M, int N, int ld, void* stream);
 
 /* GRU recurrence of one layer, both directions: gi (B,T,2,3H) = W_ih x + b_ih per direction; whh0/whh1 (3H,H),
  * bhh0/bhh1 (3H) = forward / reverse direction; out (B,T,2H); saved (B,T,2,4,H) = r,z,n,hn or null. */
