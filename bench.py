@@ -196,8 +196,8 @@ def main():
     task = SEDTask4(config, Enc(), student, opt=opt, scheduler=sched).to(dev)
     opt.arena = task.sed_student.arena
     task.train()
-    if os.environ.get("SED_OVERLAP_TEACHER") is not None:
-        task.overlap_teacher = os.environ["SED_OVERLAP_TEACHER"] == "1"
+    if os.environ.get("SED_OVERLAP_TAILS") is not None:
+        task.overlap_tails = os.environ["SED_OVERLAP_TAILS"] == "1"
     driver = StepDriver(task, world_size=world)
     audio, labels = synthetic_batch(dev, 1234 + rank)
 

@@ -106,25 +106,32 @@ class CRNN(nn.Module):
         return features.specaug_bounds(B, n_freq, n_time, self.specaugm_f_l, self.specaugm_f_p, self.specaugm_t_l,
                                        self.specaugm_t_p, device, iid_masks=self.specaugm_iid_masks)
 
-    def forward(self, x, pad_mask=None, embeddings=None, classes_mask=None):
-        if pad_mask is not None or embeddings is not None or classes_mask is not None:
-            raise NotImplementedError("pad_mask / embeddings / classes_mask: next rows (SURVEY 8f)")
+    def forward_cnn(self, x):
+        """First half of forward(): SpecAugment + the 7 CNN blocks.  x (B, n_mels, T) -> (B, T', C) channels-last."""
         if x.dim() != 3:
             raise ValueError("expected (batch, n_mels, frames)")
         xt = features.as_btf(x)                                           # (B, T, F), no copy for our own views
-        arena = self.arena
         bounds = self._specaug_bounds(xt.shape[0], xt.shape[2], xt.shape[1], xt.device) if self.training else None
-        h = self.cnn(xt, bounds=bounds, arena=arena)                      # (B, T', F', C)
+        h = self.cnn(xt, bounds=bounds, arena=self.arena)                 # (B, T', F', C)
         bs, frames, freq, chan = h.shape
         if freq != 1:
             raise NotImplementedError("CNN output keeps %d frequency bins; the recurrent stage expects 1" % freq)
-        h = h.view(bs, frames, chan)
+        return h.view(bs, frames, chan)
+
+    def forward_tail(self, h):
+        """Second half of forward(): BiGRU + dropout + attention head.  (B, T', C) -> strong (B,nclass,T'), weak."""
+        arena = self.arena
         h = self.rnn(h, arena=arena)                                      # (B, T', 256)
         drop = self.dropout.training and self.dropout_p > 0
         cfg = dict(dropout_p=self.dropout_p, apply_dropout=drop, seed=new_seed() if drop else 0, arena=arena)
         strong, weak = HeadFn.apply(h, self.dense.weight, self.dense.bias, self.dense_softmax.weight,
                                     self.dense_softmax.bias, cfg)
         return strong.transpose(1, 2), weak
+
+    def forward(self, x, pad_mask=None, embeddings=None, classes_mask=None):
+        if pad_mask is not None or embeddings is not None or classes_mask is not None:
+            raise NotImplementedError("pad_mask / embeddings / classes_mask: next rows (SURVEY 8f)")
+        return self.forward_tail(self.forward_cnn(x))
 
     def train(self, mode=True):
         """Mirrors CRNN.train (CRNN.py:308-323), including that it returns None."""

@@ -119,11 +119,13 @@ class SEDTask4(_Base):
         return self.train_loader
 
     # ---- the hot path -----------------------------------------------------------------------------
-    overlap_teacher = False         # teacher forward on a side stream (GPU only): measured no gain on MI355X (queues did not overlap), off by default
+    overlap_tails = True            # student / teacher GRU+head tails on two HIP streams (GPU only)
     _tstream = None
 
-    def _teacher_stream(self, device):
-        if device.type != "cuda" or not self.overlap_teacher:
+    def _tail_stream(self, device):
+        from .nnet.CRNN import CRNN
+        if (device.type != "cuda" or not self.overlap_tails or not isinstance(self.sed_student, CRNN)
+                or not isinstance(self.sed_teacher, CRNN)):
             return None
         if self._tstream is None:
             self._tstream = torch.cuda.Stream(device=device)
@@ -147,23 +149,27 @@ class SEDTask4(_Base):
             mixup_inplace_(features_[strong_sl], labels[strong_sl], mixup_label_type=mixup_type)
 
         x = self.scaled_logmel(features_)                                 # shared by student and teacher
-        strong_s, weak_s = self.sed_student(x)
-        tstream = self._teacher_stream(x.device)
+        tstream = self._tail_stream(x.device)
         if tstream is None:
+            strong_s, weak_s = self.sed_student(x)
             with torch.no_grad():
                 strong_t, weak_t = self.sed_teacher(x)
         else:
-            # The teacher forward is independent of the student's: run it on a second HIP stream so its
-            # latency-bound phases (GRU recurrence, the small late-layer grids) fill CUs the student leaves idle.
+            # Both CNN encoders first (they fill the GPU), then the two latency-bound tails -- BiGRU recurrence (96
+            # workgroups each) + head -- side by side on two HIP streams: they are independent and together still leave
+            # CUs idle.  (Running the WHOLE teacher forward concurrently was measured to be a net loss.)
+            hs = self.sed_student.forward_cnn(x)
+            with torch.no_grad():
+                ht = self.sed_teacher.forward_cnn(x)
             main = torch.cuda.current_stream(x.device)
-            tstream.wait_stream(main)                                     # x is ready (student kernels are only queued)
+            tstream.wait_stream(main)
             with torch.cuda.stream(tstream), torch.no_grad():
-                strong_t, weak_t = self.sed_teacher(x)
+                strong_t, weak_t = self.sed_teacher.forward_tail(ht)
+            strong_s, weak_s = self.sed_student.forward_tail(hs)
             main.wait_stream(tstream)
-            x.record_stream(tstream)
+            ht.record_stream(tstream)
             strong_t.record_stream(main)
             weak_t.record_stream(main)
-
         sched = self.scheduler["scheduler"]
         weight = self.hparams["training"]["const_max"] * sched._get_scaling_factor()
         out = MeanTeacherLossFn.apply(strong_s.transpose(1, 2), weak_s, strong_t.transpose(1, 2), weak_t, labels, labels_weak,
