@@ -34,6 +34,45 @@ extern "C" int sed_conv_pack_weights(const float* W, float* Wf, float* Wd, int C
     SED_LAUNCH(pack_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, Wf, Wd, COUT, CIN);
     return sed_check_launch();
 }
+// All conv layers of one model in ONE launch (student / teacher weights change every step).
+struct PackJobs {
+    const float* W[8];
+    float* Wf[8];
+    float* Wd[8];
+    int cout[8], cin[8], start[9];
+    int n;
+};
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackJobs jobs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= jobs.start[jobs.n]) return;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) j += (q < jobs.n && i >= jobs.start[q]) ? 1 : 0;
+    const int e = i - jobs.start[j], COUT = jobs.cout[j], CIN = jobs.cin[j];
+    const int b = e % 3, a = (e / 3) % 3, ci = (e / 9) % CIN, co = e / (9 * CIN);
+    const float w = jobs.W[j][e];
+    jobs.Wf[j][((a * 3 + b) * CIN + ci) * COUT + co] = w;
+    if (jobs.Wd[j]) jobs.Wd[j][(((2 - a) * 3 + (2 - b)) * COUT + co) * CIN + ci] = w;
+}
+// n <= 8 layers; W/Wf/Wd: host arrays of n device pointers (Wd entries may be null); cout/cin: host int arrays.
+extern "C" int sed_conv_pack_multi(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout, const int* cin,
+                                   void* stream) {
+    if (n < 1 || n > 8) return SED_ERR_ARG;
+    PackJobs jobs;
+    int tot = 0;
+    for (int j = 0; j < n; ++j) {
+        jobs.W[j] = (const float*)W[j]; jobs.Wf[j] = (float*)Wf[j]; jobs.Wd[j] = Wd ? (float*)Wd[j] : nullptr;
+        jobs.cout[j] = cout[j]; jobs.cin[j] = cin[j]; jobs.start[j] = tot;
+        tot += cout[j] * cin[j] * 9;
+    }
+    for (int j = n; j < 8; ++j) { jobs.W[j] = nullptr; jobs.Wf[j] = nullptr; jobs.Wd[j] = nullptr; jobs.cout[j] = 0; jobs.cin[j] = 0; jobs.start[j] = tot; }
+    jobs.start[n] = tot;
+    jobs.start[8] = tot;
+    jobs.n = n;
+    SED_LAUNCH(pack_weights_multi_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, jobs);
+    return sed_check_launch();
+}
+
 // partials[part][tap][ci][co] -> dW (COUT, CIN, 3, 3): fixed-order (deterministic) sum over the workgroup partials
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ parts, float* __restrict__ dW, int nparts,
                                                            int COUT, int CIN) {
@@ -122,15 +161,28 @@ __global__ __launch_bounds__(CONV_THREADS(COUT)) void conv3x3_kernel(const float
     for (int cc = 0; cc < NCH; ++cc) {
         // ---- stage the halo patch of this cin chunk ----
         constexpr int V = CK / 4;
-        for (int idx = tid; idx < PP * V; idx += THREADS) {
-            const int pix = idx / V, v = idx - pix * V;
-            const int i = pix / PW, j = pix - i * PW;
-            const int t = t0 - 1 + i, f = f0 - 1 + j;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < T && f >= 0 && f < F)
-                val = *(const float4*)(x + (((size_t)b * T + t) * F + f) * CIN + cc * CK + 4 * v);
-            float* d = patch + pix * CKP + 4 * v;
-            d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+        {   // all loads of the patch first, LDS stores after: one memory latency per chunk instead of one per load
+            constexpr int NLD = (PP * V + THREADS - 1) / THREADS;
+            float4 ld[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int idx = tid + THREADS * u;
+                const int pix = idx / V, v = idx - pix * V;
+                const int i = pix / PW, j = pix - i * PW;
+                const int t = t0 - 1 + i, f = f0 - 1 + j;
+                ld[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < PP * V && t >= 0 && t < T && f >= 0 && f < F)
+                    ld[u] = *(const float4*)(x + (((size_t)b * T + t) * F + f) * CIN + cc * CK + 4 * v);
+            }
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int idx = tid + THREADS * u;
+                if (idx < PP * V) {
+                    const int pix = idx / V, v = idx - pix * V;
+                    float* d = patch + pix * CKP + 4 * v;
+                    d[0] = ld[u].x; d[1] = ld[u].y; d[2] = ld[u].z; d[3] = ld[u].w;
+                }
+            }
         }
         // ---- tap 0 weights straight to LDS buffer 0 ----
         {
@@ -434,24 +486,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
         const int p0 = tile * KT;
         __syncthreads();
         // stage shifted x and dy for pixels p0 .. p0+KT-1 (zero outside the image / beyond npix)
-        for (int idx = tid; idx < KT * (CIN / 4); idx += 256) {
-            const int r = idx / (CIN / 4), v = idx - r * (CIN / 4);
-            const int p = p0 + r;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < npix) {
-                const int f = p % F, t = (p / F) % T, bb = p / (F * T);
-                const int t2 = t + da, f2 = f + db;
-                if (t2 >= 0 && t2 < T && f2 >= 0 && f2 < F)
-                    val = *(const float4*)(x + (((size_t)bb * T + t2) * F + f2) * CIN + 4 * v);
+        {   // loads first (x tile shifted by the tap, then the dy tile), LDS stores after
+            constexpr int NX = KT * (CIN / 4) / 256, ND = KT * (COUT / 4) / 256;
+            float4 lx[NX], ldy[ND];
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                const int idx = tid + 256 * u, r = idx / (CIN / 4), v = idx - r * (CIN / 4);
+                const int p = p0 + r;
+                lx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < npix) {
+                    const int f = p % F, t = (p / F) % T, bb = p / (F * T);
+                    const int t2 = t + da, f2 = f + db;
+                    if (t2 >= 0 && t2 < T && f2 >= 0 && f2 < F)
+                        lx[u] = *(const float4*)(x + (((size_t)bb * T + t2) * F + f2) * CIN + 4 * v);
+                }
             }
-            *(float4*)(xs + r * CIN + 4 * v) = val;
-        }
-        for (int idx = tid; idx < KT * (COUT / 4); idx += 256) {
-            const int r = idx / (COUT / 4), v = idx - r * (COUT / 4);
-            const int p = p0 + r;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < npix) val = *(const float4*)(dy + (size_t)p * COUT + 4 * v);
-            *(float4*)(ds + r * COUT + 4 * v) = val;
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                const int idx = tid + 256 * u, r = idx / (COUT / 4), v = idx - r * (COUT / 4);
+                const int p = p0 + r;
+                ldy[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < npix) ldy[u] = *(const float4*)(dy + (size_t)p * COUT + 4 * v);
+            }
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                const int idx = tid + 256 * u, r = idx / (CIN / 4), v = idx - r * (CIN / 4);
+                *(float4*)(xs + r * CIN + 4 * v) = lx[u];
+            }
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                const int idx = tid + 256 * u, r = idx / (COUT / 4), v = idx - r * (COUT / 4);
+                *(float4*)(ds + r * COUT + 4 * v) = ldy[u];
+            }
         }
         __syncthreads();
         // this wave's K slice: rows [wk*KT/WK, (wk+1)*KT/WK)
@@ -530,20 +596,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_alltaps_kernel(const float* __
         const int ft = tile % ftiles, tt = (tile / ftiles) % ttiles, b = tile / (ftiles * ttiles);
         const int t0 = tt * TR, f0 = ft * TF;
         __syncthreads();
-        for (int idx = tid; idx < PP * (CIN / 4); idx += 256) {
-            const int pix = idx / (CIN / 4), v = idx - pix * (CIN / 4);
-            const int i = pix / PW, j = pix - i * PW;
-            const int t = t0 - 1 + i, f = f0 - 1 + j;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < T && f >= 0 && f < F) val = *(const float4*)(x + (((size_t)b * T + t) * F + f) * CIN + 4 * v);
-            *(float4*)(xs + pix * CIN + 4 * v) = val;
-        }
-        for (int idx = tid; idx < 128 * (COUT / 4); idx += 256) {
-            const int p = idx / (COUT / 4), v = idx - p * (COUT / 4);
-            const int t = t0 + p / TF, f = f0 + p % TF;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < T) val = *(const float4*)(dy + (((size_t)b * T + t) * F + f) * COUT + 4 * v);
-            *(float4*)(ds + p * COUT + 4 * v) = val;
+        {   // loads first, LDS stores after
+            constexpr int NX = (PP * (CIN / 4) + 255) / 256, ND = 128 * (COUT / 4) / 256;
+            float4 lx[NX], ldy[ND];
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                const int idx = tid + 256 * u, pix = idx / (CIN / 4), v = idx - pix * (CIN / 4);
+                const int i = pix / PW, j = pix - i * PW;
+                const int t = t0 - 1 + i, f = f0 - 1 + j;
+                lx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < PP * (CIN / 4) && t >= 0 && t < T && f >= 0 && f < F)
+                    lx[u] = *(const float4*)(x + (((size_t)b * T + t) * F + f) * CIN + 4 * v);
+            }
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                const int idx = tid + 256 * u, p = idx / (COUT / 4), v = idx - p * (COUT / 4);
+                const int t = t0 + p / TF, f = f0 + p % TF;
+                ldy[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t < T) ldy[u] = *(const float4*)(dy + (((size_t)b * T + t) * F + f) * COUT + 4 * v);
+            }
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                const int idx = tid + 256 * u;
+                if (idx < PP * (CIN / 4)) *(float4*)(xs + (idx / (CIN / 4)) * CIN + 4 * (idx % (CIN / 4))) = lx[u];
+            }
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                const int idx = tid + 256 * u;
+                *(float4*)(ds + (idx / (COUT / 4)) * COUT + 4 * (idx % (COUT / 4))) = ldy[u];
+            }
         }
         __syncthreads();
         constexpr int KS = 128 / WK;

@@ -57,18 +57,29 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
         __syncthreads();
-        for (int idx = tid; idx < ROWS * (C / 4); idx += 256) {
-            const int m = idx / (C / 4), v = idx - m * (C / 4);
-            int o, t, f;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f)) {
-                val = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
-                const float* s = sc + 4 * v;
-                val.x = fmaf(val.x, s[0], s[C + 0]); val.y = fmaf(val.y, s[1], s[C + 1]);
-                val.z = fmaf(val.z, s[2], s[C + 2]); val.w = fmaf(val.w, s[3], s[C + 3]);
+        {   // all global loads of the tile are issued before the first LDS store (one HBM latency per tile, not one per load)
+            constexpr int NLD = ROWS * (C / 4) / 256;
+            float4 ld[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
+                int o, t, f;
+                ld[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f)) ld[u] = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
             }
-            float* d = xs + m * CP + 4 * v;
-            d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
+                int o, t, f;
+                float4 val = ld[u];
+                if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f)) {
+                    const float* s = sc + 4 * v;
+                    val.x = fmaf(val.x, s[0], s[C + 0]); val.y = fmaf(val.y, s[1], s[C + 1]);
+                    val.z = fmaf(val.z, s[2], s[C + 2]); val.w = fmaf(val.w, s[3], s[C + 3]);
+                }
+                float* d = xs + m * CP + 4 * v;
+                d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+            }
         }
         __syncthreads();
         f32x16 acc[NT];
@@ -330,18 +341,29 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
         __syncthreads();
-        for (int idx = tid; idx < ROWS * (C / 4); idx += 256) {
-            const int m = idx / (C / 4), v = idx - m * (C / 4);
-            int o, t, f;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f)) {
-                val = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
-                const float* mu = sc + 4 * v;
-                val.x = (val.x - mu[0]) * mu[C + 0]; val.y = (val.y - mu[1]) * mu[C + 1];
-                val.z = (val.z - mu[2]) * mu[C + 2]; val.w = (val.w - mu[3]) * mu[C + 3];
+        {   // loads first, LDS stores after (see glu_fwd_kernel)
+            constexpr int NLD = ROWS * (C / 4) / 256;
+            float4 ld[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
+                int o, t, f;
+                ld[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f)) ld[u] = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
             }
-            float* d = xh + m * CP + 4 * v;
-            d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
+                int o, t, f;
+                float4 val = ld[u];
+                if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f)) {
+                    const float* mu = sc + 4 * v;
+                    val.x = (val.x - mu[0]) * mu[C + 0]; val.y = (val.y - mu[1]) * mu[C + 1];
+                    val.z = (val.z - mu[2]) * mu[C + 2]; val.w = (val.w - mu[3]) * mu[C + 3];
+                }
+                float* d = xh + m * CP + 4 * v;
+                d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+            }
         }
         __syncthreads();
         // ---- GEMM1: lin = xn . Wg^T ----

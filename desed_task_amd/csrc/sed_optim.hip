@@ -49,3 +49,10 @@ extern "C" int sed_adam_step(float* p, const float* g, float* m, float* v, long 
                inv_bc2_sqrt, grad_scale);
     return sed_check_launch();
 }
+
+// Zero up to four (small) accumulator buffers in one launch; null / 0 entries are skipped.
+extern "C" int sed_zero_buffers(float* p0, long long n0, float* p1, long long n1, float* p2, long long n2, float* p3, long long n3,
+                                void* stream) {
+    sed_zero4((hipStream_t)stream, p0, (int)n0, p1, (int)n1, p2, (int)n2, p3, (int)n3);
+    return sed_check_launch();
+}

@@ -69,8 +69,12 @@ class ConvBlockFn(torch.autograd.Function):
             lib.call("sed_conv0_fwd", x.data_ptr(), conv_w.data_ptr(), _p(conv_b), _p(bounds), y.data_ptr(), _p(partial),
                      B, T, F, COUT, st)
         else:
-            wf = torch.empty(9 * CIN * COUT, device=dev, dtype=torch.float32)
-            lib.call("sed_conv_pack_weights", conv_w.data_ptr(), wf.data_ptr(), None, COUT, CIN, st)
+            packed = cfg.get("packed")
+            if packed is not None:
+                wf = packed[0]
+            else:
+                wf = torch.empty(9 * CIN * COUT, device=dev, dtype=torch.float32)
+                lib.call("sed_conv_pack_weights", conv_w.data_ptr(), wf.data_ptr(), None, COUT, CIN, st)
             lib.call("sed_conv3x3", x.data_ptr(), wf.data_ptr(), _p(conv_b), y.data_ptr(), _p(partial), B, T, F, CIN, COUT, st)
         stats = torch.empty(4 * COUT, device=dev, dtype=torch.float32)
         lib.call("sed_bn_finalize", _p(partial), nblk, COUT, float(B * T * F), bn_w.data_ptr(), bn_b.data_ptr(),
@@ -115,9 +119,13 @@ class ConvBlockFn(torch.autograd.Function):
             scratch = torch.empty(int(lib.value("sed_conv_wgrad_scratch_floats", B, T, F, CIN, COUT)), **f32)
             lib.call("sed_conv_wgrad", x.data_ptr(), dy.data_ptr(), scratch.data_ptr(), d_w.data_ptr(), B, T, F, CIN, COUT, st)
             if ctx.needs_input_grad[0]:
-                wd = torch.empty(9 * CIN * COUT, **f32)
-                wf = torch.empty(9 * CIN * COUT, **f32)
-                lib.call("sed_conv_pack_weights", conv_w.data_ptr(), wf.data_ptr(), wd.data_ptr(), COUT, CIN, st)
+                packed = cfg.get("packed")
+                if packed is not None and packed[1] is not None:
+                    wd = packed[1]                # packed with the forward weights (same values: no optimizer step in between)
+                else:
+                    wd = torch.empty(9 * CIN * COUT, **f32)
+                    wf = torch.empty(9 * CIN * COUT, **f32)
+                    lib.call("sed_conv_pack_weights", conv_w.data_ptr(), wf.data_ptr(), wd.data_ptr(), COUT, CIN, st)
                 dx = torch.empty_like(x)
                 lib.call("sed_conv3x3", dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, B, T, F, COUT, CIN, st)
         return dx, d_w, d_bias, d_gamma, d_beta, d_glu_w, d_glu_b, None, None, None
@@ -173,8 +181,10 @@ class BiGRULayerFn(torch.autograd.Function):
                  dgi.data_ptr(), dgh.data_ptr(), hprev.data_ptr(), B, T, H, st)
         BT = B * T
         split = max(1, min(32, BT // 256))
-        dwi = [_grad_buf(cfg, w_ih_f).zero_(), _grad_buf(cfg, w_ih_r).zero_()]
-        dwh = [_grad_buf(cfg, w_hh_f).zero_(), _grad_buf(cfg, w_hh_r).zero_()]
+        dwi = [_grad_buf(cfg, w_ih_f), _grad_buf(cfg, w_ih_r)]
+        dwh = [_grad_buf(cfg, w_hh_f), _grad_buf(cfg, w_hh_r)]
+        lib.call("sed_zero_buffers", dwi[0].data_ptr(), dwi[0].numel(), dwi[1].data_ptr(), dwi[1].numel(),
+                 dwh[0].data_ptr(), dwh[0].numel(), dwh[1].data_ptr(), dwh[1].numel(), st)     # split-K GEMMs accumulate
         dbi = [_grad_buf(cfg, b_ih_f), _grad_buf(cfg, b_ih_r)]
         dbh = [_grad_buf(cfg, b_hh_f), _grad_buf(cfg, b_hh_r)]
         off = 3 * H * 4

@@ -49,6 +49,10 @@ int sed_specaug(const float* x, float* y, const int* bounds, int B, int T, int F
  * flipped taps, transposed channels); Wd may be null. */
 int sed_conv_pack_weights(const float* W, float* Wf, float* Wd, int COUT, int CIN, void* stream);
 
+/* The same for up to 8 layers in one launch.  W/Wf/Wd: HOST arrays of n device pointers (Wd or its entries may be null). */
+int sed_conv_pack_multi(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout, const int* cin,
+                        void* stream);
+
 /* Number of workgroups (= rows of `partial`, 2*COUT floats each) a forward conv launch writes. */
 int sed_conv_fwd_blocks(int B, int T, int F, int CIN, int COUT);
 
@@ -146,6 +150,10 @@ int sed_ema_update(float* teacher, const float* student, long long n, float alph
 /* torch.optim.Adam step (train_sed.py:199-201) over the whole arena; grad_scale folds in 1/world_size. */
 int sed_adam_step(float* p, const float* g, float* m, float* v, long long n, float b1, float b2, float eps,
                   float step_size, float inv_bc2_sqrt, float grad_scale, void* stream);
+
+/* Zero up to four small accumulator buffers in one launch (null / 0 entries are skipped). */
+int sed_zero_buffers(float* p0, long long n0, float* p1, long long n1, float* p2, long long n2, float* p3, long long n3,
+                     void* stream);
 
 /* Hardware self-test of the MFMA lane maps (no reference counterpart): C = A[M][K] * B[K][M], M = shape (32|16). */
 int sed_selftest_mfma(const float* A, const float* Bm, float* C, int K, int shape, void* stream);
