@@ -22,12 +22,13 @@ struct GluGeom {
 };
 
 // map row m of a tile starting at window o0 to the input pixel; returns false when the window is out of range
+// Fo = 1 << fsh (F is a power of two by the conv kernels' contract), so the window -> (to, fo) split is shift/mask.
 template <int PT, int PF>
-__device__ __forceinline__ bool row_pixel(int m, int o0, int NWC, int Fo, int& o, int& t, int& f) {
+__device__ __forceinline__ bool row_pixel(int m, int o0, int NWC, int fsh, int& o, int& t, int& f) {
     constexpr int WIN = PT * PF;
     const int q = m % WIN;
     o = o0 + m / WIN;
-    const int to = o / Fo, fo = o - to * Fo;
+    const int to = o >> fsh, fo = o & ((1 << fsh) - 1);
     t = to * PT + q / PF;
     f = fo * PF + q % PF;
     return o < NWC;
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ 
     float* sc = xs + ROWS * CP;         // scale[C], shift[C], bg[C]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const int To = T / PT, Fo = F / PF, NWC = To * Fo;
+    const int fsh = 31 - __builtin_clz(Fo);
     const int tiles_per_clip = (NWC + NW - 1) / NW, ntiles = B * tiles_per_clip;
 
     for (int i = tid; i < C * C; i += 256) wg[(i / C) * CP + (i % C)] = Wg[i];
@@ -65,14 +67,14 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ 
                 const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
                 int o, t, f;
                 ld[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f)) ld[u] = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
+                if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) ld[u] = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
             }
 #pragma unroll
             for (int u = 0; u < NLD; ++u) {
                 const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
                 int o, t, f;
                 float4 val = ld[u];
-                if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f)) {
+                if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) {
                     const float* s = sc + 4 * v;
                     val.x = fmaf(val.x, s[0], s[C + 0]); val.y = fmaf(val.y, s[1], s[C + 1]);
                     val.z = fmaf(val.z, s[2], s[C + 2]); val.w = fmaf(val.w, s[3], s[C + 3]);
@@ -95,27 +97,31 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ 
                 acc[nt] = mfma32(av, bv, acc[nt]);
             }
         }
-        // ---- epilogue: gate, dropout, pool ----
+        // ---- epilogue: gate, dropout, pool (row -> pixel arithmetic once per row, shared by all channel tiles) ----
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = nt * 32 + lo;
-            if (n < C) {
-                const float bias = sc[2 * C + n];
+        for (int j = 0; j < 4; ++j) {
+            const int mbase = 32 * w + 8 * j + 4 * hi;
+            uint32_t ebase[4];
+            bool okr[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+            for (int q = 0; q < 4; ++q) {
+                int o, t, f;
+                okr[q] = row_pixel<PT, PF>(mbase + q, o0, NWC, fsh, o, t, f);
+                ebase[q] = (uint32_t)((((size_t)b * T + t) * F + f) * C);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nt * 32 + lo;
+                if (n < C) {
+                    const float bias = sc[2 * C + n];
                     float v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int m = 32 * w + 8 * j + 4 * hi + q;
-                        int o, t, f;
-                        const bool ok = row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f);
-                        const float xn = xs[m * CP + n];
+                        const float xn = xs[(mbase + q) * CP + n];
                         float r = (acc[nt][4 * j + q] + bias) * sed_fast_sigmoid(xn);
-                        const uint32_t e = (uint32_t)((((size_t)b * T + t) * F + f) * C + n);
-                        r = (ok && sed_keep(e, seed, thr24)) ? r * dscale : 0.f;
+                        r = (okr[q] && sed_keep(ebase[q] + n, seed, thr24)) ? r * dscale : 0.f;
                         v[q] = r;
                     }
-                    const int mbase = 32 * w + 8 * j + 4 * hi;
                     if (WIN == 4) {
                         const int o = o0 + mbase / 4;
                         if (o < NWC) out[((size_t)b * NWC + o) * C + n] = 0.25f * ((v[0] + v[1]) + (v[2] + v[3]));
@@ -321,6 +327,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const int wm = w % WM, wn = w / WM;
     const int To = T / PT, Fo = F / PF, NWC = To * Fo;
+    const int fsh = 31 - __builtin_clz(Fo);
     const int tiles_per_clip = (NWC + NW - 1) / NW, ntiles = B * tiles_per_clip;
 
     for (int i = tid; i < C * C; i += 256) wg[(i / C) * CP + (i % C)] = Wg[i];
@@ -349,14 +356,14 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
                 const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
                 int o, t, f;
                 ld[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f)) ld[u] = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
+                if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) ld[u] = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
             }
 #pragma unroll
             for (int u = 0; u < NLD; ++u) {
                 const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
                 int o, t, f;
                 float4 val = ld[u];
-                if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f)) {
+                if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) {
                     const float* mu = sc + 4 * v;
                     val.x = (val.x - mu[0]) * mu[C + 0]; val.y = (val.y - mu[1]) * mu[C + 1];
                     val.z = (val.z - mu[2]) * mu[C + 2]; val.w = (val.w - mu[3]) * mu[C + 3];
@@ -383,31 +390,42 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
                 }
             }
         }
-        // ---- epilogue 1: dlin -> LDS, e -> acc (seed of GEMM2) ----
+        // ---- epilogue 1: dlin -> LDS, e -> acc (seed of GEMM2); row -> pixel arithmetic once per row ----
+        {
+            bool nokv[NTW];
+            float biasv[NTW], gnv[NTW], bnv[NTW];
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int n = (wn * NTW + nt) * 32 + lo;
-            const bool nok = n < C;
-            const float bias = nok ? sc[4 * C + n] : 0.f, gn = nok ? gam[n] : 0.f, bn = nok ? bet[n] : 0.f;
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int n = (wn * NTW + nt) * 32 + lo;
+                nokv[nt] = n < C;
+                biasv[nt] = nokv[nt] ? sc[4 * C + n] : 0.f;
+                gnv[nt] = nokv[nt] ? gam[n] : 0.f;
+                bnv[nt] = nokv[nt] ? bet[n] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = 32 * wm + mfma32_row(r, lane);
                 int o, t, f;
-                const bool ok = row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f) && nok;
-                float dlin = 0.f, e = 0.f;
-                if (ok) {
-                    const float xn = fmaf(xh[m * CP + n], gn, bn);
-                    const float sg = sed_fast_sigmoid(xn);
-                    const float lin = acc[nt][r] + bias;
-                    const uint32_t ei = (uint32_t)((((size_t)b * T + t) * F + f) * C + n);
-                    float g = gout[((size_t)b * NWC + o) * C + n] * (1.0f / WIN);
-                    g = sed_keep(ei, seed, thr24) ? g * dscale : 0.f;
-                    dlin = g * sg;
-                    e = g * lin * sg * (1.0f - sg);
+                const bool rok = row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f);
+                const uint32_t ebase = (uint32_t)((((size_t)b * T + t) * F + f) * C);
+                const size_t gbase = ((size_t)b * NWC + o) * C;
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int n = (wn * NTW + nt) * 32 + lo;
+                    float dlin = 0.f, e = 0.f;
+                    if (rok && nokv[nt]) {
+                        const float xn = fmaf(xh[m * CP + n], gnv[nt], bnv[nt]);
+                        const float sg = sed_fast_sigmoid(xn);
+                        const float lin = acc[nt][r] + biasv[nt];
+                        float g = gout[gbase + n] * (1.0f / WIN);
+                        g = sed_keep(ebase + n, seed, thr24) ? g * dscale : 0.f;
+                        dlin = g * sg;
+                        e = g * lin * sg * (1.0f - sg);
+                    }
+                    if (nokv[nt]) dl[m * CP + n] = dlin;
+                    acc[nt][r] = e;
+                    a_dbg[nt] += dlin;
                 }
-                if (nok) dl[m * CP + n] = dlin;
-                acc[nt][r] = e;
-                a_dbg[nt] += dlin;
             }
         }
         __syncthreads();
@@ -427,19 +445,20 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
         }
         // ---- epilogue 2: dz = dxn * gamma, BN reductions ----
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int c = (wn * NTW + nt) * 32 + lo;
-            const bool cok = c < C;
-            const float gc = cok ? gam[c] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * wm + mfma32_row(r, lane);
+            int o, t, f;
+            if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) {
+                float* dzr = dz + (((size_t)b * T + t) * F + f) * C;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = 32 * wm + mfma32_row(r, lane);
-                int o, t, f;
-                if (row_pixel<PT, PF>(m, o0, NWC, Fo, o, t, f) && cok) {
-                    const float dxn = acc[nt][r];
-                    a_dgam[nt] += dxn * xh[m * CP + c];
-                    a_dbet[nt] += dxn;
-                    dz[(((size_t)b * T + t) * F + f) * C + c] = dxn * gc;
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int c = (wn * NTW + nt) * 32 + lo;
+                    if (c < C) {
+                        const float dxn = acc[nt][r];
+                        a_dgam[nt] += dxn * xh[m * CP + c];
+                        a_dbet[nt] += dxn;
+                        dzr[c] = dxn * gam[c];
+                    }
                 }
             }
         }
