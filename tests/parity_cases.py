@@ -334,3 +334,75 @@ def case_training_step(dev, small=False, golden=None):
             mine = st[n].detach().cpu().numpy().reshape(-1)[:256]
             assert np.linalg.norm(mine - ref) <= 0.15 * np.linalg.norm(ref - init) + 1e-6, n
     return task
+
+
+# ------------------------------------------------------------------------------------------------
+# drop-in CRNN module vs the REFERENCE's own outputs (golden G5: eval and train-mode posteriors, G7: gradients)
+# ------------------------------------------------------------------------------------------------
+def case_crnn_vs_reference_golden(dev, golden):
+    from desed_task_amd.nnet.CRNN import CRNN
+    sd = O.make_state_dict(seed=7)
+    xin = O.lcg_fill((3, 128, 160), 21, 1.0)
+    cfg = dict(recipe_config()["net"])
+    # eval mode (inference path: running statistics, no dropout / SpecAugment)
+    net = CRNN(**cfg)
+    net.load_state_dict({k: v.clone() for k, v in sd.items()})
+    net = net.to(dev) if dev != "cpu" else net
+    net.eval()
+    with torch.no_grad():
+        strong, weak = net(to(dev, xin))
+    assert tuple(strong.shape) == (3, 10, 40) and tuple(weak.shape) == (3, 10)
+    assert np.abs(strong.cpu().numpy() - golden["g5_eval_strong"]).max() < 2e-5
+    assert np.abs(weak.cpu().numpy() - golden["g5_eval_weak"]).max() < 2e-5
+    # train mode, dropout 0, SpecAugment off: posteriors, BN running stats and gradients recorded from the reference
+    cfg["dropout"] = 0.0
+    net = CRNN(**cfg, specaugm_t_p=0.0, specaugm_f_p=0.0)
+    net.load_state_dict({k: v.clone() for k, v in sd.items()})
+    net = net.to(dev) if dev != "cpu" else net
+    net.train()
+    strong, weak = net(to(dev, xin))
+    assert np.abs(strong.detach().cpu().numpy() - golden["g5_train_strong"]).max() < 2e-5
+    assert np.abs(weak.detach().cpu().numpy() - golden["g5_train_weak"]).max() < 2e-5
+    for i in range(7):
+        bn = getattr(net.cnn.cnn, "batchnorm%d" % i)
+        assert np.abs(bn.running_mean.cpu().numpy() - golden["g3_train_rm%d" % i]).max() < 1e-5
+        assert np.abs(bn.running_var.cpu().numpy() - golden["g3_train_rv%d" % i]).max() < 1e-5
+    tgt_s = to(dev, (O.lcg_fill(tuple(strong.shape), 31, 0.5, 0.5) < 0.2).float())
+    tgt_w = to(dev, (O.lcg_fill(tuple(weak.shape), 32, 0.5, 0.5) < 0.3).float())
+    loss = torch.nn.functional.binary_cross_entropy(strong, tgt_s) + torch.nn.functional.binary_cross_entropy(weak, tgt_w)
+    assert abs(loss.item() - float(golden["g7_loss"][0])) < 2e-6
+    loss.backward()
+    names = list(golden["g7_param_names"])
+    norms = golden["g7_grad_norms"]
+    params = dict(net.named_parameters())
+    for n, ref in zip(names, norms):
+        if n.startswith("cnn.cnn.conv") and n.endswith(".bias"):
+            continue                                  # analytically zero (see case_training_step)
+        g = params[n].grad
+        assert abs(g.norm().item() - ref) <= 2e-3 * ref + 1e-7, n
+        key = "g7_grad__" + n
+        if key in golden.files:
+            got = g.detach().cpu().numpy().reshape(-1)[:512]
+            assert np.abs(got - golden[key]).max() <= 1e-4 * np.abs(golden[key]).max() + 1e-7, n
+
+
+def case_edge_shapes(dev):
+    """Ragged / degenerate inputs: odd frame counts (AvgPool floor drops the last frame), a single clip,
+    clips shorter than one pooling window, and an empty batch."""
+    from desed_task_amd.nnet.CRNN import CRNN
+    sd = O.make_state_dict(seed=7)
+    net = CRNN(**recipe_config()["net"])
+    net.load_state_dict({k: v.clone() for k, v in sd.items()})
+    net = net.to(dev) if dev != "cpu" else net
+    net.eval()
+    for B, T in ((1, 37), (2, 9), (1, 4)):
+        x = O.lcg_fill((B, 128, T), 50 + T, 1.0)
+        with torch.no_grad():
+            strong, weak = net(to(dev, x))
+            ref_s, ref_w = O.crnn_forward(sd, x, training=False)
+        assert tuple(strong.shape) == (B, 10, T // 4)
+        assert (strong.cpu() - ref_s).abs().max().item() < 2e-5 and (weak.cpu() - ref_w).abs().max().item() < 2e-5
+    mel = make_mel()
+    empty = mel(to(dev, torch.zeros(0, 4096)))
+    assert tuple(empty.shape) == (0, 128, 17)
+    assert tuple(Fh.minmax_scale(empty, apply_log=True).shape) == (0, 128, 17)

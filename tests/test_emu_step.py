@@ -25,3 +25,14 @@ def test_state_dict_layout(emu):
 
 def test_training_steps_match_oracle(emu):
     P.case_training_step("cpu", small=True)
+
+
+def test_crnn_matches_reference_golden(emu):
+    import os
+    import numpy as np
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden.npz"))
+    P.case_crnn_vs_reference_golden("cpu", G)
+
+
+def test_edge_shapes(emu):
+    P.case_edge_shapes("cpu")

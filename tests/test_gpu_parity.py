@@ -73,3 +73,14 @@ def test_training_steps_vs_oracle_and_reference_golden():
     import os
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden.npz"))
     P.case_training_step("cuda", small=False, golden=G)
+
+
+def test_crnn_matches_reference_golden():
+    """Drop-in CRNN (eval and train mode) against tensors recorded from the reference's own CRNN (fixtures G3/G5/G7)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden.npz"))
+    P.case_crnn_vs_reference_golden("cuda", G)
+
+
+def test_edge_shapes():
+    P.case_edge_shapes("cuda")
