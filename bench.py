@@ -105,6 +105,20 @@ def conv_flops(key):
     return 2.0 * B * T * F * 9 * CIN * COUT
 
 
+def pmc_traffic(cin, cout, F):
+    """HBM bytes per launch of the matching conv3x3 kernel from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        kernels = json.load(open(path))["kernels"]
+    except Exception:  # noqa: BLE001
+        return None
+    tf = min(F, 32)
+    for name, rec in kernels.items():
+        if name.startswith("conv3x3_kernel<%d, %d, %d, true" % (cin, cout, tf)):
+            return rec["hbm_bytes"]
+    return None
+
+
 def cpu_baseline():
     """One full oracle training step (training_step + EMA + backward + Adam) on a 12-clip batch of 10 s clips."""
     from oracle import sed_oracle as O
@@ -241,7 +255,11 @@ def main():
         roofline = {"bound": "mfma", "kernel": "conv3x3_kernel<CIN=%d,COUT=%d> (B,T,F)=(%d,%d,%d) f32 MFMA 32x32x2" %
                     (dom_key[4], dom_key[5], dom_key[1], dom_key[2], dom_key[3]),
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": pmc_traffic(dom_key[4], dom_key[5], dom_key[3]),
+                    "traffic_note": "HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
+                                    "(profiles/r01_pmc_fetch_write.md); algorithmic in+out+weights = %d bytes"
+                                    % (4 * dom_key[1] * dom_key[2] * dom_key[3] * (dom_key[4] + dom_key[5]) + 36 * dom_key[4] * dom_key[5]),
                     "launches_timed": dom[0], "avg_launch_ms": round(dom[1], 4),
                     "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
                     "conv_share_of_step": round(sum(v[2] for v in summ.values()) / (dt * 1e3), 3)}
