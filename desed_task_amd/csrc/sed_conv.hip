@@ -319,16 +319,24 @@ extern "C" int sed_conv3x3(const float* x, const float* Wp, const float* bias, f
 // predicate (CRNN.py:207-219) into the load.  Tile = 16 frames x F mel bins.
 // ---------------------------------------------------------------------------------------------
 #define C0_TR 16
+// Lane layout: 4 lanes per pixel, each owning 4 of the 16 output channels -> one wave store covers 16 pixels x 64 B
+// = 1 KB contiguous (the kernel is bound by writing y0, 64 B per pixel).
 template <int COUT>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                     const float* __restrict__ bias, const int* __restrict__ bounds,
                                                     float* __restrict__ y, float* __restrict__ partial, int B, int T, int F) {
+    static_assert(COUT == 16, "4 lanes x 4 channels");
     __shared__ float tile[(C0_TR + 2) * (128 + 2)];
-    __shared__ float sw[COUT * 9], sb[COUT];
     __shared__ float red[4][2 * COUT];
     const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * C0_TR, PW = F + 2;
-    if (tid < COUT * 9) sw[tid] = W[tid];
-    if (tid < COUT) sb[tid] = bias ? bias[tid] : 0.f;
+    const int cq = tid & 3;                                    // channel quad
+    float wreg[4][9], breg[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        breg[c] = bias ? bias[4 * cq + c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wreg[c][k] = W[(4 * cq + c) * 9 + k];
+    }
     int mf0 = 0, mf1 = 0, mt0 = 0, mt1 = 0;
     if (bounds) { mf0 = bounds[4 * b]; mf1 = bounds[4 * b + 1]; mt0 = bounds[4 * b + 2]; mt1 = bounds[4 * b + 3]; }
     for (int idx = tid; idx < (C0_TR + 2) * PW; idx += 256) {
@@ -342,10 +350,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
         tile[idx] = v;
     }
     __syncthreads();
-    float s[COUT], s2[COUT];
-#pragma unroll
-    for (int c = 0; c < COUT; ++c) { s[c] = 0.f; s2[c] = 0.f; }
-    for (int p = tid; p < C0_TR * F; p += 256) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = tid >> 2; p < C0_TR * F; p += 64) {
         const int pr = p / F, pc = p - pr * F, t = t0 + pr;
         if (t < T) {
             float in[9];
@@ -353,27 +359,27 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int bb = 0; bb < 3; ++bb) in[a * 3 + bb] = tile[(pr + a) * PW + pc + bb];
-            float o[COUT];
+            float o[4];
 #pragma unroll
-            for (int c = 0; c < COUT; ++c) {
+            for (int c = 0; c < 4; ++c) {
                 float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) acc = fmaf(in[k], sw[c * 9 + k], acc);
-                acc += sb[c];
+                for (int k = 0; k < 9; ++k) acc = fmaf(in[k], wreg[c][k], acc);
+                acc += breg[c];
                 o[c] = acc;
                 s[c] += acc;
                 s2[c] += acc * acc;
             }
-            float4* dst = (float4*)(y + (((size_t)b * T + t) * F + pc) * COUT);
-#pragma unroll
-            for (int c = 0; c < COUT; c += 4) dst[c / 4] = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+            *(float4*)(y + (((size_t)b * T + t) * F + pc) * COUT + 4 * cq) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
     if (partial) {
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) {
-            const float a = wave_sum(s[c]), q = wave_sum(s2[c]);
-            if ((tid & 63) == 0) { red[tid >> 6][c] = a; red[tid >> 6][COUT + c] = q; }
+        for (int c = 0; c < 4; ++c) {
+            float a = s[c], q = s2[c];
+#pragma unroll
+            for (int m = 4; m <= 32; m <<= 1) { a += __shfl_xor(a, m); q += __shfl_xor(q, m); }
+            if ((tid & 63) < 4) { red[tid >> 6][4 * cq + c] = a; red[tid >> 6][COUT + 4 * cq + c] = q; }
         }
         __syncthreads();
         if (tid < 2 * COUT)
@@ -705,19 +711,35 @@ extern "C" int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float
 
 // ---------------------------------------------------------------------------------------------
 // layer-0 weight gradient: dW[co][tap] = sum_p x[p + tap] * dy[p][co], CIN = 1, COUT = 16.
-// K = 9 taps x 16 channels is no dense contraction: direct VALU, 144 accumulators per thread.  Same 16 x F
-// LDS tile as the forward (SpecAugment predicate fused); each thread walks pixels of its tile, dy is read
-// once (64 B per pixel, coalesced across lanes); one wave-shuffle reduction + 144 atomics per workgroup.
+// K = 9 taps x 16 channels is no dense contraction: direct VALU.  Lanes = (pixel, channel quad) as in the forward,
+// 36 accumulators per lane; same 16 x F LDS tile of x (SpecAugment predicate fused).  The training-mode
+// BatchNorm backward (dz -> dy, see bn_bwd_apply_kernel) is fused into the load: nobody else consumes dy of the
+// first block, so the 3 x 246 MB in-place pass is replaced by reading y alongside dz here.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const int* __restrict__ bounds,
-                                                          const float* __restrict__ dy, float* __restrict__ dW, int B, int T, int F,
-                                                          int tiles_t) {
+                                                          const float* __restrict__ dyz, const float* __restrict__ y,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                          float* __restrict__ dW, int B, int T, int F, int tiles_t, int fuse_bn,
+                                                          int training, float inv_count) {
+    constexpr int C = 16;
     __shared__ float tile[(C0_TR + 2) * (128 + 2)];
     __shared__ float red[4][144];
-    const int tid = threadIdx.x, PW = F + 2;
-    float acc[144];
+    const int tid = threadIdx.x, PW = F + 2, cq = tid & 3;
+    float acc[4][9];
 #pragma unroll
-    for (int i = 0; i < 144; ++i) acc[i] = 0.f;
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[c][k] = 0.f;
+    float mean[4], istd[4], m1[4], m2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = 4 * cq + c;
+        mean[c] = fuse_bn ? stats[ch] : 0.f;
+        istd[c] = fuse_bn ? stats[C + ch] : 1.f;
+        m1[c] = (fuse_bn && training) ? gamma[ch] * dbeta[ch] * inv_count : 0.f;
+        m2[c] = (fuse_bn && training) ? gamma[ch] * dgamma[ch] * inv_count : 0.f;
+    }
     const int ntiles = B * tiles_t;
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const int b = tl / tiles_t, t0 = (tl - b * tiles_t) * C0_TR;
@@ -735,42 +757,56 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
             tile[idx] = v;
         }
         __syncthreads();
-        for (int p = tid; p < C0_TR * F; p += 256) {
+        for (int p = tid >> 2; p < C0_TR * F; p += 64) {
             const int pr = p / F, pc = p - pr * F, t = t0 + pr;
             if (t < T) {
-                const float4* g4 = (const float4*)(dy + (((size_t)b * T + t) * F + pc) * 16);
-                float g[16];
+                const size_t off = (((size_t)b * T + t) * F + pc) * C + 4 * cq;
+                const float4 gz = *(const float4*)(dyz + off);
+                float g[4] = {gz.x, gz.y, gz.z, gz.w};
+                if (fuse_bn) {
+                    const float4 yv = *(const float4*)(y + off);
+                    const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const float4 v = g4[q]; g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w; }
+                    for (int c = 0; c < 4; ++c) g[c] = istd[c] * (g[c] - m1[c] - (yy[c] - mean[c]) * istd[c] * m2[c]);
+                }
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
                     for (int bb = 0; bb < 3; ++bb) {
                         const float xv = tile[(pr + a) * PW + pc + bb];
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) acc[c * 9 + a * 3 + bb] = fmaf(xv, g[c], acc[c * 9 + a * 3 + bb]);
+                        for (int c = 0; c < 4; ++c) acc[c][a * 3 + bb] = fmaf(xv, g[c], acc[c][a * 3 + bb]);
                     }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 144; ++i) {
-        const float v = wave_sum(acc[i]);
-        if ((tid & 63) == 0) red[tid >> 6][i] = v;
-    }
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float v = acc[c][k];
+#pragma unroll
+            for (int m = 4; m <= 32; m <<= 1) v += __shfl_xor(v, m);
+            if ((tid & 63) < 4) red[tid >> 6][(4 * cq + c) * 9 + k] = v;
+        }
     __syncthreads();
     if (tid < 144) atomicAdd(dW + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
 }
 // dW (16,1,3,3) PyTorch layout, accumulated with atomics (zeroed here).
-extern "C" int sed_conv0_wgrad(const float* x, const int* bounds, const float* dy, float* dW, int B, int T, int F, int COUT,
-                               void* stream) {
+// fuse_bn = 0: `dyz` is dy.  fuse_bn = 1: `dyz` is dz = dL/d(xhat) and the BatchNorm backward is applied on the fly
+// (y, stats, gamma, dgamma, dbeta as for sed_bn_bwd_apply); dbias (16) then receives the conv-bias gradient.
+extern "C" int sed_conv0_wgrad(const float* x, const int* bounds, const float* dyz, const float* y, const float* stats,
+                               const float* gamma, const float* dgamma, const float* dbeta, float* dW, float* dbias, int B, int T,
+                               int F, int COUT, int fuse_bn, int training, void* stream) {
     if (COUT != 16 || F > 128 || F < 1) return SED_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(dW, 0, 16 * 9 * sizeof(float), s) != hipSuccess) return SED_ERR_LAUNCH;
+    sed_zero4(s, dW, 16 * 9, fuse_bn ? dbias : nullptr, fuse_bn ? 16 : 0, nullptr, 0, nullptr, 0);
     if (B <= 0 || T <= 0) return SED_OK;
+    if (fuse_bn && !training) return SED_ERR_UNSUPPORTED;      // eval-mode BN backward keeps the unfused path (bias gradient != 0)
     const int tiles_t = (T + C0_TR - 1) / C0_TR;
     int grid = B * tiles_t;
     if (grid > 1024) grid = 1024;
-    SED_LAUNCH(conv0_wgrad_kernel, dim3(grid), dim3(256), 0, s, x, bounds, dy, dW, B, T, F, tiles_t);
+    SED_LAUNCH(conv0_wgrad_kernel, dim3(grid), dim3(256), 0, s, x, bounds, dyz, y, stats, gamma, dgamma, dbeta, dW, B, T, F, tiles_t,
+               fuse_bn, training, 1.0f / ((float)B * (float)T * (float)F));
     return sed_check_launch();
 }

@@ -108,13 +108,19 @@ class ConvBlockFn(torch.autograd.Function):
                  gout.data_ptr(), dz.data_ptr(), d_glu_w.data_ptr(), d_glu_b.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(),
                  B, T, F, COUT, PT, PF, seed, thr24, dscale, st)
         d_bias = _grad_buf(cfg, conv_b)
+        d_w = _grad_buf(cfg, conv_w)
+        dx = None
+        if first and training:
+            # nobody but the weight gradient consumes dy of the first block: BN backward fused into its load
+            lib.call("sed_conv0_wgrad", x.data_ptr(), _p(bounds), dz.data_ptr(), y.data_ptr(), stats.data_ptr(), bn_w.data_ptr(),
+                     d_gamma.data_ptr(), d_beta.data_ptr(), d_w.data_ptr(), d_bias.data_ptr(), B, T, F, COUT, 1, 1, st)
+            return dx, d_w, d_bias, d_gamma, d_beta, d_glu_w, d_glu_b, None, None, None
         lib.call("sed_bn_bwd_apply", y.data_ptr(), dz.data_ptr(), stats.data_ptr(), bn_w.data_ptr(), d_gamma.data_ptr(),
                  d_beta.data_ptr(), d_bias.data_ptr(), B * T * F, COUT, int(training), st)
         dy = dz
-        d_w = _grad_buf(cfg, conv_w)
-        dx = None
         if first:
-            lib.call("sed_conv0_wgrad", x.data_ptr(), _p(bounds), dy.data_ptr(), d_w.data_ptr(), B, T, F, COUT, st)
+            lib.call("sed_conv0_wgrad", x.data_ptr(), _p(bounds), dy.data_ptr(), None, None, None, None, None, d_w.data_ptr(), None,
+                     B, T, F, COUT, 0, int(training), st)
         else:
             scratch = torch.empty(int(lib.value("sed_conv_wgrad_scratch_floats", B, T, F, CIN, COUT)), **f32)
             lib.call("sed_conv_wgrad", x.data_ptr(), dy.data_ptr(), scratch.data_ptr(), d_w.data_ptr(), B, T, F, CIN, COUT, st)

@@ -94,9 +94,12 @@ long long sed_conv_wgrad_scratch_floats(int B, int T, int F, int CIN, int COUT);
 int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
                    void* stream);
 
-/* Layer-0 weight gradient: x (B,T,F) (+ SpecAugment bounds or null), dy (B,T,F,16) -> dW (16,1,3,3). */
-int sed_conv0_wgrad(const float* x, const int* bounds, const float* dy, float* dW, int B, int T, int F, int COUT,
-                    void* stream);
+/* Layer-0 weight gradient: x (B,T,F) (+ SpecAugment bounds or null) -> dW (16,1,3,3).  fuse_bn = 0: dyz = dy (B,T,F,16).
+ * fuse_bn = 1 (training mode): dyz = dz from sed_glu_bwd and the BatchNorm backward (sed_bn_bwd_apply) is applied while
+ * loading (y, stats, gamma, dgamma, dbeta as there); dbias (16) receives the (zero) conv-bias gradient. */
+int sed_conv0_wgrad(const float* x, const int* bounds, const float* dyz, const float* y, const float* stats,
+                    const float* gamma, const float* dgamma, const float* dbeta, float* dW, float* dbias, int B, int T,
+                    int F, int COUT, int fuse_bn, int training, void* stream);
 
 /* ---- K7: bidirectional GRU (desed_task/nnet/RNN.py:19-30) ---------------------------------------------------- */
 
