@@ -12,6 +12,7 @@
     hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));      // 8 bf16 bit patterns (one MFMA operand fragment)
 #endif
 
 #include <stdint.h>
@@ -64,6 +65,30 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 #endif
+}
+
+// bf16 MFMA 32x32x16 (16x the f32 rate): lane l supplies A[i=l&31][k=8*(l>>5)+e] and B[k=8*(l>>5)+e][j=l&31], e=0..7;
+// D uses the same map as mfma32.  Used for the split-bf16 ("bf16x3") paths: x = hi + lo with hi = bf16(x),
+// lo = bf16(x - hi); a*b ~ hi*hi + hi*lo + lo*hi keeps ~16 mantissa bits (rel. error ~8e-6) at 3/16 of the f32 MFMA cost.
+__device__ __forceinline__ f32x16 mfma32_bf16(s16x8 a, s16x8 b, f32x16 c) {
+#ifdef SED_EMU
+    return emu_mfma_32x32x16_bf16(a, b, c);
+#else
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#endif
+}
+// round-to-nearest-even fp32 -> bf16 bit pattern (finite inputs)
+__device__ __forceinline__ unsigned short f32_to_bf16(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+// x -> (hi, lo) bf16 pair with x ~ hi + lo
+__device__ __forceinline__ void bf16_split(float x, unsigned short& hi, unsigned short& lo) {
+    hi = f32_to_bf16(x);
+    lo = f32_to_bf16(x - bf16_to_f32(hi));
 }
 
 __device__ __forceinline__ f32x16 f32x16_zero() {

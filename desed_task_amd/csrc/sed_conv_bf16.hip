@@ -1,0 +1,277 @@
+// K6, split-bf16 ("bf16x3") variant of the 3x3 convolution (forward and data gradient) of blocks 1-6.
+//
+// Same implicit-GEMM tiling as conv3x3_kernel (sed_conv.hip) but on v_mfma_f32_32x32x16_bf16, which runs at 16x the
+// rate of the exact-f32 MFMA.  fp32 accuracy is kept by splitting BOTH operands into bf16 pairs x = hi + lo
+// (hi = bf16(x), lo = bf16(x - hi)) and issuing three MFMAs per product: hi*hi + hi*lo + lo*hi (the lo*lo term is
+// < 2^-16 relative and dropped).  Every product is exact in the fp32 accumulator; the only loss is the 2^-17
+// representation error of the operands, i.e. ~8e-6 relative on a dot product -- measured in tests/ against the fp32
+// oracle with the same tolerances as the f32 path.  Net MFMA cost: 3/16 of the f32 path.
+//
+// Activations are split while the halo patch is staged into LDS (two bf16 planes, pixel-row stride CK+8 elements so the
+// 16-byte fragment reads of a wave are conflict-free); weights are pre-split and pre-transposed once per forward by
+// pack_weights_bf16_kernel into [tap][cin-chunk][plane][cout][cin] slabs that are copied verbatim into LDS.
+#include "sed_common.h"
+
+#define CONVB_THREADS(COUT) ((COUT) >= 64 ? 512 : 256)
+
+template <int CIN, int COUT, int TF, int MP = 128>
+struct ConvBCfg {
+    static constexpr int TR = MP / TF;
+    static constexpr int PW = TF + 2, PH = TR + 2, PP = PW * PH;
+    static constexpr int CK = CIN < 32 ? CIN : 32;       // channels per chunk (one or two MFMA k-steps of 16)
+    static constexpr int RSS = CK + 8;                   // LDS row stride in bf16 elements (80 B / 48 B)
+    static constexpr int NCH = CIN / CK;
+    static constexpr int NT = (COUT + 31) / 32;
+    static constexpr int NCOL = NT * 32;                 // weight rows kept in LDS (padded to the MFMA tile)
+    static constexpr int WM = MP / 32;
+    static constexpr int THREADS = CONVB_THREADS(COUT);
+    static constexpr int WN = THREADS / 64 / WM;
+    static constexpr int NTW = NT / WN;
+    static_assert(NTW >= 1 && NTW * WN == NT, "wave split must tile COUT");
+    static constexpr int PATCH_S = 2 * PP * RSS;         // shorts: hi plane | lo plane
+    static constexpr int WBUF_S = 2 * NCOL * RSS;        // shorts per weight buffer: hi | lo
+    static constexpr int SMEM = (PATCH_S + 2 * WBUF_S) * 2 + 64;
+    static constexpr int SLAB = 2 * COUT * CK;           // shorts per (tap, chunk) slab in global memory
+};
+
+// W (COUT, CIN, 3, 3) fp32 -> forward slabs Wf[tap][cc][plane][co][ci_local] and data-gradient slabs
+// Wd[tap'][ccd][plane][ci][co_local] (taps flipped, channels transposed), bf16 hi/lo planes.
+struct PackBJobs {
+    const float* W[8];
+    unsigned short* Wf[8];
+    unsigned short* Wd[8];
+    int cout[8], cin[8], start[9];
+    int n;
+};
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(PackBJobs jobs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= jobs.start[jobs.n]) return;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) j += (q < jobs.n && i >= jobs.start[q]) ? 1 : 0;
+    const int e = i - jobs.start[j], COUT = jobs.cout[j], CIN = jobs.cin[j];
+    const int b = e % 3, a = (e / 3) % 3, ci = (e / 9) % CIN, co = e / (9 * CIN);
+    unsigned short hi, lo;
+    bf16_split(jobs.W[j][e], hi, lo);
+    {
+        const int CK = CIN < 32 ? CIN : 32, NCH = CIN / CK, tap = a * 3 + b, cc = ci / CK, cl = ci % CK;
+        unsigned short* d = jobs.Wf[j] + ((size_t)(tap * NCH + cc) * 2 * COUT + co) * CK + cl;
+        d[0] = hi;
+        d[(size_t)COUT * CK] = lo;
+    }
+    if (jobs.Wd[j]) {
+        const int CK = COUT < 32 ? COUT : 32, NCH = COUT / CK, tap = (2 - a) * 3 + (2 - b), cc = co / CK, cl = co % CK;
+        unsigned short* d = jobs.Wd[j] + ((size_t)(tap * NCH + cc) * 2 * CIN + ci) * CK + cl;
+        d[0] = hi;
+        d[(size_t)CIN * CK] = lo;
+    }
+}
+// n <= 8 layers; Wf / Wd buffers of 9*CIN*COUT*4 BYTES each (same size as the fp32 packs).
+extern "C" int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout,
+                                        const int* cin, void* stream) {
+    if (n < 1 || n > 8) return SED_ERR_ARG;
+    PackBJobs jobs;
+    int tot = 0;
+    for (int j = 0; j < n; ++j) {
+        jobs.W[j] = (const float*)W[j]; jobs.Wf[j] = (unsigned short*)Wf[j]; jobs.Wd[j] = Wd ? (unsigned short*)Wd[j] : nullptr;
+        jobs.cout[j] = cout[j]; jobs.cin[j] = cin[j]; jobs.start[j] = tot;
+        tot += cout[j] * cin[j] * 9;
+    }
+    for (int j = n; j < 8; ++j) { jobs.W[j] = nullptr; jobs.Wf[j] = nullptr; jobs.Wd[j] = nullptr; jobs.cout[j] = 0; jobs.cin[j] = 0; jobs.start[j] = tot; }
+    jobs.start[n] = tot;
+    jobs.start[8] = tot;
+    jobs.n = n;
+    SED_LAUNCH(pack_weights_bf16_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, jobs);
+    return sed_check_launch();
+}
+
+template <int CIN, int COUT, int TF, bool STATS, int MP = 128>
+__global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const float* __restrict__ x,
+                                                                            const unsigned short* __restrict__ Wp,
+                                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                                            float* __restrict__ partial, int B, int T, int F) {
+    using Cfg = ConvBCfg<CIN, COUT, TF, MP>;
+    constexpr int TR = Cfg::TR, PW = Cfg::PW, PP = Cfg::PP, CK = Cfg::CK, RSS = Cfg::RSS, NCH = Cfg::NCH, NT = Cfg::NT,
+                  NTW = Cfg::NTW, THREADS = Cfg::THREADS, WM = Cfg::WM, NCOL = Cfg::NCOL, SLAB = Cfg::SLAB, WBUF_S = Cfg::WBUF_S;
+    SED_DYN_SMEM(smem_raw);
+    unsigned short* patch = (unsigned short*)(((uintptr_t)smem_raw + 15) & ~(uintptr_t)15);   // hi plane, then lo plane
+    unsigned short* wbuf = patch + Cfg::PATCH_S;
+    const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) % WM, wn = (tid >> 6) / WM, lo = lane & 31, hi = lane >> 5;
+    const int ftiles = F / TF, ttiles = (T + TR - 1) / TR;
+    const int bid = blockIdx.x;
+    const int ft = bid % ftiles, tt = (bid / ftiles) % ttiles, b = bid / (ftiles * ttiles);
+    const int t0 = tt * TR, f0 = ft * TF;
+    const int p = 32 * w + lo;
+    const int abase = ((p / TF) * PW + (p % TF)) * RSS + 8 * hi;       // this lane's A-fragment offset inside a plane
+
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[nt] = f32x16_zero();
+
+    // weight rows beyond COUT (narrow data-gradient outputs) stay zero for the whole kernel
+    if (NCOL > COUT) {
+        for (int i = tid; i < 2 * WBUF_S; i += THREADS) wbuf[i] = 0;
+        __syncthreads();
+    }
+    constexpr int WPIECES = SLAB / 8;                                   // 16-byte pieces per slab
+    constexpr int WV = (WPIECES + THREADS - 1) / THREADS;
+    uint4 wreg[WV];
+    auto w_dst = [&](int buf, int piece) -> unsigned short* {
+        const int plane = piece / (COUT * CK / 8), rem = piece - plane * (COUT * CK / 8);
+        const int co = rem / (CK / 8), pc = rem - co * (CK / 8);
+        return wbuf + buf * WBUF_S + plane * NCOL * RSS + co * RSS + 8 * pc;
+    };
+
+    for (int cc = 0; cc < NCH; ++cc) {
+        // ---- stage the halo patch of this cin chunk, split into bf16 hi / lo planes ----
+        constexpr int V = CK / 4;
+        {
+            constexpr int NLD = (PP * V + THREADS - 1) / THREADS;
+            float4 ld[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int idx = tid + THREADS * u;
+                const int pix = idx / V, v = idx - pix * V;
+                const int i = pix / PW, j = pix - i * PW;
+                const int t = t0 - 1 + i, f = f0 - 1 + j;
+                ld[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < PP * V && t >= 0 && t < T && f >= 0 && f < F)
+                    ld[u] = *(const float4*)(x + (((size_t)b * T + t) * F + f) * CIN + cc * CK + 4 * v);
+            }
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int idx = tid + THREADS * u;
+                if (idx < PP * V) {
+                    const int pix = idx / V, v = idx - pix * V;
+                    unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+                    bf16_split(ld[u].x, h0, l0); bf16_split(ld[u].y, h1, l1);
+                    bf16_split(ld[u].z, h2, l2); bf16_split(ld[u].w, h3, l3);
+                    uint2 hv, lv;
+                    hv.x = (unsigned)h0 | ((unsigned)h1 << 16); hv.y = (unsigned)h2 | ((unsigned)h3 << 16);
+                    lv.x = (unsigned)l0 | ((unsigned)l1 << 16); lv.y = (unsigned)l2 | ((unsigned)l3 << 16);
+                    *(uint2*)(patch + pix * RSS + 4 * v) = hv;
+                    *(uint2*)(patch + PP * RSS + pix * RSS + 4 * v) = lv;
+                }
+            }
+        }
+        // ---- tap 0 weight slab straight to LDS buffer 0 ----
+        {
+            const uint4* src = (const uint4*)(Wp + ((size_t)0 * NCH + cc) * SLAB);
+#pragma unroll
+            for (int i = 0; i < WV; ++i) {
+                const int piece = tid + THREADS * i;
+                if (piece < WPIECES) *(uint4*)w_dst(0, piece) = src[piece];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) {
+                const uint4* src = (const uint4*)(Wp + ((size_t)(tap + 1) * NCH + cc) * SLAB);
+#pragma unroll
+                for (int i = 0; i < WV; ++i) {
+                    const int piece = tid + THREADS * i;
+                    if (piece < WPIECES) wreg[i] = src[piece];
+                }
+            }
+            const unsigned short* wb = wbuf + (tap & 1) * WBUF_S;
+            const unsigned short* ap = patch + abase + ((tap / 3) * PW + (tap % 3)) * RSS;
+#pragma unroll
+            for (int ks = 0; ks < CK / 16; ++ks) {
+                const s16x8 a_hi = *(const s16x8*)(ap + 16 * ks);
+                const s16x8 a_lo = *(const s16x8*)(ap + PP * RSS + 16 * ks);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const unsigned short* bp = wb + ((wn * NTW + nt) * 32 + lo) * RSS + 16 * ks + 8 * hi;
+                    const s16x8 b_hi = *(const s16x8*)bp;
+                    const s16x8 b_lo = *(const s16x8*)(bp + NCOL * RSS);
+                    acc[nt] = mfma32_bf16(a_lo, b_hi, acc[nt]);
+                    acc[nt] = mfma32_bf16(a_hi, b_lo, acc[nt]);
+                    acc[nt] = mfma32_bf16(a_hi, b_hi, acc[nt]);
+                }
+            }
+            if (tap + 1 < 9) {
+#pragma unroll
+                for (int i = 0; i < WV; ++i) {
+                    const int piece = tid + THREADS * i;
+                    if (piece < WPIECES) *(uint4*)w_dst((tap + 1) & 1, piece) = wreg[i];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: bias, store, per-channel partial statistics (identical to the f32 kernel) ----
+    float* red = (float*)wbuf;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int co = (wn * NTW + nt) * 32 + lo;
+        const float bv = (bias != nullptr && co < COUT) ? bias[co] : 0.f;
+        float s = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pp = 32 * w + mfma32_row(r, lane);
+            const int t = t0 + pp / TF, f = f0 + pp % TF;
+            if (t < T && co < COUT) {
+                const float v = acc[nt][r] + bv;
+                y[(((size_t)b * T + t) * F + f) * COUT + co] = v;
+                s += v;
+                s2 += v * v;
+            }
+        }
+        if (STATS) {
+            s += __shfl_xor(s, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (hi == 0) {
+                red[(w * 2 + 0) * (NT * 32) + co] = s;
+                red[(w * 2 + 1) * (NT * 32) + co] = s2;
+            }
+        }
+    }
+    if (STATS) {
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const int which = tid / COUT, co = tid - which * COUT;
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < WM; ++ww) v += red[(ww * 2 + which) * (NT * 32) + co];
+            partial[(size_t)bid * 2 * COUT + tid] = v;
+        }
+    }
+}
+
+template <int CIN, int COUT, int TF, int MP = 128>
+static int launch_convb(const float* x, const unsigned short* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
+                        hipStream_t s) {
+    using Cfg = ConvBCfg<CIN, COUT, TF, MP>;
+    const int nblk = B * ((T + Cfg::TR - 1) / Cfg::TR) * (F / TF);
+    if (partial) {
+        SED_MAX_SMEM((conv3x3_bf16_kernel<CIN, COUT, TF, true, MP>), Cfg::SMEM);
+        SED_LAUNCH((conv3x3_bf16_kernel<CIN, COUT, TF, true, MP>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
+    } else {
+        SED_MAX_SMEM((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP>), Cfg::SMEM);
+        SED_LAUNCH((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
+    }
+    return sed_check_launch();
+}
+
+// Same contract as sed_conv3x3 (incl. the partial layout given by sed_conv_fwd_blocks) with Wp from sed_conv_pack_multi_bf16.
+extern "C" int sed_conv3x3_bf16x3(const float* x, const void* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
+                                  int CIN, int COUT, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0 || T <= 0) return SED_OK;
+    const int TF = F >= 32 ? 32 : F;
+    if (F % TF != 0 || (F & (F - 1)) != 0 || F < 2) return SED_ERR_UNSUPPORTED;
+    const unsigned short* W = (const unsigned short*)Wp;
+    if (CIN == 128 && COUT == 128 && TF == 4) return launch_convb<128, 128, 4, 64>(x, W, bias, y, partial, B, T, F, s);
+    if (CIN == 128 && COUT == 128 && TF == 2) return launch_convb<128, 128, 2, 64>(x, W, bias, y, partial, B, T, F, s);
+#define CONVB_CASE(ci, co, tf) \
+    if (CIN == ci && COUT == co && TF == tf) return launch_convb<ci, co, tf>(x, W, bias, y, partial, B, T, F, s);
+    CONVB_CASE(16, 32, 32) CONVB_CASE(32, 64, 32) CONVB_CASE(64, 128, 16) CONVB_CASE(128, 128, 8)
+    CONVB_CASE(32, 16, 32) CONVB_CASE(64, 32, 32) CONVB_CASE(128, 64, 16)
+    // small-shape variants used by the unit tests / other n_mels
+    CONVB_CASE(16, 32, 16) CONVB_CASE(32, 64, 8) CONVB_CASE(64, 128, 4) CONVB_CASE(128, 128, 16) CONVB_CASE(128, 128, 32)
+    CONVB_CASE(32, 16, 16) CONVB_CASE(64, 32, 8) CONVB_CASE(128, 64, 4) CONVB_CASE(64, 128, 32) CONVB_CASE(64, 128, 8)
+    CONVB_CASE(32, 64, 16) CONVB_CASE(64, 32, 16) CONVB_CASE(128, 64, 8) CONVB_CASE(128, 64, 32)
+#undef CONVB_CASE
+    return SED_ERR_UNSUPPORTED;
+}

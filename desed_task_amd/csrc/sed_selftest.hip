@@ -24,8 +24,26 @@ __global__ __launch_bounds__(64) void selftest_mfma16_kernel(const float* A, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) C[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[r];
 }
+// bf16 32x32x16: C[32][32] = A[32][K] * B[K][32] with operands rounded to bf16 (K multiple of 16)
+__global__ __launch_bounds__(64) void selftest_mfma32_bf16_kernel(const float* A, const float* Bm, float* C, int K) {
+    const int lane = threadIdx.x;
+    f32x16 acc = f32x16_zero();
+    for (int k = 0; k < K; k += 16) {
+        s16x8 a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = k + 8 * (lane >> 5) + e;
+            a[e] = (short)f32_to_bf16(A[(lane & 31) * K + kk]);
+            b[e] = (short)f32_to_bf16(Bm[kk * 32 + (lane & 31)]);
+        }
+        acc = mfma32_bf16(a, b, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) C[mfma32_row(r, lane) * 32 + (lane & 31)] = acc[r];
+}
 extern "C" int sed_selftest_mfma(const float* A, const float* Bm, float* C, int K, int shape, void* stream) {
     if (shape == 32) SED_LAUNCH(selftest_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, C, K);
+    else if (shape == 3216) SED_LAUNCH(selftest_mfma32_bf16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, C, K);
     else if (shape == 16) SED_LAUNCH(selftest_mfma16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, C, K);
     else return SED_ERR_ARG;
     return sed_check_launch();

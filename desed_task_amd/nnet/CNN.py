@@ -5,13 +5,12 @@ These modules only HOLD parameters/buffers under the reference's names (`cnn.con
 and (b) a given torch seed yields the reference's initial weights.  They never run torch arithmetic: the
 forward of every block is desed_task_amd.ops.ConvBlockFn (HIP kernels).
 """
-import ctypes
+import os
 
 import torch
 import torch.nn as nn
 
-from .. import _lib
-from ..ops import ConvBlockFn, new_seed
+from ..ops import ConvBlockFn, new_seed, pack_conv_weights
 
 
 class GLU(nn.Module):
@@ -34,6 +33,11 @@ class CNN(nn.Module):
                  **transformer_kwargs):
         super().__init__()
         self.nb_filters = nb_filters
+        # arithmetic of the 3x3 convolutions of blocks 1..: "f32" = exact-f32 MFMA, "bf16x3" = split-bf16 MFMA
+        # (three bf16 MFMAs per product, fp32-level accuracy; see csrc/sed_conv_bf16.hip)
+        self.conv_precision = os.environ.get("SED_CONV_PRECISION", transformer_kwargs.get("conv_precision", "bf16x3"))
+        if self.conv_precision not in ("f32", "bf16x3"):
+            raise ValueError("conv_precision must be 'f32' or 'bf16x3'")
         self.n_in_channel = n_in_channel
         self.conv_dropout = conv_dropout
         self.pooling = [tuple(p) for p in pooling]
@@ -69,30 +73,11 @@ class CNN(nn.Module):
                 module._pending_batches[i] = 0
 
     def _pack_weights(self, device, need_dgrad):
-        """Repack the conv weights of blocks 1.. into the kernels' K-major layouts, all layers in ONE launch.
-        -> {layer: (Wf, Wd or None)}"""
+        """Repack the conv weights of blocks 1.. into the kernels' layouts, all layers in ONE launch -> {layer: (Wf, Wd)}."""
         mods = self.cnn._modules
-        layers = [i for i in range(1, len(self.nb_filters))]
-        if not layers:
-            return {}
-        sizes = [mods["conv%d" % i].weight.numel() for i in layers]
-        buf = torch.empty((2 if need_dgrad else 1) * sum(sizes), device=device, dtype=torch.float32)
-        out, off = {}, 0
-        n = len(layers)
-        W = (ctypes.c_void_p * n)(); Wf = (ctypes.c_void_p * n)(); Wd = (ctypes.c_void_p * n)()
-        co = (ctypes.c_int * n)(); ci = (ctypes.c_int * n)()
-        for k, i in enumerate(layers):
-            w = mods["conv%d" % i].weight
-            wf = buf[off:off + sizes[k]]; off += sizes[k]
-            wd = None
-            if need_dgrad:
-                wd = buf[off:off + sizes[k]]; off += sizes[k]
-            out[i] = (wf, wd)
-            W[k] = w.data_ptr(); Wf[k] = wf.data_ptr(); Wd[k] = wd.data_ptr() if wd is not None else None
-            co[k] = w.shape[0]; ci[k] = w.shape[1]
-        _lib.check_tensor(buf, "packed conv weights")
-        _lib.get().call("sed_conv_pack_multi", n, W, Wf, Wd, co, ci, _lib.stream_ptr(buf))
-        return out
+        layers = list(range(1, len(self.nb_filters)))
+        packs = pack_conv_weights([mods["conv%d" % i].weight for i in layers], need_dgrad, self.conv_precision)
+        return dict(zip(layers, packs))
 
     def forward(self, x, bounds=None, arena=None):
         """x: (B, T, F) scaled log-mel (channels-last with C = 1).  Returns (B, T', F', C_last) channels-last.
@@ -106,7 +91,7 @@ class CNN(nn.Module):
             apply_drop = drop is not None and drop.training and p_drop > 0
             cfg = dict(pool=self.pooling[i], bn_training=bn.training, dropout_p=p_drop, apply_dropout=apply_drop,
                        seed=new_seed() if apply_drop else 0, bounds=bounds if i == 0 else None, update_running=True,
-                       arena=arena, packed=packed.get(i))
+                       arena=arena, packed=packed.get(i), conv_precision=self.conv_precision)
             x = ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, glu.linear.weight, glu.linear.bias,
                                   bn.running_mean, bn.running_var, cfg)
             if bn.training:

@@ -40,6 +40,35 @@ def _grad_buf(cfg, param):
     return torch.empty_like(param)
 
 
+def pack_conv_weights(weights, need_dgrad=True, precision="f32"):
+    """Repack a list of nn.Conv2d weights (COUT,CIN,3,3) into the conv kernels' layouts, ALL layers in ONE launch.
+    precision "f32": K-major fp32 (sed_conv3x3); "bf16x3": split-bf16 slabs (sed_conv3x3_bf16x3).
+    -> [(Wf, Wd or None), ...] (views into one buffer; Wd = flipped/transposed pack for the data gradient)."""
+    import ctypes
+    n = len(weights)
+    if n == 0:
+        return []
+    dev = weights[0].device
+    sizes = [w.numel() for w in weights]
+    buf = torch.empty((2 if need_dgrad else 1) * sum(sizes), device=dev, dtype=torch.float32)
+    _lib.check_tensor(buf, "packed conv weights")
+    W = (ctypes.c_void_p * n)(); Wf = (ctypes.c_void_p * n)(); Wd = (ctypes.c_void_p * n)()
+    co = (ctypes.c_int * n)(); ci = (ctypes.c_int * n)()
+    out, off = [], 0
+    for k, w in enumerate(weights):
+        w = w.contiguous()
+        wf = buf[off:off + sizes[k]]; off += sizes[k]
+        wd = None
+        if need_dgrad:
+            wd = buf[off:off + sizes[k]]; off += sizes[k]
+        out.append((wf, wd))
+        W[k] = w.data_ptr(); Wf[k] = wf.data_ptr(); Wd[k] = wd.data_ptr() if wd is not None else None
+        co[k] = w.shape[0]; ci[k] = w.shape[1]
+    entry = "sed_conv_pack_multi_bf16" if precision == "bf16x3" else "sed_conv_pack_multi"
+    _lib.get().call(entry, n, W, Wf, Wd, co, ci, _lib.stream_ptr(buf))
+    return out
+
+
 class ConvBlockFn(torch.autograd.Function):
     """One CNN block: Conv2d(3x3,p1) -> BatchNorm2d -> GLU -> Dropout -> AvgPool2d  (CNN.py:66-98).
 
@@ -70,12 +99,13 @@ class ConvBlockFn(torch.autograd.Function):
                      B, T, F, COUT, st)
         else:
             packed = cfg.get("packed")
+            bf16x3 = cfg.get("conv_precision", "f32") == "bf16x3" and packed is not None
             if packed is not None:
                 wf = packed[0]
             else:
                 wf = torch.empty(9 * CIN * COUT, device=dev, dtype=torch.float32)
                 lib.call("sed_conv_pack_weights", conv_w.data_ptr(), wf.data_ptr(), None, COUT, CIN, st)
-            lib.call("sed_conv3x3", x.data_ptr(), wf.data_ptr(), _p(conv_b), y.data_ptr(), _p(partial), B, T, F, CIN, COUT, st)
+            lib.call("sed_conv3x3_bf16x3" if bf16x3 else "sed_conv3x3", x.data_ptr(), wf.data_ptr(), _p(conv_b), y.data_ptr(), _p(partial), B, T, F, CIN, COUT, st)
         stats = torch.empty(4 * COUT, device=dev, dtype=torch.float32)
         lib.call("sed_bn_finalize", _p(partial), nblk, COUT, float(B * T * F), bn_w.data_ptr(), bn_b.data_ptr(),
                  running_mean.data_ptr(), running_var.data_ptr(), BN_MOMENTUM, BN_EPS, stats.data_ptr(), int(training),
@@ -126,14 +156,16 @@ class ConvBlockFn(torch.autograd.Function):
             lib.call("sed_conv_wgrad", x.data_ptr(), dy.data_ptr(), scratch.data_ptr(), d_w.data_ptr(), B, T, F, CIN, COUT, st)
             if ctx.needs_input_grad[0]:
                 packed = cfg.get("packed")
+                bf16x3 = False
                 if packed is not None and packed[1] is not None:
                     wd = packed[1]                # packed with the forward weights (same values: no optimizer step in between)
+                    bf16x3 = cfg.get("conv_precision", "f32") == "bf16x3"
                 else:
                     wd = torch.empty(9 * CIN * COUT, **f32)
                     wf = torch.empty(9 * CIN * COUT, **f32)
                     lib.call("sed_conv_pack_weights", conv_w.data_ptr(), wf.data_ptr(), wd.data_ptr(), COUT, CIN, st)
                 dx = torch.empty_like(x)
-                lib.call("sed_conv3x3", dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, B, T, F, COUT, CIN, st)
+                lib.call("sed_conv3x3_bf16x3" if bf16x3 else "sed_conv3x3", dy.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), None, B, T, F, COUT, CIN, st)
         return dx, d_w, d_bias, d_gamma, d_beta, d_glu_w, d_glu_b, None, None, None
 
 

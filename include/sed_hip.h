@@ -62,6 +62,14 @@ int sed_conv_fwd_blocks(int B, int T, int F, int CIN, int COUT);
 int sed_conv3x3(const float* x, const float* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
                 int CIN, int COUT, void* stream);
 
+/* Split-bf16 ("bf16x3") variant of the two entries above: weights pre-split into bf16 hi/lo planes (buffers of the same
+ * byte size as the fp32 packs), the convolution on v_mfma_f32_32x32x16_bf16 with three MFMAs per product
+ * (hi*hi + hi*lo + lo*hi): fp32-level accuracy (~8e-6 relative) at 3/16 of the f32 MFMA cost.  Same tensors/contract. */
+int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout,
+                             const int* cin, void* stream);
+int sed_conv3x3_bf16x3(const float* x, const void* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
+                       int CIN, int COUT, void* stream);
+
 /* Layer 0 (CIN=1): direct conv with the SpecAugment predicate (CRNN.py:207-219) fused into the load.
  * x (B,T,F) scaled log-mel; W (16,1,3,3) PyTorch layout; bounds (B,4) int32 [f0,f1,t0,t1) or null. */
 int sed_conv0_fwd(const float* x, const float* W, const float* bias, const int* bounds, float* y, float* partial,

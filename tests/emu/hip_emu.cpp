@@ -6,7 +6,7 @@
 EmuFiber* emu_cur = nullptr;
 dim3 emu_blockIdx, emu_blockDim, emu_gridDim;
 char* emu_dyn_smem = nullptr;
-float emu_wave_xchg[16][64][4];
+float emu_wave_xchg[16][64][8];
 
 static void* emu_sched_sp = nullptr;
 static const std::function<void()>* emu_body = nullptr;

@@ -53,7 +53,7 @@ struct EmuFiber {
 extern EmuFiber* emu_cur;
 extern dim3 emu_blockIdx, emu_blockDim, emu_gridDim;
 extern char* emu_dyn_smem;
-extern float emu_wave_xchg[16][64][4];   // [wave][lane][slot] exchange area for collectives
+extern float emu_wave_xchg[16][64][8];   // [wave][lane][slot] exchange area for collectives
 
 void emu_launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
 void emu_block_barrier();
@@ -113,6 +113,31 @@ template <typename T> static inline T max(T a, T b) { return a > b ? a : b; }
 // ---- MFMA emulation ---------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));      // 8 bf16 bit patterns
+
+static inline float emu_bf16_to_f32(short h) { unsigned u = ((unsigned)(unsigned short)h) << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31], e=0..7; D as the f32 32x32 map
+static inline f32x16 emu_mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+    int w = emu_wave(), l = emu_lane();
+    memcpy(&emu_wave_xchg[w][l][0], &a, 16);
+    memcpy(&emu_wave_xchg[w][l][4], &b, 16);
+    emu_wave_sync();
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int kh = 0; kh < 2; ++kh) {
+            s16x8 av, bv;
+            memcpy(&av, &emu_wave_xchg[w][row + 32 * kh][0], 16);
+            memcpy(&bv, &emu_wave_xchg[w][col + 32 * kh][4], 16);
+            for (int e = 0; e < 8; ++e) acc += emu_bf16_to_f32(av[e]) * emu_bf16_to_f32(bv[e]);
+        }
+        c[r] = acc;
+    }
+    emu_wave_sync();
+    return c;
+}
 
 // v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
 static inline f32x16 emu_mfma_32x32x2(float a, float b, f32x16 c) {

@@ -25,6 +25,16 @@ def case_mfma_selftest(dev):
         ref = (A.double() @ B.double()).float()
         err = (Cd.cpu() - ref).abs().max().item()
         assert err < 1e-4, (shape, K, err)
+    # bf16 32x32x16 map (split-bf16 paths): operands rounded to bf16 on both sides
+    for K in (16, 64):
+        A = torch.randn(32, K, generator=g)
+        B = torch.randn(K, 32, generator=g)
+        C = torch.zeros(32, 32)
+        Ad, Bd, Cd = to(dev, A, B, C)
+        lib.call("sed_selftest_mfma", Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), K, 3216, _lib.stream_ptr(Ad))
+        ref = (A.bfloat16().double() @ B.bfloat16().double()).float()
+        err = (Cd.cpu() - ref).abs().max().item()
+        assert err < 1e-4, ("bf16", K, err)
 
 
 def make_mel():
@@ -88,9 +98,9 @@ def np_keep_mask(shape, seed, p):
     return torch.from_numpy(((x >> np.uint64(8)) >= thr).astype(np.float32)).reshape(shape)
 
 
-def case_cnn_block(dev, layer, B, T, F, training=True, dropout_p=0.5, seed=1234, tol=2e-5):
+def case_cnn_block(dev, layer, B, T, F, training=True, dropout_p=0.5, seed=1234, tol=2e-5, precision="f32"):
     import torch.nn.functional as TF
-    from desed_task_amd.ops import ConvBlockFn
+    from desed_task_amd.ops import ConvBlockFn, pack_conv_weights
     filt = (1,) + O.NB_FILTERS
     CIN, COUT = filt[layer], filt[layer + 1]
     PT, PF = O.POOLING[layer]
@@ -130,7 +140,9 @@ def case_cnn_block(dev, layer, B, T, F, training=True, dropout_p=0.5, seed=1234,
     pd = [to(dev, t).requires_grad_(True) for t in (w, bias, gam, bet, wg, bg)]
     rm_d, rv_d = to(dev, rm.clone()), to(dev, rv.clone())
     cfg = dict(pool=(PT, PF), bn_training=training, dropout_p=dropout_p, apply_dropout=dropout_p > 0, seed=seed,
-               bounds=to(dev, bounds) if bounds is not None else None, update_running=True)
+               bounds=to(dev, bounds) if bounds is not None else None, update_running=True, conv_precision=precision)
+    if layer > 0 and precision != "f32":
+        cfg["packed"] = pack_conv_weights([pd[0].detach()], True, precision)[0]
     out = ConvBlockFn.apply(xd, *pd, rm_d, rv_d, cfg)
     out.backward(to(dev, gout))
 

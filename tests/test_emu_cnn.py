@@ -17,3 +17,9 @@ def test_block_train(emu, layer, B, T, F):
 @pytest.mark.parametrize("layer,B,T,F", [(0, 1, 5, 8), (2, 1, 4, 32), (6, 1, 70, 2)])
 def test_block_eval_nodrop(emu, layer, B, T, F):
     P.case_cnn_block("cpu", layer, B, T, F, training=False, dropout_p=0.0)
+
+
+@pytest.mark.parametrize("layer,B,T,F", [c for c in CASES if c[0] > 0])
+def test_block_train_split_bf16(emu, layer, B, T, F):
+    """Same blocks with the split-bf16 (bf16x3) convolution: fp32-level accuracy is part of the contract."""
+    P.case_cnn_block("cpu", layer, B, T, F, training=True, dropout_p=0.5, precision="bf16x3", tol=1e-4)

@@ -84,3 +84,8 @@ def test_crnn_matches_reference_golden():
 
 def test_edge_shapes():
     P.case_edge_shapes("cuda")
+
+
+@pytest.mark.parametrize("layer,T,F", [c for c in CNN_SHAPES if c[0] > 0])
+def test_cnn_block_train_split_bf16(layer, T, F):
+    P.case_cnn_block("cuda", layer, 3, T, F, training=True, dropout_p=0.5, tol=1e-4, precision="bf16x3")
