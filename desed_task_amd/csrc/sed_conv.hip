@@ -156,28 +156,9 @@ __global__ __launch_bounds__(CONV_THREADS(COUT)) void conv3x3_kernel(const float
     for (int nt = 0; nt < NTW; ++nt) acc[nt] = f32x16_zero();
 
     constexpr int WV = (WCH / 4 + THREADS - 1) / THREADS;
-    constexpr int WD = 3;                        // weight slabs in flight (register ring): L2 latency >> one tap's MFMAs
-    float4 wreg[WD][WV];
-    auto w_load = [&](int slot, int cc, int tap) {
-        const float4* src = (const float4*)(Wp + ((size_t)tap * CIN + cc * CK) * COUT);
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int idx = tid + THREADS * i;
-            if (idx < WCH / 4) wreg[slot][i] = src[idx];
-        }
-    };
-    auto w_store = [&](int slot, int buf) {
-        float4* dst = (float4*)(wbuf + buf * WCH);
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int idx = tid + THREADS * i;
-            if (idx < WCH / 4) dst[idx] = wreg[slot][i];
-        }
-    };
+    float4 wreg[WV];
 
     for (int cc = 0; cc < NCH; ++cc) {
-        // the first WD weight slabs of the chunk go in flight together with the patch loads
-        w_load(0, cc, 0); w_load(1, cc, 1); w_load(2, cc, 2);
         // ---- stage the halo patch of this cin chunk ----
         constexpr int V = CK / 4;
         {   // all loads of the patch first, LDS stores after: one memory latency per chunk instead of one per load
@@ -203,11 +184,26 @@ __global__ __launch_bounds__(CONV_THREADS(COUT)) void conv3x3_kernel(const float
                 }
             }
         }
-        w_store(0, 0);
-        __syncthreads();
+        // ---- tap 0 weights straight to LDS buffer 0 ----
+        {
+            const float4* src = (const float4*)(Wp + ((size_t)0 * CIN + cc * CK) * COUT);
 #pragma unroll
+            for (int i = 0; i < WV; ++i) {
+                const int idx = tid + THREADS * i;
+                if (idx < WCH / 4) ((float4*)wbuf)[idx] = src[idx];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap + WD < 9) w_load(tap % WD, cc, tap + WD);     // slot of `tap` was parked in LDS one iteration ago
+            if (tap + 1 < 9) {
+                const float4* src = (const float4*)(Wp + ((size_t)(tap + 1) * CIN + cc * CK) * COUT);
+#pragma unroll
+                for (int i = 0; i < WV; ++i) {
+                    const int idx = tid + THREADS * i;
+                    if (idx < WCH / 4) wreg[i] = src[idx];
+                }
+            }
             const float* wb = wbuf + (tap & 1) * WCH;
             const float* ap = patch + abase + ((tap / 3) * PW + (tap % 3)) * CKP;
 #pragma unroll
@@ -219,7 +215,14 @@ __global__ __launch_bounds__(CONV_THREADS(COUT)) void conv3x3_kernel(const float
                     acc[nt] = mfma32(av, bv, acc[nt]);
                 }
             }
-            if (tap + 1 < 9) w_store((tap + 1) % WD, (tap + 1) & 1);
+            if (tap + 1 < 9) {
+                float4* dst = (float4*)(wbuf + ((tap + 1) & 1) * WCH);
+#pragma unroll
+                for (int i = 0; i < WV; ++i) {
+                    const int idx = tid + THREADS * i;
+                    if (idx < WCH / 4) dst[idx] = wreg[i];
+                }
+            }
             __syncthreads();
         }
     }

@@ -115,32 +115,14 @@ __global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const
     }
     constexpr int WPIECES = SLAB / 8;                                   // 16-byte pieces per slab
     constexpr int WV = (WPIECES + THREADS - 1) / THREADS;
-    constexpr int WD = 3;                        // weight slabs in flight (register ring): L2 latency >> one tap's MFMAs
-    uint4 wreg[WD][WV];
-    auto w_load = [&](int slot, int cc, int tap) {
-        const uint4* src = (const uint4*)(Wp + ((size_t)tap * NCH + cc) * SLAB);
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int piece = tid + THREADS * i;
-            if (piece < WPIECES) wreg[slot][i] = src[piece];
-        }
-    };
+    uint4 wreg[WV];
     auto w_dst = [&](int buf, int piece) -> unsigned short* {
         const int plane = piece / (COUT * CK / 8), rem = piece - plane * (COUT * CK / 8);
         const int co = rem / (CK / 8), pc = rem - co * (CK / 8);
         return wbuf + buf * WBUF_S + plane * NCOL * RSS + co * RSS + 8 * pc;
     };
 
-    auto w_store = [&](int slot, int buf) {
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int piece = tid + THREADS * i;
-            if (piece < WPIECES) *(uint4*)w_dst(buf, piece) = wreg[slot][i];
-        }
-    };
-
     for (int cc = 0; cc < NCH; ++cc) {
-        w_load(0, cc, 0); w_load(1, cc, 1); w_load(2, cc, 2);        // in flight together with the patch loads
         // ---- stage the halo patch of this cin chunk, split into bf16 hi / lo planes ----
         constexpr int V = CK / 4;
         {
@@ -172,11 +154,26 @@ __global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const
                 }
             }
         }
-        w_store(0, 0);
-        __syncthreads();
+        // ---- tap 0 weight slab straight to LDS buffer 0 ----
+        {
+            const uint4* src = (const uint4*)(Wp + ((size_t)0 * NCH + cc) * SLAB);
 #pragma unroll
+            for (int i = 0; i < WV; ++i) {
+                const int piece = tid + THREADS * i;
+                if (piece < WPIECES) *(uint4*)w_dst(0, piece) = src[piece];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap + WD < 9) w_load(tap % WD, cc, tap + WD);     // slot of `tap` was parked in LDS one iteration ago
+            if (tap + 1 < 9) {
+                const uint4* src = (const uint4*)(Wp + ((size_t)(tap + 1) * NCH + cc) * SLAB);
+#pragma unroll
+                for (int i = 0; i < WV; ++i) {
+                    const int piece = tid + THREADS * i;
+                    if (piece < WPIECES) wreg[i] = src[piece];
+                }
+            }
             const unsigned short* wb = wbuf + (tap & 1) * WBUF_S;
             const unsigned short* ap = patch + abase + ((tap / 3) * PW + (tap % 3)) * RSS;
 #pragma unroll
@@ -193,7 +190,13 @@ __global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const
                     acc[nt] = mfma32_bf16(a_hi, b_hi, acc[nt]);
                 }
             }
-            if (tap + 1 < 9) w_store((tap + 1) % WD, (tap + 1) & 1);
+            if (tap + 1 < 9) {
+#pragma unroll
+                for (int i = 0; i < WV; ++i) {
+                    const int piece = tid + THREADS * i;
+                    if (piece < WPIECES) *(uint4*)w_dst((tap + 1) & 1, piece) = wreg[i];
+                }
+            }
             __syncthreads();
         }
     }
