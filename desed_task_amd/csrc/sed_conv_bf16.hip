@@ -11,6 +11,7 @@
 // 16-byte fragment reads of a wave are conflict-free); weights are pre-split and pre-transposed once per forward by
 // pack_weights_bf16_kernel into [tap][cin-chunk][plane][cout][cin] slabs that are copied verbatim into LDS.
 #include "sed_common.h"
+#include <stdlib.h>
 
 #define CONVB_THREADS(COUT) ((COUT) >= 64 ? 512 : 256)
 
@@ -254,7 +255,25 @@ static int launch_convb(const float* x, const unsigned short* Wp, const float* b
     return sed_check_launch();
 }
 
-// Same contract as sed_conv3x3 (incl. the partial layout given by sed_conv_fwd_blocks) with Wp from sed_conv_pack_multi_bf16.
+// Pixels per workgroup for the split-bf16 kernel.  The MFMA phase per (chunk, tap) step is 5x shorter than in the f32
+// kernel, so the per-step costs (weight-slab streaming, barrier) must be amortised over more pixels: 256-pixel tiles
+// (each wave 32 px x all couts) wherever that still leaves >= ~230 workgroups.
+static inline int convb_mp(int F, int CIN, int COUT) {
+    const char* e = getenv("SED_CONVB_MP");            // tuning override (tools/conv_microbench.py)
+    if (e && COUT >= 64) return atoi(e);
+    if (COUT < 64) return 128;
+    if (CIN == 128 && COUT == 128 && F <= 2) return 64;
+    if (CIN == 128 && COUT == 128 && F <= 4) return 128;
+    return 256;
+}
+extern "C" int sed_conv_fwd_blocks_bf16(int B, int T, int F, int CIN, int COUT) {
+    if (CIN == 1) return B * ((T + 15) / 16);
+    const int TF = F >= 32 ? 32 : F;
+    const int TR = convb_mp(F, CIN, COUT) / TF;
+    return B * ((T + TR - 1) / TR) * (F / TF);
+}
+
+// Same contract as sed_conv3x3 with Wp from sed_conv_pack_multi_bf16; the partial layout is sed_conv_fwd_blocks_bf16's.
 extern "C" int sed_conv3x3_bf16x3(const float* x, const void* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
                                   int CIN, int COUT, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -262,16 +281,23 @@ extern "C" int sed_conv3x3_bf16x3(const float* x, const void* Wp, const float* b
     const int TF = F >= 32 ? 32 : F;
     if (F % TF != 0 || (F & (F - 1)) != 0 || F < 2) return SED_ERR_UNSUPPORTED;
     const unsigned short* W = (const unsigned short*)Wp;
-    if (CIN == 128 && COUT == 128 && TF == 4) return launch_convb<128, 128, 4, 64>(x, W, bias, y, partial, B, T, F, s);
-    if (CIN == 128 && COUT == 128 && TF == 2) return launch_convb<128, 128, 2, 64>(x, W, bias, y, partial, B, T, F, s);
-#define CONVB_CASE(ci, co, tf) \
-    if (CIN == ci && COUT == co && TF == tf) return launch_convb<ci, co, tf>(x, W, bias, y, partial, B, T, F, s);
-    CONVB_CASE(16, 32, 32) CONVB_CASE(32, 64, 32) CONVB_CASE(64, 128, 16) CONVB_CASE(128, 128, 8)
-    CONVB_CASE(32, 16, 32) CONVB_CASE(64, 32, 32) CONVB_CASE(128, 64, 16)
+    const int MP = convb_mp(F, CIN, COUT);
+#define CONVB_CASE(ci, co, tf, mp) \
+    if (CIN == ci && COUT == co && TF == tf && MP == mp) return launch_convb<ci, co, tf, mp>(x, W, bias, y, partial, B, T, F, s);
+    // production shapes of the 2023 recipe (forward, then data gradient)
+    CONVB_CASE(16, 32, 32, 128)
+    CONVB_CASE(32, 64, 32, 128) CONVB_CASE(32, 64, 32, 256)
+    CONVB_CASE(64, 128, 16, 128) CONVB_CASE(64, 128, 16, 256)
+    CONVB_CASE(128, 128, 8, 128) CONVB_CASE(128, 128, 8, 256)
+    CONVB_CASE(128, 128, 4, 64) CONVB_CASE(128, 128, 4, 128) CONVB_CASE(128, 128, 4, 256)
+    CONVB_CASE(128, 128, 2, 64) CONVB_CASE(128, 128, 2, 128)
+    CONVB_CASE(32, 16, 32, 128) CONVB_CASE(64, 32, 32, 128)
+    CONVB_CASE(128, 64, 16, 128) CONVB_CASE(128, 64, 16, 256)
     // small-shape variants used by the unit tests / other n_mels
-    CONVB_CASE(16, 32, 16) CONVB_CASE(32, 64, 8) CONVB_CASE(64, 128, 4) CONVB_CASE(128, 128, 16) CONVB_CASE(128, 128, 32)
-    CONVB_CASE(32, 16, 16) CONVB_CASE(64, 32, 8) CONVB_CASE(128, 64, 4) CONVB_CASE(64, 128, 32) CONVB_CASE(64, 128, 8)
-    CONVB_CASE(32, 64, 16) CONVB_CASE(64, 32, 16) CONVB_CASE(128, 64, 8) CONVB_CASE(128, 64, 32)
+    CONVB_CASE(16, 32, 16, 128) CONVB_CASE(32, 64, 8, 256) CONVB_CASE(32, 64, 16, 256) CONVB_CASE(64, 128, 4, 256) CONVB_CASE(64, 128, 8, 256)
+    CONVB_CASE(64, 128, 32, 256) CONVB_CASE(128, 128, 16, 256) CONVB_CASE(128, 128, 32, 256)
+    CONVB_CASE(32, 16, 16, 128) CONVB_CASE(64, 32, 8, 128) CONVB_CASE(64, 32, 16, 128) CONVB_CASE(128, 64, 4, 256) CONVB_CASE(128, 64, 8, 256)
+    CONVB_CASE(128, 64, 32, 256)
 #undef CONVB_CASE
     return SED_ERR_UNSUPPORTED;
 }

@@ -91,7 +91,8 @@ class ConvBlockFn(torch.autograd.Function):
         st = _lib.stream_ptr(x)
         dev = x.device
         y = torch.empty(B, T, F, COUT, device=dev, dtype=torch.float32)
-        nblk = lib.value("sed_conv_fwd_blocks", B, T, F, CIN, COUT)
+        bf16x3 = (not first) and cfg.get("conv_precision", "f32") == "bf16x3" and cfg.get("packed") is not None
+        nblk = lib.value("sed_conv_fwd_blocks_bf16" if bf16x3 else "sed_conv_fwd_blocks", B, T, F, CIN, COUT)
         partial = torch.empty(nblk * 2 * COUT, device=dev, dtype=torch.float32) if training else None
         conv_w = conv_w.contiguous()
         if first:
@@ -99,7 +100,6 @@ class ConvBlockFn(torch.autograd.Function):
                      B, T, F, COUT, st)
         else:
             packed = cfg.get("packed")
-            bf16x3 = cfg.get("conv_precision", "f32") == "bf16x3" and packed is not None
             if packed is not None:
                 wf = packed[0]
             else:

@@ -69,6 +69,7 @@ int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const* Wf, void*
                              const int* cin, void* stream);
 int sed_conv3x3_bf16x3(const float* x, const void* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
                        int CIN, int COUT, void* stream);
+int sed_conv_fwd_blocks_bf16(int B, int T, int F, int CIN, int COUT);   /* rows of `partial` for the bf16x3 forward */
 
 /* Layer 0 (CIN=1): direct conv with the SpecAugment predicate (CRNN.py:207-219) fused into the load.
  * x (B,T,F) scaled log-mel; W (16,1,3,3) PyTorch layout; bounds (B,4) int32 [f0,f1,t0,t1) or null. */
