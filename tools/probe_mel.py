@@ -1,5 +1,5 @@
 import time, torch, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 from tests import parity_cases as P
 from oracle import sed_oracle as O
 mel = P.make_mel()

@@ -1,6 +1,6 @@
 """Per-stage wall-clock probe of the training step on the GPU (diagnostics; prints progressively)."""
 import sys, time, os
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 import torch, numpy as np, random
 import bench
 from desed_task_amd import _lib
