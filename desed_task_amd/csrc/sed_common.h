@@ -91,6 +91,13 @@ __device__ __forceinline__ void bf16_split(float x, unsigned short& hi, unsigned
     lo = f32_to_bf16(x - bf16_to_f32(hi));
 }
 
+// compiler scheduling fence: nothing moves across it (bounds the live ranges of hoisted LDS reads in fully unrolled MFMA chains)
+__device__ __forceinline__ void sed_sched_fence() {
+#ifndef SED_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 __device__ __forceinline__ f32x16 f32x16_zero() {
     f32x16 z;
 #pragma unroll

@@ -283,6 +283,154 @@ __global__ __launch_bounds__(256) void glu16_bwd_kernel(const float* __restrict_
     if (g == 0) { atomicAdd(dgamma + i, a_dgam); atomicAdd(dbeta + i, a_dbet); atomicAdd(dbg + i, a_dbg); }
 }
 
+// ---------------------------------------------------------------------------------------------
+// C = 64 / 128 with (1,2) pooling: "weight-stationary in registers".  8 waves; wave (wm, wn) owns N tile wn
+// (32 output channels) and keeps its whole B operand -- Wg[n][k] for its 32 n, all k -- in C/2 VGPRs, so LDS
+// holds only the activation tile (66 KB at C = 128 -> two workgroups per CU instead of one) and the MFMA loop
+// issues one LDS read per MFMA.  The next tile is prefetched into registers under the current tile's MFMAs.
+// ---------------------------------------------------------------------------------------------
+// acc += sum_k A[k] * bf(k) over K2 k-steps with the A operand read from LDS at ap[2*ks] in software-pipelined groups
+// of G (one group in flight under the previous group's MFMAs; the fences keep the unrolled chain from hoisting more).
+template <int K2, int G, class BF>
+__device__ __forceinline__ void mfma_chain(const float* ap, BF&& bf, f32x16& acc) {
+    float a[G], an[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) a[i] = ap[2 * i];
+#pragma unroll
+    for (int ch = 0; ch < K2 / G; ++ch) {
+        if (ch + 1 < K2 / G) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) an[i] = ap[2 * (G * (ch + 1) + i)];
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) acc = mfma32(a[i], bf(G * ch + i), acc);
+#pragma unroll
+        for (int i = 0; i < G; ++i) a[i] = an[i];
+        sed_sched_fence();
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(512, 4) void glu_wide_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                           const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                           float* __restrict__ out, int B, int T, int F, uint32_t seed,
+                                                           uint32_t thr24, float dscale) {
+    constexpr int PT = 1, PF = 2, WIN = 2, CP = C + 1, NT = C / 32;
+    constexpr int WN = NT, WM = 8 / WN, MS = 1, ROWS = 32 * WM * MS, NW = ROWS / WIN;   // C=128: 4 x 2 waves, 64 rows; C=64: 2 x 4, 128
+    constexpr int NLD = ROWS * (C / 4) / 512;
+    static_assert(512 % (C / 4) == 0, "each thread keeps one channel quad");
+    SED_DYN_SMEM(smem);
+    float* xs = (float*)smem;                                          // [ROWS][CP] BN output xn
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int wn = w % WN, wm = w / WN;
+    const int To = T / PT, Fo = F / PF, NWC = To * Fo;
+    const int fsh = 31 - __builtin_clz(Fo);
+    const int tiles_per_clip = (NWC + NW - 1) / NW, ntiles = B * tiles_per_clip;
+    const int n = wn * 32 + lo;
+    // B fragments: Wg goes through LDS so the global reads stay coalesced (a per-lane row gather would cost
+    // ~32 cache lines per load instruction, x C/2 instructions x 16 waves on one CU's address unit)
+    float breg[C / 2];
+    constexpr int WROWS = ROWS < C ? ROWS : C;
+#pragma unroll
+    for (int p = 0; p < C / WROWS; ++p) {
+        __syncthreads();
+        for (int i = tid; i < WROWS * (C / 4); i += 512) {
+            const int row = i / (C / 4), q = i - row * (C / 4);
+            const float4 val = *(const float4*)(Wg + (size_t)(p * WROWS + row) * C + 4 * q);
+            float* d = xs + row * CP + 4 * q;
+            d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+        }
+        __syncthreads();
+        if (wn * 32 / WROWS == p) {
+#pragma unroll
+            for (int ks = 0; ks < C / 2; ++ks) breg[ks] = xs[(n - p * WROWS) * CP + 2 * ks + hi];
+        }
+    }
+    const float bias_n = bg[n];
+    const int v = tid % (C / 4), r0 = tid / (C / 4);                   // this thread's channel quad / first row when staging
+    float sc4[4], sh4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sc4[i] = stats[2 * C + 4 * v + i]; sh4[i] = stats[3 * C + 4 * v + i]; }
+
+    float4 ld[NLD];
+    auto load_tile = [&](int tile) {
+        const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int m = r0 + (512 / (C / 4)) * u;
+            int o, t, f;
+            ld[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) {
+                float4 val = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
+                val.x = fmaf(val.x, sc4[0], sh4[0]); val.y = fmaf(val.y, sc4[1], sh4[1]);
+                val.z = fmaf(val.z, sc4[2], sh4[2]); val.w = fmaf(val.w, sc4[3], sh4[3]);
+                ld[u] = val;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            float* d = xs + (r0 + (512 / (C / 4)) * u) * CP + 4 * v;
+            d[0] = ld[u].x; d[1] = ld[u].y; d[2] = ld[u].z; d[3] = ld[u].w;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
+        __syncthreads();                                               // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);    // in flight under the MFMAs below
+        f32x16 acc[MS];
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) acc[ms] = f32x16_zero();
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms)
+            mfma_chain<C / 2, (C > 64 ? 4 : 8)>(xs + ((wm * MS + ms) * 32 + lo) * CP + hi, [&](int ks) { return breg[ks]; }, acc[ms]);
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int mbase = (wm * MS + ms) * 32 + 8 * j + 4 * hi;
+                float vv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int o, t, f;
+                    const bool ok = row_pixel<PT, PF>(mbase + q, o0, NWC, fsh, o, t, f);
+                    const uint32_t e = (uint32_t)((((size_t)b * T + t) * F + f) * C + n);
+                    const float xn = xs[(mbase + q) * CP + n];
+                    float r = (acc[ms][4 * j + q] + bias_n) * sed_fast_sigmoid(xn);
+                    vv[q] = (ok && sed_keep(e, seed, thr24)) ? r * dscale : 0.f;
+                }
+                const int o = o0 + mbase / 2;
+                if (o < NWC) out[((size_t)b * NWC + o) * C + n] = 0.5f * (vv[0] + vv[1]);
+                if (o + 1 < NWC) out[((size_t)b * NWC + o + 1) * C + n] = 0.5f * (vv[2] + vv[3]);
+            }
+        }
+    }
+}
+// persistent-grid cap; SED_GLU_GRID_CAP (tests) forces several tiles per workgroup on small problems
+static inline int glu_grid_cap(int dflt) {
+    const char* e = getenv("SED_GLU_GRID_CAP");
+    return e ? atoi(e) : dflt;
+}
+template <int C>
+static int launch_glu_wide_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
+                               uint32_t seed, uint32_t thr24, float dscale, hipStream_t s) {
+    constexpr int ROWS = 32 * (8 / (C / 32));
+    constexpr int SMEM = ROWS * (C + 1) * 4;
+    const int NWC = T * (F / 2);
+    const int ntiles = B * ((NWC + ROWS / 2 - 1) / (ROWS / 2));
+    const int cap = glu_grid_cap(512);                                  // two 8-wave workgroups per CU
+    int grid = ntiles < cap ? ntiles : cap;
+    if (grid < 1) return SED_OK;
+    SED_MAX_SMEM((glu_wide_fwd_kernel<C>), SMEM);
+    SED_LAUNCH((glu_wide_fwd_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale);
+    return sed_check_launch();
+}
+
 // y (B,T,F,C); stats 4*C (mean, invstd, scale, shift); Wg (C,C) [out][in]; out (B,T/PT,F/PF,C).
 // dropout: keep element e when hash(e, seed) >> 8 >= thr24 (thr24 = round(p * 2^24)); dscale = 1/(1-p).
 extern "C" int sed_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
@@ -296,6 +444,10 @@ extern "C" int sed_glu_fwd(const float* y, const float* stats, const float* Wg, 
         if (grid > 2048) grid = 2048;
         SED_LAUNCH(glu16_fwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale);
         return sed_check_launch();
+    }
+    if (PT == 1 && PF == 2 && (F & (F - 1)) == 0) {
+        if (C == 128) return launch_glu_wide_fwd<128>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, s);
+        if (C == 64) return launch_glu_wide_fwd<64>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, s);
     }
 #define GLU_CASE(c, pt, pf) \
     if (C == c && PT == pt && PF == pf) return launch_glu_fwd<c, pt, pf>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, s);
@@ -526,6 +678,190 @@ static int launch_glu_bwd(const float* y, const float* stats, const float* gamma
     return sed_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// C = 64 / 128, (1,2) pooling: weight-stationary backward.  8 waves; wave (wm, wn) owns the 32x32 output tile
+// (row block wm, channel block wn) of GEMM1 and GEMM2 and keeps BOTH orientations of Wg in registers
+// (b1[k] = gamma_k Wg[n][k] -- the BN affine is folded into the weights, beta's contribution into the bias --
+// and b2[k] = Wg[k][c]), so LDS holds only xhat and dlin tiles and every MFMA needs one LDS read.  The next
+// tile's y rows and this tile's gout values are fetched into registers before GEMM1.
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512) void glu_wide_bwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                           const float* __restrict__ gout, float* __restrict__ dz,
+                                                           float* __restrict__ dWg, float* __restrict__ dbg,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int T,
+                                                           int F, uint32_t seed, uint32_t thr24, float dscale) {
+    constexpr int PT = 1, PF = 2, WIN = 2, CP = C + 1, NT = C / 32, WN = NT, WM = 8 / WN, ROWS = 32 * WM, NW = ROWS / WIN;
+    constexpr int NLD = ROWS * (C / 4) / 512, RSTEP = 512 / (C / 4);
+    constexpr int NT3 = NT * NT, TPW = NT3 >= 8 ? NT3 / 8 : 1, KSPLIT = NT3 >= 8 ? 1 : 8 / NT3, KROWS = ROWS / KSPLIT;
+    SED_DYN_SMEM(smem);
+    float* xh = (float*)smem;           // [ROWS][CP] xhat
+    float* dl = xh + ROWS * CP;         // [ROWS][CP] d lin
+    float* wg = dl + ROWS * CP;         // [C][CP] Wg, only when B2_LDS
+    constexpr bool B2_LDS = C > 64;     // 2 x C/2 weight registers do not fit next to the accumulators at C = 128
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int wn = w % WN, wm = w / WN, n = wn * 32 + lo;
+    const int To = T / PT, Fo = F / PF, NWC = To * Fo;
+    const int fsh = 31 - __builtin_clz(Fo);
+    const int tiles_per_clip = (NWC + NW - 1) / NW, ntiles = B * tiles_per_clip;
+
+    // Wg through LDS (coalesced global reads; see glu_wide_fwd_kernel): resident in `wg` at C = 128, staged in the
+    // not-yet-used xhat tile at C = 64
+    float b1[C / 2], b2[B2_LDS ? 1 : C / 2];
+    float* wl = B2_LDS ? wg : xh;
+    static_assert(B2_LDS || ROWS >= C, "xhat tile must hold Wg while the fragments are read");
+    for (int i = tid; i < C * (C / 4); i += 512) {
+        const int row = i / (C / 4), q = i - row * (C / 4);
+        const float4 val = *(const float4*)(Wg + (size_t)row * C + 4 * q);
+        float* d = wl + row * CP + 4 * q;
+        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+    }
+    __syncthreads();
+    float biasp = bg[n];
+#pragma unroll
+    for (int ks = 0; ks < C / 2; ++ks) {
+        const float w0 = wl[n * CP + 2 * ks], w1 = wl[n * CP + 2 * ks + 1];
+        biasp = fmaf(beta[2 * ks], w0, biasp);
+        biasp = fmaf(beta[2 * ks + 1], w1, biasp);
+        b1[ks] = gamma[2 * ks + hi] * (hi ? w1 : w0);
+        if (!B2_LDS) b2[ks] = wl[(2 * ks + hi) * CP + n];
+        if ((ks & 7) == 7) sed_sched_fence();
+    }
+    const float gn = gamma[n], bn = beta[n];
+    const int v = tid % (C / 4), r0 = tid / (C / 4);
+    float mu4[4], is4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { mu4[i] = stats[4 * v + i]; is4[i] = stats[C + 4 * v + i]; }
+
+    f32x16 P[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) P[i] = f32x16_zero();
+    float a_dbg = 0.f, a_dgam = 0.f, a_dbet = 0.f;
+
+    float4 ld[NLD];
+    auto load_tile = [&](int tile) {
+        const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            int o, t, f;
+            ld[u] = make_float4(mu4[0], mu4[1], mu4[2], mu4[3]);                     // -> xhat 0 for rows past the clip
+            if (row_pixel<PT, PF>(r0 + RSTEP * u, o0, NWC, fsh, o, t, f)) ld[u] = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            float* d = xh + (r0 + RSTEP * u) * CP + 4 * v;
+            d[0] = (ld[u].x - mu4[0]) * is4[0]; d[1] = (ld[u].y - mu4[1]) * is4[1];
+            d[2] = (ld[u].z - mu4[2]) * is4[2]; d[3] = (ld[u].w - mu4[3]) * is4[3];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+        // this lane's 16 accumulator rows pair up into 8 pooling windows: fetch their gout values now
+        float g8[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int o = o0 + (32 * wm + 8 * j + 4 * hi + 2 * h) / 2;
+                g8[2 * j + h] = o < NWC ? gout[((size_t)b * NWC + o) * C + n] * (0.5f * dscale) : 0.f;
+            }
+        // ---- GEMM1: lin = xn . Wg^T  (= xhat . (gamma Wg)^T + beta-folded bias) ----
+        f32x16 acc = f32x16_zero();
+        {
+            mfma_chain<C / 2, 8>(xh + (32 * wm + lo) * CP + hi, [&](int ks) { return b1[ks]; }, acc);
+        }
+        // ---- epilogue 1: dlin -> LDS, e -> acc (seed of GEMM2) ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * wm + mfma32_row(r, lane);
+            int o, t, f;
+            const bool rok = row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f);
+            const uint32_t e_idx = (uint32_t)((((size_t)b * T + t) * F + f) * C + n);
+            float dlin = 0.f, e = 0.f;
+            if (rok) {
+                const float xn = fmaf(xh[m * CP + n], gn, bn);
+                const float sg = sed_fast_sigmoid(xn);
+                const float lin = acc[r] + biasp;
+                const float g = sed_keep(e_idx, seed, thr24) ? g8[(r >> 2) * 2 + ((r & 3) >> 1)] : 0.f;
+                dlin = g * sg;
+                e = g * lin * sg * (1.0f - sg);
+            }
+            dl[m * CP + n] = dlin;
+            acc[r] = e;
+            a_dbg += dlin;
+        }
+        __syncthreads();
+        // ---- GEMM2: dxn = dlin . Wg + e ----
+        {
+            const float* ap = dl + (32 * wm + lo) * CP + hi;
+            if (B2_LDS) {
+                const float* bp = wg + hi * CP + n;
+#pragma unroll 8
+                for (int ks = 0; ks < C / 2; ++ks) acc = mfma32(ap[2 * ks], bp[2 * ks * CP], acc);
+            } else {
+                mfma_chain<C / 2, 8>(ap, [&](int ks) { return b2[B2_LDS ? 0 : ks]; }, acc);
+            }
+        }
+        // ---- epilogue 2: dz = dxn * gamma, BN reductions ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * wm + mfma32_row(r, lane);
+            int o, t, f;
+            if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) {
+                const float dxn = acc[r];
+                a_dgam = fmaf(dxn, xh[m * CP + n], a_dgam);
+                a_dbet += dxn;
+                dz[(((size_t)b * T + t) * F + f) * C + n] = dxn * gn;
+            }
+        }
+        // ---- GEMM3: P[n'][c] += sum_rows dlin[row][n'] * xn[row][c] ----
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int id = NT3 >= 8 ? w * TPW + i : w % NT3, mt = id / NT, ct = id % NT;
+            const int k0 = NT3 >= 8 ? 0 : (w / NT3) * KROWS;
+            const int c = ct * 32 + lo;
+            const float gc = gamma[c], bc = beta[c];
+#pragma unroll 8
+            for (int k = k0; k < k0 + KROWS; k += 2) {
+                const float av = dl[(k + hi) * CP + mt * 32 + lo];
+                const float bv = fmaf(xh[(k + hi) * CP + c], gc, bc);
+                P[i] = mfma32(av, bv, P[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int id = NT3 >= 8 ? w * TPW + i : w % NT3, mt = id / NT, ct = id % NT, c = ct * 32 + lo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(dWg + (size_t)(mt * 32 + mfma32_row(r, lane)) * C + c, P[i][r]);
+    }
+    a_dbg += __shfl_xor(a_dbg, 32); a_dgam += __shfl_xor(a_dgam, 32); a_dbet += __shfl_xor(a_dbet, 32);
+    if (hi == 0) { atomicAdd(dbg + n, a_dbg); atomicAdd(dgamma + n, a_dgam); atomicAdd(dbeta + n, a_dbet); }
+}
+template <int C>
+static int launch_glu_wide_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
+                               const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
+                               int B, int T, int F, uint32_t seed, uint32_t thr24, float dscale, hipStream_t s) {
+    constexpr int ROWS = 32 * (8 / (C / 32));
+    constexpr int SMEM = (2 * ROWS + (C > 64 ? C : 0)) * (C + 1) * 4;
+    const int NWC = T * (F / 2);
+    const int ntiles = B * ((NWC + ROWS / 2 - 1) / (ROWS / 2));
+    const int cap = glu_grid_cap(256);                                  // register-bound: one workgroup per CU
+    int grid = ntiles < cap ? ntiles : cap;
+    if (grid < 1) return SED_OK;
+    SED_MAX_SMEM((glu_wide_bwd_kernel<C>), SMEM);
+    SED_LAUNCH((glu_wide_bwd_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma,
+               dbeta, B, T, F, seed, thr24, dscale);
+    return sed_check_launch();
+}
+
 // gout (B,T/PT,F/PF,C) -> dz (B,T,F,C) = dL/d xhat; dWg (C,C), dbg, dgamma, dbeta (C) are ZEROED here and
 // accumulated with fp32 atomics.  When T % PT != 0 the dropped frames of dz are zeroed too.
 extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
@@ -543,6 +879,10 @@ extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamm
         SED_LAUNCH(glu16_bwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B,
                    T, F, seed, thr24, dscale);
         return sed_check_launch();
+    }
+    if (PT == 1 && PF == 2 && (F & (F - 1)) == 0) {
+        if (C == 128) return launch_glu_wide_bwd<128>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B, T, F, seed, thr24, dscale, s);
+        if (C == 64) return launch_glu_wide_bwd<64>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B, T, F, seed, thr24, dscale, s);
     }
 #define GLU_CASE(c, pt, pf)                                                                                              \
     if (C == c && PT == pt && PF == pf)                                                                                  \

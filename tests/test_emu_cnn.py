@@ -23,3 +23,10 @@ def test_block_eval_nodrop(emu, layer, B, T, F):
 def test_block_train_split_bf16(emu, layer, B, T, F):
     """Same blocks with the split-bf16 (bf16x3) convolution: fp32-level accuracy is part of the contract."""
     P.case_cnn_block("cpu", layer, B, T, F, training=True, dropout_p=0.5, precision="bf16x3", tol=1e-4)
+
+
+@pytest.mark.parametrize("layer,B,T,F", [(2, 2, 6, 32), (6, 2, 35, 2)])
+def test_block_persistent_tiles(emu, layer, B, T, F, monkeypatch):
+    """Wide GLU kernels with several tiles per workgroup: exercises the register prefetch of the next tile."""
+    monkeypatch.setenv("SED_GLU_GRID_CAP", "3")
+    P.case_cnn_block("cpu", layer, B, T, F, training=True, dropout_p=0.5)
