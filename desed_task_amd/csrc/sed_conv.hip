@@ -73,24 +73,31 @@ extern "C" int sed_conv_pack_multi(int n, const void* const* W, void* const* Wf,
     return sed_check_launch();
 }
 
-// partials[part][tap][ci][co] -> dW (COUT, CIN, 3, 3): fixed-order (deterministic) sum over the workgroup partials
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ parts, float* __restrict__ dW, int nparts,
-                                                           int COUT, int CIN) {
-    const int j = blockIdx.x * 256 + threadIdx.x;          // packed index (tap, ci, co): coalesced reads
+// partials[part][tap][ci][co] -> dW (COUT, CIN, 3, 3): fixed-order (deterministic) sum over the workgroup partials.
+// One workgroup per 64 consecutive packed outputs: 16 float4 columns x G = blockDim/16 groups of partials (the narrow
+// layers have ~1000 partials of only 4.6K outputs: the partial range, not the output range, carries the parallelism).
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ parts, float* __restrict__ dW, int nparts,
+                                                            int COUT, int CIN) {
+    __shared__ float4 red[64][16];
+    const int tid = threadIdx.x, col = tid & 15, grp = tid >> 4, G = blockDim.x >> 4;
+    const int j = blockIdx.x * 64 + 4 * col;               // packed index (tap, ci, co): coalesced float4 reads
     const int n = 9 * CIN * COUT;
-    if (j >= n) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;         // independent chains: the loads overlap
-    int p = 0;
-    for (; p + 4 <= nparts; p += 4) {
-        a0 += parts[(size_t)p * n + j];
-        a1 += parts[(size_t)(p + 1) * n + j];
-        a2 += parts[(size_t)(p + 2) * n + j];
-        a3 += parts[(size_t)(p + 3) * n + j];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < n) {
+#pragma unroll 4
+        for (int p = grp; p < nparts; p += G) {
+            const float4 v = *(const float4*)(parts + (size_t)p * n + j);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
     }
-    for (; p < nparts; ++p) a0 += parts[(size_t)p * n + j];
-    const float acc = (a0 + a1) + (a2 + a3);
-    const int co = j % COUT, ci = (j / COUT) % CIN, tap = j / (COUT * CIN);
-    dW[((size_t)co * CIN + ci) * 9 + tap] = acc;
+    red[grp][col] = acc;
+    __syncthreads();
+    if (grp == 0 && j < n) {
+        for (int g = 1; g < G; ++g) { const float4 v = red[g][col]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        const int co = j % COUT, ci = (j / COUT) % CIN, tap = j / (COUT * CIN);     // COUT % 4 == 0: one (tap, ci) per float4
+        float* d = dW + ((size_t)co * CIN + ci) * 9 + tap;
+        d[0] = acc.x; d[(size_t)CIN * 9] = acc.y; d[(size_t)2 * CIN * 9] = acc.z; d[(size_t)3 * CIN * 9] = acc.w;
+    }
 }
 // number of workgroup partials the weight-gradient launch writes (each 9*CIN*COUT floats)
 static inline int wgrad_parts(int CIN, int COUT, int B, int T, int F) {
@@ -704,8 +711,8 @@ extern "C" int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float
 #undef WG_CASE
     if (rc != SED_OK) return rc;
     const int n = COUT * CIN * 9;
-    SED_LAUNCH(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)dWp, dW, wgrad_parts(CIN, COUT, B, T, F),
-               COUT, CIN);
+    const int nparts = wgrad_parts(CIN, COUT, B, T, F);
+    SED_LAUNCH(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(nparts >= 256 ? 1024 : 256), 0, s, (const float*)dWp, dW, nparts, COUT, CIN);
     return sed_check_launch();
 }
 

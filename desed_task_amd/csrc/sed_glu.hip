@@ -289,6 +289,12 @@ __global__ __launch_bounds__(256) void glu16_bwd_kernel(const float* __restrict_
 // holds only the activation tile (66 KB at C = 128 -> two workgroups per CU instead of one) and the MFMA loop
 // issues one LDS read per MFMA.  The next tile is prefetched into registers under the current tile's MFMAs.
 // ---------------------------------------------------------------------------------------------
+// GLU_ABL: timing-ablation mask for tools/glu_variants.py (0 in the product build): 1 = no MFMA, 2 = no epilogue
+// math, 4 = no global tile loads, 8 = no global stores.
+#ifndef GLU_ABL
+#define GLU_ABL 0
+#endif
+
 // acc += sum_k A[k] * bf(k) over K2 k-steps with the A operand read from LDS at ap[2*ks] in software-pipelined groups
 // of G (one group in flight under the previous group's MFMAs; the fences keep the unrolled chain from hoisting more).
 template <int K2, int G, class BF>
@@ -303,7 +309,10 @@ __device__ __forceinline__ void mfma_chain(const float* ap, BF&& bf, f32x16& acc
             for (int i = 0; i < G; ++i) an[i] = ap[2 * (G * (ch + 1) + i)];
         }
 #pragma unroll
-        for (int i = 0; i < G; ++i) acc = mfma32(a[i], bf(G * ch + i), acc);
+        for (int i = 0; i < G; ++i) {
+            if (GLU_ABL & 1) acc[0] += a[i] * bf(G * ch + i);
+            else acc = mfma32(a[i], bf(G * ch + i), acc);
+        }
 #pragma unroll
         for (int i = 0; i < G; ++i) a[i] = an[i];
         sed_sched_fence();
@@ -315,17 +324,17 @@ __global__ __launch_bounds__(512, 4) void glu_wide_fwd_kernel(const float* __res
                                                            const float* __restrict__ Wg, const float* __restrict__ bg,
                                                            float* __restrict__ out, int B, int T, int F, uint32_t seed,
                                                            uint32_t thr24, float dscale) {
-    constexpr int PT = 1, PF = 2, WIN = 2, CP = C + 1, NT = C / 32;
-    constexpr int WN = NT, WM = 8 / WN, MS = 1, ROWS = 32 * WM * MS, NW = ROWS / WIN;   // C=128: 4 x 2 waves, 64 rows; C=64: 2 x 4, 128
+    // With (1,2) pooling the pooled pair (f, f+1) is two consecutive pixels, so a tile is simply ROWS consecutive
+    // rows of the flattened (B*T*F, C) activation: row r <-> pixel r, window r/2, dropout counter r*C + n.
+    constexpr int CP = C + 1, NT = C / 32;
+    constexpr int WN = NT, WM = 8 / WN, MS = 1, ROWS = 32 * WM * MS;   // C=128: 4 x 2 waves, 64 rows; C=64: 2 x 4, 128
     constexpr int NLD = ROWS * (C / 4) / 512;
     static_assert(512 % (C / 4) == 0, "each thread keeps one channel quad");
     SED_DYN_SMEM(smem);
     float* xs = (float*)smem;                                          // [ROWS][CP] BN output xn
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const int wn = w % WN, wm = w / WN;
-    const int To = T / PT, Fo = F / PF, NWC = To * Fo;
-    const int fsh = 31 - __builtin_clz(Fo);
-    const int tiles_per_clip = (NWC + NW - 1) / NW, ntiles = B * tiles_per_clip;
+    const int R = B * T * F, ntiles = (R + ROWS - 1) / ROWS;
     const int n = wn * 32 + lo;
     // B fragments: Wg goes through LDS so the global reads stay coalesced (a per-lane row gather would cost
     // ~32 cache lines per load instruction, x C/2 instructions x 16 waves on one CU's address unit)
@@ -354,14 +363,13 @@ __global__ __launch_bounds__(512, 4) void glu_wide_fwd_kernel(const float* __res
 
     float4 ld[NLD];
     auto load_tile = [&](int tile) {
-        const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
+        const int row0 = tile * ROWS;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int m = r0 + (512 / (C / 4)) * u;
-            int o, t, f;
             ld[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) {
-                float4 val = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
+            if (row0 + m < R && !(GLU_ABL & 4)) {
+                float4 val = *(const float4*)(y + (size_t)(row0 + m) * C + 4 * v);
                 val.x = fmaf(val.x, sc4[0], sh4[0]); val.y = fmaf(val.y, sc4[1], sh4[1]);
                 val.z = fmaf(val.z, sc4[2], sh4[2]); val.w = fmaf(val.w, sc4[3], sh4[3]);
                 ld[u] = val;
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(512, 4) void glu_wide_fwd_kernel(const float* __res
     int tile = blockIdx.x;
     if (tile < ntiles) load_tile(tile);
     for (; tile < ntiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
+        const int row0 = tile * ROWS;
         __syncthreads();                                               // previous tile fully consumed
         store_tile();
         __syncthreads();
@@ -397,16 +405,16 @@ __global__ __launch_bounds__(512, 4) void glu_wide_fwd_kernel(const float* __res
                 float vv[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    int o, t, f;
-                    const bool ok = row_pixel<PT, PF>(mbase + q, o0, NWC, fsh, o, t, f);
-                    const uint32_t e = (uint32_t)((((size_t)b * T + t) * F + f) * C + n);
+                    if (GLU_ABL & 2) { vv[q] = acc[ms][4 * j + q]; continue; }
+                    const uint32_t e = (uint32_t)(row0 + mbase + q) * (uint32_t)C + (uint32_t)n;
                     const float xn = xs[(mbase + q) * CP + n];
                     float r = (acc[ms][4 * j + q] + bias_n) * sed_fast_sigmoid(xn);
-                    vv[q] = (ok && sed_keep(e, seed, thr24)) ? r * dscale : 0.f;
+                    vv[q] = sed_keep(e, seed, thr24) ? r * dscale : 0.f;
                 }
-                const int o = o0 + mbase / 2;
-                if (o < NWC) out[((size_t)b * NWC + o) * C + n] = 0.5f * (vv[0] + vv[1]);
-                if (o + 1 < NWC) out[((size_t)b * NWC + o + 1) * C + n] = 0.5f * (vv[2] + vv[3]);
+                if (GLU_ABL & 8) { if (vv[0] + vv[1] + vv[2] + vv[3] == 123.456f) out[0] = 1.f; continue; }
+                const int o = (row0 + mbase) / 2;                      // rows past R hold zeros and are never stored
+                if (2 * o < R) out[(size_t)o * C + n] = 0.5f * (vv[0] + vv[1]);
+                if (2 * o + 2 < R) out[(size_t)(o + 1) * C + n] = 0.5f * (vv[2] + vv[3]);
             }
         }
     }
@@ -421,8 +429,7 @@ static int launch_glu_wide_fwd(const float* y, const float* stats, const float* 
                                uint32_t seed, uint32_t thr24, float dscale, hipStream_t s) {
     constexpr int ROWS = 32 * (8 / (C / 32));
     constexpr int SMEM = ROWS * (C + 1) * 4;
-    const int NWC = T * (F / 2);
-    const int ntiles = B * ((NWC + ROWS / 2 - 1) / (ROWS / 2));
+    const int ntiles = (B * T * F + ROWS - 1) / ROWS;
     const int cap = glu_grid_cap(512);                                  // two 8-wave workgroups per CU
     int grid = ntiles < cap ? ntiles : cap;
     if (grid < 1) return SED_OK;
@@ -445,13 +452,13 @@ extern "C" int sed_glu_fwd(const float* y, const float* stats, const float* Wg, 
         SED_LAUNCH(glu16_fwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale);
         return sed_check_launch();
     }
-    if (PT == 1 && PF == 2 && (F & (F - 1)) == 0) {
+    if (PT == 1 && PF == 2) {
         if (C == 128) return launch_glu_wide_fwd<128>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, s);
         if (C == 64) return launch_glu_wide_fwd<64>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, s);
     }
 #define GLU_CASE(c, pt, pf) \
     if (C == c && PT == pt && PF == pf) return launch_glu_fwd<c, pt, pf>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, s);
-    GLU_CASE(16, 2, 2) GLU_CASE(32, 2, 2) GLU_CASE(64, 1, 2) GLU_CASE(128, 1, 2)
+    GLU_CASE(16, 2, 2) GLU_CASE(32, 2, 2)
 #undef GLU_CASE
     return SED_ERR_UNSUPPORTED;
 }
@@ -690,10 +697,9 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ Wg, const float* __restrict__ bg,
                                                            const float* __restrict__ gout, float* __restrict__ dz,
-                                                           float* __restrict__ dWg, float* __restrict__ dbg,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int T,
+                                                           float* __restrict__ part, int B, int T,
                                                            int F, uint32_t seed, uint32_t thr24, float dscale) {
-    constexpr int PT = 1, PF = 2, WIN = 2, CP = C + 1, NT = C / 32, WN = NT, WM = 8 / WN, ROWS = 32 * WM, NW = ROWS / WIN;
+    constexpr int CP = C + 1, NT = C / 32, WN = NT, WM = 8 / WN, ROWS = 32 * WM;   // flat row tiles, see glu_wide_fwd_kernel
     constexpr int NLD = ROWS * (C / 4) / 512, RSTEP = 512 / (C / 4);
     constexpr int NT3 = NT * NT, TPW = NT3 >= 8 ? NT3 / 8 : 1, KSPLIT = NT3 >= 8 ? 1 : 8 / NT3, KROWS = ROWS / KSPLIT;
     SED_DYN_SMEM(smem);
@@ -703,9 +709,7 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_kernel(const float* __restri
     constexpr bool B2_LDS = C > 64;     // 2 x C/2 weight registers do not fit next to the accumulators at C = 128
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const int wn = w % WN, wm = w / WN, n = wn * 32 + lo;
-    const int To = T / PT, Fo = F / PF, NWC = To * Fo;
-    const int fsh = 31 - __builtin_clz(Fo);
-    const int tiles_per_clip = (NWC + NW - 1) / NW, ntiles = B * tiles_per_clip;
+    const int R = B * T * F, ntiles = (R + ROWS - 1) / ROWS;
 
     // Wg through LDS (coalesced global reads; see glu_wide_fwd_kernel): resident in `wg` at C = 128, staged in the
     // not-yet-used xhat tile at C = 64
@@ -742,18 +746,18 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_kernel(const float* __restri
 
     float4 ld[NLD];
     auto load_tile = [&](int tile) {
-        const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
+        const int row0 = tile * ROWS;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
-            int o, t, f;
-            ld[u] = make_float4(mu4[0], mu4[1], mu4[2], mu4[3]);                     // -> xhat 0 for rows past the clip
-            if (row_pixel<PT, PF>(r0 + RSTEP * u, o0, NWC, fsh, o, t, f)) ld[u] = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
+            const int m = r0 + RSTEP * u;
+            ld[u] = make_float4(mu4[0], mu4[1], mu4[2], mu4[3]);                     // -> xhat 0 for rows past the end
+            if (row0 + m < R && !(GLU_ABL & 4)) ld[u] = *(const float4*)(y + (size_t)(row0 + m) * C + 4 * v);
         }
     };
     int tile = blockIdx.x;
     if (tile < ntiles) load_tile(tile);
     for (; tile < ntiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
+        const int row0 = tile * ROWS;
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
@@ -769,8 +773,8 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_kernel(const float* __restri
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int o = o0 + (32 * wm + 8 * j + 4 * hi + 2 * h) / 2;
-                g8[2 * j + h] = o < NWC ? gout[((size_t)b * NWC + o) * C + n] * (0.5f * dscale) : 0.f;
+                const int rr = row0 + 32 * wm + 8 * j + 4 * hi + 2 * h;
+                g8[2 * j + h] = (rr < R && !(GLU_ABL & 4)) ? gout[(size_t)(rr / 2) * C + n] * (0.5f * dscale) : 0.f;
             }
         // ---- GEMM1: lin = xn . Wg^T  (= xhat . (gamma Wg)^T + beta-folded bias) ----
         f32x16 acc = f32x16_zero();
@@ -781,11 +785,10 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = 32 * wm + mfma32_row(r, lane);
-            int o, t, f;
-            const bool rok = row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f);
-            const uint32_t e_idx = (uint32_t)((((size_t)b * T + t) * F + f) * C + n);
+            const uint32_t e_idx = (uint32_t)(row0 + m) * (uint32_t)C + (uint32_t)n;
             float dlin = 0.f, e = 0.f;
-            if (rok) {
+            if (GLU_ABL & 2) { dlin = acc[r]; e = g8[r & 7]; }
+            else if (row0 + m < R) {
                 const float xn = fmaf(xh[m * CP + n], gn, bn);
                 const float sg = sed_fast_sigmoid(xn);
                 const float lin = acc[r] + biasp;
@@ -804,7 +807,10 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_kernel(const float* __restri
             if (B2_LDS) {
                 const float* bp = wg + hi * CP + n;
 #pragma unroll 8
-                for (int ks = 0; ks < C / 2; ++ks) acc = mfma32(ap[2 * ks], bp[2 * ks * CP], acc);
+                for (int ks = 0; ks < C / 2; ++ks) {
+                    if (GLU_ABL & 1) acc[0] += ap[2 * ks] * bp[2 * ks * CP];
+                    else acc = mfma32(ap[2 * ks], bp[2 * ks * CP], acc);
+                }
             } else {
                 mfma_chain<C / 2, 8>(ap, [&](int ks) { return b2[B2_LDS ? 0 : ks]; }, acc);
             }
@@ -813,12 +819,11 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = 32 * wm + mfma32_row(r, lane);
-            int o, t, f;
-            if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) {
+            if (row0 + m < R) {
                 const float dxn = acc[r];
                 a_dgam = fmaf(dxn, xh[m * CP + n], a_dgam);
                 a_dbet += dxn;
-                dz[(((size_t)b * T + t) * F + f) * C + n] = dxn * gn;
+                if (!(GLU_ABL & 8)) dz[(size_t)(row0 + m) * C + n] = dxn * gn;
             }
         }
         // ---- GEMM3: P[n'][c] += sum_rows dlin[row][n'] * xn[row][c] ----
@@ -832,43 +837,106 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_kernel(const float* __restri
             for (int k = k0; k < k0 + KROWS; k += 2) {
                 const float av = dl[(k + hi) * CP + mt * 32 + lo];
                 const float bv = fmaf(xh[(k + hi) * CP + c], gc, bc);
-                P[i] = mfma32(av, bv, P[i]);
+                if (GLU_ABL & 1) P[i][0] += av * bv;
+                else P[i] = mfma32(av, bv, P[i]);
             }
         }
     }
+    // ---- per-workgroup partial sums -> scratch (plain stores; glu_bwd_reduce_kernel adds them in a fixed order:
+    // device-scope float atomics from 256 workgroups onto the same 16K addresses cost more than the kernel body) ----
+    float* mine = part + (size_t)blockIdx.x * (KSPLIT * C * C + WM * 3 * C);
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int id = NT3 >= 8 ? w * TPW + i : w % NT3, mt = id / NT, ct = id % NT, c = ct * 32 + lo;
+        float* dst = mine + (NT3 >= 8 ? 0 : w / NT3) * C * C;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(dWg + (size_t)(mt * 32 + mfma32_row(r, lane)) * C + c, P[i][r]);
+        for (int r = 0; r < 16; ++r) dst[(mt * 32 + mfma32_row(r, lane)) * C + c] = P[i][r];
     }
     a_dbg += __shfl_xor(a_dbg, 32); a_dgam += __shfl_xor(a_dgam, 32); a_dbet += __shfl_xor(a_dbet, 32);
-    if (hi == 0) { atomicAdd(dbg + n, a_dbg); atomicAdd(dgamma + n, a_dgam); atomicAdd(dbeta + n, a_dbet); }
+    if (hi == 0) {
+        float* dst = mine + KSPLIT * C * C + wm * 3 * C;
+        dst[n] = a_dbg; dst[C + n] = a_dgam; dst[2 * C + n] = a_dbet;
+    }
+}
+// sums the nblk per-workgroup partials of glu_wide_bwd_kernel: [KS][C][C] dWg slabs, then [WMS][3][C] (dbg, dgamma, dbeta).
+// One workgroup per 64 consecutive outputs: 16 float4 columns x 16 groups of partials, fixed summation order.
+__global__ __launch_bounds__(256) void glu_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dWg,
+                                                             float* __restrict__ dbg, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int nblk, int C, int KS, int WMS) {
+    __shared__ float4 red[16][16];
+    const int tid = threadIdx.x, col = tid & 15, grp = tid >> 4, e = blockIdx.x * 64 + 4 * col;
+    const int CC = C * C, PART = KS * CC + WMS * 3 * C;
+    // outputs [0, CC) are dWg with KS slabs per partial; [CC, CC + 3C) the three vectors with WMS slabs (C % 4 == 0 keeps
+    // a float4 inside one of them)
+    const bool isw = e < CC;
+    const int nsl = isw ? KS : WMS, sstride = isw ? CC : 3 * C;
+    const size_t off = isw ? (size_t)e : (size_t)KS * CC + (e - CC);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < CC + 3 * C) {
+        const int total = nblk * nsl;                                  // (partial, slab) pairs, split over the 16 groups
+#pragma unroll 4
+        for (int i = grp; i < total; i += 16) {
+            const int b = i / nsl, k = i - b * nsl;
+            const float4 v = *(const float4*)(part + (size_t)b * PART + off + (size_t)k * sstride);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[grp][col] = acc;
+    __syncthreads();
+    if (grp == 0 && e < CC + 3 * C) {
+#pragma unroll
+        for (int g = 1; g < 16; ++g) { const float4 v = red[g][col]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        float* dst;
+        if (isw) dst = dWg + e;
+        else {
+            const int j2 = e - CC, which = j2 / C;
+            dst = (which == 0 ? dbg : which == 1 ? dgamma : dbeta) + (j2 - which * C);
+        }
+        *(float4*)dst = acc;
+    }
 }
 template <int C>
 static int launch_glu_wide_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
                                const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
-                               int B, int T, int F, uint32_t seed, uint32_t thr24, float dscale, hipStream_t s) {
-    constexpr int ROWS = 32 * (8 / (C / 32));
+                               float* scratch, int B, int T, int F, uint32_t seed, uint32_t thr24, float dscale, hipStream_t s) {
+    constexpr int ROWS = 32 * (8 / (C / 32)), WMS = 8 / (C / 32), KS = (C / 32) * (C / 32) >= 8 ? 1 : 8 / ((C / 32) * (C / 32));
+    if (!scratch) return SED_ERR_ARG;
     constexpr int SMEM = (2 * ROWS + (C > 64 ? C : 0)) * (C + 1) * 4;
-    const int NWC = T * (F / 2);
-    const int ntiles = B * ((NWC + ROWS / 2 - 1) / (ROWS / 2));
+    const int ntiles = (B * T * F + ROWS - 1) / ROWS;
     const int cap = glu_grid_cap(256);                                  // register-bound: one workgroup per CU
     int grid = ntiles < cap ? ntiles : cap;
-    if (grid < 1) return SED_OK;
+    if (grid < 1) { sed_zero4(s, dWg, C * C, dbg, C, dgamma, C, dbeta, C); return SED_OK; }
     SED_MAX_SMEM((glu_wide_bwd_kernel<C>), SMEM);
-    SED_LAUNCH((glu_wide_bwd_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma,
-               dbeta, B, T, F, seed, thr24, dscale);
+    SED_LAUNCH((glu_wide_bwd_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, gamma, beta, Wg, bg, gout, dz, scratch, B, T, F,
+               seed, thr24, dscale);
+    SED_LAUNCH(glu_bwd_reduce_kernel, dim3((C * C + 3 * C + 63) / 64), dim3(256), 0, s, scratch, dWg, dbg, dgamma, dbeta, grid, C, KS, WMS);
     return sed_check_launch();
 }
 
-// gout (B,T/PT,F/PF,C) -> dz (B,T,F,C) = dL/d xhat; dWg (C,C), dbg, dgamma, dbeta (C) are ZEROED here and
-// accumulated with fp32 atomics.  When T % PT != 0 the dropped frames of dz are zeroed too.
+// Floats of scratch sed_glu_bwd needs: the 64/128-channel (1,2)-pooled blocks keep one partial (dWg, dbg, dgamma,
+// dbeta) per workgroup (at most 256) and reduce them in a fixed order; the narrow blocks accumulate with atomics (0).
+extern "C" long long sed_glu_bwd_scratch_floats(int B, int T, int F, int C, int PT, int PF) {
+    (void)B; (void)T; (void)F;
+    if (PT == 1 && PF == 2 && (C == 64 || C == 128)) {
+        const int nt3 = (C / 32) * (C / 32), ks = nt3 >= 8 ? 1 : 8 / nt3, wms = 8 / (C / 32);
+        return 256LL * (ks * C * C + wms * 3 * C);
+    }
+    return 0;
+}
+
+// gout (B,T/PT,F/PF,C) -> dz (B,T,F,C) = dL/d xhat; dWg (C,C), dbg, dgamma, dbeta (C) are overwritten (zeroed here and
+// accumulated with fp32 atomics on the narrow blocks; reduced from `scratch`, see above, on the wide ones).
+// When T % PT != 0 the dropped frames of dz are zeroed too.
 extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
                            const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
-                           int B, int T, int F, int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, void* stream) {
+                           float* scratch, int B, int T, int F, int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale,
+                           void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (F % PF != 0) return SED_ERR_UNSUPPORTED;
+    if (PT == 1 && PF == 2) {
+        if (C == 128) return launch_glu_wide_bwd<128>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, s);
+        if (C == 64) return launch_glu_wide_bwd<64>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, s);
+    }
     sed_zero4(s, dWg, C * C, dbg, C, dgamma, C, dbeta, C);
     if (T % PT != 0) (void)hipMemsetAsync(dz, 0, (size_t)B * T * F * C * 4, s);
     if (C == 16 && PT == 2 && PF == 2 && F % 8 == 0) {
@@ -880,15 +948,11 @@ extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamm
                    T, F, seed, thr24, dscale);
         return sed_check_launch();
     }
-    if (PT == 1 && PF == 2 && (F & (F - 1)) == 0) {
-        if (C == 128) return launch_glu_wide_bwd<128>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B, T, F, seed, thr24, dscale, s);
-        if (C == 64) return launch_glu_wide_bwd<64>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B, T, F, seed, thr24, dscale, s);
-    }
 #define GLU_CASE(c, pt, pf)                                                                                              \
     if (C == c && PT == pt && PF == pf)                                                                                  \
         return launch_glu_bwd<c, pt, pf>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B, T, F, seed, thr24, \
                                          dscale, s);
-    GLU_CASE(16, 2, 2) GLU_CASE(32, 2, 2) GLU_CASE(64, 1, 2) GLU_CASE(128, 1, 2)
+    GLU_CASE(16, 2, 2) GLU_CASE(32, 2, 2)
 #undef GLU_CASE
     return SED_ERR_UNSUPPORTED;
 }

@@ -134,9 +134,11 @@ class ConvBlockFn(torch.autograd.Function):
         d_glu_b = _grad_buf(cfg, glu_b)
         d_gamma = _grad_buf(cfg, bn_w)
         d_beta = _grad_buf(cfg, bn_b)
+        nscr = int(lib.value("sed_glu_bwd_scratch_floats", B, T, F, COUT, PT, PF))
+        gscratch = torch.empty(nscr, **f32) if nscr else None
         lib.call("sed_glu_bwd", y.data_ptr(), stats.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(), glu_w.data_ptr(), glu_b.data_ptr(),
                  gout.data_ptr(), dz.data_ptr(), d_glu_w.data_ptr(), d_glu_b.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(),
-                 B, T, F, COUT, PT, PF, seed, thr24, dscale, st)
+                 _p(gscratch), B, T, F, COUT, PT, PF, seed, thr24, dscale, st)
         d_bias = _grad_buf(cfg, conv_b)
         d_w = _grad_buf(cfg, conv_w)
         dx = None

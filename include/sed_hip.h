@@ -87,10 +87,14 @@ int sed_bn_finalize(const float* partial, int nblocks, int C, float count, const
 int sed_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
                 int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, void* stream);
 
-/* Backward of the above: gout -> dz = dL/d(xhat) (B,T,F,C) and dWg (C,C), dbg, dgamma, dbeta (C) (zeroed inside). */
+/* Floats of scratch sed_glu_bwd needs (per-workgroup partial sums, reduced in a fixed order; 0 = none). */
+long long sed_glu_bwd_scratch_floats(int B, int T, int F, int C, int PT, int PF);
+
+/* Backward of the above: gout -> dz = dL/d(xhat) (B,T,F,C) and dWg (C,C), dbg, dgamma, dbeta (C) (overwritten). */
 int sed_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
                 const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
-                int B, int T, int F, int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, void* stream);
+                float* scratch, int B, int T, int F, int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale,
+                void* stream);
 
 /* BatchNorm backward apply in place: dz -> dy = dL/d(conv output); dbias (C) = conv-bias gradient. */
 int sed_bn_bwd_apply(const float* y, float* dz, const float* stats, const float* gamma, const float* dgamma,

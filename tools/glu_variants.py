@@ -1,0 +1,50 @@
+"""Timing ablation of the wide GLU kernels (diagnostics).  Builds sed_glu.hip with -DGLU_ABL=mask into
+tools/_glu_v{mask}.so (1 = no MFMA, 2 = no epilogue math, 4 = no global loads, 8 = no global stores) and times
+sed_glu_fwd / sed_glu_bwd on the recipe's layer-2 (C=64) and layer-3 (C=128) shapes at B=48."""
+import ctypes, os, subprocess, sys
+import torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(ROOT, "desed_task_amd", "csrc")
+variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 4, 8, 15]
+for v in variants:
+    so = os.path.join(HERE, "_glu_v%d.so" % v)
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(CSRC, "sed_glu.hip")):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC,
+                               "-I", os.path.join(ROOT, "include"), "-DGLU_ABL=%d" % v, os.path.join(CSRC, "sed_glu.hip"), "-o", so])
+if not torch.cuda.is_available():
+    sys.exit(0)
+P = ctypes.c_void_p
+I = ctypes.c_int
+for (C, T, F) in [(64, 156, 32), (128, 156, 16), (128, 156, 2)]:
+    B = 48
+    y = torch.randn(B, T, F, C, device="cuda")
+    stats = torch.cat([torch.zeros(C), torch.ones(C), torch.ones(C), torch.zeros(C)]).cuda()
+    gamma, beta = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    Wg, bg = torch.randn(C, C, device="cuda") * 0.05, torch.zeros(C, device="cuda")
+    out = torch.empty(B, T, F // 2, C, device="cuda")
+    gout = torch.randn_like(out)
+    dz = torch.empty_like(y)
+    dWg, dbg, dgam, dbet = torch.empty(C, C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    scr = torch.empty(256 * (2 * C * C + 12 * C), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for v in variants:
+        lib = ctypes.CDLL(os.path.join(HERE, "_glu_v%d.so" % v))
+        ff, fb = lib.sed_glu_fwd, lib.sed_glu_bwd
+        ff.argtypes = [P] * 5 + [I] * 6 + [ctypes.c_uint, ctypes.c_uint, ctypes.c_float, P]
+        fb.argtypes = [P] * 13 + [I] * 6 + [ctypes.c_uint, ctypes.c_uint, ctypes.c_float, P]
+        fa = (y.data_ptr(), stats.data_ptr(), Wg.data_ptr(), bg.data_ptr(), out.data_ptr(), B, T, F, C, 1, 2, 7, 1 << 23, 2.0, st)
+        ba = (y.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Wg.data_ptr(), bg.data_ptr(), gout.data_ptr(), dz.data_ptr(),
+              dWg.data_ptr(), dbg.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), scr.data_ptr(), B, T, F, C, 1, 2, 7, 1 << 23, 2.0, st)
+        res = []
+        for f, a in ((ff, fa), (fb, ba)):
+            for _ in range(3):
+                assert f(*a) == 0
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                f(*a)
+            e1.record(); torch.cuda.synchronize()
+            res.append(e0.elapsed_time(e1) / 20 * 1e3)
+        print("C=%3d F=%2d abl=%2d: fwd %.1f us  bwd %.1f us (incl. zero4)" % (C, F, v, res[0], res[1]), flush=True)
