@@ -95,7 +95,8 @@ __global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const
     constexpr int TR = Cfg::TR, PW = Cfg::PW, PP = Cfg::PP, CK = Cfg::CK, RSS = Cfg::RSS, NCH = Cfg::NCH, NT = Cfg::NT,
                   NTW = Cfg::NTW, THREADS = Cfg::THREADS, WM = Cfg::WM, NCOL = Cfg::NCOL, SLAB = Cfg::SLAB, WBUF_S = Cfg::WBUF_S;
     SED_DYN_SMEM(smem_raw);
-    unsigned short* patch = (unsigned short*)(((uintptr_t)smem_raw + 15) & ~(uintptr_t)15);   // hi plane, then lo plane
+    // (no integer round-trip on the LDS pointer: that would demote every LDS access to a flat_* instruction)
+    unsigned short* patch = (unsigned short*)smem_raw;                  // 16-byte aligned; hi plane, then lo plane
     unsigned short* wbuf = patch + Cfg::PATCH_S;
     const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) % WM, wn = (tid >> 6) / WM, lo = lane & 31, hi = lane >> 5;
     const int ftiles = F / TF, ttiles = (T + TR - 1) / TR;

@@ -111,6 +111,8 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < NTN; ++i) acc[i] = f32x16_zero();
     float4 ra[AV], rb[BV];
+    // (guarded loads are written as `v = 0; if (ok) v = load` -- a `ok ? *p : zero` select makes the compiler pick between
+    // two ADDRESSES and emit scalar flat loads)
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto load_tile = [&](int k0) {
@@ -120,11 +122,13 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
             if (TA == 0) {
                 const int m = i / (BK / 4), kq = i % (BK / 4);
                 const int gm = m0 + m, gk = k0 + 4 * kq;
-                ra[u] = (gm < M && gk < kend) ? *(const float4*)(A + (size_t)gm * lda + gk) : zero4;
+                ra[u] = zero4;
+                if (gm < M && gk < kend) ra[u] = *(const float4*)(A + (size_t)gm * lda + gk);
             } else {
                 const int k = i / (BM / 4), mq = i % (BM / 4);
                 const int gm = m0 + 4 * mq, gk = k0 + k;
-                ra[u] = (gm < M && gk < kend) ? *(const float4*)(A + (size_t)gk * lda + gm) : zero4;
+                ra[u] = zero4;
+                if (gm < M && gk < kend) ra[u] = *(const float4*)(A + (size_t)gk * lda + gm);
             }
         }
 #pragma unroll
@@ -133,11 +137,13 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
             if (TB == 0) {
                 const int k = i / (BN / 4), nq = i % (BN / 4);
                 const int gn = n0 + 4 * nq, gk = k0 + k;
-                rb[u] = (gn < N && gk < kend) ? *(const float4*)(Bm + (size_t)gk * ldb + gn) : zero4;
+                rb[u] = zero4;
+                if (gn < N && gk < kend) rb[u] = *(const float4*)(Bm + (size_t)gk * ldb + gn);
             } else {
                 const int n = i / (BK / 4), kq = i % (BK / 4);
                 const int gn = n0 + n, gk = k0 + 4 * kq;
-                rb[u] = (gn < N && gk < kend) ? *(const float4*)(Bm + (size_t)gn * ldb + gk) : zero4;
+                rb[u] = zero4;
+                if (gn < N && gk < kend) rb[u] = *(const float4*)(Bm + (size_t)gn * ldb + gk);
             }
         }
     };
