@@ -404,7 +404,9 @@ extern "C" int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1
 __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                       const float* __restrict__ saved, const float* __restrict__ whh0,
                                                       const float* __restrict__ whh1, float* __restrict__ dgi,
-                                                      float* __restrict__ dgh, float* __restrict__ hprev_out, int B, int T) {
+                                                      float* __restrict__ dgh, float* __restrict__ hprev_out,
+                                                      float* __restrict__ dbi0, float* __restrict__ dbi1,
+                                                      float* __restrict__ dbh0, float* __restrict__ dbh1, int B, int T) {
     constexpr int H = GRU_H, KH = H / 4, CH = GRU_CH, NT_ = GRU_THREADS;
     constexpr int IB_F = CH * 6 * H, OB_F = CH * 7 * H;
     __shared__ __attribute__((aligned(16))) float gbuf[2][3 * H];
@@ -466,6 +468,7 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __res
     park_chunk(0);
     __syncthreads();
     float dh_carry = 0.f;
+    float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_hn = 0.f;     // bias gradients: sums over this clip's steps (off the chain)
     int cur = 0;
     for (int c = 0; c < nchunks; ++c) {
         if (c + 1 < nchunks) load_chunk(c + 1);
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __res
             const float da_z = dzg * z * (1.0f - z);
             const float da_r = da_n * hn * r * (1.0f - r);
             const float dhn = da_n * r;
+            sb_r += da_r; sb_z += da_z; sb_n += da_n; sb_hn += dhn;
             if (half == 0) {
                 gbuf[cur][k] = da_r; gbuf[cur][H + k] = da_z; gbuf[cur][2 * H + k] = dhn;
                 float* o = och + s * 7 * H;
@@ -519,13 +523,22 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __res
         __syncthreads();
     }
     flush_chunk(nchunks - 1);
+    // db_ih = sum over (clip, step) of dgi, db_hh likewise of dgh: one atomic per (clip, direction, gate row)
+    float* dbi = dir ? dbi1 : dbi0;
+    float* dbh = dir ? dbh1 : dbh0;
+    if (half == 0 && dbi != nullptr) { atomicAdd(dbi + k, sb_r); atomicAdd(dbi + H + k, sb_z); atomicAdd(dbi + 2 * H + k, sb_n); }
+    if (half == 1 && dbh != nullptr) { atomicAdd(dbh + k, sb_r); atomicAdd(dbh + H + k, sb_z); atomicAdd(dbh + 2 * H + k, sb_hn); }
 }
 extern "C" int sed_gru_bwd(const float* dout, const float* out, const float* saved, const float* whh0, const float* whh1,
-                           float* dgi, float* dgh, float* hprev, int B, int T, int H, void* stream) {
+                           float* dgi, float* dgh, float* hprev, float* dbi0, float* dbi1, float* dbh0, float* dbh1, int B, int T,
+                           int H, void* stream) {
     if (H != GRU_H) return SED_ERR_UNSUPPORTED;
+    if ((dbi0 == nullptr) != (dbi1 == nullptr) || (dbh0 == nullptr) != (dbh1 == nullptr)) return SED_ERR_ARG;
+    if (dbi0 || dbh0) sed_zero4((hipStream_t)stream, dbi0, dbi0 ? 3 * H : 0, dbi1, dbi1 ? 3 * H : 0, dbh0, dbh0 ? 3 * H : 0, dbh1, dbh1 ? 3 * H : 0);
     if (B <= 0 || T <= 0) return SED_OK;
     const int smem = (2 * GRU_CH * 6 * GRU_H + 2 * GRU_CH * 7 * GRU_H) * 4;
     SED_MAX_SMEM(gru_bwd_kernel, smem);
-    SED_LAUNCH(gru_bwd_kernel, dim3(2 * B), dim3(GRU_THREADS), smem, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh, hprev, B, T);
+    SED_LAUNCH(gru_bwd_kernel, dim3(2 * B), dim3(GRU_THREADS), smem, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh, hprev,
+               dbi0, dbi1, dbh0, dbh1, B, T);
     return sed_check_launch();
 }

@@ -5,82 +5,107 @@
 //         clips, weak on the next n_weak), the two teacher BCEs (logging), MSE student-vs-teacher on all clips;
 //         emits the scalars and the gradient seeds d(total)/d(strong_s), d(total)/d(weak_s).
 // Layout: x (B,T,D=256); strong/sof (B,T,NC) (the Python side returns the (B,NC,T) transposed view);
-// labels stay in the reference layout (B,NC,T).  One workgroup per clip; one thread per frame.
+// labels stay in the reference layout (B,NC,T).
 #include "sed_common.h"
 
 #define HEAD_D 256
 
+// Forward: one workgroup per clip (the attention pooling sums over the clip's frames), FOUR lanes per frame: lane
+// quarter q owns the input features k with (k / 4) % 4 == q, so the four lanes of a frame read 64 contiguous bytes of
+// x and adjacent LDS banks of the weights; the 2*NC partial logits are combined with two xor-shuffles.
+#define HEAD_THREADS 1024
 template <int NC>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W1,
-                                                       const float* __restrict__ b1, const float* __restrict__ W2,
-                                                       const float* __restrict__ b2, float* __restrict__ strong,
-                                                       float* __restrict__ psoft, float* __restrict__ weak,
-                                                       float* __restrict__ den, int T, uint32_t seed, uint32_t thr24,
-                                                       float dscale) {
-    constexpr int D = HEAD_D;
-    __shared__ float w1[NC * D], w2[NC * D];
-    __shared__ float red[4][2 * NC];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    for (int i = tid; i < NC * D; i += 256) { w1[i] = W1[i]; w2[i] = W2[i]; }
+__global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W1,
+                                                                const float* __restrict__ b1, const float* __restrict__ W2,
+                                                                const float* __restrict__ b2, float* __restrict__ strong,
+                                                                float* __restrict__ psoft, float* __restrict__ weak,
+                                                                float* __restrict__ den, int T, uint32_t seed, uint32_t thr24,
+                                                                float dscale) {
+    constexpr int D = HEAD_D, FPP = HEAD_THREADS / 4;          // frames per pass
+    __shared__ __attribute__((aligned(16))) float w1[NC * D];
+    __shared__ __attribute__((aligned(16))) float w2[NC * D];
+    __shared__ float red[HEAD_THREADS / 64][2 * NC];
+    const int tid = threadIdx.x, b = blockIdx.x, q = tid & 3;
+    for (int i = tid; i < NC * D; i += HEAD_THREADS) { w1[i] = W1[i]; w2[i] = W2[i]; }
     __syncthreads();
     float num[NC], dn[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) { num[c] = 0.f; dn[c] = 0.f; }
-    for (int t = tid; t < T; t += 256) {
-        const float* xr = x + ((size_t)b * T + t) * D;
+    for (int t0 = 0; t0 < T; t0 += FPP) {                      // uniform trip count: the shuffles below need whole quads
+        const int t = t0 + (tid >> 2);
+        const bool live = t < T;
+        const float* xr = x + ((size_t)b * T + (live ? t : 0)) * D;
         float l1[NC], l2[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { l1[c] = b1[c]; l2[c] = b2[c]; }
-        for (int k = 0; k < D; k += 4) {
-            float4 v = *(const float4*)(xr + k);
-            const uint32_t e = (uint32_t)(((size_t)b * T + t) * D + k);
-            v.x = sed_keep(e, seed, thr24) ? v.x * dscale : 0.f;
-            v.y = sed_keep(e + 1, seed, thr24) ? v.y * dscale : 0.f;
-            v.z = sed_keep(e + 2, seed, thr24) ? v.z * dscale : 0.f;
-            v.w = sed_keep(e + 3, seed, thr24) ? v.w * dscale : 0.f;
+        for (int c = 0; c < NC; ++c) { l1[c] = 0.f; l2[c] = 0.f; }
+        if (live) {
+#pragma unroll 4
+            for (int i = 0; i < D / 16; ++i) {
+                const int k = 16 * i + 4 * q;
+                float4 v = *(const float4*)(xr + k);
+                const uint32_t e = (uint32_t)(((size_t)b * T + t) * D + k);
+                v.x = sed_keep(e, seed, thr24) ? v.x * dscale : 0.f;
+                v.y = sed_keep(e + 1, seed, thr24) ? v.y * dscale : 0.f;
+                v.z = sed_keep(e + 2, seed, thr24) ? v.z * dscale : 0.f;
+                v.w = sed_keep(e + 3, seed, thr24) ? v.w * dscale : 0.f;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const float* a = w1 + c * D + k;
-                const float* q = w2 + c * D + k;
-                l1[c] = fmaf(v.x, a[0], fmaf(v.y, a[1], fmaf(v.z, a[2], fmaf(v.w, a[3], l1[c]))));
-                l2[c] = fmaf(v.x, q[0], fmaf(v.y, q[1], fmaf(v.z, q[2], fmaf(v.w, q[3], l2[c]))));
+                for (int c = 0; c < NC; ++c) {
+                    const float4 a = *(const float4*)(w1 + c * D + k);
+                    const float4 g = *(const float4*)(w2 + c * D + k);
+                    l1[c] = fmaf(v.x, a.x, fmaf(v.y, a.y, fmaf(v.z, a.z, fmaf(v.w, a.w, l1[c]))));
+                    l2[c] = fmaf(v.x, g.x, fmaf(v.y, g.y, fmaf(v.z, g.z, fmaf(v.w, g.w, l2[c]))));
+                }
             }
         }
-        float mx = l2[0];
-#pragma unroll
-        for (int c = 1; c < NC; ++c) mx = fmaxf(mx, l2[c]);
-        float se = 0.f;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { l2[c] = expf(l2[c] - mx); se += l2[c]; }
-        const float inv = 1.0f / se;
-        float* so = strong + ((size_t)b * T + t) * NC;
-        float* po = psoft + ((size_t)b * T + t) * NC;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const float s = sed_sigmoid(l1[c]);
-            const float p = l2[c] * inv;
-            const float a = fminf(fmaxf(p, 1e-7f), 1.0f);
-            so[c] = s;
-            po[c] = p;
-            num[c] += s * a;
-            dn[c] += a;
+            l1[c] += __shfl_xor(l1[c], 1); l1[c] += __shfl_xor(l1[c], 2);
+            l2[c] += __shfl_xor(l2[c], 1); l2[c] += __shfl_xor(l2[c], 2);
+        }
+        if (live && q == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { l1[c] += b1[c]; l2[c] += b2[c]; }
+            float mx = l2[0];
+#pragma unroll
+            for (int c = 1; c < NC; ++c) mx = fmaxf(mx, l2[c]);
+            float se = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { l2[c] = expf(l2[c] - mx); se += l2[c]; }
+            const float inv = 1.0f / se;
+            float* so = strong + ((size_t)b * T + t) * NC;
+            float* po = psoft + ((size_t)b * T + t) * NC;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float s = sed_sigmoid(l1[c]);
+                const float p = l2[c] * inv;
+                const float a = fminf(fmaxf(p, 1e-7f), 1.0f);
+                so[c] = s;
+                po[c] = p;
+                num[c] += s * a;
+                dn[c] += a;
+            }
         }
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const float a = wave_sum(num[c]), q = wave_sum(dn[c]);
-        if ((tid & 63) == 0) { red[tid >> 6][c] = a; red[tid >> 6][NC + c] = q; }
+        const float a = wave_sum(num[c]), g = wave_sum(dn[c]);
+        if ((tid & 63) == 0) { red[tid >> 6][c] = a; red[tid >> 6][NC + c] = g; }
     }
     __syncthreads();
     if (tid < NC) {
-        const float n = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        const float d = red[0][NC + tid] + red[1][NC + tid] + red[2][NC + tid] + red[3][NC + tid];
+        float n = 0.f, d = 0.f;
+#pragma unroll
+        for (int w = 0; w < HEAD_THREADS / 64; ++w) { n += red[w][tid]; d += red[w][NC + tid]; }
         weak[b * NC + tid] = n / d;
         den[b * NC + tid] = d;
     }
 }
 
-// backward: d_strong (B,T,NC), d_weak (B,NC) -> dx (B,T,D), dW1,dW2 (NC,D), db1,db2 (NC) (atomics; zeroed by caller)
+// backward: d_strong (B,T,NC), d_weak (B,NC) -> dx (B,T,D), dW1,dW2 (NC,D), db1,db2 (NC) (atomics; zeroed by caller).
+// Grid = (clip, frame slice of HEAD_TS frames): nothing in the backward couples frames, so the slices fill the chip.
+// Phase 1: four lanes per frame as in the forward (logit gradients, then this lane's quarter of the dx row);
+// phase 2: thread k owns input feature k over the slice's frames.
+#define HEAD_TS 64
 template <int NC>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W1,
                                                        const float* __restrict__ W2, const float* __restrict__ strong,
@@ -89,55 +114,60 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ d_weak, float* __restrict__ dx,
                                                        float* __restrict__ dW1, float* __restrict__ dW2, float* __restrict__ db1,
                                                        float* __restrict__ db2, int T, uint32_t seed, uint32_t thr24, float dscale) {
-    constexpr int D = HEAD_D;
+    constexpr int D = HEAD_D, TS = HEAD_TS;
     SED_DYN_SMEM(smem);
     float* w1 = (float*)smem;            // NC*D
     float* w2 = w1 + NC * D;             // NC*D
-    float* dl = w2 + NC * D;             // T * 2*NC  (d logit1 | d logit2 per frame)
-    const int tid = threadIdx.x, b = blockIdx.x;
+    float* dl = w2 + NC * D;             // TS * 2*NC: (d logit1 | d logit2) per frame of the slice
+    const int tid = threadIdx.x, b = blockIdx.y, tbeg = blockIdx.x * TS, tn = min(TS, T - tbeg), q = tid & 3;
     for (int i = tid; i < NC * D; i += 256) { w1[i] = W1[i]; w2[i] = W2[i]; }
+    for (int i = tid; i < TS * 2 * NC; i += 256) dl[i] = 0.f;
     __syncthreads();
-    // ---- phase 1: per-frame logit gradients and dx rows ----
-    for (int t = tid; t < T; t += 256) {
-        const size_t bt = (size_t)b * T + t;
-        float g1[NC], g2[NC];
-        float dot = 0.f;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const float s = strong[bt * NC + c], p = psoft[bt * NC + c];
-            const float a = fminf(fmaxf(p, 1e-7f), 1.0f);
-            const float dw = d_weak[b * NC + c], dd = den[b * NC + c], wk = weak[b * NC + c];
-            const float ds = d_strong[bt * NC + c] + dw * a / dd;
-            g1[c] = ds * s * (1.0f - s);
-            const float da = dw * (s - wk) / dd;
-            const float dp = (p >= 1e-7f && p <= 1.0f) ? da : 0.f;
-            g2[c] = dp;
-            dot += p * dp;
-        }
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            g2[c] = psoft[bt * NC + c] * (g2[c] - dot);
-            dl[t * 2 * NC + c] = g1[c];
-            dl[t * 2 * NC + NC + c] = g2[c];
-        }
-        float* dr = dx + bt * D;
-        for (int k = 0; k < D; k += 4) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- phase 1: per-frame logit gradients and dx rows (TS == 256 / 4 frames in one pass) ----
+    {
+        const int tl = tid >> 2, t = tbeg + tl;
+        if (tl < tn) {
+            const size_t bt = (size_t)b * T + t;
+            float g1[NC], g2[NC];
+            float dot = 0.f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const float* a = w1 + c * D + k;
-                const float* q = w2 + c * D + k;
-                acc.x = fmaf(g1[c], a[0], fmaf(g2[c], q[0], acc.x));
-                acc.y = fmaf(g1[c], a[1], fmaf(g2[c], q[1], acc.y));
-                acc.z = fmaf(g1[c], a[2], fmaf(g2[c], q[2], acc.z));
-                acc.w = fmaf(g1[c], a[3], fmaf(g2[c], q[3], acc.w));
+                const float s = strong[bt * NC + c], p = psoft[bt * NC + c];
+                const float a = fminf(fmaxf(p, 1e-7f), 1.0f);
+                const float dw = d_weak[b * NC + c], dd = den[b * NC + c], wk = weak[b * NC + c];
+                const float ds = d_strong[bt * NC + c] + dw * a / dd;
+                g1[c] = ds * s * (1.0f - s);
+                const float da = dw * (s - wk) / dd;
+                const float dp = (p >= 1e-7f && p <= 1.0f) ? da : 0.f;
+                g2[c] = dp;
+                dot += p * dp;
             }
-            const uint32_t e = (uint32_t)(bt * D + k);
-            acc.x = sed_keep(e, seed, thr24) ? acc.x * dscale : 0.f;
-            acc.y = sed_keep(e + 1, seed, thr24) ? acc.y * dscale : 0.f;
-            acc.z = sed_keep(e + 2, seed, thr24) ? acc.z * dscale : 0.f;
-            acc.w = sed_keep(e + 3, seed, thr24) ? acc.w * dscale : 0.f;
-            *(float4*)(dr + k) = acc;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                g2[c] = psoft[bt * NC + c] * (g2[c] - dot);
+                if (q == 0) { dl[tl * 2 * NC + c] = g1[c]; dl[tl * 2 * NC + NC + c] = g2[c]; }
+            }
+            float* dr = dx + bt * D;
+#pragma unroll 2
+            for (int i = 0; i < D / 16; ++i) {
+                const int k = 16 * i + 4 * q;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float4 a = *(const float4*)(w1 + c * D + k);
+                    const float4 g = *(const float4*)(w2 + c * D + k);
+                    acc.x = fmaf(g1[c], a.x, fmaf(g2[c], g.x, acc.x));
+                    acc.y = fmaf(g1[c], a.y, fmaf(g2[c], g.y, acc.y));
+                    acc.z = fmaf(g1[c], a.z, fmaf(g2[c], g.z, acc.z));
+                    acc.w = fmaf(g1[c], a.w, fmaf(g2[c], g.w, acc.w));
+                }
+                const uint32_t e = (uint32_t)(bt * D + k);
+                acc.x = sed_keep(e, seed, thr24) ? acc.x * dscale : 0.f;
+                acc.y = sed_keep(e + 1, seed, thr24) ? acc.y * dscale : 0.f;
+                acc.z = sed_keep(e + 2, seed, thr24) ? acc.z * dscale : 0.f;
+                acc.w = sed_keep(e + 3, seed, thr24) ? acc.w * dscale : 0.f;
+                *(float4*)(dr + k) = acc;
+            }
         }
     }
     __syncthreads();
@@ -147,21 +177,21 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         float a1[NC], a2[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) { a1[c] = 0.f; a2[c] = 0.f; }
-        for (int t = 0; t < T; ++t) {
-            const size_t bt = (size_t)b * T + t;
+        for (int tl = 0; tl < tn; ++tl) {
+            const size_t bt = (size_t)b * T + tbeg + tl;
             float v = x[bt * D + k];
             v = sed_keep((uint32_t)(bt * D + k), seed, thr24) ? v * dscale : 0.f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                a1[c] = fmaf(dl[t * 2 * NC + c], v, a1[c]);
-                a2[c] = fmaf(dl[t * 2 * NC + NC + c], v, a2[c]);
+                a1[c] = fmaf(dl[tl * 2 * NC + c], v, a1[c]);
+                a2[c] = fmaf(dl[tl * 2 * NC + NC + c], v, a2[c]);
             }
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) { atomicAdd(dW1 + c * D + k, a1[c]); atomicAdd(dW2 + c * D + k, a2[c]); }
         if (tid < 2 * NC) {
             float s = 0.f;
-            for (int t = 0; t < T; ++t) s += dl[t * 2 * NC + tid];
+            for (int tl = 0; tl < tn; ++tl) s += dl[tl * 2 * NC + tid];
             atomicAdd(tid < NC ? db1 + tid : db2 + (tid - NC), s);
         }
     }
@@ -174,7 +204,7 @@ extern "C" int sed_head_fwd(const float* x, const float* W1, const float* b1, co
     if (B <= 0 || T <= 0) return SED_OK;
     hipStream_t s = (hipStream_t)stream;
 #define HEAD_CASE(nc) \
-    if (NC == nc) { SED_LAUNCH((head_fwd_kernel<nc>), dim3(B), dim3(256), 0, s, x, W1, b1, W2, b2, strong, psoft, weak, den, T, seed, thr24, dscale); return sed_check_launch(); }
+    if (NC == nc) { SED_LAUNCH((head_fwd_kernel<nc>), dim3(B), dim3(HEAD_THREADS), 0, s, x, W1, b1, W2, b2, strong, psoft, weak, den, T, seed, thr24, dscale); return sed_check_launch(); }
     HEAD_CASE(10) HEAD_CASE(27)
 #undef HEAD_CASE
     return SED_ERR_UNSUPPORTED;
@@ -188,16 +218,16 @@ extern "C" int sed_head_bwd(const float* x, const float* W1, const float* W2, co
     hipStream_t s = (hipStream_t)stream;
     sed_zero4(s, dW1, NC * D, dW2, NC * D, db1, NC, db2, NC);
     if (B <= 0 || T <= 0) return SED_OK;
-    const int smem = (2 * NC * D + T * 2 * NC) * 4;
+    const int smem = (2 * NC * D + HEAD_TS * 2 * NC) * 4;
 #define HEAD_CASE(nc) \
-    if (NC == nc) { SED_MAX_SMEM((head_bwd_kernel<nc>), smem); SED_LAUNCH((head_bwd_kernel<nc>), dim3(B), dim3(256), smem, s, x, W1, W2, strong, psoft, weak, den, d_strong, d_weak, dx, dW1, dW2, db1, db2, T, seed, thr24, dscale); return sed_check_launch(); }
+    if (NC == nc) { SED_MAX_SMEM((head_bwd_kernel<nc>), smem); SED_LAUNCH((head_bwd_kernel<nc>), dim3((T + HEAD_TS - 1) / HEAD_TS, B), dim3(256), smem, s, x, W1, W2, strong, psoft, weak, den, d_strong, d_weak, dx, dW1, dW2, db1, db2, T, seed, thr24, dscale); return sed_check_launch(); }
     HEAD_CASE(10) HEAD_CASE(27)
 #undef HEAD_CASE
     return SED_ERR_UNSUPPORTED;
 }
 
 // ---------------------------------------------------------------------------------------------
-// mean-teacher losses + gradient seeds.  Single workgroup (the tensors are ~75k elements).
+// mean-teacher losses + gradient seeds.  One workgroup per clip.
 // scalars[0..5] = BCE strong (student), BCE weak (student), BCE strong (teacher), BCE weak (teacher),
 //                 MSE strong, MSE weak.  g_strong (B,T,NC), g_weak (B,NC) = d(total)/d(student outputs) with
 // total = BCE_s + BCE_w + weight * (MSE_s + MSE_w).  torch.nn.BCELoss semantics: log clamped at -100,
@@ -206,19 +236,20 @@ extern "C" int sed_head_bwd(const float* x, const float* W1, const float* W2, co
 __device__ __forceinline__ float bce_term(float s, float y) {
     return -(y * fmaxf(logf(s), -100.0f) + (1.0f - y) * fmaxf(logf(1.0f - s), -100.0f));
 }
-__global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ strong_s, const float* __restrict__ weak_s,
-                                                    const float* __restrict__ strong_t, const float* __restrict__ weak_t,
-                                                    const float* __restrict__ labels, const float* __restrict__ labels_weak,
-                                                    float* __restrict__ scalars, float* __restrict__ g_strong,
-                                                    float* __restrict__ g_weak, int B, int T, int NC, int n_strong, int n_weak,
-                                                    float weight) {
-    __shared__ float red[16][6];
-    const int tid = threadIdx.x;
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ strong_s, const float* __restrict__ weak_s,
+                                                   const float* __restrict__ strong_t, const float* __restrict__ weak_t,
+                                                   const float* __restrict__ labels, const float* __restrict__ labels_weak,
+                                                   float* __restrict__ scalars, float* __restrict__ g_strong,
+                                                   float* __restrict__ g_weak, int B, int T, int NC, int n_strong, int n_weak,
+                                                   float weight) {
+    // one workgroup per clip; the six scalars (zeroed by the launcher) collect pre-scaled per-clip sums
+    __shared__ float red[4][6];
+    const int tid = threadIdx.x, b = blockIdx.x;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int ns_el = n_strong * T * NC, all_el = B * T * NC;
+    const int ns_el = n_strong * T * NC, all_el = B * T * NC, clip_el = T * NC;
     const float inv_bs = ns_el > 0 ? 1.0f / (float)ns_el : 0.f, inv_all = 1.0f / (float)all_el;
-    for (int i = tid; i < all_el; i += 1024) {
-        const int c = i % NC, t = (i / NC) % T, b = i / (NC * T);
+    for (int j = tid; j < clip_el; j += 256) {
+        const int i = b * clip_el + j, c = j % NC, t = j / NC;
         const float s = strong_s[i], q = strong_t[i];
         float g = weight * 2.0f * (s - q) * inv_all;
         const float d = s - q;
@@ -233,8 +264,8 @@ __global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ st
     }
     const int nw_el = n_weak * NC, allw = B * NC;
     const float inv_bw = nw_el > 0 ? 1.0f / (float)nw_el : 0.f, inv_allw = 1.0f / (float)allw;
-    for (int i = tid; i < allw; i += 1024) {
-        const int c = i % NC, b = i / NC;
+    if (tid < NC) {
+        const int c = tid, i = b * NC + c;
         const float s = weak_s[i], q = weak_t[i];
         float g = weight * 2.0f * (s - q) * inv_allw;
         const float d = s - q;
@@ -254,17 +285,17 @@ __global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ st
     }
     __syncthreads();
     if (tid < 6) {
-        float v = 0.f;
-        for (int w = 0; w < 16; ++w) v += red[w][tid];
+        const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         const float sc = tid == 0 || tid == 2 ? inv_bs : (tid == 1 || tid == 3 ? inv_bw : (tid == 4 ? inv_all : inv_allw));
-        scalars[tid] = v * sc;
+        atomicAdd(scalars + tid, v * sc);
     }
 }
 extern "C" int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
                            const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
                            int T, int NC, int n_strong, int n_weak, float weight, void* stream) {
-    if (B <= 0 || T <= 0 || NC <= 0 || n_strong + n_weak > B) return SED_ERR_ARG;
-    SED_LAUNCH(loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, strong_s, weak_s, strong_t, weak_t, labels, labels_weak,
+    if (B <= 0 || T <= 0 || NC <= 0 || NC > 256 || n_strong + n_weak > B) return SED_ERR_ARG;
+    sed_zero4((hipStream_t)stream, scalars, 6, nullptr, 0, nullptr, 0, nullptr, 0);
+    SED_LAUNCH(loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, strong_s, weak_s, strong_t, weak_t, labels, labels_weak,
                scalars, g_strong, g_weak, B, T, NC, n_strong, n_weak, weight);
     return sed_check_launch();
 }

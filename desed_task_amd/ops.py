@@ -217,24 +217,24 @@ class BiGRULayerFn(torch.autograd.Function):
         dgi = torch.empty(B, T, 2, 3 * H, **f32)
         dgh = torch.empty(B, T, 2, 3 * H, **f32)
         hprev = torch.empty(B, T, 2, H, **f32)
+        dbi = [_grad_buf(cfg, b_ih_f), _grad_buf(cfg, b_ih_r)]
+        dbh = [_grad_buf(cfg, b_hh_f), _grad_buf(cfg, b_hh_r)]
+        # the recurrence also emits the bias gradients (column sums of dgi / dgh)
         lib.call("sed_gru_bwd", dout.data_ptr(), out.data_ptr(), saved.data_ptr(), w_hh_f.data_ptr(), w_hh_r.data_ptr(),
-                 dgi.data_ptr(), dgh.data_ptr(), hprev.data_ptr(), B, T, H, st)
+                 dgi.data_ptr(), dgh.data_ptr(), hprev.data_ptr(), dbi[0].data_ptr(), dbi[1].data_ptr(), dbh[0].data_ptr(),
+                 dbh[1].data_ptr(), B, T, H, st)
         BT = B * T
         split = max(1, min(32, BT // 256))
         dwi = [_grad_buf(cfg, w_ih_f), _grad_buf(cfg, w_ih_r)]
         dwh = [_grad_buf(cfg, w_hh_f), _grad_buf(cfg, w_hh_r)]
         lib.call("sed_zero_buffers", dwi[0].data_ptr(), dwi[0].numel(), dwi[1].data_ptr(), dwi[1].numel(),
                  dwh[0].data_ptr(), dwh[0].numel(), dwh[1].data_ptr(), dwh[1].numel(), st)     # split-K GEMMs accumulate
-        dbi = [_grad_buf(cfg, b_ih_f), _grad_buf(cfg, b_ih_r)]
-        dbh = [_grad_buf(cfg, b_hh_f), _grad_buf(cfg, b_hh_r)]
         off = 3 * H * 4
         # dW_ih[d] = dgi[d]^T . x   and   dW_hh[d] = dgh[d]^T . hprev[d]   (K = B*T, split-K, both directions per launch)
         lib.call("sed_gemm_pair", dgi.data_ptr(), dgi.data_ptr() + off, x.data_ptr(), x.data_ptr(), None, None,
                  dwi[0].data_ptr(), dwi[1].data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, 0, st)
         lib.call("sed_gemm_pair", dgh.data_ptr(), dgh.data_ptr() + off, hprev.data_ptr(), hprev.data_ptr() + H * 4, None, None,
                  dwh[0].data_ptr(), dwh[1].data_ptr(), 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, 0, st)
-        lib.call("sed_colsum", dgi.data_ptr(), dbi[0].data_ptr(), dbi[1].data_ptr(), 3 * H, BT, 6 * H, 6 * H, st)
-        lib.call("sed_colsum", dgh.data_ptr(), dbh[0].data_ptr(), dbh[1].data_ptr(), 3 * H, BT, 6 * H, 6 * H, st)
         d_w_ih, d_w_hh, d_b_ih, d_b_hh = dwi, dwh, dbi, dbh
         dx = None
         if ctx.needs_input_grad[0]:
