@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured hipGraph step")
     args = ap.parse_args()
 
     from desed_task_amd import _lib
@@ -213,16 +214,25 @@ def main():
     task.train()
     if os.environ.get("SED_OVERLAP_TAILS") is not None:
         task.overlap_tails = os.environ["SED_OVERLAP_TAILS"] == "1"
-    driver = StepDriver(task, world_size=world)
+    use_graph = not args.no_graph
+    if use_graph:
+        # the step is captured once into a hipGraph (desed_task_amd/graph.py) and replayed: 3 eager steps, 1 capture step
+        from desed_task_amd.graph import GraphedStepDriver
+        driver = GraphedStepDriver(task, world_size=world, warmup=3)
+    else:
+        driver = StepDriver(task, world_size=world)
     audio, labels = synthetic_batch(dev, 1234 + rank)
 
     def one_step(i):
         driver.run_step((audio, labels.clone(), None, None), i)
 
-    for i in range(args.warmup):
+    # untimed: the W warm-up steps, plus (graph mode) whatever is still missing for the capture to lie outside the timed region
+    n_untimed = max(args.warmup, 5) if use_graph else args.warmup
+    for i in range(n_untimed):
         one_step(i)
     timer = KernelTimer({"sed_conv3x3", "sed_conv3x3_bf16x3"})
-    timer.wrap(_lib.get())
+    if not use_graph:
+        timer.wrap(_lib.get())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -235,6 +245,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if use_graph:
+        # per-launch HIP events cannot be placed inside a graph replay: time the roofline kernel over eager steps of the
+        # same workload right after the timed region (same process, same tensors, same stream)
+        timer.wrap(_lib.get())
+        for i in range(5):
+            driver.eager.run_step((audio, labels.clone(), None, None), i)
+        torch.cuda.synchronize()
     timer.unwrap()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -266,12 +283,14 @@ def main():
                     "traffic_note": "HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes on the "
                                     "f32 kernel of the same shape (profiles/r01_pmc_fetch_write.md); algorithmic in+out+weights = %d "
                                     "bytes" % (4 * dom_key[1] * dom_key[2] * dom_key[3] * (dom_key[4] + dom_key[5]) + 36 * dom_key[4] * dom_key[5]),
-                    "note": "achieved = algorithmic FLOPs (2*B*T*F*9*CIN*COUT) / mean launch time (HIP events, timed region); for the "
+                    "note": "achieved = algorithmic FLOPs (2*B*T*F*9*CIN*COUT) / mean launch time (HIP events; %s); for the "
                             "split-bf16 kernel the MFMA pipe issues 3x that (mfma_issue_frac); f32-equivalent peak would be %.1f"
-                            % PEAK_F32_MFMA_TFLOPS,
+                            % ("5 eager steps right after the timed region, whose steps are hipGraph replays" if use_graph
+                               else "timed region", PEAK_F32_MFMA_TFLOPS),
                     "launches_timed": dom[0], "avg_launch_ms": round(dom[1], 4),
                     "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
-                    "conv_share_of_step": round(sum(v[2] for v in summ.values()) / (dt * 1e3), 3)}
+                    "conv_share_of_step": round(sum(v[2] for v in summ.values()) / (5 if use_graph else args.steps)
+                                                    / (dt * 1e3 / args.steps), 3)}
     clips = sum(BATCH) * world * args.steps
     out = {
         "metric": "10s-clips/sec CRNN mean-teacher train @batch48",
@@ -280,7 +299,9 @@ def main():
         "dtype": "f32 (3x3 convs as split-bf16 MFMA with fp32-level accuracy; everything else exact f32)", "data": "synthetic",
         "config": {"workload": "dcase2023 CRNN mean-teacher train step, 128-mel 10s@16kHz, batch 48/GPU (12 strong/12 weak/24 "
                                "unlabelled), dropout+SpecAugment+mixup on, fp32 accuracy (conv_precision=%s)" % task.sed_student.cnn.conv_precision,
-                   "global_batch": sum(BATCH) * world, "parallelism": "dp%d" % world, "last_loss_strong": round(loss_val, 5)},
+                   "global_batch": sum(BATCH) * world, "parallelism": "dp%d" % world, "last_loss_strong": round(loss_val, 5),
+                   "launch": "hipGraph replay of the captured step (3 eager + 1 capture step before the timed region)" if use_graph
+                             else "eager launches", "untimed_steps": n_untimed},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:

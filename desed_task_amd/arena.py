@@ -12,6 +12,7 @@ import math
 import torch
 
 from . import _lib
+from . import graph as _graph
 
 
 class ParamArena:
@@ -79,10 +80,11 @@ def ema_update_(teacher_params, student_params, alpha, teacher_arena=None, stude
     """theta_t <- alpha*theta_t + (1-alpha)*theta_s.  One launch when both models sit in matching arenas."""
     lib = _lib.get()
     a, oma = float(alpha), float(1.0 - alpha)
+    a_dev = getattr(alpha, "dev", None)              # graph.DynFloat: the kernel reads alpha from device memory
     if (teacher_arena is not None and student_arena is not None and teacher_arena.numel == student_arena.numel
             and teacher_arena.offsets == student_arena.offsets and teacher_arena.is_intact() and student_arena.is_intact()):
         t, s = teacher_arena.flat, student_arena.flat
-        lib.call("sed_ema_update", t.data_ptr(), s.data_ptr(), t.numel(), a, oma, _lib.stream_ptr(t))
+        lib.call("sed_ema_update", t.data_ptr(), s.data_ptr(), t.numel(), a, oma, a_dev, _lib.stream_ptr(t))
         return 1
     n = 0
     for pt, ps in zip(teacher_params, student_params):
@@ -91,9 +93,9 @@ def ema_update_(teacher_params, student_params, alpha, teacher_arena=None, stude
             raise RuntimeError("ema_update_: parameters must be contiguous")
         _lib.check_tensor(td, "teacher parameter")
         if td.data_ptr() % 16 == 0 and sd.data_ptr() % 16 == 0:
-            lib.call("sed_ema_update", td.data_ptr(), sd.data_ptr(), td.numel(), a, oma, _lib.stream_ptr(td))
+            lib.call("sed_ema_update", td.data_ptr(), sd.data_ptr(), td.numel(), a, oma, a_dev, _lib.stream_ptr(td))
         else:   # unaligned tail-only form
-            lib.call("sed_ema_update", td.data_ptr(), sd.data_ptr(), min(td.numel(), 3), a, oma, _lib.stream_ptr(td))
+            lib.call("sed_ema_update", td.data_ptr(), sd.data_ptr(), min(td.numel(), 3), a, oma, a_dev, _lib.stream_ptr(td))
             if td.numel() > 3:
                 raise RuntimeError("ema_update_: unaligned parameter storage")
         n += 1
@@ -111,13 +113,13 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale = grad_scale
         self._flat_state = None
 
-    def _launch(self, p, g, m, v, n, group, step):
+    def _launch(self, p, g, m, v, n, group, step, hyper_dev=None):
         b1, b2 = group["betas"]
         bc1 = 1.0 - b1 ** step
         bc2 = 1.0 - b2 ** step
         _lib.get().call("sed_adam_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, float(b1), float(b2),
                         float(group["eps"]), float(group["lr"] / bc1), float(1.0 / math.sqrt(bc2)), float(self.grad_scale),
-                        _lib.stream_ptr(p))
+                        hyper_dev, _lib.stream_ptr(p))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -132,6 +134,21 @@ class FusedAdam(torch.optim.Optimizer):
             if self._flat_state is None:
                 self._flat_state = dict(step=0, m=torch.zeros_like(arena.flat), v=torch.zeros_like(arena.flat))
             st = self._flat_state
+            dyn = _graph.active()
+            if dyn is not None:
+                # hipGraph replay: step counter and the two step-dependent factors are host logic re-run every step
+                group = self.param_groups[0]
+                b1, b2 = group["betas"]
+
+                def advance():
+                    st["step"] += 1
+                    dyn.hf[dyn.F_ADAM_STEP] = group["lr"] / (1.0 - b1 ** st["step"])
+                    dyn.hf[dyn.F_ADAM_IBC2] = 1.0 / math.sqrt(1.0 - b2 ** st["step"])
+
+                dyn.host(advance)
+                self._launch(arena.flat, arena.flat_grad, st["m"], st["v"], arena.numel, group, st["step"],
+                             hyper_dev=dyn.ptr(dyn.F_ADAM_STEP))
+                return loss
             st["step"] += 1
             self._launch(arena.flat, arena.flat_grad, st["m"], st["v"], arena.numel, self.param_groups[0], st["step"])
             return loss

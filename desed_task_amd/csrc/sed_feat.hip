@@ -97,7 +97,12 @@ extern "C" int sed_take_log(const float* x, float* y, long long n, void* stream)
 // ---- mixup ------------------------------------------------------------------------------------
 // data[i] = c*src[i] + omc*src[perm[i]]   (src = snapshot of the group; mode 1/2 = soft/hard label clamp)
 __global__ __launch_bounds__(256) void mixup_kernel(float* __restrict__ data, const float* __restrict__ src,
-                                                    const int* __restrict__ perm, float c, float omc, int L, int mode) {
+                                                    const int* __restrict__ perm, float c, float omc, int L, int mode,
+                                                    const float* __restrict__ c_dev) {
+    if (c_dev) {                                // coefficient in device memory (hipGraph replays); 1 = "no mixup this step"
+        c = c_dev[0]; omc = c_dev[1];           // {c, 1-c} exactly as the host would have passed them by value
+        if (c == 1.0f) return;
+    }
     const int i = blockIdx.y;
     const int j = perm[i];
     const float* a = src + (size_t)i * L;
@@ -112,12 +117,13 @@ __global__ __launch_bounds__(256) void mixup_kernel(float* __restrict__ data, co
     }
 }
 // data: (n, L) in place; tmp: (n, L) scratch; perm: n int32 on device.  mode 0 = features, 1 = soft labels, 2 = hard labels.
-extern "C" int sed_mixup(float* data, float* tmp, const int* perm, float c, float one_minus_c, int n, int L, int mode, void* stream) {
+extern "C" int sed_mixup(float* data, float* tmp, const int* perm, float c, float one_minus_c, int n, int L, int mode,
+                         const float* c_dev, void* stream) {
     if (n <= 0 || L <= 0) return SED_OK;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemcpyAsync(tmp, data, (size_t)n * L * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return SED_ERR_LAUNCH;
     int gx = min(64, (L + 255) / 256);
-    SED_LAUNCH(mixup_kernel, dim3(gx, n), dim3(256), 0, s, data, (const float*)tmp, perm, c, one_minus_c, L, mode);
+    SED_LAUNCH(mixup_kernel, dim3(gx, n), dim3(256), 0, s, data, (const float*)tmp, perm, c, one_minus_c, L, mode, c_dev);
     return sed_check_launch();
 }
 

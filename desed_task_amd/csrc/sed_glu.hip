@@ -41,7 +41,8 @@ template <int C, int PT, int PF>
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
                                                       const float* __restrict__ Wg, const float* __restrict__ bg,
                                                       float* __restrict__ out, int B, int T, int F, uint32_t seed,
-                                                      uint32_t thr24, float dscale) {
+                                                      uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     using G = GluGeom<C, PT, PF>;
     constexpr int WIN = G::WIN, CP = G::CP, NT = G::NT, ROWS = 128, NW = ROWS / WIN;
     SED_DYN_SMEM(smem);
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ 
 
 template <int C, int PT, int PF>
 static int launch_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
-                          uint32_t seed, uint32_t thr24, float dscale, hipStream_t s) {
+                          uint32_t seed, uint32_t thr24, float dscale, const unsigned* seed_dev, hipStream_t s) {
     using G = GluGeom<C, PT, PF>;
     constexpr int SMEM = (C * G::CP + 128 * G::CP + 3 * C) * 4;
     const int NWC = (T / PT) * (F / PF);
@@ -147,7 +148,7 @@ static int launch_glu_fwd(const float* y, const float* stats, const float* Wg, c
     int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
     if (grid < 1) return SED_OK;
     SED_MAX_SMEM((glu_fwd_kernel<C, PT, PF>), SMEM);
-    SED_LAUNCH((glu_fwd_kernel<C, PT, PF>), dim3(grid), dim3(256), SMEM, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale);
+    SED_LAUNCH((glu_fwd_kernel<C, PT, PF>), dim3(grid), dim3(256), SMEM, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev);
     return sed_check_launch();
 }
 
@@ -162,7 +163,8 @@ static int launch_glu_fwd(const float* y, const float* stats, const float* Wg, c
 __global__ __launch_bounds__(256) void glu16_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
                                                         const float* __restrict__ Wg, const float* __restrict__ bg,
                                                         float* __restrict__ out, int B, int T, int F, uint32_t seed,
-                                                        uint32_t thr24, float dscale) {
+                                                        uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     constexpr int C = 16;
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     float wa[4], sc[4], sh[4], bgr[4];
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(256) void glu16_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ gout, float* __restrict__ dz,
                                                         float* __restrict__ dWg, float* __restrict__ dbg,
                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int T, int F,
-                                                        uint32_t seed, uint32_t thr24, float dscale) {
+                                                        uint32_t seed, uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     constexpr int C = 16;
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     float wa1[4], wb2[4], idb[4], mu[4], istd[4], gam4[4], bet4[4], bgr[4];
@@ -323,7 +326,8 @@ template <int C>
 __global__ __launch_bounds__(512, 4) void glu_wide_fwd_kernel(const float* __restrict__ y, const float* __restrict__ stats,
                                                            const float* __restrict__ Wg, const float* __restrict__ bg,
                                                            float* __restrict__ out, int B, int T, int F, uint32_t seed,
-                                                           uint32_t thr24, float dscale) {
+                                                           uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     // With (1,2) pooling the pooled pair (f, f+1) is two consecutive pixels, so a tile is simply ROWS consecutive
     // rows of the flattened (B*T*F, C) activation: row r <-> pixel r, window r/2, dropout counter r*C + n.
     constexpr int CP = C + 1, NT = C / 32;
@@ -426,7 +430,7 @@ static inline int glu_grid_cap(int dflt) {
 }
 template <int C>
 static int launch_glu_wide_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
-                               uint32_t seed, uint32_t thr24, float dscale, hipStream_t s) {
+                               uint32_t seed, uint32_t thr24, float dscale, const unsigned* seed_dev, hipStream_t s) {
     constexpr int ROWS = 32 * (8 / (C / 32));
     constexpr int SMEM = ROWS * (C + 1) * 4;
     const int ntiles = (B * T * F + ROWS - 1) / ROWS;
@@ -434,14 +438,15 @@ static int launch_glu_wide_fwd(const float* y, const float* stats, const float* 
     int grid = ntiles < cap ? ntiles : cap;
     if (grid < 1) return SED_OK;
     SED_MAX_SMEM((glu_wide_fwd_kernel<C>), SMEM);
-    SED_LAUNCH((glu_wide_fwd_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale);
+    SED_LAUNCH((glu_wide_fwd_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev);
     return sed_check_launch();
 }
 
 // y (B,T,F,C); stats 4*C (mean, invstd, scale, shift); Wg (C,C) [out][in]; out (B,T/PT,F/PF,C).
 // dropout: keep element e when hash(e, seed) >> 8 >= thr24 (thr24 = round(p * 2^24)); dscale = 1/(1-p).
 extern "C" int sed_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
-                           int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, void* stream) {
+                           int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale,
+                           const unsigned* seed_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (F % PF != 0) return SED_ERR_UNSUPPORTED;
     if (C == 16 && PT == 2 && PF == 2 && F % 8 == 0) {
@@ -449,15 +454,15 @@ extern "C" int sed_glu_fwd(const float* y, const float* stats, const float* Wg, 
         if (ntiles <= 0) return SED_OK;
         int grid = (ntiles + 3) / 4;
         if (grid > 2048) grid = 2048;
-        SED_LAUNCH(glu16_fwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale);
+        SED_LAUNCH(glu16_fwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev);
         return sed_check_launch();
     }
     if (PT == 1 && PF == 2) {
-        if (C == 128) return launch_glu_wide_fwd<128>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, s);
-        if (C == 64) return launch_glu_wide_fwd<64>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, s);
+        if (C == 128) return launch_glu_wide_fwd<128>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev, s);
+        if (C == 64) return launch_glu_wide_fwd<64>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev, s);
     }
 #define GLU_CASE(c, pt, pf) \
-    if (C == c && PT == pt && PF == pf) return launch_glu_fwd<c, pt, pf>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, s);
+    if (C == c && PT == pt && PF == pf) return launch_glu_fwd<c, pt, pf>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev, s);
     GLU_CASE(16, 2, 2) GLU_CASE(32, 2, 2)
 #undef GLU_CASE
     return SED_ERR_UNSUPPORTED;
@@ -473,7 +478,8 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gout, float* __restrict__ dz,
                                                       float* __restrict__ dWg, float* __restrict__ dbg,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int T, int F,
-                                                      uint32_t seed, uint32_t thr24, float dscale) {
+                                                      uint32_t seed, uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     using G = GluGeom<C, PT, PF>;
     constexpr int WIN = G::WIN, CP = G::CP, NT = G::NT;
     constexpr int ROWS = C >= 64 ? 64 : 128, WM = ROWS / 32, WN = 4 / WM, NTW = NT / WN, NW = ROWS / WIN;
@@ -669,7 +675,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
 template <int C, int PT, int PF>
 static int launch_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
                           const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
-                          int B, int T, int F, uint32_t seed, uint32_t thr24, float dscale, hipStream_t s) {
+                          int B, int T, int F, uint32_t seed, uint32_t thr24, float dscale, const unsigned* seed_dev, hipStream_t s) {
     using G = GluGeom<C, PT, PF>;
     constexpr int ROWS = C >= 64 ? 64 : 128;
     constexpr int SMEM = (C * G::CP + 2 * ROWS * G::CP + 5 * C) * 4;
@@ -681,7 +687,7 @@ static int launch_glu_bwd(const float* y, const float* stats, const float* gamma
     if (grid < 1) return SED_OK;
     SED_MAX_SMEM((glu_bwd_kernel<C, PT, PF>), SMEM);
     SED_LAUNCH((glu_bwd_kernel<C, PT, PF>), dim3(grid), dim3(256), SMEM, s, y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg,
-               dgamma, dbeta, B, T, F, seed, thr24, dscale);
+               dgamma, dbeta, B, T, F, seed, thr24, dscale, seed_dev);
     return sed_check_launch();
 }
 
@@ -698,7 +704,8 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_kernel(const float* __restri
                                                            const float* __restrict__ Wg, const float* __restrict__ bg,
                                                            const float* __restrict__ gout, float* __restrict__ dz,
                                                            float* __restrict__ part, int B, int T,
-                                                           int F, uint32_t seed, uint32_t thr24, float dscale) {
+                                                           int F, uint32_t seed, uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     constexpr int CP = C + 1, NT = C / 32, WN = NT, WM = 8 / WN, ROWS = 32 * WM;   // flat row tiles, see glu_wide_fwd_kernel
     constexpr int NLD = ROWS * (C / 4) / 512, RSTEP = 512 / (C / 4);
     constexpr int NT3 = NT * NT, TPW = NT3 >= 8 ? NT3 / 8 : 1, KSPLIT = NT3 >= 8 ? 1 : 8 / NT3, KROWS = ROWS / KSPLIT;
@@ -898,7 +905,7 @@ __global__ __launch_bounds__(256) void glu_bwd_reduce_kernel(const float* __rest
 template <int C>
 static int launch_glu_wide_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
                                const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
-                               float* scratch, int B, int T, int F, uint32_t seed, uint32_t thr24, float dscale, hipStream_t s) {
+                               float* scratch, int B, int T, int F, uint32_t seed, uint32_t thr24, float dscale, const unsigned* seed_dev, hipStream_t s) {
     constexpr int ROWS = 32 * (8 / (C / 32)), WMS = 8 / (C / 32), KS = (C / 32) * (C / 32) >= 8 ? 1 : 8 / ((C / 32) * (C / 32));
     if (!scratch) return SED_ERR_ARG;
     constexpr int SMEM = (2 * ROWS + (C > 64 ? C : 0)) * (C + 1) * 4;
@@ -908,7 +915,7 @@ static int launch_glu_wide_bwd(const float* y, const float* stats, const float* 
     if (grid < 1) { sed_zero4(s, dWg, C * C, dbg, C, dgamma, C, dbeta, C); return SED_OK; }
     SED_MAX_SMEM((glu_wide_bwd_kernel<C>), SMEM);
     SED_LAUNCH((glu_wide_bwd_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, gamma, beta, Wg, bg, gout, dz, scratch, B, T, F,
-               seed, thr24, dscale);
+               seed, thr24, dscale, seed_dev);
     SED_LAUNCH(glu_bwd_reduce_kernel, dim3((C * C + 3 * C + 63) / 64), dim3(256), 0, s, scratch, dWg, dbg, dgamma, dbeta, grid, C, KS, WMS);
     return sed_check_launch();
 }
@@ -930,12 +937,12 @@ extern "C" long long sed_glu_bwd_scratch_floats(int B, int T, int F, int C, int 
 extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
                            const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
                            float* scratch, int B, int T, int F, int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale,
-                           void* stream) {
+                           const unsigned* seed_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (F % PF != 0) return SED_ERR_UNSUPPORTED;
     if (PT == 1 && PF == 2) {
-        if (C == 128) return launch_glu_wide_bwd<128>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, s);
-        if (C == 64) return launch_glu_wide_bwd<64>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, s);
+        if (C == 128) return launch_glu_wide_bwd<128>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
+        if (C == 64) return launch_glu_wide_bwd<64>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
     }
     sed_zero4(s, dWg, C * C, dbg, C, dgamma, C, dbeta, C);
     if (T % PT != 0) (void)hipMemsetAsync(dz, 0, (size_t)B * T * F * C * 4, s);
@@ -945,13 +952,13 @@ extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamm
         int grid = (ntiles + 3) / 4;
         if (grid > 1024) grid = 1024;
         SED_LAUNCH(glu16_bwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B,
-                   T, F, seed, thr24, dscale);
+                   T, F, seed, thr24, dscale, seed_dev);
         return sed_check_launch();
     }
 #define GLU_CASE(c, pt, pf)                                                                                              \
     if (C == c && PT == pt && PF == pf)                                                                                  \
         return launch_glu_bwd<c, pt, pf>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B, T, F, seed, thr24, \
-                                         dscale, s);
+                                         dscale, seed_dev, s);
     GLU_CASE(16, 2, 2) GLU_CASE(32, 2, 2)
 #undef GLU_CASE
     return SED_ERR_UNSUPPORTED;

@@ -20,7 +20,8 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
                                                                 const float* __restrict__ b2, float* __restrict__ strong,
                                                                 float* __restrict__ psoft, float* __restrict__ weak,
                                                                 float* __restrict__ den, int T, uint32_t seed, uint32_t thr24,
-                                                                float dscale) {
+                                                                float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     constexpr int D = HEAD_D, FPP = HEAD_THREADS / 4;          // frames per pass
     __shared__ __attribute__((aligned(16))) float w1[NC * D];
     __shared__ __attribute__((aligned(16))) float w2[NC * D];
@@ -113,7 +114,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ den, const float* __restrict__ d_strong,
                                                        const float* __restrict__ d_weak, float* __restrict__ dx,
                                                        float* __restrict__ dW1, float* __restrict__ dW2, float* __restrict__ db1,
-                                                       float* __restrict__ db2, int T, uint32_t seed, uint32_t thr24, float dscale) {
+                                                       float* __restrict__ db2, int T, uint32_t seed, uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     constexpr int D = HEAD_D, TS = HEAD_TS;
     SED_DYN_SMEM(smem);
     float* w1 = (float*)smem;            // NC*D
@@ -199,12 +201,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 
 extern "C" int sed_head_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, float* strong,
                             float* psoft, float* weak, float* den, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
-                            float dscale, void* stream) {
+                            float dscale, const unsigned* seed_dev, void* stream) {
     if (D != HEAD_D) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
     hipStream_t s = (hipStream_t)stream;
 #define HEAD_CASE(nc) \
-    if (NC == nc) { SED_LAUNCH((head_fwd_kernel<nc>), dim3(B), dim3(HEAD_THREADS), 0, s, x, W1, b1, W2, b2, strong, psoft, weak, den, T, seed, thr24, dscale); return sed_check_launch(); }
+    if (NC == nc) { SED_LAUNCH((head_fwd_kernel<nc>), dim3(B), dim3(HEAD_THREADS), 0, s, x, W1, b1, W2, b2, strong, psoft, weak, den, T, seed, thr24, dscale, seed_dev); return sed_check_launch(); }
     HEAD_CASE(10) HEAD_CASE(27)
 #undef HEAD_CASE
     return SED_ERR_UNSUPPORTED;
@@ -213,14 +215,14 @@ extern "C" int sed_head_fwd(const float* x, const float* W1, const float* b1, co
 extern "C" int sed_head_bwd(const float* x, const float* W1, const float* W2, const float* strong, const float* psoft,
                             const float* weak, const float* den, const float* d_strong, const float* d_weak, float* dx, float* dW1,
                             float* dW2, float* db1, float* db2, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
-                            float dscale, void* stream) {
+                            float dscale, const unsigned* seed_dev, void* stream) {
     if (D != HEAD_D) return SED_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     sed_zero4(s, dW1, NC * D, dW2, NC * D, db1, NC, db2, NC);
     if (B <= 0 || T <= 0) return SED_OK;
     const int smem = (2 * NC * D + HEAD_TS * 2 * NC) * 4;
 #define HEAD_CASE(nc) \
-    if (NC == nc) { SED_MAX_SMEM((head_bwd_kernel<nc>), smem); SED_LAUNCH((head_bwd_kernel<nc>), dim3((T + HEAD_TS - 1) / HEAD_TS, B), dim3(256), smem, s, x, W1, W2, strong, psoft, weak, den, d_strong, d_weak, dx, dW1, dW2, db1, db2, T, seed, thr24, dscale); return sed_check_launch(); }
+    if (NC == nc) { SED_MAX_SMEM((head_bwd_kernel<nc>), smem); SED_LAUNCH((head_bwd_kernel<nc>), dim3((T + HEAD_TS - 1) / HEAD_TS, B), dim3(256), smem, s, x, W1, W2, strong, psoft, weak, den, d_strong, d_weak, dx, dW1, dW2, db1, db2, T, seed, thr24, dscale, seed_dev); return sed_check_launch(); }
     HEAD_CASE(10) HEAD_CASE(27)
 #undef HEAD_CASE
     return SED_ERR_UNSUPPORTED;
@@ -241,7 +243,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
                                                    const float* __restrict__ labels, const float* __restrict__ labels_weak,
                                                    float* __restrict__ scalars, float* __restrict__ g_strong,
                                                    float* __restrict__ g_weak, int B, int T, int NC, int n_strong, int n_weak,
-                                                   float weight) {
+                                                   float weight, const float* __restrict__ weight_dev) {
+    if (weight_dev) weight = *weight_dev;       // consistency weight in device memory (hipGraph replays)
     // one workgroup per clip; the six scalars (zeroed by the launcher) collect pre-scaled per-clip sums
     __shared__ float red[4][6];
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -292,10 +295,10 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
 }
 extern "C" int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
                            const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
-                           int T, int NC, int n_strong, int n_weak, float weight, void* stream) {
+                           int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, void* stream) {
     if (B <= 0 || T <= 0 || NC <= 0 || NC > 256 || n_strong + n_weak > B) return SED_ERR_ARG;
     sed_zero4((hipStream_t)stream, scalars, 6, nullptr, 0, nullptr, 0, nullptr, 0);
     SED_LAUNCH(loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, strong_s, weak_s, strong_t, weak_t, labels, labels_weak,
-               scalars, g_strong, g_weak, B, T, NC, n_strong, n_weak, weight);
+               scalars, g_strong, g_weak, B, T, NC, n_strong, n_weak, weight, weight_dev);
     return sed_check_launch();
 }

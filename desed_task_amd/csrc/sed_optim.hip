@@ -5,7 +5,9 @@
 #include "sed_common.h"
 
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ teacher, const float* __restrict__ student, size_t n4,
-                                                  size_t n, float alpha, float one_minus_alpha) {
+                                                  size_t n, float alpha, float one_minus_alpha,
+                                                  const float* __restrict__ alpha_dev) {
+    if (alpha_dev) { alpha = alpha_dev[0]; one_minus_alpha = alpha_dev[1]; }   // device-resident (hipGraph replays)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) {
         float4 t = ((float4*)teacher)[i];
@@ -17,17 +19,21 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ teacher, c
     if (i == 0) for (size_t j = n4 * 4; j < n; ++j) teacher[j] = teacher[j] * alpha + one_minus_alpha * student[j];
 }
 // teacher <- alpha * teacher + (1 - alpha) * student over n floats (16-byte aligned buffers)
-extern "C" int sed_ema_update(float* teacher, const float* student, long long n, float alpha, float one_minus_alpha, void* stream) {
+extern "C" int sed_ema_update(float* teacher, const float* student, long long n, float alpha, float one_minus_alpha,
+                              const float* alpha_dev, void* stream) {
     if (n <= 0) return SED_OK;
     const size_t n4 = (size_t)n / 4;
     const int grid = (int)((n4 + 255) / 256) + (n4 == 0 ? 1 : 0);
-    SED_LAUNCH(ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, teacher, student, n4, (size_t)n, alpha, one_minus_alpha);
+    SED_LAUNCH(ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, teacher, student, n4, (size_t)n, alpha, one_minus_alpha,
+               alpha_dev);
     return sed_check_launch();
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t n, float b1, float b2, float eps,
-                                                   float step_size, float inv_bc2_sqrt, float grad_scale) {
+                                                   float step_size, float inv_bc2_sqrt, float grad_scale,
+                                                   const float* __restrict__ hyper_dev) {
+    if (hyper_dev) { step_size = hyper_dev[0]; inv_bc2_sqrt = hyper_dev[1]; }   // device-resident (hipGraph replays)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float gi = g[i] * grad_scale;
         const float mi = m[i] * b1 + (1.0f - b1) * gi;
@@ -41,12 +47,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // torch.optim.Adam (no weight decay, no amsgrad): step_size = lr / (1 - b1^t), inv_bc2_sqrt = 1 / sqrt(1 - b2^t).
 // grad_scale folds the data-parallel 1/world_size averaging into the update.
 extern "C" int sed_adam_step(float* p, const float* g, float* m, float* v, long long n, float b1, float b2, float eps,
-                             float step_size, float inv_bc2_sqrt, float grad_scale, void* stream) {
+                             float step_size, float inv_bc2_sqrt, float grad_scale, const float* hyper_dev, void* stream) {
     if (n <= 0) return SED_OK;
     int grid = (int)(((size_t)n + 255) / 256);
     if (grid > 2048) grid = 2048;
     SED_LAUNCH(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, b1, b2, eps, step_size,
-               inv_bc2_sqrt, grad_scale);
+               inv_bc2_sqrt, grad_scale, hyper_dev);
     return sed_check_launch();
 }
 

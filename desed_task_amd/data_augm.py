@@ -21,8 +21,24 @@ def mixup(data, target=None, alpha=0.2, beta=0.2, mixup_label_type="soft"):
         return mixed, mixed_t
 
 
-def mixup_inplace_(data, target, alpha=0.2, beta=0.2, mixup_label_type="soft"):
-    """Same draws, but mixes `data` and `target` (batch-major slices) in place: no gather/scatter copies."""
+def mixup_inplace_(data, target, alpha=0.2, beta=0.2, mixup_label_type="soft", dyn=None, gate=None):
+    """Same draws, but mixes `data` and `target` (batch-major slices) in place: no gather/scatter copies.
+
+    dyn (graph.DynArgs): the launches are issued unconditionally and read c / perm from device memory; `gate()` tells,
+    each step, whether mixup applies (if not: c = 1, which turns the kernels into no-ops)."""
+    if dyn is not None:
+        n = data.size(0)
+
+        def draw():
+            if gate is not None and not gate():
+                return None
+            return np.random.beta(alpha, beta), torch.randperm(n)
+
+        c_dev, perm_dev = dyn.mix_site(n, draw)
+        mode = 1 if mixup_label_type == "soft" else 2
+        features.mixup_(data, None, 1.0, mode=0, c_dev=c_dev, perm_dev=perm_dev)
+        features.mixup_(target, None, 1.0, mode=mode, c_dev=c_dev, perm_dev=perm_dev)
+        return None, None
     c = np.random.beta(alpha, beta)
     perm = torch.randperm(data.size(0))
     features.mixup_(data, perm, c, mode=0)

@@ -138,9 +138,10 @@ def minmax_scale(x, eps=1e-8, apply_log=False, return_minmax=False):
     return (res, mm) if return_minmax else res
 
 
-def mixup_(data, perm, c, mode=0):
+def mixup_(data, perm, c, mode=0, c_dev=None, perm_dev=None):
     """In-place mixup of a group: data[i] <- c*data[i] + (1-c)*data[perm[i]] (perm: int tensor on any device).
-    `data` must be a batch-major slice whose clips are contiguous blocks."""
+    `data` must be a batch-major slice whose clips are contiguous blocks.
+    c_dev / perm_dev: device addresses of the coefficient and the int32 permutation (graph.DynArgs) instead of c / perm."""
     n = data.shape[0]
     if n == 0:
         return data
@@ -153,9 +154,11 @@ def mixup_(data, perm, c, mode=0):
     _lib.check_tensor(base, "mixup data")
     L = base.numel() // n
     tmp = torch.empty_like(base)
-    perm_d = perm.to(device=base.device, dtype=torch.int32, non_blocking=True)
-    _lib.get().call("sed_mixup", base.data_ptr(), tmp.data_ptr(), perm_d.data_ptr(), float(np.float32(c)),
-                    float(np.float32(1.0 - c)), n, L, int(mode), _lib.stream_ptr(base))
+    if perm_dev is None:
+        perm_d = perm.to(device=base.device, dtype=torch.int32, non_blocking=True)
+        perm_dev = perm_d.data_ptr()
+    _lib.get().call("sed_mixup", base.data_ptr(), tmp.data_ptr(), perm_dev, float(np.float32(c)),
+                    float(np.float32(1.0 - c)), n, L, int(mode), c_dev, _lib.stream_ptr(base))
     return data
 
 

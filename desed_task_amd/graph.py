@@ -1,0 +1,274 @@
+"""Whole-step HIP graphs: capture one mean-teacher training step once, replay it every step.
+
+A step is ~330 kernel launches issued from one Python thread; on a busy host the enqueue time (3.5-8 ms) rivals the
+GPU time (~6 ms).  Capturing the step (both forwards, the losses, the EMA, backward, Adam) into ONE hipGraph makes the
+step time independent of the host.  What a capture freezes is every by-value launch argument, so everything that
+changes from step to step lives in a small DEVICE buffer (`DynArgs`) that the kernels read through the nullable
+`*_dev` pointers of include/sed_hip.h:
+
+    dropout seeds (one per dropout call site), mixup coefficients + permutations, consistency-loss weight,
+    EMA factor, Adam step size / bias correction.
+
+The host half of a step -- RNG draws in the reference's order, the lr/rampup schedule, step counters -- is recorded
+during the capture pass as a list of closures (`DynArgs.host`) and re-run before every replay; it fills a pinned host
+mirror that is uploaded with one async copy.  The capture pass itself IS a real step: its host half runs inline,
+the device half runs at the first replay.  `GraphedStepDriver` keeps Lightning's step order (launcher.StepDriver).
+
+On a CPU "device" (the fiber emulator used by the tests) DynArgs aliases the host buffer as the device buffer and no
+graph is involved: the same kernels, reading their step-varying arguments from memory, can be checked against the
+plain eager path.
+"""
+import torch
+
+_active = None
+
+
+def active():
+    """The DynArgs the current step runs under (None = plain eager launches with by-value arguments)."""
+    return _active
+
+
+class DynSeed(int):
+    """A dropout seed that lives in device memory: int value 0 (the by-value part), `.dev` = address of the seed word."""
+    dev = None
+
+
+class DynFloat(float):
+    """A scalar that lives in device memory: float value = the capture-time value, `.dev` = address, `.tensor` = 0-d view."""
+    dev = None
+    tensor = None
+
+
+def seed_dev(seed):
+    return getattr(seed, "dev", None)
+
+
+class DynArgs:
+    F_LOSS_W, F_EMA_ALPHA, F_EMA_OMA, F_ADAM_STEP, F_ADAM_IBC2, F_MIX_C0 = 0, 1, 2, 3, 4, 5   # float slots; {c, 1-c} per group
+    SEED0, N_SEEDS = 16, 32
+    PERM0, PERM_LEN, N_PERMS = 48, 64, 4
+
+    def __init__(self, device):
+        n = self.PERM0 + self.PERM_LEN * self.N_PERMS
+        device = torch.device(device)
+        self.device = device
+        if device.type == "cuda":
+            self.hbuf = torch.zeros(n, dtype=torch.int32).pin_memory()
+            self.dev = torch.zeros(n, dtype=torch.int32, device=device)
+        else:
+            self.hbuf = torch.zeros(n, dtype=torch.int32)
+            self.dev = self.hbuf
+        self.hf = self.hbuf.view(torch.float32)
+        self.df = self.dev.view(torch.float32)
+        self.ops = []               # host half of the step, in program order
+        self.recording = False
+        self.state = {}
+        self._sites = {"seed": 0, "mix": 0}
+
+    # ---- addresses ---------------------------------------------------------------------------------
+    def ptr(self, slot):
+        return self.dev.data_ptr() + 4 * slot
+
+    def begin_step(self):
+        self._sites = {"seed": 0, "mix": 0}
+
+    # ---- host half -----------------------------------------------------------------------------------
+    def host(self, fn):
+        """Run a piece of the step's host logic now; while recording, keep it for the replays."""
+        fn()
+        if self.recording:
+            self.ops.append(fn)
+
+    def run_host_ops(self):
+        for fn in self.ops:
+            fn()
+
+    def upload(self):
+        if self.dev is not self.hbuf:
+            self.dev.copy_(self.hbuf, non_blocking=True)
+
+    # ---- call sites ------------------------------------------------------------------------------------
+    def new_seed(self, draw):
+        """One dropout call site: the seed word is drawn on the host by `draw()` every step, read by the kernel from HBM."""
+        i = self._sites["seed"]
+        if i >= self.N_SEEDS:
+            raise RuntimeError("DynArgs: more dropout call sites than seed slots")
+        self._sites["seed"] = i + 1
+        slot = self.SEED0 + i
+        host = self.hbuf
+
+        def fill():
+            host[slot] = int(draw())                    # 31-bit draw; the kernels add the word to the by-value seed 0
+
+        self.host(fill)
+        s = DynSeed(0)
+        s.dev = self.ptr(slot)
+        s.slot = slot
+        return s
+
+    def seed_value(self, seed):
+        """The effective 32-bit seed of a DynSeed for the CURRENT host buffer contents (tests)."""
+        return int(self.hbuf[seed.slot])
+
+    def scalar(self, slot, compute, complement=False):
+        """A float argument recomputed by `compute()` on the host every step (complement: slot + 1 <- 1 - value, in the
+        same double -> float32 rounding the by-value path uses)."""
+        hf = self.hf
+
+        def fill():
+            v = float(compute())
+            hf[slot] = v
+            if complement:
+                hf[slot + 1] = 1.0 - v
+
+        self.host(fill)
+        v = DynFloat(float(hf[slot]))
+        v.dev = self.ptr(slot)
+        v.tensor = self.df[slot]
+        return v
+
+    def mix_site(self, n, draw):
+        """One mixup group of n clips: `draw()` -> (c, perm) or None (= no mixup this step: c = 1, identity)."""
+        g = self._sites["mix"]
+        if g >= self.N_PERMS or n > self.PERM_LEN:
+            raise RuntimeError("DynArgs: mixup group does not fit the permutation slots")
+        self._sites["mix"] = g + 1
+        cslot, pslot = self.F_MIX_C0 + 2 * g, self.PERM0 + g * self.PERM_LEN
+        hf, host = self.hf, self.hbuf
+        ident = torch.arange(n, dtype=torch.int32)
+
+        def fill():
+            r = draw()
+            if r is None:
+                hf[cslot] = 1.0
+                hf[cslot + 1] = 0.0
+                host[pslot:pslot + n] = ident
+            else:
+                hf[cslot] = float(r[0])
+                hf[cslot + 1] = 1.0 - float(r[0])
+                host[pslot:pslot + n] = r[1].to(torch.int32)
+
+        self.host(fill)
+        return self.ptr(cslot), self.ptr(pslot)
+
+
+class dyn_step:
+    """Context manager: run one step's Python under `dyn` (kernels take their step-varying arguments from HBM)."""
+
+    def __init__(self, dyn, record=False):
+        self.dyn, self.record = dyn, record
+
+    def __enter__(self):
+        global _active
+        self.prev = _active
+        _active = self.dyn
+        self.dyn.begin_step()
+        if self.record:
+            self.dyn.ops = []
+        self.dyn.recording = self.record
+        return self.dyn
+
+    def __exit__(self, *exc):
+        global _active
+        _active = self.prev
+        self.dyn.recording = False
+        return False
+
+
+class GraphedStepDriver:
+    """launcher.StepDriver with the step captured in a hipGraph (see the module docstring).
+
+    The first `warmup` steps run eagerly (they are ordinary training steps and let the allocator, the lazily built
+    buffers and hipFuncSetAttribute calls settle); the next step is captured; every later step re-runs the recorded
+    host half, uploads DynArgs, copies the batch into the static input buffers and replays.
+
+    Every step -- eager warm-up, capture, replay -- runs on the driver's OWN stream: autograd's AccumulateGrad nodes are
+    bound to the stream of the first backward and live as long as the parameters, and a node bound to the legacy default
+    stream cannot take part in a capture (hipStreamEndCapture faults).  The caller's current stream is joined on entry
+    and exit, so callers need no extra synchronisation.
+
+    world_size > 1: the graph ends after backward; the RCCL all-reduce of the flat gradient arena and the Adam launch
+    stay eager (one collective + one kernel), so no collective is ever captured."""
+
+    def __init__(self, task, world_size=1, warmup=3, ema_side_stream=True):
+        from .launcher import StepDriver
+        self.eager = StepDriver(task, world_size, ema_side_stream=ema_side_stream)
+        self.task = task
+        self.world = world_size
+        self.warmup = warmup
+        self.n = 0
+        self.graph = None
+        self.dyn = None
+        self.static = None
+        self.loss = None
+        self.stream = None
+
+    def _device(self):
+        return next(self.task.sed_student.parameters()).device
+
+    def _step_body(self, batch):
+        """One step in Lightning's order; under world_size > 1 it stops after backward."""
+        d = self.eager
+        task = self.task
+        loss = task.training_step(batch, 0)
+        if d.side is not None:
+            main = torch.cuda.current_stream()
+            d.side.wait_stream(main)
+            with torch.cuda.stream(d.side):
+                task.on_before_zero_grad()
+        else:
+            task.on_before_zero_grad()
+        d.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if d.side is not None:
+            torch.cuda.current_stream().wait_stream(d.side)
+        if self.world <= 1:
+            d.opt.step()
+            task.lr_scheduler_step(d.sched, 0, None)
+        return loss
+
+    def _finish_multi(self):
+        """Eager tail under data parallelism: gradient all-reduce + Adam + scheduler (by-value arguments)."""
+        d = self.eager
+        d.allreduce_grads()
+        d.opt.step()
+        self.task.lr_scheduler_step(d.sched, 0, None)
+
+    def run_step(self, batch, batch_idx=0):
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedStepDriver needs a GPU (use StepDriver, or graph.dyn_step for CPU checks)")
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+        caller = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream):
+            loss = self._run_step(batch, batch_idx, dev)
+        caller.wait_stream(self.stream)
+        return loss
+
+    def _run_step(self, batch, batch_idx, dev):
+        self.n += 1
+        if self.n <= self.warmup:
+            return self.eager.run_step(batch, batch_idx)
+        audio, labels = batch[0], batch[1]
+        if self.graph is None:
+            if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+            self.dyn = DynArgs(dev)
+            self.static = (torch.empty_like(audio), torch.empty_like(labels))
+            self.static[0].copy_(audio); self.static[1].copy_(labels)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with dyn_step(self.dyn, record=True):
+                with torch.cuda.graph(self.graph, stream=self.stream):
+                    self.loss = self._step_body((self.static[0], self.static[1]) + tuple(batch[2:]))
+        else:
+            self.static[0].copy_(audio, non_blocking=True)
+            self.static[1].copy_(labels, non_blocking=True)
+            self.dyn.run_host_ops()
+        self.dyn.upload()
+        self.graph.replay()
+        if self.world > 1:
+            self._finish_multi()
+        return self.loss

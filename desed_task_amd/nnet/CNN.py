@@ -10,6 +10,7 @@ import os
 import torch
 import torch.nn as nn
 
+from .. import graph as _graph
 from ..ops import ConvBlockFn, new_seed, pack_conv_weights
 
 
@@ -95,5 +96,9 @@ class CNN(nn.Module):
             x = ConvBlockFn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, glu.linear.weight, glu.linear.bias,
                                   bn.running_mean, bn.running_var, cfg)
             if bn.training:
-                self._pending_batches[i] += 1
+                dyn = _graph.active()
+                if dyn is not None:                 # hipGraph step: host bookkeeping is re-run before every replay
+                    dyn.host(lambda i=i: self._pending_batches.__setitem__(i, self._pending_batches[i] + 1))
+                else:
+                    self._pending_batches[i] += 1
         return x

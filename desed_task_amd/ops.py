@@ -6,6 +6,7 @@ path runs in libsed_hip.so.  Activations are channels-last (B, T, F, C) fp32.
 import torch
 
 from . import _lib
+from . import graph as _graph
 
 BN_EPS = 1e-3        # desed_task/nnet/CNN.py:76
 BN_MOMENTUM = 0.99
@@ -25,8 +26,14 @@ def dropout_params(p):
 
 
 def new_seed(generator=None):
-    """A fresh 31-bit dropout seed from torch's CPU generator (host side, no device sync)."""
-    return int(torch.randint(0, 2 ** 31 - 1, (1,), generator=generator).item())
+    """A fresh 31-bit dropout seed from torch's CPU generator (host side, no device sync).
+    Under a graph.DynArgs step the draw is repeated every replay and the seed travels through device memory."""
+    def draw():
+        return int(torch.randint(0, 2 ** 31 - 1, (1,), generator=generator).item())
+    dyn = _graph.active()
+    if dyn is not None:
+        return dyn.new_seed(draw)
+    return draw()
 
 
 def _grad_buf(cfg, param):
@@ -86,7 +93,8 @@ class ConvBlockFn(torch.autograd.Function):
         PT, PF = cfg["pool"]
         training = bool(cfg["bn_training"])
         thr24, dscale = dropout_params(cfg.get("dropout_p", 0.0) if cfg.get("apply_dropout", False) else 0.0)
-        seed = int(cfg.get("seed", 0))
+        seed = cfg.get("seed", 0)
+        seed = seed if isinstance(seed, _graph.DynSeed) else int(seed)
         bounds = cfg.get("bounds") if first else None
         st = _lib.stream_ptr(x)
         dev = x.device
@@ -113,7 +121,7 @@ class ConvBlockFn(torch.autograd.Function):
         out = torch.empty(B, T // PT, F // PF, COUT, device=dev, dtype=torch.float32)
         glu_w = glu_w.contiguous()
         lib.call("sed_glu_fwd", y.data_ptr(), stats.data_ptr(), glu_w.data_ptr(), glu_b.data_ptr(), out.data_ptr(), B, T, F, COUT,
-                 PT, PF, seed, thr24, dscale, st)
+                 PT, PF, int(seed), thr24, dscale, _graph.seed_dev(seed), st)
         ctx.save_for_backward(x, y, stats, conv_w, bn_w, bn_b, glu_w, glu_b, conv_b)
         ctx.meta = (first, B, T, F, CIN, COUT, PT, PF, training, seed, thr24, dscale, bounds)
         ctx.cfg = cfg
@@ -138,7 +146,7 @@ class ConvBlockFn(torch.autograd.Function):
         gscratch = torch.empty(nscr, **f32) if nscr else None
         lib.call("sed_glu_bwd", y.data_ptr(), stats.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(), glu_w.data_ptr(), glu_b.data_ptr(),
                  gout.data_ptr(), dz.data_ptr(), d_glu_w.data_ptr(), d_glu_b.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(),
-                 _p(gscratch), B, T, F, COUT, PT, PF, seed, thr24, dscale, st)
+                 _p(gscratch), B, T, F, COUT, PT, PF, int(seed), thr24, dscale, _graph.seed_dev(seed), st)
         d_bias = _grad_buf(cfg, conv_b)
         d_w = _grad_buf(cfg, conv_w)
         dx = None
@@ -257,7 +265,8 @@ class HeadFn(torch.autograd.Function):
         B, T, D = x.shape
         NC = w1.shape[0]
         thr24, dscale = dropout_params(cfg.get("dropout_p", 0.0) if cfg.get("apply_dropout", False) else 0.0)
-        seed = int(cfg.get("seed", 0))
+        seed = cfg.get("seed", 0)
+        seed = seed if isinstance(seed, _graph.DynSeed) else int(seed)
         f32 = dict(device=x.device, dtype=torch.float32)
         strong = torch.empty(B, T, NC, **f32)
         psoft = torch.empty(B, T, NC, **f32)
@@ -265,7 +274,8 @@ class HeadFn(torch.autograd.Function):
         den = torch.empty(B, NC, **f32)
         w1, w2 = w1.contiguous(), w2.contiguous()
         lib.call("sed_head_fwd", x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), strong.data_ptr(),
-                 psoft.data_ptr(), weak.data_ptr(), den.data_ptr(), B, T, D, NC, seed, thr24, dscale, _lib.stream_ptr(x))
+                 psoft.data_ptr(), weak.data_ptr(), den.data_ptr(), B, T, D, NC, int(seed), thr24, dscale, _graph.seed_dev(seed),
+                 _lib.stream_ptr(x))
         ctx.save_for_backward(x, w1, w2, strong, psoft, weak, den, b1, b2)
         ctx.meta = (B, T, D, NC, seed, thr24, dscale)
         ctx.cfg = cfg
@@ -285,7 +295,7 @@ class HeadFn(torch.autograd.Function):
         db1, db2 = _grad_buf(cfg, b1), _grad_buf(cfg, b2)
         lib.call("sed_head_bwd", x.data_ptr(), w1.data_ptr(), w2.data_ptr(), strong.data_ptr(), psoft.data_ptr(), weak.data_ptr(),
                  den.data_ptr(), d_strong.data_ptr(), d_weak.data_ptr(), dx.data_ptr(), dw1.data_ptr(), dw2.data_ptr(),
-                 db1.data_ptr(), db2.data_ptr(), B, T, D, NC, seed, thr24, dscale, _lib.stream_ptr(x))
+                 db1.data_ptr(), db2.data_ptr(), B, T, D, NC, int(seed), thr24, dscale, _graph.seed_dev(seed), _lib.stream_ptr(x))
         return dx, dw1, db1, dw2, db2, None
 
 
@@ -308,8 +318,9 @@ class MeanTeacherLossFn(torch.autograd.Function):
         g_weak = torch.empty(B, NC, **f32)
         lib.call("sed_mt_loss", strong_s.data_ptr(), weak_s.data_ptr(), strong_t.data_ptr(), weak_t.data_ptr(), labels.data_ptr(),
                  labels_weak.data_ptr(), scalars.data_ptr(), g_strong.data_ptr(), g_weak.data_ptr(), B, T, NC, int(n_strong),
-                 int(n_weak), float(weight), _lib.stream_ptr(strong_s))
-        total = scalars[0] + scalars[1] + float(weight) * (scalars[4] + scalars[5])
+                 int(n_weak), float(weight), getattr(weight, "dev", None), _lib.stream_ptr(strong_s))
+        w = weight.tensor if isinstance(weight, _graph.DynFloat) else float(weight)
+        total = scalars[0] + scalars[1] + w * (scalars[4] + scalars[5])
         ctx.save_for_backward(g_strong, g_weak)
         return torch.cat([scalars, total.reshape(1)])
 

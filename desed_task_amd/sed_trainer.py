@@ -16,6 +16,7 @@ from copy import deepcopy
 import torch
 
 from . import features
+from . import graph as _graph
 from .arena import ema_update_
 from .data_augm import mixup_inplace_
 from .ops import MeanTeacherLossFn
@@ -94,7 +95,11 @@ class SEDTask4(_Base):
 
     # ---- optimisation hooks -----------------------------------------------------------------------
     def lr_scheduler_step(self, scheduler, optimizer_idx=None, metric=None):
-        scheduler.step()
+        dyn = _graph.active()
+        if dyn is not None:
+            dyn.host(scheduler.step)            # pure host arithmetic: re-run before every graph replay
+        else:
+            scheduler.step()
 
     def update_ema(self, alpha, global_step, model, ema_model):
         alpha = min(1 - 1 / (global_step + 1), alpha)
@@ -102,8 +107,15 @@ class SEDTask4(_Base):
                     getattr(ema_model, "arena", None), getattr(model, "arena", None))
 
     def on_before_zero_grad(self, *args, **kwargs):
-        self.update_ema(self.hparams["training"]["ema_factor"], self.scheduler["scheduler"].step_num,
-                        self.sed_student, self.sed_teacher)
+        factor = self.hparams["training"]["ema_factor"]
+        sched = self.scheduler["scheduler"]
+        dyn = _graph.active()
+        if dyn is not None:
+            alpha = dyn.scalar(dyn.F_EMA_ALPHA, lambda: min(1 - 1 / (sched.step_num + 1), factor), complement=True)
+            ema_update_(list(self.sed_teacher.parameters()), list(self.sed_student.parameters()), alpha,
+                        getattr(self.sed_teacher, "arena", None), getattr(self.sed_student, "arena", None))
+            return
+        self.update_ema(factor, sched.step_num, self.sed_student, self.sed_teacher)
 
     def configure_optimizers(self):
         return [self.opt], [self.scheduler]
@@ -144,7 +156,17 @@ class SEDTask4(_Base):
         labels_weak = (torch.sum(labels[weak_sl], -1) > 0).float()
 
         mixup_type = self.hparams["training"].get("mixup")
-        if mixup_type is not None and 0.5 > random.random():
+        dyn = _graph.active()
+        if dyn is not None and mixup_type is not None:
+            # hipGraph step: the mixup launches are always part of the graph; the coin flip, c and the permutations are
+            # host draws (same order as below) re-run before every replay and read by the kernels from device memory
+            def flip():
+                dyn.state["mixup"] = 0.5 > random.random()
+            dyn.host(flip)
+            gate = lambda: dyn.state["mixup"]       # noqa: E731
+            mixup_inplace_(features_[weak_sl], labels_weak, mixup_label_type=mixup_type, dyn=dyn, gate=gate)
+            mixup_inplace_(features_[strong_sl], labels[strong_sl], mixup_label_type=mixup_type, dyn=dyn, gate=gate)
+        elif mixup_type is not None and 0.5 > random.random():
             mixup_inplace_(features_[weak_sl], labels_weak, mixup_label_type=mixup_type)
             mixup_inplace_(features_[strong_sl], labels[strong_sl], mixup_label_type=mixup_type)
 
@@ -171,19 +193,27 @@ class SEDTask4(_Base):
             strong_t.record_stream(main)
             weak_t.record_stream(main)
         sched = self.scheduler["scheduler"]
-        weight = self.hparams["training"]["const_max"] * sched._get_scaling_factor()
+        const_max = self.hparams["training"]["const_max"]
+        if dyn is not None:
+            weight = dyn.scalar(dyn.F_LOSS_W, lambda: const_max * sched._get_scaling_factor())
+        else:
+            weight = const_max * sched._get_scaling_factor()
         out = MeanTeacherLossFn.apply(strong_s.transpose(1, 2), weak_s, strong_t.transpose(1, 2), weak_t, labels, labels_weak,
                                       indx_synth, indx_weak, weight)
         loss_strong, loss_weak, loss_strong_t, loss_weak_t, strong_self, weak_self, tot_loss = out.unbind(0)
-        tot_self_loss = (strong_self + weak_self).detach() * weight
+        tot_self_loss = (strong_self + weak_self).detach() * (weight.tensor if dyn is not None else weight)
 
         self.log("train/student/loss_strong", loss_strong.detach())
         self.log("train/student/loss_weak", loss_weak.detach())
         self.log("train/teacher/loss_strong", loss_strong_t.detach())
         self.log("train/teacher/loss_weak", loss_weak_t.detach())
+        if dyn is not None:     # host-side scalars: refreshed before every replay (the device-side ones are static tensors)
+            dyn.host(lambda: (self.log("train/step", sched.step_num, prog_bar=True),
+                              self.log("train/lr", self.opt.param_groups[-1]["lr"] if self.opt is not None else 0.0,
+                                       prog_bar=True)))
         self.log("train/step", sched.step_num, prog_bar=True)
         self.log("train/student/tot_self_loss", tot_self_loss, prog_bar=True)
-        self.log("train/weight", weight)
+        self.log("train/weight", weight.tensor if dyn is not None else weight)
         self.log("train/student/tot_supervised", strong_self.detach(), prog_bar=True)      # sic (reference :351)
         self.log("train/student/weak_self_sup_loss", weak_self.detach())
         self.log("train/student/strong_self_sup_loss", strong_self.detach())

@@ -35,9 +35,20 @@ int sed_logscale_fwd(const float* x, float* logbuf, float* out, float* partial, 
 /* K3 alone: amp_to_db(mels).clamp(-50, 80) with amin = 1e-5 (sed_trainer.py:262-264). */
 int sed_take_log(const float* x, float* y, long long n, void* stream);
 
+/* ---- step-varying arguments in device memory (hipGraph replay) ---------------------------------------------------
+ * A captured training step freezes every by-value launch argument.  The entry points whose arguments change from
+ * step to step therefore take one extra, NULLABLE device pointer that overrides the by-value argument when set:
+ *   seed_dev   (sed_glu_*, sed_head_*) : *seed_dev is added to `seed` (wrapping) -- the dropout entropy of this step;
+ *   c_dev      (sed_mixup)             : {c, 1-c} (c == 1 makes the launch a no-op);
+ *   weight_dev (sed_mt_loss)           : consistency-loss weight;
+ *   alpha_dev  (sed_ema_update)        : {alpha, 1-alpha};
+ *   hyper_dev  (sed_adam_step)         : {step_size, inv_bc2_sqrt}.
+ * Null pointers give the plain eager behaviour.  Host side: desed_task_amd/graph.py. */
+
 /* K2: desed_task/data_augm.py:31-51 mixup on a group of n clips of L floats, in place (tmp = scratch copy).
  * mode 0 = features, 1 = soft labels (clamp 0..1), 2 = hard labels. */
-int sed_mixup(float* data, float* tmp, const int* perm, float c, float one_minus_c, int n, int L, int mode, void* stream);
+int sed_mixup(float* data, float* tmp, const int* perm, float c, float one_minus_c, int n, int L, int mode,
+              const float* c_dev, void* stream);
 
 /* K5: the two axis masks of CRNN.apply_specaugment (desed_task/nnet/CRNN.py:207-219) on (B,T,F);
  * bounds (B,4) int32 = [f0,f1,t0,t1). */
@@ -85,7 +96,7 @@ int sed_bn_finalize(const float* partial, int nblocks, int C, float count, const
 /* BN-apply + GLU (CNN.py:11-16) + Dropout (:90-91) + AvgPool2d (:96-98), fused.  y (B,T,F,C) -> out (B,T/PT,F/PF,C).
  * Dropout keeps element e iff (hash(e,seed)>>8) >= thr24; dscale = 1/(1-p). */
 int sed_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
-                int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, void* stream);
+                int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, const unsigned* seed_dev, void* stream);
 
 /* Floats of scratch sed_glu_bwd needs (per-workgroup partial sums, reduced in a fixed order; 0 = none). */
 long long sed_glu_bwd_scratch_floats(int B, int T, int F, int C, int PT, int PF);
@@ -94,7 +105,7 @@ long long sed_glu_bwd_scratch_floats(int B, int T, int F, int C, int PT, int PF)
 int sed_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
                 const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
                 float* scratch, int B, int T, int F, int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale,
-                void* stream);
+                const unsigned* seed_dev, void* stream);
 
 /* BatchNorm backward apply in place: dz -> dy = dL/d(conv output); dbias (C) = conv-bias gradient. */
 int sed_bn_bwd_apply(const float* y, float* dz, const float* stats, const float* gamma, const float* dgamma,
@@ -146,28 +157,29 @@ int sed_gru_bwd(const float* dout, const float* out, const float* saved, const f
  * weak (B,NC) = sum_t(strong*clamp(psoft)) / sum_t(clamp(psoft)), den (B,NC) = the denominators. */
 int sed_head_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, float* strong,
                  float* psoft, float* weak, float* den, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
-                 float dscale, void* stream);
+                 float dscale, const unsigned* seed_dev, void* stream);
 
 int sed_head_bwd(const float* x, const float* W1, const float* W2, const float* strong, const float* psoft,
                  const float* weak, const float* den, const float* d_strong, const float* d_weak, float* dx, float* dW1,
                  float* dW2, float* db1, float* db2, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
-                 float dscale, void* stream);
+                 float dscale, const unsigned* seed_dev, void* stream);
 
 /* Mean-teacher losses of SEDTask4.training_step (recipes/dcase2023_task4_baseline/local/sed_trainer.py:309-342):
  * scalars[6] = BCE strong/weak (student), BCE strong/weak (teacher), MSE strong/weak; g_strong (B,T,NC), g_weak (B,NC)
  * = d(BCE_s + BCE_w + weight*(MSE_s + MSE_w)) / d(student outputs).  labels (B,NC,T); labels_weak (n_weak,NC). */
 int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
                 const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
-                int T, int NC, int n_strong, int n_weak, float weight, void* stream);
+                int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, void* stream);
 
 /* ---- K10 + K11: flat parameter arena ------------------------------------------------------------------------- */
 
 /* SEDTask4.update_ema (sed_trainer.py:187-199) over the whole arena: teacher = alpha*teacher + (1-alpha)*student. */
-int sed_ema_update(float* teacher, const float* student, long long n, float alpha, float one_minus_alpha, void* stream);
+int sed_ema_update(float* teacher, const float* student, long long n, float alpha, float one_minus_alpha,
+                   const float* alpha_dev, void* stream);
 
 /* torch.optim.Adam step (train_sed.py:199-201) over the whole arena; grad_scale folds in 1/world_size. */
 int sed_adam_step(float* p, const float* g, float* m, float* v, long long n, float b1, float b2, float eps,
-                  float step_size, float inv_bc2_sqrt, float grad_scale, void* stream);
+                  float step_size, float inv_bc2_sqrt, float grad_scale, const float* hyper_dev, void* stream);
 
 /* Zero up to four small accumulator buffers in one launch (null / 0 entries are skipped). */
 int sed_zero_buffers(float* p0, long long n0, float* p1, long long n1, float* p2, long long n2, float* p3, long long n3,

@@ -418,3 +418,74 @@ def case_edge_shapes(dev):
     empty = mel(to(dev, torch.zeros(0, 4096)))
     assert tuple(empty.shape) == (0, 128, 17)
     assert tuple(Fh.minmax_scale(empty, apply_log=True).shape) == (0, 128, 17)
+
+
+def case_dyn_args_step(dev, graph=False, steps=4):
+    """Step-varying arguments through device memory (desed_task_amd/graph.py) == the by-value eager path.
+
+    Two identical tasks, identical host RNG streams: one runs the plain StepDriver, the other runs every step under a
+    DynArgs context (CPU / emulator: same launches, arguments read from memory) or, with graph=True, through
+    GraphedStepDriver (GPU: eager warm-up steps, one capture, then replays).  Dropout, mixup (both outcomes of the coin
+    flip), the rampup weight, the EMA factor and Adam's bias corrections all change from step to step."""
+    import random
+    from desed_task_amd import graph as G
+    from desed_task_amd.launcher import StepDriver
+    bs, n_samp = (1, 1, 2), 16000 + 1024
+    B = sum(bs)
+    sd = O.make_state_dict(seed=7)
+    audio = O.synth_audio(B, n_samp, seed=77)
+    n_out = (1 + n_samp // 256) // 4
+    labels = O.synth_labels(bs, 10, n_out, seed=5)
+
+    def seed_all(step):
+        random.seed(40 + step); np.random.seed(100 + step); torch.manual_seed(100 + step)
+        if dev != "cpu":
+            torch.cuda.manual_seed(100 + step)
+
+    results = []
+    for mode in ("eager", "dyn"):
+        task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=5)
+        if mode == "eager":
+            driver = StepDriver(task, world_size=1)
+        elif graph:
+            driver = G.GraphedStepDriver(task, world_size=1, warmup=1)
+        else:
+            driver = StepDriver(task, world_size=1, ema_side_stream=False)
+            dyn = G.DynArgs(dev)
+        flips = []
+        for step in range(steps):
+            seed_all(step)
+            flips.append(random.random() < 0.5)
+            seed_all(step)
+            batch = (to(dev, audio.clone()), to(dev, labels.clone()), None, None)
+            if mode == "dyn" and not graph:
+                with G.dyn_step(dyn):
+                    loss = driver.run_step(batch, step)
+            else:
+                loss = driver.run_step(batch, step)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        results.append((float(loss.detach()), {k: v.detach().cpu().clone() for k, v in task.sed_student.state_dict().items()},
+                        {k: v.detach().cpu().clone() for k, v in task.sed_teacher.state_dict().items()},
+                        task.scheduler["scheduler"].step_num))
+        assert any(flips) and not all(flips), "the seeds should exercise both outcomes of the mixup coin flip"
+    (l0, s0, t0, n0), (l1, s1, t1, n1) = results
+    assert n0 == n1 == steps + 1                    # ExponentialWarmup.step_num starts at 1
+    # CPU emulator: launches and atomics are sequential, the two paths are arithmetically identical.
+    # GPU: fp32 atomics (narrow GLU blocks, head, split-K GEMMs) reorder sums from run to run, and Adam's
+    # g/sqrt(v) turns a sign flip of a near-zero gradient element into a +-lr step: a few elements may differ by
+    # O(lr * steps) while the bulk agrees to rounding (same criterion as case_training_step).
+    strict = dev == "cpu"
+    assert abs(l0 - l1) <= (2e-5 if strict else 2e-3) * max(1.0, abs(l0)), (l0, l1)
+    lr = 1e-3
+    for name, a, b in (("student", s0, s1), ("teacher", t0, t1)):
+        for k in a:
+            if a[k].dtype.is_floating_point:
+                d = (a[k] - b[k]).abs()
+                if strict:
+                    assert d.max().item() <= 2e-5, (name, k, d.max().item())
+                else:
+                    assert d.max().item() <= 2.5 * lr * steps, (name, k, d.max().item())
+                    assert (d > 5e-5).float().mean().item() <= 0.05, (name, k, (d > 5e-5).float().mean().item())
+            else:
+                assert torch.equal(a[k], b[k]), (name, k)

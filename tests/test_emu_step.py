@@ -36,3 +36,8 @@ def test_crnn_matches_reference_golden(emu):
 
 def test_edge_shapes(emu):
     P.case_edge_shapes("cpu")
+
+
+def test_dyn_args_step_equals_eager(emu):
+    """graph.DynArgs: dropout seeds, mixup c/perm, loss weight, EMA factor and Adam factors read from memory."""
+    P.case_dyn_args_step("cpu", graph=False, steps=3)

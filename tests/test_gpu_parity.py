@@ -89,3 +89,9 @@ def test_edge_shapes():
 @pytest.mark.parametrize("layer,T,F", [c for c in CNN_SHAPES if c[0] > 0])
 def test_cnn_block_train_split_bf16(layer, T, F):
     P.case_cnn_block("cuda", layer, 3, T, F, training=True, dropout_p=0.5, tol=1e-4, precision="bf16x3")
+
+
+def test_graph_replay_step_equals_eager():
+    """GraphedStepDriver (1 eager step, 1 capture, 3 replays; dropout + SpecAugment + mixup on) against the eager
+    StepDriver on identical host RNG streams: the hipGraph path reads every step-varying argument from device memory."""
+    P.case_dyn_args_step("cuda", graph=True, steps=5)
