@@ -106,16 +106,16 @@ def conv_flops(key):
     return 2.0 * B * T * F * 9 * CIN * COUT
 
 
-def pmc_traffic(cin, cout, F):
+def pmc_traffic(cin, cout, F, split):
     """HBM bytes per launch of the matching conv3x3 kernel from the committed rocprofv3 --pmc passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json" if split else "r01_pmc_traffic.json")
     try:
         kernels = json.load(open(path))["kernels"]
     except Exception:  # noqa: BLE001
         return None
     tf = min(F, 32)
     for name, rec in kernels.items():
-        if name.startswith("conv3x3_kernel<%d, %d, %d, true" % (cin, cout, tf)):
+        if name.startswith("%s<%d, %d, %d, true" % ("conv3x3_bf16_kernel" if split else "conv3x3_kernel", cin, cout, tf)):
             return rec["hbm_bytes"]
     return None
 
@@ -279,9 +279,9 @@ def main():
                                else "v_mfma_f32_32x32x2_f32"),
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "mfma_issue_frac": round((3.0 if split else 1.0) * achieved / peak, 4),
-                    "traffic": pmc_traffic(dom_key[4], dom_key[5], dom_key[3]),
-                    "traffic_note": "HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes on the "
-                                    "f32 kernel of the same shape (profiles/r01_pmc_fetch_write.md); algorithmic in+out+weights = %d "
+                    "traffic": pmc_traffic(dom_key[4], dom_key[5], dom_key[3], split),
+                    "traffic_note": "HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes on this "
+                                    "kernel (profiles/r01_h_pmc_fetch_write.md, r01_h_pmc_traffic.json); algorithmic in+out+weights = %d "
                                     "bytes" % (4 * dom_key[1] * dom_key[2] * dom_key[3] * (dom_key[4] + dom_key[5]) + 36 * dom_key[4] * dom_key[5]),
                     "note": "achieved = algorithmic FLOPs (2*B*T*F*9*CIN*COUT) / mean launch time (HIP events; %s); for the "
                             "split-bf16 kernel the MFMA pipe issues 3x that (mfma_issue_frac); f32-equivalent peak would be %.1f"

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Combine a FETCH_SIZE and a WRITE_SIZE rocprofv3 --pmc pass (two rocpd databases) into the per-kernel HBM-traffic JSON
+bench.py reads: hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE half-count correction, see
+/opt/skills/guides/MI355X_MICROARCH.md and profiles/r01_pmc_fetch_write.md)."""
+import collections, json, re, sqlite3, sys
+
+
+def short(n):
+    return re.sub(r"\(.*$", "", re.sub(r"^void ", "", n))[:90]
+
+
+def means(path, counter):
+    cur = sqlite3.connect(path).cursor()
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for name, cname, val in cur.execute("select name, counter_name, counter_value from pmc_events"):
+        if cname == counter:
+            a = agg[short(name)]; a[0] += 1; a[1] += val
+    return {k: v[1] / v[0] for k, v in agg.items()}
+
+
+fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
+out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --no-graph; HBM bytes = "
+               "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count correction)", "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+    if f + w < 64:
+        continue
+    out["kernels"][k] = {"fetch_kib_raw": round(f, 1), "write_kib": round(w, 1), "hbm_bytes": int((2 * f + w) * 1024)}
+json.dump(out, sys.stdout, indent=1)
