@@ -179,8 +179,8 @@ def cpu_baseline_bounded(timeout_s=150):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)        # >= 50 timed steps after >= 10 warm-up
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured hipGraph step")
     args = ap.parse_args()
@@ -303,6 +303,14 @@ def main():
                    "launch": "hipGraph replay of the captured step (3 eager + 1 capture step before the timed region)" if use_graph
                              else "eager launches", "untimed_steps": n_untimed},
         "roofline": roofline,
+        # SURVEY 8(d) step-level yardsticks (algorithmic work per clip x measured clips/s, per GPU)
+        "step_roofline": {
+            "mfma_tflops": round(6.464e9 * clips / dt / world / 1e12, 2),
+            "mfma_frac_of_f32_peak": round(6.464e9 * clips / dt / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+            "mfma_frac_of_bf16_peak": round(6.464e9 * clips / dt / world / (PEAK_BF16_MFMA_TFLOPS * 1e12), 5),
+            "mel_hbm_frac": round(960512.0 * clips / dt / world / 8.0e12, 6),
+            "note": "6.464 GFLOP/clip = conv1-6 + GLU1-6, student fwd + dgrad + wgrad + teacher fwd; 960 512 B/clip = mel path in+out; "
+                    "whole-step clips/s, so both are diluted by the GRU recurrence and the HBM-bound narrow blocks (DESIGN.md 8)"},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_bounded()

@@ -98,6 +98,25 @@ __device__ __forceinline__ void sed_sched_fence() {
 #endif
 }
 
+// Two values at once -> packed bf16 pairs (low half = a): hi = (bf16(a), bf16(b)), lo = bf16 of the exact remainders.
+// gfx950 converts a pair with one v_cvt_pk_bf16_f32 (RNE, same rounding as f32_to_bf16): 5 VALU ops per pair instead of ~24.
+__device__ __forceinline__ void bf16_split2(float a, float b, unsigned& hi, unsigned& lo) {
+#ifdef SED_EMU
+    unsigned short h0, l0, h1, l1;
+    bf16_split(a, h0, l0);
+    bf16_split(b, h1, l1);
+    hi = (unsigned)h0 | ((unsigned)h1 << 16);
+    lo = (unsigned)l0 | ((unsigned)l1 << 16);
+#else
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    const f32x2_t hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2_t));
+#endif
+}
+
 __device__ __forceinline__ f32x16 f32x16_zero() {
     f32x16 z;
 #pragma unroll

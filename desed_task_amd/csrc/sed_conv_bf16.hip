@@ -145,12 +145,9 @@ __global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const
                 const int idx = tid + THREADS * u;
                 if (idx < PP * V) {
                     const int pix = idx / V, v = idx - pix * V;
-                    unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-                    bf16_split(ld[u].x, h0, l0); bf16_split(ld[u].y, h1, l1);
-                    bf16_split(ld[u].z, h2, l2); bf16_split(ld[u].w, h3, l3);
                     uint2 hv, lv;
-                    hv.x = (unsigned)h0 | ((unsigned)h1 << 16); hv.y = (unsigned)h2 | ((unsigned)h3 << 16);
-                    lv.x = (unsigned)l0 | ((unsigned)l1 << 16); lv.y = (unsigned)l2 | ((unsigned)l3 << 16);
+                    bf16_split2(ld[u].x, ld[u].y, hv.x, lv.x);
+                    bf16_split2(ld[u].z, ld[u].w, hv.y, lv.y);
                     *(uint2*)(patch + pix * RSS + 4 * v) = hv;
                     *(uint2*)(patch + PP * RSS + pix * RSS + 4 * v) = lv;
                 }

@@ -1,0 +1,188 @@
+// Split-bf16 ("bf16x3") variant of the K7 GEMMs (GRU input projections, dW_ih / dW_hh, dX): same contract as
+// sed_gemm / sed_gemm_pair in sed_gru.hip, fp32 in / fp32 out / fp32 accumulate, but every product is issued as
+// three v_mfma_f32_32x32x16_bf16 on operands split x = hi + lo (hi = bf16(x), lo = bf16(x - hi)): hi*hi + hi*lo +
+// lo*hi, ~8e-6 relative on a dot product (see sed_common.h) at 3/16 of the f32-MFMA cost.  The f32 kernels sit at
+// 27-40 % of the f32 MFMA peak on these shapes (K = 128..384 is only 4-12 K tiles per workgroup); with the cheaper
+// MFMA the launches become streaming-bound.
+//
+// Tile 128 x (32*NTN) x 32, 4 waves (wave w: rows 32w..32w+31 x all columns).  Both operands are staged into LDS as
+// bf16 hi / lo planes in [row][k] order (row stride 40 bf16 = 80 B: the 16-byte A/B fragment reads of a quarter wave
+// hit 16 distinct 4-bank groups), whatever their layout in HBM:
+//   k-contiguous operand (A with TA = 0, B with TB = 1): a float4 along k -> one 8-byte store per plane;
+//   row-contiguous operand (A with TA = 1, B with TB = 0): two float4 along the row for k, k+1 -> four 4-byte stores
+//   per plane (the transposition happens in the LDS write).
+// The next K tile is prefetched into registers under the MFMAs of the current one.
+#include "sed_common.h"
+
+namespace {
+
+constexpr int GB_BM = 128, GB_BK = 32, GB_RS = 40;
+
+__device__ __forceinline__ void split4(const float4 v, uint2& h, uint2& l) {
+    bf16_split2(v.x, v.y, h.x, l.x);
+    bf16_split2(v.z, v.w, h.y, l.y);
+}
+
+// One operand tile of ROWS rows x 32 k.  KC = true: element (row, k) at base[row * ld + k]; false: base[k * ld + row].
+// NV float4 per thread.  load(): global -> registers (zero outside [0, nrows) x [k0, kend)); store(): registers -> LDS planes.
+template <int ROWS, bool KC>
+struct OperandTile {
+    static constexpr int NV = ROWS * GB_BK / 4 / 256;
+    float4 r[NV];
+    __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int nrows, int k0, int kend, int tid) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KC) {
+                const int i = tid + 256 * u, row = i / (GB_BK / 4), kq = i % (GB_BK / 4);
+                const int gr = row0 + row, gk = k0 + 4 * kq;
+                if (gr < nrows && gk < kend) r[u] = *(const float4*)(base + (size_t)gr * ld + gk);
+            } else {
+                // pair p = (k pair kp, row quad rq); this thread's float4 #u: pair (tid + 256 * (u / 2)), k = 2 kp + (u & 1)
+                const int p = tid + 256 * (u >> 1), kp = p & 3, rest = p >> 2;
+                const int rq = rest % (ROWS / 4), kph = rest / (ROWS / 4);
+                const int gk = k0 + 2 * (kp + 4 * kph) + (u & 1), gr = row0 + 4 * rq;
+                if (gr < nrows && gk < kend) r[u] = *(const float4*)(base + (size_t)gk * ld + gr);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short* __restrict__ hi_plane, unsigned short* __restrict__ lo_plane, int tid) const {
+        if (KC) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int i = tid + 256 * u, row = i / (GB_BK / 4), kq = i % (GB_BK / 4);
+                uint2 h, l;
+                split4(r[u], h, l);
+                *(uint2*)(hi_plane + row * GB_RS + 4 * kq) = h;
+                *(uint2*)(lo_plane + row * GB_RS + 4 * kq) = l;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NV; u += 2) {
+                const int p = tid + 256 * (u >> 1), kp = p & 3, rest = p >> 2;
+                const int rq = rest % (ROWS / 4), kph = rest / (ROWS / 4);
+                const int k = 2 * (kp + 4 * kph);
+                uint2 h0, l0, h1, l1;                          // rows 4rq..4rq+3 at k (r[u]) and k+1 (r[u+1])
+                split4(r[u], h0, l0);
+                split4(r[u + 1], h1, l1);
+                const unsigned hk[4] = {h0.x & 0xFFFFu, h0.x >> 16, h0.y & 0xFFFFu, h0.y >> 16};
+                const unsigned hk1[4] = {h1.x & 0xFFFFu, h1.x >> 16, h1.y & 0xFFFFu, h1.y >> 16};
+                const unsigned lk[4] = {l0.x & 0xFFFFu, l0.x >> 16, l0.y & 0xFFFFu, l0.y >> 16};
+                const unsigned lk1[4] = {l1.x & 0xFFFFu, l1.x >> 16, l1.y & 0xFFFFu, l1.y >> 16};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    *(unsigned*)(hi_plane + (4 * rq + j) * GB_RS + k) = hk[j] | (hk1[j] << 16);
+                    *(unsigned*)(lo_plane + (4 * rq + j) * GB_RS + k) = lk[j] | (lk1[j] << 16);
+                }
+            }
+        }
+    }
+};
+
+template <int TA, int TB, int NTN>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                          const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K,
+                                                          int lda, int ldb, int ldc, int k_per_slice, int atomic,
+                                                          const float* __restrict__ A1, const float* __restrict__ B1,
+                                                          const float* __restrict__ bias1, float* __restrict__ C1, int nbatch) {
+    constexpr int BM = GB_BM, BN = 32 * NTN, BK = GB_BK, RS = GB_RS;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * BM * RS];     // hi plane, lo plane
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * BN * RS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int zb = nbatch == 2 ? (blockIdx.z & 1) : 0, zs = nbatch == 2 ? (blockIdx.z >> 1) : blockIdx.z;
+    if (zb) { A = A1; Bm = B1; bias = bias1; Cm = C1; }          // second problem of a batch of two
+    const int kbeg = zs * k_per_slice, kend = min(K, kbeg + k_per_slice);
+    f32x16 acc[NTN];
+#pragma unroll
+    for (int i = 0; i < NTN; ++i) acc[i] = f32x16_zero();
+    OperandTile<BM, TA == 0> ta;
+    OperandTile<BN, TB == 1> tb;
+
+    if (kbeg < kend) { ta.load(A, lda, m0, M, kbeg, kend, tid); tb.load(Bm, ldb, n0, N, kbeg, kend, tid); }
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();                 // everyone finished reading the previous tile
+        ta.store(As, As + BM * RS, tid);
+        tb.store(Bs, Bs + BN * RS, tid);
+        __syncthreads();
+        if (k0 + BK < kend) { ta.load(A, lda, m0, M, k0 + BK, kend, tid); tb.load(Bm, ldb, n0, N, k0 + BK, kend, tid); }
+        const unsigned short* ap = As + (32 * w + lo) * RS + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const s16x8 a_hi = *(const s16x8*)(ap + 16 * ks);
+            const s16x8 a_lo = *(const s16x8*)(ap + BM * RS + 16 * ks);
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) {
+                const unsigned short* bp = Bs + (nt * 32 + lo) * RS + 16 * ks + 8 * hi;
+                const s16x8 b_hi = *(const s16x8*)bp;
+                const s16x8 b_lo = *(const s16x8*)(bp + BN * RS);
+                acc[nt] = mfma32_bf16(a_lo, b_hi, acc[nt]);
+                acc[nt] = mfma32_bf16(a_hi, b_lo, acc[nt]);
+                acc[nt] = mfma32_bf16(a_hi, b_hi, acc[nt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int gn = n0 + nt * 32 + lo;
+        if (gn < N) {
+            const float bv = (bias != nullptr && zs == 0) ? bias[gn] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + 32 * w + mfma32_row(r, lane);
+                if (gm < M) {
+                    float* dst = Cm + (size_t)gm * ldc + gn;
+                    const float v = acc[nt][r] + bv;
+                    if (atomic) atomicAdd(dst, v); else *dst = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// defined in sed_gru.hip: the exact-f32 path, used when the operands do not meet the 16-byte requirements below
+extern "C" int sed_gemm(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
+                        int ldc, int transA, int transB, int split_k, int accumulate, void* stream);
+extern "C" int sed_gemm_pair(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
+                             const float* bias1, float* C0, float* C1, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                             int transB, int split_k, int accumulate, void* stream);
+
+static int gemmb_dispatch(const float* A, const float* Bm, const float* bias, float* Cm, const float* A1, const float* B1,
+                          const float* bias1, float* C1, int nbatch, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                          int transB, int split_k, int accumulate, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0) return SED_OK;
+    bool ok = ((uintptr_t)A % 16 == 0) && ((uintptr_t)Bm % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 &&
+              ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0) && !(transA && transB);
+    if (nbatch == 2) ok = ok && ((uintptr_t)A1 % 16 == 0) && ((uintptr_t)B1 % 16 == 0);
+    if (!ok) {
+        if (nbatch == 2) return sed_gemm_pair(A, A1, Bm, B1, bias, bias1, Cm, C1, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate, s);
+        return sed_gemm(A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate, s);
+    }
+    if (split_k < 1) split_k = 1;
+    int kps = ((K + split_k - 1) / split_k + 31) / 32 * 32;
+    split_k = (K + kps - 1) / kps;
+    const int atomic = (split_k > 1 || accumulate) ? 1 : 0;
+    const int ntn = N > 64 ? 4 : 2;
+    dim3 grid((N + 32 * ntn - 1) / (32 * ntn), (M + 127) / 128, split_k * nbatch);
+#define GEMMB_CASE(ta, tb, nn) \
+    if (transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_bf16x3_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic, A1, B1, bias1, C1, nbatch); return sed_check_launch(); }
+    GEMMB_CASE(0, 0, 2) GEMMB_CASE(0, 0, 4) GEMMB_CASE(0, 1, 2) GEMMB_CASE(0, 1, 4) GEMMB_CASE(1, 0, 2) GEMMB_CASE(1, 0, 4)
+#undef GEMMB_CASE
+    return SED_ERR_UNSUPPORTED;
+}
+
+// Same contract as sed_gemm, split-bf16 products (fp32-level accuracy, ~8e-6 relative).
+extern "C" int sed_gemm_bf16x3(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
+                               int ldc, int transA, int transB, int split_k, int accumulate, void* stream) {
+    return gemmb_dispatch(A, Bm, bias, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, transA, transB, split_k,
+                          accumulate, (hipStream_t)stream);
+}
+// Same contract as sed_gemm_pair, split-bf16 products.
+extern "C" int sed_gemm_pair_bf16x3(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
+                                    const float* bias1, float* C0, float* C1, int M, int N, int K, int lda, int ldb, int ldc,
+                                    int transA, int transB, int split_k, int accumulate, void* stream) {
+    return gemmb_dispatch(A0, B0, bias0, C0, A1, B1, bias1, C1, 2, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate,
+                          (hipStream_t)stream);
+}

@@ -3,6 +3,8 @@
 PyTorch here is plumbing: it owns the HBM buffers, the stream and the autograd tape; every FLOP of the
 path runs in libsed_hip.so.  Activations are channels-last (B, T, F, C) fp32.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -10,6 +12,16 @@ from . import graph as _graph
 
 BN_EPS = 1e-3        # desed_task/nnet/CNN.py:76
 BN_MOMENTUM = 0.99
+
+
+def gemm_entry(cfg, pair=True):
+    """C-ABI entry of the GRU GEMMs: split-bf16 products by default (fp32-level accuracy, see sed_gemm_bf16.hip),
+    exact-f32 MFMA with cfg["gemm_precision"] = "f32" or SED_GEMM_PRECISION=f32."""
+    prec = (cfg or {}).get("gemm_precision") or os.environ.get("SED_GEMM_PRECISION", "bf16x3")
+    if prec not in ("bf16x3", "f32"):
+        raise ValueError("gemm_precision must be 'bf16x3' or 'f32'")
+    name = "sed_gemm_pair" if pair else "sed_gemm"
+    return name + "_bf16x3" if prec == "bf16x3" else name
 
 
 def _p(t):
@@ -200,7 +212,7 @@ class BiGRULayerFn(torch.autograd.Function):
         w_ih = [w_ih_f.contiguous(), w_ih_r.contiguous()]
         w_hh = [w_hh_f.contiguous(), w_hh_r.contiguous()]
         # both directions' input projections in one launch: gi[:, :, d, :] = x . W_ih[d]^T + b_ih[d]
-        lib.call("sed_gemm_pair", x.data_ptr(), x.data_ptr(), w_ih[0].data_ptr(), w_ih[1].data_ptr(), b_ih_f.data_ptr(),
+        lib.call(gemm_entry(cfg), x.data_ptr(), x.data_ptr(), w_ih[0].data_ptr(), w_ih[1].data_ptr(), b_ih_f.data_ptr(),
                  b_ih_r.data_ptr(), gi.data_ptr(), gi.data_ptr() + 3 * H * 4, B * T, 3 * H, I, I, I, 6 * H, 0, 1, 1, 0, st)
         out = torch.empty(B, T, 2 * H, **f32)
         need = any(ctx.needs_input_grad)
@@ -239,16 +251,16 @@ class BiGRULayerFn(torch.autograd.Function):
                  dwh[0].data_ptr(), dwh[0].numel(), dwh[1].data_ptr(), dwh[1].numel(), st)     # split-K GEMMs accumulate
         off = 3 * H * 4
         # dW_ih[d] = dgi[d]^T . x   and   dW_hh[d] = dgh[d]^T . hprev[d]   (K = B*T, split-K, both directions per launch)
-        lib.call("sed_gemm_pair", dgi.data_ptr(), dgi.data_ptr() + off, x.data_ptr(), x.data_ptr(), None, None,
+        lib.call(gemm_entry(cfg), dgi.data_ptr(), dgi.data_ptr() + off, x.data_ptr(), x.data_ptr(), None, None,
                  dwi[0].data_ptr(), dwi[1].data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, 0, st)
-        lib.call("sed_gemm_pair", dgh.data_ptr(), dgh.data_ptr() + off, hprev.data_ptr(), hprev.data_ptr() + H * 4, None, None,
+        lib.call(gemm_entry(cfg), dgh.data_ptr(), dgh.data_ptr() + off, hprev.data_ptr(), hprev.data_ptr() + H * 4, None, None,
                  dwh[0].data_ptr(), dwh[1].data_ptr(), 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, 0, st)
         d_w_ih, d_w_hh, d_b_ih, d_b_hh = dwi, dwh, dbi, dbh
         dx = None
         if ctx.needs_input_grad[0]:
             # dx = dgi[fwd] . W_ih[fwd] + dgi[rev] . W_ih[rev]: one launch, both products accumulate into dx
             dx = torch.zeros(B, T, I, **f32)
-            lib.call("sed_gemm_pair", dgi.data_ptr(), dgi.data_ptr() + 3 * H * 4, w_ih_f.data_ptr(), w_ih_r.data_ptr(), None, None,
+            lib.call(gemm_entry(cfg), dgi.data_ptr(), dgi.data_ptr() + 3 * H * 4, w_ih_f.data_ptr(), w_ih_r.data_ptr(), None, None,
                      dx.data_ptr(), dx.data_ptr(), BT, I, 3 * H, 6 * H, I, I, 0, 0, 1, 1, st)
         return (dx, d_w_ih[0], d_w_hh[0], d_b_ih[0], d_b_hh[0], d_w_ih[1], d_w_hh[1], d_b_ih[1], d_b_hh[1], None)
 

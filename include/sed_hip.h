@@ -137,6 +137,14 @@ int sed_gemm_pair(const float* A0, const float* A1, const float* B0, const float
                   const float* bias1, float* C0, float* C1, int M, int N, int K, int lda, int ldb, int ldc, int transA,
                   int transB, int split_k, int accumulate, void* stream);
 
+/* The same two contracts with split-bf16 products (x = hi + lo in bf16, three bf16 MFMAs per product, fp32 accumulate:
+ * ~8e-6 relative, fp32 in/out).  Falls back to the exact-f32 kernels when an operand is not 16-byte aligned. */
+int sed_gemm_bf16x3(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
+                    int ldc, int transA, int transB, int split_k, int accumulate, void* stream);
+int sed_gemm_pair_bf16x3(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
+                         const float* bias1, float* C0, float* C1, int M, int N, int K, int lda, int ldb, int ldc,
+                         int transA, int transB, int split_k, int accumulate, void* stream);
+
 /* Column sums (bias gradients): out[n] = sum_m X[m*ld + n] for n < nsplit, out1[n-nsplit] for nsplit <= n < N. */
 int sed_colsum(const float* X, float* out, float* out1, int nsplit, int M, int N, int ld, void* stream);
 

@@ -203,17 +203,21 @@ def case_bigru(dev, B=2, T=7, I=128, tol=2e-5):
         cmp("dw%d" % i, a.grad, b.grad)
 
 
-def case_gemm(dev):
+def case_gemm(dev, entry="sed_gemm"):
     lib = _lib.get()
     g = torch.Generator().manual_seed(5)
-    for (M, N, K, ta, tb, split) in ((130, 70, 45, 0, 1, 1), (130, 200, 64, 0, 0, 1), (96, 40, 300, 1, 0, 4), (33, 384, 128, 0, 1, 1)):
+    shapes = ((130, 70, 45, 0, 1, 1), (130, 200, 64, 0, 0, 1), (96, 40, 300, 1, 0, 4), (33, 384, 128, 0, 1, 1))
+    if entry != "sed_gemm":         # 16-byte-friendly shapes that stay on the split-bf16 kernels, all three layouts, ragged tiles
+        shapes = ((132, 72, 48, 0, 1, 1), (132, 200, 64, 0, 0, 1), (96, 40, 300, 1, 0, 4), (36, 384, 128, 0, 1, 1),
+                  (384, 128, 520, 1, 0, 3), (260, 256, 384, 0, 0, 1)) + shapes[:1]
+    for (M, N, K, ta, tb, split) in shapes:
         A = torch.randn((K, M) if ta else (M, K), generator=g)
         Bm = torch.randn((N, K) if tb else (K, N), generator=g)
         bias = torch.randn(N, generator=g)
         ref = (A.t() if ta else A).double() @ (Bm.t() if tb else Bm).double() + bias.double()
         Ad, Bd, bd = to(dev, A, Bm, bias)
         C = torch.zeros(M, N, device=Ad.device)
-        lib.call("sed_gemm", Ad.data_ptr(), Bd.data_ptr(), bd.data_ptr(), C.data_ptr(), M, N, K, A.shape[1], Bm.shape[1], N, ta, tb,
+        lib.call(entry, Ad.data_ptr(), Bd.data_ptr(), bd.data_ptr(), C.data_ptr(), M, N, K, A.shape[1], Bm.shape[1], N, ta, tb,
                  split, 0, _lib.stream_ptr(Ad))
         err = (C.cpu().double() - ref).abs().max().item()
         assert err < 1e-4 * max(1.0, ref.abs().max().item()), (M, N, K, ta, tb, err)
@@ -489,3 +493,105 @@ def case_dyn_args_step(dev, graph=False, steps=4):
                     assert (d > 5e-5).float().mean().item() <= 0.05, (name, k, (d > 5e-5).float().mean().item())
             else:
                 assert torch.equal(a[k], b[k]), (name, k)
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size cases (BASELINE.json configs): 10 s clips, production batch shapes
+# ------------------------------------------------------------------------------------------------
+def case_full_size_step_vs_oracle(dev, bs=(4, 4, 8)):
+    """One mean-teacher step on full 10 s clips at the C1 batch (16 clips = [4,4,8]; the reference's CPU-runnable
+    configuration) against the oracle trainer: logged scalars, the 1e-3 posterior criterion and all gradients."""
+    import random
+    from desed_task_amd.launcher import StepDriver
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    B, n_samp = sum(bs), 160000
+    sd = O.make_state_dict(seed=11)
+    audio = O.synth_audio(B, n_samp, seed=3)
+    n_out = (1 + n_samp // 256) // 4
+    assert n_out == 156
+    labels = O.synth_labels(bs, 10, n_out, seed=9)
+    task = build_task(dev, bs, sd, dropout=0.0, specaug=False, rampup=100)
+    driver = StepDriver(task, world_size=1)
+    orc = O.OracleTrainer(sd, batch_sizes=bs, lr=1e-3, rampup_len=100)
+    random.seed(4); np.random.seed(7); torch.manual_seed(7)
+    assert random.random() < 0.5
+    cw = np.random.beta(0.2, 0.2); pw = torch.randperm(bs[1]); cs = np.random.beta(0.2, 0.2); ps = torch.randperm(bs[0])
+    random.seed(4); np.random.seed(7); torch.manual_seed(7)
+    loss = driver.run_step((to(dev, audio.clone()), to(dev, labels.clone()), None, None), 0)
+    tot, logs = orc.training_step(audio, labels, mix=dict(c_weak=cw, perm_weak=pw, c_strong=cs, perm_strong=ps))
+    ref_grads = orc.optimizer_step(tot)
+    got = {k: (float(v) if not torch.is_tensor(v) else float(v.detach().cpu())) for k, v in task.logged.items()}
+    got["loss"] = float(loss.detach().cpu()); logs["loss"] = tot.item()
+    for k in sorted(logs):
+        assert abs(got[k] - logs[k]) <= 2e-5 + 2e-4 * abs(logs[k]), "%s: hip %.8g oracle %.8g" % (k, got[k], logs[k])
+    s_s, w_s, s_t, w_t = [t.detach().cpu() for t in task.last_outputs]
+    assert tuple(s_s.shape) == (B, 10, 156) and tuple(w_s.shape) == (B, 10)
+    for a, b in ((s_s, "strong_s"), (w_s, "weak_s"), (s_t, "strong_t"), (w_t, "weak_t")):
+        assert (a - orc.last[b]).abs().max().item() < 1e-3, b
+    params = dict(task.sed_student.named_parameters())
+    for k in O.PARAM_KEYS:
+        if k.startswith("cnn.cnn.conv") and k.endswith(".bias"):
+            continue
+        g, r = params[k].grad.detach().cpu(), ref_grads[k]
+        assert (g - r).abs().max().item() <= 2e-4 * r.abs().max().item() + 5e-8, k
+
+
+def case_full_size_properties(dev, B=48):
+    """Size-independent properties at the bench configuration (B = 48 = 12/12/24 clips of 10 s), no oracle run needed:
+      P1 eval-mode forward is clip-wise: a 48-clip batch == three 16-clip batches (BN on running stats);
+      P2 weak posteriors are convex combinations over time of the strong ones: min_t strong <= weak <= max_t strong;
+      P3 first step without dropout/SpecAugment: teacher == student, so both consistency losses are exactly 0 and the
+         EMA at alpha = 1 - 1/2 leaves the teacher on the segment between old and new student parameters;
+      P4 mixup with the gate off leaves features/labels untouched; the scaler output spans exactly [-1, 1] per clip;
+      P5 the gradient of the flat arena is what Adam consumes: one step moves every parameter by at most lr (|m/sqrt(v)| <= 1
+         at t = 1 up to eps) and by exactly lr*sign(g) where |g| is not tiny."""
+    import random
+    from desed_task_amd.launcher import StepDriver
+    from desed_task_amd.nnet.CRNN import CRNN
+    bs = (B // 4, B // 4, B // 2)
+    sd = O.make_state_dict(seed=13)
+    audio = to(dev, O.synth_audio(B, 160000, seed=5))
+    labels = to(dev, O.synth_labels(bs, 10, 156, seed=6))
+    # ---- P1, P2: eval-mode CRNN on real features ----
+    task = build_task(dev, bs, sd, dropout=0.0, specaug=False, rampup=100)
+    with torch.no_grad():
+        feats = task.scaled_logmel(task.mel_spec(audio))
+    assert tuple(feats.shape) == (B, 128, 626)
+    fmin, fmax = feats.amin(dim=(1, 2)), feats.amax(dim=(1, 2))
+    assert (fmin + 1).abs().max().item() < 1e-6 and (fmax - 1).abs().max().item() < 1e-5           # P4 (scaler)
+    net = task.sed_student
+    net.eval()
+    with torch.no_grad():
+        strong, weak = net(feats)
+        parts = [net(feats[i:i + B // 3].contiguous()) for i in range(0, B, B // 3)]
+    assert tuple(strong.shape) == (B, 10, 156)
+    assert (strong - torch.cat([p[0] for p in parts])).abs().max().item() < 2e-6                    # P1
+    assert (weak - torch.cat([p[1] for p in parts])).abs().max().item() < 2e-6
+    assert bool(((weak <= strong.amax(dim=2) + 1e-6) & (weak >= strong.amin(dim=2) - 1e-6)).all())  # P2
+    # ---- P3, P4, P5: one training step at full size ----
+    task = build_task(dev, bs, sd, dropout=0.0, specaug=False, rampup=100, lr=1e-3)
+    before = task.sed_student.arena.flat.detach().clone()
+    t_before = task.sed_teacher.arena.flat.detach().clone()
+    driver = StepDriver(task, world_size=1)
+    random.seed(2)
+    assert random.random() >= 0.5                       # gate off -> no mixup this step
+    random.seed(2)
+    lab_in = labels.clone()
+    loss = driver.run_step((audio, lab_in, None, None), 0)
+    if dev != "cpu":
+        torch.cuda.synchronize()
+    assert torch.equal(lab_in, labels)                                                               # P4 (labels untouched)
+    assert float(task.logged["train/student/strong_self_sup_loss"]) == 0.0                           # P3
+    assert float(task.logged["train/student/weak_self_sup_loss"]) == 0.0
+    s_s, w_s, s_t, w_t = task.last_outputs
+    assert torch.equal(s_s.detach(), s_t) and torch.equal(w_s.detach(), w_t)
+    assert torch.isfinite(loss).item()
+    after = task.sed_student.arena.flat.detach()
+    grad = task.sed_student.arena.flat_grad.detach()
+    step = (after - before).abs()
+    assert step.max().item() <= 1e-3 * 1.0001                                                        # P5
+    big = grad.abs() > 1e-4                             # eps / |g| <= 1e-4: the step is lr * sign(g) to 1e-7
+    assert big.float().mean().item() > 0.02
+    assert ((after - before)[big] + 1e-3 * torch.sign(grad[big])).abs().max().item() < 5e-7
+    t_after = task.sed_teacher.arena.flat.detach()
+    assert (t_after - (0.5 * t_before + 0.5 * before)).abs().max().item() < 1e-7                     # P3 (EMA, alpha = 1/2)

@@ -5,6 +5,7 @@ from tests.emu_support import emu  # noqa: F401
 
 def test_gemm(emu):
     P.case_gemm("cpu")
+    P.case_gemm("cpu", entry="sed_gemm_bf16x3")
 
 
 def test_bigru_layer0(emu):

@@ -59,6 +59,7 @@ def test_cnn_block_eval(layer, T, F):
 
 def test_gemm():
     P.case_gemm("cuda")
+    P.case_gemm("cuda", entry="sed_gemm_bf16x3")
 
 
 def test_bigru_production_shape():
@@ -95,3 +96,13 @@ def test_graph_replay_step_equals_eager():
     """GraphedStepDriver (1 eager step, 1 capture, 3 replays; dropout + SpecAugment + mixup on) against the eager
     StepDriver on identical host RNG streams: the hipGraph path reads every step-varying argument from device memory."""
     P.case_dyn_args_step("cuda", graph=True, steps=5)
+
+
+def test_full_size_step_vs_oracle_c1_batch():
+    """Full 10 s clips, 16 clips = [4,4,8] (the reference's CPU-runnable C1 configuration) against the oracle."""
+    P.case_full_size_step_vs_oracle("cuda")
+
+
+def test_full_size_properties_bench_batch():
+    """Size-independent properties at the bench configuration (48 clips of 10 s)."""
+    P.case_full_size_properties("cuda", B=48)
