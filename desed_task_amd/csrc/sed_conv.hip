@@ -208,7 +208,9 @@ __global__ __launch_bounds__(CONV_THREADS(COUT)) void conv3x3_kernel(const float
 #pragma unroll
                 for (int i = 0; i < WV; ++i) {
                     const int idx = tid + THREADS * i;
-                    if (idx < WCH / 4) wreg[i] = src[idx];
+                    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);     // (through a temporary: a guarded `wreg[i] = *p` sends wreg to scratch)
+                    if (idx < WCH / 4) wv = src[idx];
+                    wreg[i] = wv;
                 }
             }
             const float* wb = wbuf + (tap & 1) * WCH;

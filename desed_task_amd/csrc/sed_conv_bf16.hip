@@ -31,7 +31,7 @@ struct ConvBCfg {
     static_assert(NTW >= 1 && NTW * WN == NT, "wave split must tile COUT");
     static constexpr int PATCH_S = 2 * PP * RSS;         // shorts: hi plane | lo plane
     static constexpr int WBUF_S = 2 * NCOL * RSS;        // shorts per weight buffer: hi | lo
-    static constexpr int SMEM = (PATCH_S + 2 * WBUF_S) * 2 + 64;
+    static constexpr int SMEM = (PATCH_S + 3 * WBUF_S) * 2 + 64;    // patch + one kernel row (3 taps) of weight slabs
     static constexpr int SLAB = 2 * COUT * CK;           // shorts per (tap, chunk) slab in global memory
 };
 
@@ -86,6 +86,12 @@ extern "C" int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const
     return sed_check_launch();
 }
 
+// CONVB_ABL: timing-ablation mask for tools/convb_variants.py (0 in the product build): 1 = no weight-slab global loads,
+// 2 = no MFMAs, 4 = no patch global loads, 8 = no per-tap barrier (results are wrong under any of them).
+#ifndef CONVB_ABL
+#define CONVB_ABL 0
+#endif
+
 template <int CIN, int COUT, int TF, bool STATS, int MP = 128>
 __global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const float* __restrict__ x,
                                                                             const unsigned short* __restrict__ Wp,
@@ -112,91 +118,110 @@ __global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const
 
     // weight rows beyond COUT (narrow data-gradient outputs) stay zero for the whole kernel
     if (NCOL > COUT) {
-        for (int i = tid; i < 2 * WBUF_S; i += THREADS) wbuf[i] = 0;
+        for (int i = tid; i < 3 * WBUF_S; i += THREADS) wbuf[i] = 0;
         __syncthreads();
     }
+    // The weights stream through LDS one KERNEL ROW (3 taps x one cin chunk) at a time: the next row's three slabs are
+    // fetched into registers at the start of an iteration and parked in LDS at its end, so their L2 latency hides behind
+    // three taps of MFMAs (timing ablation, tools/convb_variants.py: with one tap per iteration the slab wait was 30-60 %
+    // of the kernel).  The halo patch of the next cin chunk is prefetched the same way during the last row of a chunk.
     constexpr int WPIECES = SLAB / 8;                                   // 16-byte pieces per slab
     constexpr int WV = (WPIECES + THREADS - 1) / THREADS;
-    uint4 wreg[WV];
+    constexpr int V = CK / 4;
+    constexpr int NLD = (PP * V + THREADS - 1) / THREADS;
+    uint4 wreg[3 * WV];
+    float4 ld[NLD];
     auto w_dst = [&](int buf, int piece) -> unsigned short* {
         const int plane = piece / (COUT * CK / 8), rem = piece - plane * (COUT * CK / 8);
         const int co = rem / (CK / 8), pc = rem - co * (CK / 8);
         return wbuf + buf * WBUF_S + plane * NCOL * RSS + co * RSS + 8 * pc;
     };
-
-    for (int cc = 0; cc < NCH; ++cc) {
-        // ---- stage the halo patch of this cin chunk, split into bf16 hi / lo planes ----
-        constexpr int V = CK / 4;
-        {
-            constexpr int NLD = (PP * V + THREADS - 1) / THREADS;
-            float4 ld[NLD];
+    auto load_row = [&](int cc, int r) {
 #pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int idx = tid + THREADS * u;
-                const int pix = idx / V, v = idx - pix * V;
-                const int i = pix / PW, j = pix - i * PW;
-                const int t = t0 - 1 + i, f = f0 - 1 + j;
-                ld[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < PP * V && t >= 0 && t < T && f >= 0 && f < F)
-                    ld[u] = *(const float4*)(x + (((size_t)b * T + t) * F + f) * CIN + cc * CK + 4 * v);
-            }
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int idx = tid + THREADS * u;
-                if (idx < PP * V) {
-                    const int pix = idx / V, v = idx - pix * V;
-                    uint2 hv, lv;
-                    bf16_split2(ld[u].x, ld[u].y, hv.x, lv.x);
-                    bf16_split2(ld[u].z, ld[u].w, hv.y, lv.y);
-                    *(uint2*)(patch + pix * RSS + 4 * v) = hv;
-                    *(uint2*)(patch + PP * RSS + pix * RSS + 4 * v) = lv;
-                }
-            }
-        }
-        // ---- tap 0 weight slab straight to LDS buffer 0 ----
-        {
-            const uint4* src = (const uint4*)(Wp + ((size_t)0 * NCH + cc) * SLAB);
+        for (int t3 = 0; t3 < 3; ++t3) {
+            const uint4* src = (const uint4*)(Wp + ((size_t)(3 * r + t3) * NCH + cc) * SLAB);
 #pragma unroll
             for (int i = 0; i < WV; ++i) {
                 const int piece = tid + THREADS * i;
-                if (piece < WPIECES) *(uint4*)w_dst(0, piece) = src[piece];
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (piece < WPIECES && !(CONVB_ABL & 1)) v = src[piece];
+                wreg[t3 * WV + i] = v;
             }
         }
-        __syncthreads();
+    };
+    auto store_row = [&]() {
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+            for (int i = 0; i < WV; ++i) {
+                const int piece = tid + THREADS * i;
+                if (piece < WPIECES) *(uint4*)w_dst(t3, piece) = wreg[t3 * WV + i];
+            }
+    };
+    auto load_patch = [&](int cc) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + THREADS * u;
+            const int pix = idx / V, v = idx - pix * V;
+            const int i = pix / PW, j = pix - i * PW;
+            const int t = t0 - 1 + i, f = f0 - 1 + j;
+            ld[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < PP * V && t >= 0 && t < T && f >= 0 && f < F && !(CONVB_ABL & 4))
+                ld[u] = *(const float4*)(x + (((size_t)b * T + t) * F + f) * CIN + cc * CK + 4 * v);
+        }
+    };
+    auto store_patch = [&]() {          // split into bf16 hi / lo planes
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + THREADS * u;
+            if (idx < PP * V) {
+                const int pix = idx / V, v = idx - pix * V;
+                uint2 hv, lv;
+                bf16_split2(ld[u].x, ld[u].y, hv.x, lv.x);
+                bf16_split2(ld[u].z, ld[u].w, hv.y, lv.y);
+                *(uint2*)(patch + pix * RSS + 4 * v) = hv;
+                *(uint2*)(patch + PP * RSS + pix * RSS + 4 * v) = lv;
+            }
+        }
+    };
+
+    load_patch(0);
+    load_row(0, 0);
+    store_patch();
+    store_row();
+    __syncthreads();
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 1 < 9) {
-                const uint4* src = (const uint4*)(Wp + ((size_t)(tap + 1) * NCH + cc) * SLAB);
+    for (int cc = 0; cc < NCH; ++cc) {
 #pragma unroll
-                for (int i = 0; i < WV; ++i) {
-                    const int piece = tid + THREADS * i;
-                    if (piece < WPIECES) wreg[i] = src[piece];
+        for (int r = 0; r < 3; ++r) {
+            const bool next_chunk = r == 2 && cc + 1 < NCH;
+            const bool more = r < 2 || cc + 1 < NCH;
+            if (more) load_row(r < 2 ? cc : cc + 1, r < 2 ? r + 1 : 0);
+            if (next_chunk) load_patch(cc + 1);
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const unsigned short* wb = wbuf + t3 * WBUF_S;
+                const unsigned short* ap = patch + abase + (r * PW + t3) * RSS;
+#pragma unroll
+                for (int ks = 0; ks < CK / 16; ++ks) {
+                    const s16x8 a_hi = *(const s16x8*)(ap + 16 * ks);
+                    const s16x8 a_lo = *(const s16x8*)(ap + PP * RSS + 16 * ks);
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const unsigned short* bp = wb + ((wn * NTW + nt) * 32 + lo) * RSS + 16 * ks + 8 * hi;
+                        const s16x8 b_hi = *(const s16x8*)bp;
+                        const s16x8 b_lo = *(const s16x8*)(bp + NCOL * RSS);
+                        if (CONVB_ABL & 2) { acc[nt][0] += (float)(a_lo[0] + b_hi[0] + a_hi[1] + b_lo[1]); continue; }
+                        acc[nt] = mfma32_bf16(a_lo, b_hi, acc[nt]);
+                        acc[nt] = mfma32_bf16(a_hi, b_lo, acc[nt]);
+                        acc[nt] = mfma32_bf16(a_hi, b_hi, acc[nt]);
+                    }
                 }
             }
-            const unsigned short* wb = wbuf + (tap & 1) * WBUF_S;
-            const unsigned short* ap = patch + abase + ((tap / 3) * PW + (tap % 3)) * RSS;
-#pragma unroll
-            for (int ks = 0; ks < CK / 16; ++ks) {
-                const s16x8 a_hi = *(const s16x8*)(ap + 16 * ks);
-                const s16x8 a_lo = *(const s16x8*)(ap + PP * RSS + 16 * ks);
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    const unsigned short* bp = wb + ((wn * NTW + nt) * 32 + lo) * RSS + 16 * ks + 8 * hi;
-                    const s16x8 b_hi = *(const s16x8*)bp;
-                    const s16x8 b_lo = *(const s16x8*)(bp + NCOL * RSS);
-                    acc[nt] = mfma32_bf16(a_lo, b_hi, acc[nt]);
-                    acc[nt] = mfma32_bf16(a_hi, b_lo, acc[nt]);
-                    acc[nt] = mfma32_bf16(a_hi, b_hi, acc[nt]);
-                }
-            }
-            if (tap + 1 < 9) {
-#pragma unroll
-                for (int i = 0; i < WV; ++i) {
-                    const int piece = tid + THREADS * i;
-                    if (piece < WPIECES) *(uint4*)w_dst((tap + 1) & 1, piece) = wreg[i];
-                }
-            }
-            __syncthreads();
+            if (!(CONVB_ABL & 8)) __syncthreads();      // every wave is done with this row's slabs (and, at r == 2, the patch)
+            if (more) store_row();
+            if (next_chunk) store_patch();
+            if (!(CONVB_ABL & 8)) __syncthreads();
         }
     }
     // ---- epilogue: bias, store, per-channel partial statistics (identical to the f32 kernel) ----

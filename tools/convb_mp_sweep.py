@@ -1,0 +1,36 @@
+"""Tile-size sweep of the split-bf16 3x3 conv (SED_CONVB_MP override) over every forward / data-gradient shape of the recipe."""
+import os, sys
+sys.path.insert(0, '.')
+import torch
+from desed_task_amd import _lib
+from desed_task_amd.ops import pack_conv_weights
+lib = _lib.get()
+B = 48
+shapes = [(16, 32, 313, 64), (32, 64, 156, 32), (64, 128, 156, 16), (128, 128, 156, 8), (128, 128, 156, 4), (128, 128, 156, 2),
+          (32, 16, 313, 64), (64, 32, 156, 32), (128, 64, 156, 16)]
+for (CIN, COUT, T, F) in shapes:
+    x = torch.randn(B, T, F, CIN, device="cuda")
+    w = torch.randn(COUT, CIN, 3, 3, device="cuda") * 0.03
+    bias = torch.zeros(COUT, device="cuda")
+    y = torch.empty(B, T, F, COUT, device="cuda")
+    partial = torch.empty(16384 * 2 * COUT, device="cuda")
+    (wf, wd), = pack_conv_weights([w], True, "bf16x3")
+    st = torch.cuda.current_stream().cuda_stream
+    res = []
+    for mp in ("default", "64", "128", "256"):
+        if mp == "default":
+            os.environ.pop("SED_CONVB_MP", None)
+        else:
+            os.environ["SED_CONVB_MP"] = mp
+        def run():
+            return lib.value("sed_conv3x3_bf16x3", x.data_ptr(), wf.data_ptr(), bias.data_ptr(), y.data_ptr(), partial.data_ptr(), B, T, F, CIN, COUT, st)
+        if run() != 0:
+            res.append("%s: n/a" % mp); continue
+        for _ in range(2): run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): run()
+        e1.record(); torch.cuda.synchronize()
+        res.append("%s: %.1f" % (mp, e0.elapsed_time(e1) / 20 * 1e3))
+    print("conv %3d->%3d T=%d F=%2d  us  " % (CIN, COUT, T, F) + "  ".join(res), flush=True)
