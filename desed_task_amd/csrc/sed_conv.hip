@@ -578,6 +578,169 @@ static int launch_wgrad(const float* x, const float* dy, float* dWp, int B, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// weight gradient of the wide layers on the split-bf16 MFMA (same grid / partial layout as conv_wgrad_kernel).
+//
+// dW[tap][ci][co] = sum_p x[p + tap][ci] * dy[p][co] contracts over PIXELS, but v_mfma_f32_32x32x16_bf16 wants each lane to
+// hold 8 consecutive K values of its row, i.e. both operands pixel-contiguous -- the transpose of the channels-last
+// tensors.  The transposition happens in registers while staging: a thread owns a 4 pixel x 4 channel block (four
+// float4 loads, coalesced along the channels), splits it into bf16 hi/lo with v_cvt_pk_bf16_f32 on PIXEL pairs and
+// writes, per channel, one 8-byte row segment (4 pixels) into xT / dyT [channel][pixel] planes.  Rows are 72 bf16
+// (144 B) apart and the pixel octets of a row are XOR-swizzled with bits 4..6 of the row index, which keeps the
+// 16-byte fragment reads conflict-free and the transposing stores at 2-way conflicts.  The tap shift is applied when
+// the x block is fetched, so every LDS access is aligned.  The next K tile is fetched into registers under the MFMAs.
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+struct WgbCfg {
+    static constexpr int KT = 64, RS = 72;              // pixels per K tile, LDS row stride (bf16)
+    static constexpr int MT = CIN / 32, NT = COUT / 32;
+    static constexpr int WM = MT >= 4 ? 2 : 1, WN = 4 / WM;
+    static constexpr int MTW = MT / WM, NTW = NT / WN;
+    static constexpr int NBX = (KT / 4) * (CIN / 4) / 256, NBD = (KT / 4) * (COUT / 4) / 256;   // 4x4 blocks per thread
+    static constexpr int SMEM = 2 * (CIN + COUT) * RS * 2;
+    static_assert(NBX >= 1 && NBD >= 1 && MTW * WM == MT && NTW * WN == NT, "tile split");
+};
+
+// 4 pixels x 4 channels (vj = pixel j) -> rows 4cq..4cq+3 of the [channel][pixel] hi / lo planes, pixels 4pq..4pq+3.
+// (Plain scalars only: pointer / reference arrays over the register blocks would push them to scratch.)
+__device__ __forceinline__ void wgb_store_row(float a, float b, float c, float d, unsigned short* __restrict__ hi_row,
+                                              unsigned short* __restrict__ lo_row) {
+    uint2 h, l;
+    bf16_split2(a, b, h.x, l.x);
+    bf16_split2(c, d, h.y, l.y);
+    *(uint2*)hi_row = h;
+    *(uint2*)lo_row = l;
+}
+__device__ __forceinline__ void wgb_store_block(const float4 v0, const float4 v1, const float4 v2, const float4 v3,
+                                                unsigned short* __restrict__ hi_plane, unsigned short* __restrict__ lo_plane,
+                                                int cq, int pq, int RS) {
+    const int off = 4 * cq * RS + 4 * (pq ^ (2 * ((cq >> 2) & 7)));     // octet swizzle by bits 4..6 of the row (row = 4cq + c)
+    wgb_store_row(v0.x, v1.x, v2.x, v3.x, hi_plane + off, lo_plane + off);
+    wgb_store_row(v0.y, v1.y, v2.y, v3.y, hi_plane + off + RS, lo_plane + off + RS);
+    wgb_store_row(v0.z, v1.z, v2.z, v3.z, hi_plane + off + 2 * RS, lo_plane + off + 2 * RS);
+    wgb_store_row(v0.w, v1.w, v2.w, v3.w, hi_plane + off + 3 * RS, lo_plane + off + 3 * RS);
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ dWp, int B, int T, int F) {
+    using Cfg = WgbCfg<CIN, COUT>;
+    constexpr int KT = Cfg::KT, RS = Cfg::RS, WN = Cfg::WN, MTW = Cfg::MTW, NTW = Cfg::NTW, NBX = Cfg::NBX, NBD = Cfg::NBD;
+    SED_DYN_SMEM(smem);
+    unsigned short* xh = (unsigned short*)smem;      // [CIN][RS] hi, then lo
+    unsigned short* xl = xh + CIN * RS;
+    unsigned short* dh = xl + CIN * RS;              // [COUT][RS] hi, then lo
+    unsigned short* dl = dh + COUT * RS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int wn = w % WN, wm = w / WN;
+    const int tap = blockIdx.y, da = tap / 3 - 1, db = tap % 3 - 1;
+    const int npix = B * T * F;
+    const int ntiles = (npix + KT - 1) / KT;
+    const int fsh = 31 - __builtin_clz(F);           // F is a power of two (checked by the launcher)
+
+    f32x16 acc[MTW][NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[m][n] = f32x16_zero();
+
+    float4 rx[NBX * 4], rd[NBD * 4];
+    auto load_tile = [&](int tile) {
+        const int p0 = tile * KT;
+#pragma unroll
+        for (int u = 0; u < NBX; ++u) {
+            const int blk = tid + 256 * u, cq = blk % (CIN / 4), pq = blk / (CIN / 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = p0 + 4 * pq + j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < npix) {
+                    const int f = p & (F - 1), tt = p >> fsh, t = tt % T, bb = tt / T;
+                    const int t2 = t + da, f2 = f + db;
+                    if (t2 >= 0 && t2 < T && f2 >= 0 && f2 < F) v = *(const float4*)(x + (((size_t)bb * T + t2) * F + f2) * CIN + 4 * cq);
+                }
+                rx[4 * u + j] = v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NBD; ++u) {
+            const int blk = tid + 256 * u, cq = blk % (COUT / 4), pq = blk / (COUT / 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = p0 + 4 * pq + j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < npix) v = *(const float4*)(dy + (size_t)p * COUT + 4 * cq);
+                rd[4 * u + j] = v;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NBX; ++u) {
+            const int blk = tid + 256 * u;
+            wgb_store_block(rx[4 * u], rx[4 * u + 1], rx[4 * u + 2], rx[4 * u + 3], xh, xl, blk % (CIN / 4), blk / (CIN / 4), RS);
+        }
+#pragma unroll
+        for (int u = 0; u < NBD; ++u) {
+            const int blk = tid + 256 * u;
+            wgb_store_block(rd[4 * u], rd[4 * u + 1], rd[4 * u + 2], rd[4 * u + 3], dh, dl, blk % (COUT / 4), blk / (COUT / 4), RS);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                  // previous tile's fragments are consumed
+        store_tile();
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+#pragma unroll
+        for (int ks = 0; ks < KT / 16; ++ks) {
+            const int oct = 2 * ks + hi;                  // this lane's pixel octet of the K tile
+            s16x8 a_hi[MTW], a_lo[MTW];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int row = (wm * MTW + m) * 32 + lo;
+                const int off = row * RS + 8 * (oct ^ ((row >> 4) & 7));
+                a_hi[m] = *(const s16x8*)(xh + off);
+                a_lo[m] = *(const s16x8*)(xl + off);
+            }
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int row = (wn * NTW + n) * 32 + lo;
+                const int off = row * RS + 8 * (oct ^ ((row >> 4) & 7));
+                const s16x8 b_hi = *(const s16x8*)(dh + off);
+                const s16x8 b_lo = *(const s16x8*)(dl + off);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    acc[m][n] = mfma32_bf16(a_lo[m], b_hi, acc[m][n]);
+                    acc[m][n] = mfma32_bf16(a_hi[m], b_lo, acc[m][n]);
+                    acc[m][n] = mfma32_bf16(a_hi[m], b_hi, acc[m][n]);
+                }
+            }
+        }
+    }
+    // ---- this workgroup's partial: dWp[split][tap][ci][co] (reduced in a fixed order by wgrad_reduce_kernel) ----
+    float* part = dWp + ((size_t)blockIdx.x * 9 + tap) * CIN * COUT;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int co = (wn * NTW + n) * 32 + lo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[(size_t)((wm * MTW + m) * 32 + mfma32_row(r, lane)) * COUT + co] = acc[m][n][r];
+        }
+}
+
+template <int CIN, int COUT>
+static int launch_wgrad_bf16(const float* x, const float* dy, float* dWp, int B, int T, int F, hipStream_t s) {
+    using Cfg = WgbCfg<CIN, COUT>;
+    const int splits = wgrad_parts(CIN, COUT, B, T, F);
+    SED_MAX_SMEM((conv_wgrad_bf16_kernel<CIN, COUT>), Cfg::SMEM);
+    SED_LAUNCH((conv_wgrad_bf16_kernel<CIN, COUT>), dim3(splits, 9), dim3(256), Cfg::SMEM, s, x, dy, dWp, B, T, F);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient, narrow layers (CIN <= 32): ALL 9 taps in one workgroup, so x and dy are read from HBM once
 // instead of once per tap.  Tile = the forward's 128-pixel TR x TF patch: halo patch of x [PP][CIN] and the dy
 // tile [128][COUT] in LDS; K = pixels of the tile, split across waves (WK) with the COUT tiles (WN); each wave
@@ -697,9 +860,8 @@ static int launch_wgrad_alltaps(const float* x, const float* dy, float* dWp, int
     return sed_check_launch();
 }
 
-// x (B,T,F,CIN), dy (B,T,F,COUT) -> dW (COUT,CIN,3,3).  dWp: scratch of sed_conv_wgrad_scratch_floats() floats.
-extern "C" int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
-                              void* stream) {
+static int conv_wgrad_impl(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
+                           bool split_bf16, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = SED_ERR_UNSUPPORTED;
     const int TF = conv_tf(F);
@@ -708,7 +870,9 @@ extern "C" int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float
     WGA_CASE(16, 32, 32) WGA_CASE(16, 32, 16) WGA_CASE(16, 32, 8) WGA_CASE(32, 64, 32) WGA_CASE(32, 64, 16) WGA_CASE(32, 64, 8)
     WGA_CASE(32, 64, 4)
 #undef WGA_CASE
-#define WG_CASE(ci, co) if (rc != SED_OK && CIN == ci && COUT == co) rc = launch_wgrad<ci, co>(x, dy, dWp, B, T, F, s);
+#define WG_CASE(ci, co)                                                                                        \
+    if (rc != SED_OK && CIN == ci && COUT == co)                                                               \
+        rc = split_bf16 ? launch_wgrad_bf16<ci, co>(x, dy, dWp, B, T, F, s) : launch_wgrad<ci, co>(x, dy, dWp, B, T, F, s);
     WG_CASE(64, 128) WG_CASE(128, 128)
 #undef WG_CASE
     if (rc != SED_OK) return rc;
@@ -716,6 +880,17 @@ extern "C" int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float
     const int nparts = wgrad_parts(CIN, COUT, B, T, F);
     SED_LAUNCH(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(nparts >= 256 ? 1024 : 256), 0, s, (const float*)dWp, dW, nparts, COUT, CIN);
     return sed_check_launch();
+}
+// x (B,T,F,CIN), dy (B,T,F,COUT) -> dW (COUT,CIN,3,3).  dWp: scratch of sed_conv_wgrad_scratch_floats() floats.
+extern "C" int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
+                              void* stream) {
+    return conv_wgrad_impl(x, dy, dWp, dW, B, T, F, CIN, COUT, false, stream);
+}
+// Same contract; the wide layers (CIN >= 64) contract on the split-bf16 MFMA (fp32-level accuracy, ~8e-6 relative), the
+// narrow ones use the exact-f32 all-taps kernel.
+extern "C" int sed_conv_wgrad_bf16x3(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN,
+                                     int COUT, void* stream) {
+    return conv_wgrad_impl(x, dy, dWp, dW, B, T, F, CIN, COUT, true, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

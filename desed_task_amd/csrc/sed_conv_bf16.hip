@@ -282,9 +282,10 @@ static int launch_convb(const float* x, const unsigned short* Wp, const float* b
 // kernel, so the per-step costs (weight-slab streaming, barrier) must be amortised over more pixels: 256-pixel tiles
 // (each wave 32 px x all couts) wherever that still leaves >= ~230 workgroups.
 static inline int convb_mp(int F, int CIN, int COUT) {
-    const char* e = getenv("SED_CONVB_MP");            // tuning override (tools/conv_microbench.py)
+    const char* e = getenv("SED_CONVB_MP");            // tuning override (tools/convb_mp_sweep.py)
     if (e && COUT >= 64) return atoi(e);
     if (COUT < 64) return 128;
+    if (CIN <= 32) return 128;          // one cin chunk: a 256-px patch + the 3-tap weight row leaves one workgroup per CU (44 vs 57 us)
     if (CIN == 128 && COUT == 128 && F <= 2) return 64;
     if (CIN == 128 && COUT == 128 && F <= 4) return 128;
     return 256;

@@ -175,7 +175,8 @@ class ConvBlockFn(torch.autograd.Function):
                      B, T, F, COUT, 0, int(training), st)
         else:
             scratch = torch.empty(int(lib.value("sed_conv_wgrad_scratch_floats", B, T, F, CIN, COUT)), **f32)
-            lib.call("sed_conv_wgrad", x.data_ptr(), dy.data_ptr(), scratch.data_ptr(), d_w.data_ptr(), B, T, F, CIN, COUT, st)
+            entry = "sed_conv_wgrad_bf16x3" if cfg.get("conv_precision", "f32") == "bf16x3" else "sed_conv_wgrad"
+            lib.call(entry, x.data_ptr(), dy.data_ptr(), scratch.data_ptr(), d_w.data_ptr(), B, T, F, CIN, COUT, st)
             if ctx.needs_input_grad[0]:
                 packed = cfg.get("packed")
                 bf16x3 = False

@@ -118,6 +118,11 @@ long long sed_conv_wgrad_scratch_floats(int B, int T, int F, int CIN, int COUT);
 int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
                    void* stream);
 
+/* Same contract with the pixel contraction of the wide layers (CIN >= 64) on the split-bf16 MFMA (x = hi + lo in bf16, three
+ * bf16 MFMAs per product, fp32 accumulate: ~8e-6 relative). */
+int sed_conv_wgrad_bf16x3(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
+                          void* stream);
+
 /* Layer-0 weight gradient: x (B,T,F) (+ SpecAugment bounds or null) -> dW (16,1,3,3).  fuse_bn = 0: dyz = dy (B,T,F,16).
  * fuse_bn = 1 (training mode): dyz = dz from sed_glu_bwd and the BatchNorm backward (sed_bn_bwd_apply) is applied while
  * loading (y, stats, gamma, dgamma, dbeta as there); dbias (16) receives the (zero) conv-bias gradient. */
