@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restric
                                                           const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K,
                                                           int lda, int ldb, int ldc, int k_per_slice, int atomic,
                                                           const float* __restrict__ A1, const float* __restrict__ B1,
-                                                          const float* __restrict__ bias1, float* __restrict__ C1, int nbatch) {
+                                                          const float* __restrict__ bias1, float* __restrict__ C1, int nbatch,
+                                                          const float* __restrict__ Bsw, int ksw) {
+    // Bsw != null: K-concatenated B -- rows k >= ksw come from Bsw (already offset by -ksw rows); ksw % 32 == 0
     constexpr int BM = GB_BM, BN = 32 * NTN, BK = GB_BK, RS = GB_RS;
     __shared__ __attribute__((aligned(16))) unsigned short As[2 * BM * RS];     // hi plane, lo plane
     __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * BN * RS];
@@ -99,13 +101,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restric
     OperandTile<BM, TA == 0> ta;
     OperandTile<BN, TB == 1> tb;
 
-    if (kbeg < kend) { ta.load(A, lda, m0, M, kbeg, kend, tid); tb.load(Bm, ldb, n0, N, kbeg, kend, tid); }
+    if (kbeg < kend) { ta.load(A, lda, m0, M, kbeg, kend, tid); tb.load((Bsw && kbeg >= ksw) ? Bsw : Bm, ldb, n0, N, kbeg, kend, tid); }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();                 // everyone finished reading the previous tile
         ta.store(As, As + BM * RS, tid);
         tb.store(Bs, Bs + BN * RS, tid);
         __syncthreads();
-        if (k0 + BK < kend) { ta.load(A, lda, m0, M, k0 + BK, kend, tid); tb.load(Bm, ldb, n0, N, k0 + BK, kend, tid); }
+        if (k0 + BK < kend) { ta.load(A, lda, m0, M, k0 + BK, kend, tid); tb.load((Bsw && k0 + BK >= ksw) ? Bsw : Bm, ldb, n0, N, k0 + BK, kend, tid); }
         const unsigned short* ap = As + (32 * w + lo) * RS + 8 * hi;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -151,11 +153,12 @@ extern "C" int sed_gemm_pair(const float* A0, const float* A1, const float* B0, 
 
 static int gemmb_dispatch(const float* A, const float* Bm, const float* bias, float* Cm, const float* A1, const float* B1,
                           const float* bias1, float* C1, int nbatch, int M, int N, int K, int lda, int ldb, int ldc, int transA,
-                          int transB, int split_k, int accumulate, hipStream_t s) {
+                          int transB, int split_k, int accumulate, hipStream_t s, const float* Bsw = nullptr, int ksw = 0) {
     if (M <= 0 || N <= 0 || K <= 0) return SED_OK;
     bool ok = ((uintptr_t)A % 16 == 0) && ((uintptr_t)Bm % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 &&
               ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0) && !(transA && transB);
     if (nbatch == 2) ok = ok && ((uintptr_t)A1 % 16 == 0) && ((uintptr_t)B1 % 16 == 0);
+    if (!ok && Bsw) return SED_ERR_UNSUPPORTED;
     if (!ok) {
         if (nbatch == 2) return sed_gemm_pair(A, A1, Bm, B1, bias, bias1, Cm, C1, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate, s);
         return sed_gemm(A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate, s);
@@ -164,10 +167,11 @@ static int gemmb_dispatch(const float* A, const float* Bm, const float* bias, fl
     int kps = ((K + split_k - 1) / split_k + 31) / 32 * 32;
     split_k = (K + kps - 1) / kps;
     const int atomic = (split_k > 1 || accumulate) ? 1 : 0;
-    const int ntn = N > 64 ? 4 : 2;
+    int ntn = N > 64 ? 4 : 2;
+    if (ntn == 4 && ((N + 127) / 128) * ((M + 127) / 128) * split_k * nbatch < 200) ntn = 2;     // too few workgroups for 256 CUs
     dim3 grid((N + 32 * ntn - 1) / (32 * ntn), (M + 127) / 128, split_k * nbatch);
 #define GEMMB_CASE(ta, tb, nn) \
-    if (transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_bf16x3_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic, A1, B1, bias1, C1, nbatch); return sed_check_launch(); }
+    if (transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_bf16x3_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic, A1, B1, bias1, C1, nbatch, Bsw, ksw); return sed_check_launch(); }
     GEMMB_CASE(0, 0, 2) GEMMB_CASE(0, 0, 4) GEMMB_CASE(0, 1, 2) GEMMB_CASE(0, 1, 4) GEMMB_CASE(1, 0, 2) GEMMB_CASE(1, 0, 4)
 #undef GEMMB_CASE
     return SED_ERR_UNSUPPORTED;
@@ -185,4 +189,13 @@ extern "C" int sed_gemm_pair_bf16x3(const float* A0, const float* A1, const floa
                                     int transA, int transB, int split_k, int accumulate, void* stream) {
     return gemmb_dispatch(A0, B0, bias0, C0, A1, B1, bias1, C1, 2, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate,
                           (hipStream_t)stream);
+}
+
+// C[M][N] = A[M][K] . [B0 ; B1]: the B operand is two row-major tensors stacked along K (rows [0, ksplit) from B0, the rest
+// from B1; ksplit % 32 == 0) -- dX of a bidirectional GRU layer, whose dgi rows hold both directions side by side.
+extern "C" int sed_gemm_kcat_bf16x3(const float* A, const float* B0, const float* B1, float* Cm, int M, int N, int K, int ksplit,
+                                    int lda, int ldb, int ldc, void* stream) {
+    if (ksplit % 32 != 0 || ksplit <= 0 || ksplit >= K) return SED_ERR_ARG;
+    return gemmb_dispatch(A, B0, nullptr, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, 0, 0, 1, 0,
+                          (hipStream_t)stream, B1 - (size_t)ksplit * ldb, ksplit);
 }

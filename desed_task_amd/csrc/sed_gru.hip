@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
                                                        const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K,
                                                        int lda, int ldb, int ldc, int k_per_slice, int atomic,
                                                        const float* __restrict__ A1, const float* __restrict__ B1,
-                                                       const float* __restrict__ bias1, float* __restrict__ C1, int nbatch) {
+                                                       const float* __restrict__ bias1, float* __restrict__ C1, int nbatch,
+                                                       const float* __restrict__ Bsw, int ksw) {
+    // Bsw != null: K-concatenated B -- rows k >= ksw come from Bsw (already offset by -ksw rows); ksw % 32 == 0
     constexpr int BM = 128, BN = 32 * NTN, BK = 32, AP = BK + 1, BNS = BN + 4;
     constexpr int AV = BM * BK / 4 / 256, BV = BK * BN / 4 / 256;     // float4 per thread per tile
     __shared__ float As[BM * AP];
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     auto load_tile = [&](int k0) {
+        const float* Bsrc = (Bsw != nullptr && k0 >= ksw) ? Bsw : Bm;
 #pragma unroll
         for (int u = 0; u < AV; ++u) {
             const int i = tid + 256 * u;
@@ -138,12 +141,12 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
                 const int k = i / (BN / 4), nq = i % (BN / 4);
                 const int gn = n0 + 4 * nq, gk = k0 + k;
                 rb[u] = zero4;
-                if (gn < N && gk < kend) rb[u] = *(const float4*)(Bm + (size_t)gk * ldb + gn);
+                if (gn < N && gk < kend) rb[u] = *(const float4*)(Bsrc + (size_t)gk * ldb + gn);
             } else {
                 const int n = i / (BK / 4), kq = i % (BK / 4);
                 const int gn = n0 + n, gk = k0 + 4 * kq;
                 rb[u] = zero4;
-                if (gn < N && gk < kend) rb[u] = *(const float4*)(Bm + (size_t)gn * ldb + gk);
+                if (gn < N && gk < kend) rb[u] = *(const float4*)(Bsrc + (size_t)gn * ldb + gk);
             }
         }
     };
@@ -209,21 +212,23 @@ __global__ __launch_bounds__(256) void gemm_vec_kernel(const float* __restrict__
 
 static int gemm_dispatch(const float* A, const float* Bm, const float* bias, float* Cm, const float* A1, const float* B1,
                          const float* bias1, float* C1, int nbatch, int M, int N, int K, int lda, int ldb, int ldc, int transA,
-                         int transB, int split_k, int accumulate, hipStream_t s) {
+                         int transB, int split_k, int accumulate, hipStream_t s, const float* Bsw = nullptr, int ksw = 0) {
     if (M <= 0 || N <= 0 || K <= 0) return SED_OK;
     if (split_k < 1) split_k = 1;
     int kps = ((K + split_k - 1) / split_k + 31) / 32 * 32;
     split_k = (K + kps - 1) / kps;
     const int atomic = (split_k > 1 || accumulate) ? 1 : 0;
-    const int ntn = N > 64 ? 4 : 2;
+    int ntn = N > 64 ? 4 : 2;
+    if (ntn == 4 && ((N + 127) / 128) * ((M + 127) / 128) * split_k * nbatch < 200) ntn = 2;     // too few workgroups for 256 CUs
     dim3 grid((N + 32 * ntn - 1) / (32 * ntn), (M + 127) / 128, split_k * nbatch);
     bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)Bm % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 &&
                ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0) && kps % 4 == 0;
     if (nbatch == 2) vec = vec && ((uintptr_t)A1 % 16 == 0) && ((uintptr_t)B1 % 16 == 0);
 #define GEMMV_CASE(ta, tb, nn) \
-    if (vec && transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_vec_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic, A1, B1, bias1, C1, nbatch); return sed_check_launch(); }
+    if (vec && transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_vec_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic, A1, B1, bias1, C1, nbatch, Bsw, ksw); return sed_check_launch(); }
     GEMMV_CASE(0, 0, 2) GEMMV_CASE(0, 0, 4) GEMMV_CASE(0, 1, 2) GEMMV_CASE(0, 1, 4) GEMMV_CASE(1, 0, 2) GEMMV_CASE(1, 0, 4)
 #undef GEMMV_CASE
+    if (Bsw != nullptr) return SED_ERR_UNSUPPORTED;      // the K-concatenated form needs the 16-byte path
     if (nbatch == 2) {          // scalar fallback: two plain launches
         int rc = gemm_dispatch(A, Bm, bias, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate, s);
         if (rc != SED_OK) return rc;
@@ -249,6 +254,15 @@ extern "C" int sed_gemm_pair(const float* A0, const float* A1, const float* B0, 
                              int transB, int split_k, int accumulate, void* stream) {
     return gemm_dispatch(A0, B0, bias0, C0, A1, B1, bias1, C1, 2, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate,
                          (hipStream_t)stream);
+}
+
+// C[M][N] = A[M][K] . [B0 ; B1]: B is two row-major tensors stacked along K (rows [0, ksplit) from B0, the rest from B1;
+// ksplit % 32 == 0).  Exact-f32 MFMA; 16-byte aligned operands required.
+extern "C" int sed_gemm_kcat(const float* A, const float* B0, const float* B1, float* Cm, int M, int N, int K, int ksplit, int lda,
+                             int ldb, int ldc, void* stream) {
+    if (ksplit % 32 != 0 || ksplit <= 0 || ksplit >= K) return SED_ERR_ARG;
+    return gemm_dispatch(A, B0, nullptr, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, 0, 0, 1, 0,
+                         (hipStream_t)stream, B1 - (size_t)ksplit * ldb, ksplit);
 }
 
 // column sums: out[n] = sum_m X[m*ld + n], n < N  (bias gradients); out is zeroed here, atomics across row chunks

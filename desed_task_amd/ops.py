@@ -28,6 +28,7 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+
 def dropout_params(p):
     """-> (thr24, dscale): keep element e iff (hash(e, seed) >> 8) >= thr24."""
     if p <= 0.0:
@@ -248,21 +249,25 @@ class BiGRULayerFn(torch.autograd.Function):
         split = max(1, min(32, BT // 256))
         dwi = [_grad_buf(cfg, w_ih_f), _grad_buf(cfg, w_ih_r)]
         dwh = [_grad_buf(cfg, w_hh_f), _grad_buf(cfg, w_hh_r)]
-        lib.call("sed_zero_buffers", dwi[0].data_ptr(), dwi[0].numel(), dwi[1].data_ptr(), dwi[1].numel(),
-                 dwh[0].data_ptr(), dwh[0].numel(), dwh[1].data_ptr(), dwh[1].numel(), st)     # split-K GEMMs accumulate
         off = 3 * H * 4
-        # dW_ih[d] = dgi[d]^T . x   and   dW_hh[d] = dgh[d]^T . hprev[d]   (K = B*T, split-K, both directions per launch)
-        lib.call(gemm_entry(cfg), dgi.data_ptr(), dgi.data_ptr() + off, x.data_ptr(), x.data_ptr(), None, None,
-                 dwi[0].data_ptr(), dwi[1].data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, 0, st)
-        lib.call(gemm_entry(cfg), dgh.data_ptr(), dgh.data_ptr() + off, hprev.data_ptr(), hprev.data_ptr() + H * 4, None, None,
-                 dwh[0].data_ptr(), dwh[1].data_ptr(), 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, 0, st)
-        d_w_ih, d_w_hh, d_b_ih, d_b_hh = dwi, dwh, dbi, dbh
         dx = None
         if ctx.needs_input_grad[0]:
-            # dx = dgi[fwd] . W_ih[fwd] + dgi[rev] . W_ih[rev]: one launch, both products accumulate into dx
-            dx = torch.zeros(B, T, I, **f32)
-            lib.call(gemm_entry(cfg), dgi.data_ptr(), dgi.data_ptr() + 3 * H * 4, w_ih_f.data_ptr(), w_ih_r.data_ptr(), None, None,
-                     dx.data_ptr(), dx.data_ptr(), BT, I, 3 * H, 6 * H, I, I, 0, 0, 1, 1, st)
+            # the critical path first.  dx = [dgi_fwd | dgi_rev] . [W_ih_fwd ; W_ih_rev]: dgi rows already hold both directions
+            # side by side, so this is ONE product over K = 6H whose B operand switches tensors at k = 3H (no atomics, no
+            # zero fill)
+            dx = torch.empty(B, T, I, **f32)
+            kcat = "sed_gemm_kcat_bf16x3" if gemm_entry(cfg).endswith("bf16x3") else "sed_gemm_kcat"
+            lib.call(kcat, dgi.data_ptr(), w_ih_f.data_ptr(), w_ih_r.data_ptr(), dx.data_ptr(), BT, I, 6 * H, 3 * H, 6 * H, I, I, st)
+        # dW_ih[d] = dgi[d]^T . x   and   dW_hh[d] = dgh[d]^T . hprev[d]   (K = B*T, split-K, both directions per launch).
+        # (Running these on a side stream beside the next layer's recurrence was measured: 5.159 vs 5.174 ms/step, not kept.)
+        ws = st
+        lib.call("sed_zero_buffers", dwi[0].data_ptr(), dwi[0].numel(), dwi[1].data_ptr(), dwi[1].numel(),
+                 dwh[0].data_ptr(), dwh[0].numel(), dwh[1].data_ptr(), dwh[1].numel(), ws)    # split-K GEMMs accumulate
+        lib.call(gemm_entry(cfg), dgi.data_ptr(), dgi.data_ptr() + off, x.data_ptr(), x.data_ptr(), None, None,
+                 dwi[0].data_ptr(), dwi[1].data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, 0, ws)
+        lib.call(gemm_entry(cfg), dgh.data_ptr(), dgh.data_ptr() + off, hprev.data_ptr(), hprev.data_ptr() + H * 4, None, None,
+                 dwh[0].data_ptr(), dwh[1].data_ptr(), 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, 0, ws)
+        d_w_ih, d_w_hh, d_b_ih, d_b_hh = dwi, dwh, dbi, dbh
         return (dx, d_w_ih[0], d_w_hh[0], d_b_ih[0], d_b_hh[0], d_w_ih[1], d_w_hh[1], d_b_ih[1], d_b_hh[1], None)
 
 

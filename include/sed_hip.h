@@ -146,6 +146,12 @@ int sed_gemm_pair(const float* A0, const float* A1, const float* B0, const float
  * ~8e-6 relative, fp32 in/out).  Falls back to the exact-f32 kernels when an operand is not 16-byte aligned. */
 int sed_gemm_bf16x3(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
                     int ldc, int transA, int transB, int split_k, int accumulate, void* stream);
+/* C[M][N] = A[M][K] . [B0 ; B1] (row-major, no transposes): B is two tensors stacked along K, rows [0, ksplit) from B0 and
+ * the rest from B1, ksplit % 32 == 0 -- dX of a bidirectional GRU layer.  16-byte aligned operands. */
+int sed_gemm_kcat(const float* A, const float* B0, const float* B1, float* Cm, int M, int N, int K, int ksplit, int lda,
+                  int ldb, int ldc, void* stream);
+int sed_gemm_kcat_bf16x3(const float* A, const float* B0, const float* B1, float* Cm, int M, int N, int K, int ksplit, int lda,
+                         int ldb, int ldc, void* stream);
 int sed_gemm_pair_bf16x3(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
                          const float* bias1, float* C0, float* C1, int M, int N, int K, int lda, int ldb, int ldc,
                          int transA, int transB, int split_k, int accumulate, void* stream);

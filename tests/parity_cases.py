@@ -221,6 +221,17 @@ def case_gemm(dev, entry="sed_gemm"):
                  split, 0, _lib.stream_ptr(Ad))
         err = (C.cpu().double() - ref).abs().max().item()
         assert err < 1e-4 * max(1.0, ref.abs().max().item()), (M, N, K, ta, tb, err)
+    # K-concatenated B operand (dX of a bidirectional GRU layer): C = A . [B0 ; B1]
+    kcat = "sed_gemm_kcat" if entry == "sed_gemm" else "sed_gemm_kcat_bf16x3"
+    for (M, N, K, ks) in ((132, 128, 768, 384), (70 * 4, 256, 96, 64)):
+        A = torch.randn(M, K, generator=g)
+        B0, B1 = torch.randn(ks, N, generator=g), torch.randn(K - ks, N, generator=g)
+        ref = A.double() @ torch.cat([B0, B1]).double()
+        Ad, B0d, B1d = to(dev, A, B0, B1)
+        C = torch.full((M, N), 7.0, device=Ad.device)             # overwritten, not accumulated
+        lib.call(kcat, Ad.data_ptr(), B0d.data_ptr(), B1d.data_ptr(), C.data_ptr(), M, N, K, ks, K, N, N, _lib.stream_ptr(Ad))
+        err = (C.cpu().double() - ref).abs().max().item()
+        assert err < 1e-4 * max(1.0, ref.abs().max().item()), (kcat, M, N, K, err)
 
 
 # ------------------------------------------------------------------------------------------------
