@@ -423,22 +423,144 @@ __global__ __launch_bounds__(512, 4) void glu_wide_fwd_kernel(const float* __res
         }
     }
 }
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 variant of the weight-stationary forward (conv_precision = "bf16x3"): the C x C linear of the gate runs as
+// three v_mfma_f32_32x32x16_bf16 per product on operands split x = hi + lo (see sed_common.h), 3/16 of the f32-MFMA
+// cost, fp32-level accuracy.  The activation tile sits in LDS as bf16 hi / lo planes [row][C + 8] (16-byte fragment
+// reads, conflict-free per quarter wave), the wave's Wg fragments (hi and lo) stay in C/2 VGPRs as before, and the
+// epilogue rebuilds xn = hi + lo (exact to 2^-17 relative) for the sigmoid gate.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_pair_sum(unsigned short h, unsigned short l) { return bf16_to_f32(h) + bf16_to_f32(l); }
+
+template <int C>
+__global__ __launch_bounds__(512, 4) void glu_wide_fwd_b_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                                const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                                float* __restrict__ out, int B, int T, int F, uint32_t seed,
+                                                                uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;
+    constexpr int RS = C + 8, NT = C / 32, WN = NT, WM = 8 / WN, ROWS = 32 * WM, KS = C / 16;
+    constexpr int NLD = ROWS * (C / 4) / 512;
+    static_assert(512 % (C / 4) == 0 && ROWS >= 64, "staging layout");
+    SED_DYN_SMEM(smem);
+    unsigned short* xh = (unsigned short*)smem;                        // [ROWS][RS] hi plane of xn
+    unsigned short* xl = xh + ROWS * RS;                               // lo plane
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int wn = w % WN, wm = w / WN;
+    const int R = B * T * F, ntiles = (R + ROWS - 1) / ROWS;
+    const int n = wn * 32 + lo;
+    const int v = tid % (C / 4), r0 = tid / (C / 4);                   // this thread's channel quad / first row when staging
+    constexpr int RSTEP = 512 / (C / 4);
+    // ---- B fragments: Wg rows through LDS (coalesced global reads), split into bf16 planes, 64 rows per pass ----
+    s16x8 bh[KS], bl[KS];
+#pragma unroll
+    for (int p = 0; p < C / 64; ++p) {
+        __syncthreads();
+        for (int i = tid; i < 64 * (C / 4); i += 512) {
+            const int row = i / (C / 4), q = i - row * (C / 4);
+            const float4 val = *(const float4*)(Wg + (size_t)(p * 64 + row) * C + 4 * q);
+            uint2 hv, lv;
+            bf16_split2(val.x, val.y, hv.x, lv.x);
+            bf16_split2(val.z, val.w, hv.y, lv.y);
+            *(uint2*)(xh + row * RS + 4 * q) = hv;
+            *(uint2*)(xl + row * RS + 4 * q) = lv;
+        }
+        __syncthreads();
+        if (wn * 32 / 64 == p) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bh[ks] = *(const s16x8*)(xh + (n - p * 64) * RS + 16 * ks + 8 * hi);
+                bl[ks] = *(const s16x8*)(xl + (n - p * 64) * RS + 16 * ks + 8 * hi);
+            }
+        }
+    }
+    const float bias_n = bg[n];
+    float sc4[4], sh4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sc4[i] = stats[2 * C + 4 * v + i]; sh4[i] = stats[3 * C + 4 * v + i]; }
+
+    float4 ld[NLD];
+    auto load_tile = [&](int tile) {
+        const int row0 = tile * ROWS;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int m = r0 + RSTEP * u;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + m < R) {
+                val = *(const float4*)(y + (size_t)(row0 + m) * C + 4 * v);
+                val.x = fmaf(val.x, sc4[0], sh4[0]); val.y = fmaf(val.y, sc4[1], sh4[1]);
+                val.z = fmaf(val.z, sc4[2], sh4[2]); val.w = fmaf(val.w, sc4[3], sh4[3]);
+            }
+            ld[u] = val;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int m = r0 + RSTEP * u;
+            uint2 hv, lv;
+            bf16_split2(ld[u].x, ld[u].y, hv.x, lv.x);
+            bf16_split2(ld[u].z, ld[u].w, hv.y, lv.y);
+            *(uint2*)(xh + m * RS + 4 * v) = hv;
+            *(uint2*)(xl + m * RS + 4 * v) = lv;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * ROWS;
+        __syncthreads();                                               // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);    // in flight under the MFMAs below
+        f32x16 acc = f32x16_zero();
+        const unsigned short* ap = xh + (wm * 32 + lo) * RS + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const s16x8 a_hi = *(const s16x8*)(ap + 16 * ks);
+            const s16x8 a_lo = *(const s16x8*)(ap + ROWS * RS + 16 * ks);
+            acc = mfma32_bf16(a_lo, bh[ks], acc);
+            acc = mfma32_bf16(a_hi, bl[ks], acc);
+            acc = mfma32_bf16(a_hi, bh[ks], acc);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mbase = wm * 32 + 8 * j + 4 * hi;
+            float vv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t e = (uint32_t)(row0 + mbase + q) * (uint32_t)C + (uint32_t)n;
+                const float xn = bf16_pair_sum(xh[(mbase + q) * RS + n], xl[(mbase + q) * RS + n]);
+                const float r = (acc[4 * j + q] + bias_n) * sed_fast_sigmoid(xn);
+                vv[q] = sed_keep(e, seed, thr24) ? r * dscale : 0.f;
+            }
+            const int o = (row0 + mbase) / 2;                          // rows past R hold zeros and are never stored
+            if (2 * o < R) out[(size_t)o * C + n] = 0.5f * (vv[0] + vv[1]);
+            if (2 * o + 2 < R) out[(size_t)(o + 1) * C + n] = 0.5f * (vv[2] + vv[3]);
+        }
+    }
+}
+
 // persistent-grid cap; SED_GLU_GRID_CAP (tests) forces several tiles per workgroup on small problems
 static inline int glu_grid_cap(int dflt) {
     const char* e = getenv("SED_GLU_GRID_CAP");
     return e ? atoi(e) : dflt;
 }
-template <int C>
+template <int C, bool SPLIT>
 static int launch_glu_wide_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
                                uint32_t seed, uint32_t thr24, float dscale, const unsigned* seed_dev, hipStream_t s) {
     constexpr int ROWS = 32 * (8 / (C / 32));
-    constexpr int SMEM = ROWS * (C + 1) * 4;
+    constexpr int SMEM = SPLIT ? 2 * ROWS * (C + 8) * 2 : ROWS * (C + 1) * 4;
     const int ntiles = (B * T * F + ROWS - 1) / ROWS;
     const int cap = glu_grid_cap(512);                                  // two 8-wave workgroups per CU
     int grid = ntiles < cap ? ntiles : cap;
     if (grid < 1) return SED_OK;
-    SED_MAX_SMEM((glu_wide_fwd_kernel<C>), SMEM);
-    SED_LAUNCH((glu_wide_fwd_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev);
+    if (SPLIT) {
+        SED_MAX_SMEM((glu_wide_fwd_b_kernel<C>), SMEM);
+        SED_LAUNCH((glu_wide_fwd_b_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev);
+    } else {
+        SED_MAX_SMEM((glu_wide_fwd_kernel<C>), SMEM);
+        SED_LAUNCH((glu_wide_fwd_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev);
+    }
     return sed_check_launch();
 }
 
@@ -446,7 +568,7 @@ static int launch_glu_wide_fwd(const float* y, const float* stats, const float* 
 // dropout: keep element e when hash(e, seed) >> 8 >= thr24 (thr24 = round(p * 2^24)); dscale = 1/(1-p).
 extern "C" int sed_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
                            int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale,
-                           const unsigned* seed_dev, void* stream) {
+                           const unsigned* seed_dev, int split_bf16, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (F % PF != 0) return SED_ERR_UNSUPPORTED;
     if (C == 16 && PT == 2 && PF == 2 && F % 8 == 0) {
@@ -458,8 +580,10 @@ extern "C" int sed_glu_fwd(const float* y, const float* stats, const float* Wg, 
         return sed_check_launch();
     }
     if (PT == 1 && PF == 2) {
-        if (C == 128) return launch_glu_wide_fwd<128>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev, s);
-        if (C == 64) return launch_glu_wide_fwd<64>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev, s);
+        if (C == 128 && split_bf16) return launch_glu_wide_fwd<128, true>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev, s);
+        if (C == 64 && split_bf16) return launch_glu_wide_fwd<64, true>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev, s);
+        if (C == 128) return launch_glu_wide_fwd<128, false>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev, s);
+        if (C == 64) return launch_glu_wide_fwd<64, false>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev, s);
     }
 #define GLU_CASE(c, pt, pf) \
     if (C == c && PT == pt && PF == pf) return launch_glu_fwd<c, pt, pf>(y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev, s);
@@ -865,12 +989,253 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_kernel(const float* __restri
         dst[n] = a_dbg; dst[C + n] = a_dgam; dst[2 * C + n] = a_dbet;
     }
 }
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 variant of the weight-stationary backward: all three GEMMs of a tile on v_mfma_f32_32x32x16_bf16 (three per
+// product, fp32-level accuracy).  GEMM1 (lin = xhat (gamma Wg)^T) and GEMM2 (dxn = dlin Wg + e) contract over channels,
+// so their A operands are row-major [row][C + 8] hi/lo planes; GEMM3 (dWg' = dlin^T xhat) contracts over ROWS, so it reads
+// [channel][ROWS + 8] planes with the pixel octets XOR-swizzled by bits 4..6 of the row (as in conv_wgrad_bf16_kernel).
+// Both layouts of xhat are written from one 4 row x 4 channel register block per thread; both layouts of dlin straight
+// from the accumulator registers of epilogue 1 (a lane holds 4 consecutive rows of its column: one 8-byte transposed store).
+// Both orientations of Wg live in registers as bf16 fragments.  GEMM3 uses xhat instead of xn = gamma xhat + beta:
+// dWg[n][c] = gamma_c dWg'[n][c] + beta_c dbg[n] is applied by glu_bwd_reduce_kernel (fix = 1).
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512) void glu_wide_bwd_b_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                             const float* __restrict__ gout, float* __restrict__ dz,
+                                                             float* __restrict__ part, int B, int T, int F, uint32_t seed,
+                                                             uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;
+    constexpr int NT = C / 32, WN = NT, WM = 8 / WN, ROWS = 32 * WM, RS = C + 8, RT = ROWS + 8, KS = C / 16;
+    constexpr int NT3 = NT * NT, TPW = NT3 >= 8 ? NT3 / 8 : 1, KSPLIT = NT3 >= 8 ? 1 : 8 / NT3, KS3 = ROWS / 16 / KSPLIT;
+    static_assert(ROWS * C / 16 == 512, "one 4x4 block per thread");
+    SED_DYN_SMEM(smem);
+    unsigned short* xh = (unsigned short*)smem;      // xhat  [ROWS][RS] hi | lo
+    unsigned short* xl = xh + ROWS * RS;
+    unsigned short* xth = xl + ROWS * RS;            // xhat^T [C][RT] hi | lo (swizzled octets)
+    unsigned short* xtl = xth + C * RT;
+    unsigned short* dh = xtl + C * RT;               // dlin  [ROWS][RS] hi | lo
+    unsigned short* dl = dh + ROWS * RS;
+    unsigned short* dth = dl + ROWS * RS;            // dlin^T [C][RT] hi | lo (swizzled octets)
+    unsigned short* dtl = dth + C * RT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int wn = w % WN, wm = w / WN, n = wn * 32 + lo;
+    const int R = B * T * F, ntiles = (R + ROWS - 1) / ROWS;
+
+    // ---- Wg fragments: b2 = columns of Wg (GEMM2), b1 = rows of gamma (.) Wg (GEMM1); beta folded into the bias ----
+    s16x8 b1h[KS], b1l[KS], b2h[KS], b2l[KS];
+    float biasp = bg[n];
+#pragma unroll
+    for (int p = 0; p < C / 64; ++p) {               // 64 rows of Wg per pass through the (still unused) xhat planes
+#pragma unroll
+        for (int fold = 0; fold < 2; ++fold) {
+            __syncthreads();
+            for (int i = tid; i < 64 * (C / 4); i += 512) {
+                const int row = i / (C / 4), q = i - row * (C / 4);
+                float4 val = *(const float4*)(Wg + (size_t)(p * 64 + row) * C + 4 * q);
+                if (fold) { val.x *= gamma[4 * q]; val.y *= gamma[4 * q + 1]; val.z *= gamma[4 * q + 2]; val.w *= gamma[4 * q + 3]; }
+                uint2 hv, lv;
+                bf16_split2(val.x, val.y, hv.x, lv.x);
+                bf16_split2(val.z, val.w, hv.y, lv.y);
+                *(uint2*)(xh + row * RS + 4 * q) = hv;
+                *(uint2*)(xl + row * RS + 4 * q) = lv;
+            }
+            __syncthreads();
+            if (!fold) {
+                // column n of rows 64p..64p+63: k-steps 4p..4p+3 of this lane's GEMM2 fragment; and beta . Wg[n][:] for rows here
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    s16x8 fh, fl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        fh[e] = (short)xh[(16 * kk + 8 * hi + e) * RS + n];
+                        fl[e] = (short)xl[(16 * kk + 8 * hi + e) * RS + n];
+                    }
+                    b2h[4 * p + kk] = fh; b2l[4 * p + kk] = fl;
+                }
+                if (wn * 32 / 64 == p) {
+                    const int rown = n - p * 64;
+                    for (int k = 0; k < C; ++k) biasp = fmaf(beta[k], bf16_pair_sum(xh[rown * RS + k], xl[rown * RS + k]), biasp);
+                }
+            } else if (wn * 32 / 64 == p) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    b1h[ks] = *(const s16x8*)(xh + (n - p * 64) * RS + 16 * ks + 8 * hi);
+                    b1l[ks] = *(const s16x8*)(xl + (n - p * 64) * RS + 16 * ks + 8 * hi);
+                }
+            }
+        }
+    }
+    const float gn = gamma[n], bn = beta[n];
+    const int cq = tid % (C / 4), rq = tid / (C / 4);      // this thread's 4x4 staging block: channels 4cq.., rows 4rq..
+    float mu4[4], is4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { mu4[i] = stats[4 * cq + i]; is4[i] = stats[C + 4 * cq + i]; }
+
+    f32x16 P[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) P[i] = f32x16_zero();
+    float a_dbg = 0.f, a_dgam = 0.f, a_dbet = 0.f;
+
+    float4 ld0, ld1, ld2, ld3;
+    auto load_row = [&](int row) -> float4 {
+        float4 val = make_float4(mu4[0], mu4[1], mu4[2], mu4[3]);       // -> xhat 0 for rows past the end
+        if (row < R) val = *(const float4*)(y + (size_t)row * C + 4 * cq);
+        val.x = (val.x - mu4[0]) * is4[0]; val.y = (val.y - mu4[1]) * is4[1];
+        val.z = (val.z - mu4[2]) * is4[2]; val.w = (val.w - mu4[3]) * is4[3];
+        return val;
+    };
+    auto load_tile = [&](int tile) {
+        const int row = tile * ROWS + 4 * rq;
+        ld0 = load_row(row); ld1 = load_row(row + 1); ld2 = load_row(row + 2); ld3 = load_row(row + 3);
+    };
+    auto store_rm = [&](const float4 val, int m) {                      // one row of the block -> row-major planes
+        uint2 hv, lv;
+        bf16_split2(val.x, val.y, hv.x, lv.x);
+        bf16_split2(val.z, val.w, hv.y, lv.y);
+        *(uint2*)(xh + m * RS + 4 * cq) = hv;
+        *(uint2*)(xl + m * RS + 4 * cq) = lv;
+    };
+    auto store_tr = [&](float a, float b, float c, float d, int ch) {   // one channel of the block -> transposed planes
+        uint2 hv, lv;
+        bf16_split2(a, b, hv.x, lv.x);
+        bf16_split2(c, d, hv.y, lv.y);
+        const int off = ch * RT + 4 * (rq ^ (2 * ((ch >> 4) & 7)));
+        *(uint2*)(xth + off) = hv;
+        *(uint2*)(xtl + off) = lv;
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * ROWS;
+        __syncthreads();
+        store_rm(ld0, 4 * rq); store_rm(ld1, 4 * rq + 1); store_rm(ld2, 4 * rq + 2); store_rm(ld3, 4 * rq + 3);
+        store_tr(ld0.x, ld1.x, ld2.x, ld3.x, 4 * cq);
+        store_tr(ld0.y, ld1.y, ld2.y, ld3.y, 4 * cq + 1);
+        store_tr(ld0.z, ld1.z, ld2.z, ld3.z, 4 * cq + 2);
+        store_tr(ld0.w, ld1.w, ld2.w, ld3.w, 4 * cq + 3);
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+        float g8[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rr = row0 + 32 * wm + 8 * j + 4 * hi + 2 * h;
+                g8[2 * j + h] = rr < R ? gout[(size_t)(rr / 2) * C + n] * (0.5f * dscale) : 0.f;
+            }
+        // ---- GEMM1 ----
+        f32x16 acc = f32x16_zero();
+        {
+            const unsigned short* ap = xh + (32 * wm + lo) * RS + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8 a_hi = *(const s16x8*)(ap + 16 * ks);
+                const s16x8 a_lo = *(const s16x8*)(ap + ROWS * RS + 16 * ks);
+                acc = mfma32_bf16(a_lo, b1h[ks], acc);
+                acc = mfma32_bf16(a_hi, b1l[ks], acc);
+                acc = mfma32_bf16(a_hi, b1h[ks], acc);
+            }
+        }
+        // ---- epilogue 1: dlin -> both LDS layouts, e -> acc (seed of GEMM2) ----
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float dv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * j + q, m = 32 * wm + 8 * j + 4 * hi + q;
+                const uint32_t e_idx = (uint32_t)(row0 + m) * (uint32_t)C + (uint32_t)n;
+                float dlin = 0.f, e = 0.f;
+                if (row0 + m < R) {
+                    const float xn = fmaf(bf16_pair_sum(xh[m * RS + n], xl[m * RS + n]), gn, bn);
+                    const float sg = sed_fast_sigmoid(xn);
+                    const float lin = acc[r] + biasp;
+                    const float g = sed_keep(e_idx, seed, thr24) ? g8[2 * j + (q >> 1)] : 0.f;
+                    dlin = g * sg;
+                    e = g * lin * sg * (1.0f - sg);
+                }
+                unsigned short hh, ll;
+                bf16_split(dlin, hh, ll);
+                dh[m * RS + n] = hh;
+                dl[m * RS + n] = ll;
+                dv[q] = dlin;
+                acc[r] = e;
+                a_dbg += dlin;
+            }
+            uint2 hv, lv;
+            bf16_split2(dv[0], dv[1], hv.x, lv.x);
+            bf16_split2(dv[2], dv[3], hv.y, lv.y);
+            const int rqd = 8 * wm + 2 * j + hi;                        // row quad of rows 32wm + 8j + 4hi .. +3
+            const int off = n * RT + 4 * (rqd ^ (2 * ((n >> 4) & 7)));
+            *(uint2*)(dth + off) = hv;
+            *(uint2*)(dtl + off) = lv;
+        }
+        __syncthreads();
+        // ---- GEMM2: dxn = dlin . Wg + e ----
+        {
+            const unsigned short* ap = dh + (32 * wm + lo) * RS + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8 a_hi = *(const s16x8*)(ap + 16 * ks);
+                const s16x8 a_lo = *(const s16x8*)(ap + ROWS * RS + 16 * ks);
+                acc = mfma32_bf16(a_lo, b2h[ks], acc);
+                acc = mfma32_bf16(a_hi, b2l[ks], acc);
+                acc = mfma32_bf16(a_hi, b2h[ks], acc);
+            }
+        }
+        // ---- epilogue 2: dz = dxn * gamma, BN reductions ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * wm + mfma32_row(r, lane);
+            if (row0 + m < R) {
+                const float dxn = acc[r];
+                a_dgam = fmaf(dxn, bf16_pair_sum(xh[m * RS + n], xl[m * RS + n]), a_dgam);
+                a_dbet += dxn;
+                dz[(size_t)(row0 + m) * C + n] = dxn * gn;
+            }
+        }
+        // ---- GEMM3: P'[n'][c] += sum_rows dlin[row][n'] * xhat[row][c] ----
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int id = NT3 >= 8 ? w * TPW + i : w % NT3, mt = id / NT, ct = id % NT;
+            const int ks0 = NT3 >= 8 ? 0 : (w / NT3) * KS3;
+            const int rowa = mt * 32 + lo, rowb = ct * 32 + lo;
+#pragma unroll
+            for (int ks = 0; ks < KS3; ++ks) {
+                const int oct = 2 * (ks0 + ks) + hi;
+                const int offa = rowa * RT + 8 * (oct ^ ((rowa >> 4) & 7)), offb = rowb * RT + 8 * (oct ^ ((rowb >> 4) & 7));
+                const s16x8 a_hi = *(const s16x8*)(dth + offa), a_lo = *(const s16x8*)(dtl + offa);
+                const s16x8 b_hi = *(const s16x8*)(xth + offb), b_lo = *(const s16x8*)(xtl + offb);
+                P[i] = mfma32_bf16(a_lo, b_hi, P[i]);
+                P[i] = mfma32_bf16(a_hi, b_lo, P[i]);
+                P[i] = mfma32_bf16(a_hi, b_hi, P[i]);
+            }
+        }
+    }
+    float* mine = part + (size_t)blockIdx.x * (KSPLIT * C * C + WM * 3 * C);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int id = NT3 >= 8 ? w * TPW + i : w % NT3, mt = id / NT, ct = id % NT, c = ct * 32 + lo;
+        float* dst = mine + (NT3 >= 8 ? 0 : w / NT3) * C * C;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(mt * 32 + mfma32_row(r, lane)) * C + c] = P[i][r];
+    }
+    a_dbg += __shfl_xor(a_dbg, 32); a_dgam += __shfl_xor(a_dgam, 32); a_dbet += __shfl_xor(a_dbet, 32);
+    if (hi == 0) {
+        float* dst = mine + KSPLIT * C * C + wm * 3 * C;
+        dst[n] = a_dbg; dst[C + n] = a_dgam; dst[2 * C + n] = a_dbet;
+    }
+}
 // sums the nblk per-workgroup partials of glu_wide_bwd_kernel: [KS][C][C] dWg slabs, then [WMS][3][C] (dbg, dgamma, dbeta).
 // One workgroup per 64 consecutive outputs: 16 float4 columns x 16 groups of partials, fixed summation order.
 __global__ __launch_bounds__(256) void glu_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dWg,
                                                              float* __restrict__ dbg, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, int nblk, int C, int KS, int WMS) {
+                                                             float* __restrict__ dbeta, int nblk, int C, int KS, int WMS,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int fix) {
+    // fix != 0 (split-bf16 kernel): the dWg slabs hold dWg' = dlin^T xhat; dWg[n][c] = gamma_c dWg'[n][c] + beta_c dbg[n]
     __shared__ float4 red[16][16];
+    __shared__ float sdb[256];
     const int tid = threadIdx.x, col = tid & 15, grp = tid >> 4, e = blockIdx.x * 64 + 4 * col;
     const int CC = C * C, PART = KS * CC + WMS * 3 * C;
     // outputs [0, CC) are dWg with KS slabs per partial; [CC, CC + 3C) the three vectors with WMS slabs (C % 4 == 0 keeps
@@ -890,9 +1255,30 @@ __global__ __launch_bounds__(256) void glu_bwd_reduce_kernel(const float* __rest
     }
     red[grp][col] = acc;
     __syncthreads();
+    float dbn = 0.f;
+    if (fix && blockIdx.x * 64 < CC) {               // dbg[n] for this block's row n = (blockIdx.x * 64) / C   (C >= 64)
+        const int nrow = (blockIdx.x * 64) / C;
+        float sacc = 0.f;
+        for (int i = tid; i < nblk * WMS; i += 256) {
+            const int b = i / WMS, k = i - b * WMS;
+            sacc += part[(size_t)b * PART + (size_t)KS * CC + k * 3 * C + nrow];
+        }
+        sdb[tid] = sacc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) sdb[tid] += sdb[tid + st];
+            __syncthreads();
+        }
+        dbn = sdb[0];
+    }
     if (grp == 0 && e < CC + 3 * C) {
 #pragma unroll
         for (int g = 1; g < 16; ++g) { const float4 v = red[g][col]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        if (fix && isw) {
+            const int c = e % C;
+            acc.x = fmaf(gamma[c], acc.x, beta[c] * dbn); acc.y = fmaf(gamma[c + 1], acc.y, beta[c + 1] * dbn);
+            acc.z = fmaf(gamma[c + 2], acc.z, beta[c + 2] * dbn); acc.w = fmaf(gamma[c + 3], acc.w, beta[c + 3] * dbn);
+        }
         float* dst;
         if (isw) dst = dWg + e;
         else {
@@ -902,21 +1288,28 @@ __global__ __launch_bounds__(256) void glu_bwd_reduce_kernel(const float* __rest
         *(float4*)dst = acc;
     }
 }
-template <int C>
+template <int C, bool SPLIT>
 static int launch_glu_wide_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
                                const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
                                float* scratch, int B, int T, int F, uint32_t seed, uint32_t thr24, float dscale, const unsigned* seed_dev, hipStream_t s) {
     constexpr int ROWS = 32 * (8 / (C / 32)), WMS = 8 / (C / 32), KS = (C / 32) * (C / 32) >= 8 ? 1 : 8 / ((C / 32) * (C / 32));
     if (!scratch) return SED_ERR_ARG;
-    constexpr int SMEM = (2 * ROWS + (C > 64 ? C : 0)) * (C + 1) * 4;
+    constexpr int SMEM = SPLIT ? 8 * (ROWS * (C + 8) + C * (ROWS + 8)) : (2 * ROWS + (C > 64 ? C : 0)) * (C + 1) * 4;
     const int ntiles = (B * T * F + ROWS - 1) / ROWS;
     const int cap = glu_grid_cap(256);                                  // register-bound: one workgroup per CU
     int grid = ntiles < cap ? ntiles : cap;
     if (grid < 1) { sed_zero4(s, dWg, C * C, dbg, C, dgamma, C, dbeta, C); return SED_OK; }
-    SED_MAX_SMEM((glu_wide_bwd_kernel<C>), SMEM);
-    SED_LAUNCH((glu_wide_bwd_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, gamma, beta, Wg, bg, gout, dz, scratch, B, T, F,
-               seed, thr24, dscale, seed_dev);
-    SED_LAUNCH(glu_bwd_reduce_kernel, dim3((C * C + 3 * C + 63) / 64), dim3(256), 0, s, scratch, dWg, dbg, dgamma, dbeta, grid, C, KS, WMS);
+    if (SPLIT) {
+        SED_MAX_SMEM((glu_wide_bwd_b_kernel<C>), SMEM);
+        SED_LAUNCH((glu_wide_bwd_b_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, gamma, beta, Wg, bg, gout, dz, scratch, B, T, F,
+                   seed, thr24, dscale, seed_dev);
+    } else {
+        SED_MAX_SMEM((glu_wide_bwd_kernel<C>), SMEM);
+        SED_LAUNCH((glu_wide_bwd_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, gamma, beta, Wg, bg, gout, dz, scratch, B, T, F,
+                   seed, thr24, dscale, seed_dev);
+    }
+    SED_LAUNCH(glu_bwd_reduce_kernel, dim3((C * C + 3 * C + 63) / 64), dim3(256), 0, s, scratch, dWg, dbg, dgamma, dbeta, grid, C, KS, WMS,
+               gamma, beta, SPLIT ? 1 : 0);
     return sed_check_launch();
 }
 
@@ -937,12 +1330,17 @@ extern "C" long long sed_glu_bwd_scratch_floats(int B, int T, int F, int C, int 
 extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
                            const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
                            float* scratch, int B, int T, int F, int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale,
-                           const unsigned* seed_dev, void* stream) {
+                           const unsigned* seed_dev, int split_bf16, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (F % PF != 0) return SED_ERR_UNSUPPORTED;
     if (PT == 1 && PF == 2) {
-        if (C == 128) return launch_glu_wide_bwd<128>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
-        if (C == 64) return launch_glu_wide_bwd<64>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
+        // (C = 128 stays on the exact-f32 kernel: both bf16 fragment sets of Wg are 128 VGPRs per wave and the split kernel
+        //  spills -- 208 vs 170 us at F = 16; SED_GLU_BWD128_SPLIT=1 selects it for experiments)
+        if (C == 128 && split_bf16 && getenv("SED_GLU_BWD128_SPLIT") != nullptr)
+            return launch_glu_wide_bwd<128, true>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
+        if (C == 64 && split_bf16) return launch_glu_wide_bwd<64, true>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
+        if (C == 128) return launch_glu_wide_bwd<128, false>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
+        if (C == 64) return launch_glu_wide_bwd<64, false>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
     }
     sed_zero4(s, dWg, C * C, dbg, C, dgamma, C, dbeta, C);
     if (T % PT != 0) (void)hipMemsetAsync(dz, 0, (size_t)B * T * F * C * 4, s);

@@ -134,7 +134,7 @@ class ConvBlockFn(torch.autograd.Function):
         out = torch.empty(B, T // PT, F // PF, COUT, device=dev, dtype=torch.float32)
         glu_w = glu_w.contiguous()
         lib.call("sed_glu_fwd", y.data_ptr(), stats.data_ptr(), glu_w.data_ptr(), glu_b.data_ptr(), out.data_ptr(), B, T, F, COUT,
-                 PT, PF, int(seed), thr24, dscale, _graph.seed_dev(seed), st)
+                 PT, PF, int(seed), thr24, dscale, _graph.seed_dev(seed), int(cfg.get("conv_precision", "f32") == "bf16x3"), st)
         ctx.save_for_backward(x, y, stats, conv_w, bn_w, bn_b, glu_w, glu_b, conv_b)
         ctx.meta = (first, B, T, F, CIN, COUT, PT, PF, training, seed, thr24, dscale, bounds)
         ctx.cfg = cfg
@@ -159,7 +159,8 @@ class ConvBlockFn(torch.autograd.Function):
         gscratch = torch.empty(nscr, **f32) if nscr else None
         lib.call("sed_glu_bwd", y.data_ptr(), stats.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(), glu_w.data_ptr(), glu_b.data_ptr(),
                  gout.data_ptr(), dz.data_ptr(), d_glu_w.data_ptr(), d_glu_b.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(),
-                 _p(gscratch), B, T, F, COUT, PT, PF, int(seed), thr24, dscale, _graph.seed_dev(seed), st)
+                 _p(gscratch), B, T, F, COUT, PT, PF, int(seed), thr24, dscale, _graph.seed_dev(seed),
+                 int(cfg.get("conv_precision", "f32") == "bf16x3"), st)
         d_bias = _grad_buf(cfg, conv_b)
         d_w = _grad_buf(cfg, conv_w)
         dx = None

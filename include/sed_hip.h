@@ -94,9 +94,11 @@ int sed_bn_finalize(const float* partial, int nblocks, int C, float count, const
                     int update_running, void* stream);
 
 /* BN-apply + GLU (CNN.py:11-16) + Dropout (:90-91) + AvgPool2d (:96-98), fused.  y (B,T,F,C) -> out (B,T/PT,F/PF,C).
- * Dropout keeps element e iff (hash(e,seed)>>8) >= thr24; dscale = 1/(1-p). */
+ * Dropout keeps element e iff (hash(e,seed)>>8) >= thr24; dscale = 1/(1-p).
+ * split_bf16 != 0: the C x C gate linear of the 64/128-channel blocks runs on the split-bf16 MFMA (fp32-level accuracy). */
 int sed_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
-                int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, const unsigned* seed_dev, void* stream);
+                int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale, const unsigned* seed_dev, int split_bf16,
+                void* stream);
 
 /* Floats of scratch sed_glu_bwd needs (per-workgroup partial sums, reduced in a fixed order; 0 = none). */
 long long sed_glu_bwd_scratch_floats(int B, int T, int F, int C, int PT, int PF);
@@ -105,7 +107,7 @@ long long sed_glu_bwd_scratch_floats(int B, int T, int F, int C, int PT, int PF)
 int sed_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
                 const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
                 float* scratch, int B, int T, int F, int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale,
-                const unsigned* seed_dev, void* stream);
+                const unsigned* seed_dev, int split_bf16, void* stream);
 
 /* BatchNorm backward apply in place: dz -> dy = dL/d(conv output); dbias (C) = conv-bias gradient. */
 int sed_bn_bwd_apply(const float* y, float* dz, const float* stats, const float* gamma, const float* dgamma,

@@ -31,11 +31,12 @@ for (C, T, F) in [(64, 156, 32), (128, 156, 16), (128, 156, 2)]:
     for v in variants:
         lib = ctypes.CDLL(os.path.join(HERE, "_glu_v%d.so" % v))
         ff, fb = lib.sed_glu_fwd, lib.sed_glu_bwd
-        ff.argtypes = [P] * 5 + [I] * 6 + [ctypes.c_uint, ctypes.c_uint, ctypes.c_float, P]
-        fb.argtypes = [P] * 13 + [I] * 6 + [ctypes.c_uint, ctypes.c_uint, ctypes.c_float, P]
-        fa = (y.data_ptr(), stats.data_ptr(), Wg.data_ptr(), bg.data_ptr(), out.data_ptr(), B, T, F, C, 1, 2, 7, 1 << 23, 2.0, st)
+        split = int(os.environ.get("GLU_SPLIT", "1"))
+        ff.argtypes = [P] * 5 + [I] * 6 + [ctypes.c_uint, ctypes.c_uint, ctypes.c_float, P, I, P]
+        fb.argtypes = [P] * 13 + [I] * 6 + [ctypes.c_uint, ctypes.c_uint, ctypes.c_float, P, I, P]
+        fa = (y.data_ptr(), stats.data_ptr(), Wg.data_ptr(), bg.data_ptr(), out.data_ptr(), B, T, F, C, 1, 2, 7, 1 << 23, 2.0, None, split, st)
         ba = (y.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Wg.data_ptr(), bg.data_ptr(), gout.data_ptr(), dz.data_ptr(),
-              dWg.data_ptr(), dbg.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), scr.data_ptr(), B, T, F, C, 1, 2, 7, 1 << 23, 2.0, st)
+              dWg.data_ptr(), dbg.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), scr.data_ptr(), B, T, F, C, 1, 2, 7, 1 << 23, 2.0, None, split, st)
         res = []
         for f, a in ((ff, fa), (fb, ba)):
             for _ in range(3):
@@ -47,4 +48,4 @@ for (C, T, F) in [(64, 156, 32), (128, 156, 16), (128, 156, 2)]:
                 f(*a)
             e1.record(); torch.cuda.synchronize()
             res.append(e0.elapsed_time(e1) / 20 * 1e3)
-        print("C=%3d F=%2d abl=%2d: fwd %.1f us  bwd %.1f us (incl. zero4)" % (C, F, v, res[0], res[1]), flush=True)
+        print("split=%d C=%3d F=%2d abl=%2d: fwd %.1f us  bwd %.1f us (incl. zero4)" % (split, C, F, v, res[0], res[1]), flush=True)
