@@ -296,7 +296,8 @@ def main():
         "metric": "10s-clips/sec CRNN mean-teacher train @batch48",
         "value": round(clips / dt, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (3x3 convs as split-bf16 MFMA with fp32-level accuracy; everything else exact f32)", "data": "synthetic",
+        "dtype": "f32 (fp32 storage and accumulation; the dense contractions of the wide layers run as split-bf16 MFMA, 3 bf16 "
+                 "products per fp32 product, fp32-level accuracy; everything else exact f32)", "data": "synthetic",
         "config": {"workload": "dcase2023 CRNN mean-teacher train step, 128-mel 10s@16kHz, batch 48/GPU (12 strong/12 weak/24 "
                                "unlabelled), dropout+SpecAugment+mixup on, fp32 accuracy (conv_precision=%s)" % task.sed_student.cnn.conv_precision,
                    "global_batch": sum(BATCH) * world, "parallelism": "dp%d" % world, "last_loss_strong": round(loss_val, 5),
