@@ -78,6 +78,17 @@ __device__ __forceinline__ f32x16 mfma32_bf16(s16x8 a, s16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 #endif
 }
+// bf16 MFMA 16x16x32 (same rate per flop): lane l supplies A[i=l&15][k=8*(l>>4)+e] and B[k=8*(l>>4)+e][j=l&15], e=0..7;
+// acc[r] is D[row=4*(l>>4)+r][col=l&15] (the 16x16x4 f32 map).  A wave can own a 16-column slice of a wide output,
+// which halves the per-wave weight-fragment registers of the 128-channel GLU backward.
+__device__ __forceinline__ f32x4 mfma16_bf16(s16x8 a, s16x8 b, f32x4 c) {
+#ifdef SED_EMU
+    return emu_mfma_16x16x32_bf16(a, b, c);
+#else
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#endif
+}
 // round-to-nearest-even fp32 -> bf16 bit pattern (finite inputs)
 __device__ __forceinline__ unsigned short f32_to_bf16(float x) {
     unsigned u = __float_as_uint(x);

@@ -1334,8 +1334,10 @@ extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamm
     hipStream_t s = (hipStream_t)stream;
     if (F % PF != 0) return SED_ERR_UNSUPPORTED;
     if (PT == 1 && PF == 2) {
-        // (C = 128 stays on the exact-f32 kernel: both bf16 fragment sets of Wg are 128 VGPRs per wave and the split kernel
-        //  spills -- 208 vs 170 us at F = 16; SED_GLU_BWD128_SPLIT=1 selects it for experiments)
+        // C = 128 stays on the exact-f32 kernel.  Both bf16 fragment sets of Wg are 128 VGPRs per wave with 32x32 tiles and the
+        // split kernel spills (208 vs 170 us at F = 16; SED_GLU_BWD128_SPLIT=1 selects it for A/B runs); a variant on the
+        // 16x16x32 MFMA (wave = 16 columns x all rows: 64 VGPRs of fragments) was measured too and lost as well (197 us):
+        // the allocator still parked one fragment set in scratch and every wave re-reads the whole A tile from LDS.
         if (C == 128 && split_bf16 && getenv("SED_GLU_BWD128_SPLIT") != nullptr)
             return launch_glu_wide_bwd<128, true>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
         if (C == 64 && split_bf16) return launch_glu_wide_bwd<64, true>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);

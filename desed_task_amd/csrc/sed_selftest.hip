@@ -41,9 +41,27 @@ __global__ __launch_bounds__(64) void selftest_mfma32_bf16_kernel(const float* A
 #pragma unroll
     for (int r = 0; r < 16; ++r) C[mfma32_row(r, lane) * 32 + (lane & 31)] = acc[r];
 }
+// bf16 16x16x32: C[16][16] = A[16][K] * B[K][16] with operands rounded to bf16 (K multiple of 32)
+__global__ __launch_bounds__(64) void selftest_mfma16_bf16_kernel(const float* A, const float* Bm, float* C, int K) {
+    const int lane = threadIdx.x;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; k += 32) {
+        s16x8 a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = k + 8 * (lane >> 4) + e;
+            a[e] = (short)f32_to_bf16(A[(lane & 15) * K + kk]);
+            b[e] = (short)f32_to_bf16(Bm[kk * 16 + (lane & 15)]);
+        }
+        acc = mfma16_bf16(a, b, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[r];
+}
 extern "C" int sed_selftest_mfma(const float* A, const float* Bm, float* C, int K, int shape, void* stream) {
     if (shape == 32) SED_LAUNCH(selftest_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, C, K);
     else if (shape == 3216) SED_LAUNCH(selftest_mfma32_bf16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, C, K);
+    else if (shape == 1632) SED_LAUNCH(selftest_mfma16_bf16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, C, K);
     else if (shape == 16) SED_LAUNCH(selftest_mfma16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, C, K);
     else return SED_ERR_ARG;
     return sed_check_launch();

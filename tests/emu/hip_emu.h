@@ -140,6 +140,28 @@ static inline f32x16 emu_mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
     return c;
 }
 
+// v_mfma_f32_16x16x32_bf16: A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][j=l&15], e=0..7; D: col=l&15, row=4*(l>>4)+r
+static inline f32x4 emu_mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
+    int w = emu_wave(), l = emu_lane();
+    memcpy(&emu_wave_xchg[w][l][0], &a, 16);
+    memcpy(&emu_wave_xchg[w][l][4], &b, 16);
+    emu_wave_sync();
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int kg = 0; kg < 4; ++kg) {
+            s16x8 av, bv;
+            memcpy(&av, &emu_wave_xchg[w][row + 16 * kg][0], 16);
+            memcpy(&bv, &emu_wave_xchg[w][col + 16 * kg][4], 16);
+            for (int e = 0; e < 8; ++e) acc += emu_bf16_to_f32(av[e]) * emu_bf16_to_f32(bv[e]);
+        }
+        c[r] = acc;
+    }
+    emu_wave_sync();
+    return c;
+}
+
 // v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
 static inline f32x16 emu_mfma_32x32x2(float a, float b, f32x16 c) {
     int w = emu_wave(), l = emu_lane();

@@ -35,6 +35,16 @@ def case_mfma_selftest(dev):
         ref = (A.bfloat16().double() @ B.bfloat16().double()).float()
         err = (Cd.cpu() - ref).abs().max().item()
         assert err < 1e-4, ("bf16", K, err)
+    # bf16 16x16x32 map (128-channel GLU backward)
+    for K in (32, 96):
+        A = torch.randn(16, K, generator=g)
+        B = torch.randn(K, 16, generator=g)
+        C = torch.zeros(16, 16)
+        Ad, Bd, Cd = to(dev, A, B, C)
+        lib.call("sed_selftest_mfma", Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr(), K, 1632, _lib.stream_ptr(Ad))
+        ref = (A.bfloat16().double() @ B.bfloat16().double()).float()
+        err = (Cd.cpu() - ref).abs().max().item()
+        assert err < 1e-4, ("bf16 16x16x32", K, err)
 
 
 def make_mel():
