@@ -57,34 +57,40 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ 
     for (int i = tid; i < C * C; i += 256) wg[(i / C) * CP + (i % C)] = Wg[i];
     if (tid < C) { sc[tid] = stats[2 * C + tid]; sc[C + tid] = stats[3 * C + tid]; sc[2 * C + tid] = bg[tid]; }
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // the next tile's rows are fetched into registers under the current tile's MFMAs / epilogue (rows past the clip: zeros)
+    constexpr int NLD = ROWS * (C / 4) / 256;
+    float4 ld[NLD];
+    auto load_tile = [&](int tile_) {
+        const int b_ = tile_ / tiles_per_clip, o0_ = (tile_ - b_ * tiles_per_clip) * NW;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
+            int o, t, f;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_pixel<PT, PF>(m, o0_, NWC, fsh, o, t, f)) val = *(const float4*)(y + (((size_t)b_ * T + t) * F + f) * C + 4 * v);
+            ld[u] = val;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
         __syncthreads();
-        {   // all global loads of the tile are issued before the first LDS store (one HBM latency per tile, not one per load)
-            constexpr int NLD = ROWS * (C / 4) / 256;
-            float4 ld[NLD];
 #pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
-                int o, t, f;
-                ld[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) ld[u] = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
+            int o, t, f;
+            float4 val = ld[u];
+            if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) {
+                const float* s = sc + 4 * v;
+                val.x = fmaf(val.x, s[0], s[C + 0]); val.y = fmaf(val.y, s[1], s[C + 1]);
+                val.z = fmaf(val.z, s[2], s[C + 2]); val.w = fmaf(val.w, s[3], s[C + 3]);
             }
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
-                int o, t, f;
-                float4 val = ld[u];
-                if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) {
-                    const float* s = sc + 4 * v;
-                    val.x = fmaf(val.x, s[0], s[C + 0]); val.y = fmaf(val.y, s[1], s[C + 1]);
-                    val.z = fmaf(val.z, s[2], s[C + 2]); val.w = fmaf(val.w, s[3], s[C + 3]);
-                }
-                float* d = xs + m * CP + 4 * v;
-                d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
-            }
+            float* d = xs + m * CP + 4 * v;
+            d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x16_zero();
@@ -177,11 +183,14 @@ __global__ __launch_bounds__(256) void glu16_fwd_kernel(const float* __restrict_
     }
     const int To = T / 2, Fo = F / 2, tpr = Fo / 4, ntiles = B * To * tpr;
     const int nwaves = gridDim.x * 4;
-    for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += nwaves) {
-        const int tr = tile % tpr, to = (tile / tpr) % To, b = tile / (tpr * To);
-        const int w = i >> 2, q = i & 3;
-        const int t = 2 * to + (q >> 1), f = 2 * (4 * tr + w) + (q & 1);
-        const size_t pix = ((size_t)b * T + t) * F + f;
+    // Work unit of a wave = one ROW of pooling windows (b, to): the index arithmetic (two runtime divisions) is paid once per
+    // row of tpr tiles, not per tile -- these kernels are VALU-bound (a register prefetch of the next tile made them slower).
+    const int w = i >> 2, q = i & 3;
+    const int nrows = B * To;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += nwaves)
+    for (int tr = 0; tr < tpr; ++tr) {
+        const int b = row / To, to = row - b * To;
+        const size_t pix = ((size_t)b * T + 2 * to + (q >> 1)) * F + 2 * (4 * tr + w) + (q & 1);
         const float4 yv = *(const float4*)(y + pix * C + 4 * g);
         float xn[4] = {fmaf(yv.x, sc[0], sh[0]), fmaf(yv.y, sc[1], sh[1]), fmaf(yv.z, sc[2], sh[2]), fmaf(yv.w, sc[3], sh[3])};
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -231,11 +240,13 @@ __global__ __launch_bounds__(256) void glu16_bwd_kernel(const float* __restrict_
     float a_dgam = 0.f, a_dbet = 0.f, a_dbg = 0.f;
     const int To = T / 2, Fo = F / 2, tpr = Fo / 4, ntiles = B * To * tpr;
     const int nwaves = gridDim.x * 4;
-    for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += nwaves) {
-        const int tr = tile % tpr, to = (tile / tpr) % To, b = tile / (tpr * To);
-        const int w = i >> 2, q = i & 3;
-        const int t = 2 * to + (q >> 1), f = 2 * (4 * tr + w) + (q & 1);
-        const size_t pix = ((size_t)b * T + t) * F + f;
+    // one row of pooling windows (b, to) per wave iteration, tiles of the row in the inner loop (see glu16_fwd_kernel)
+    const int w = i >> 2, q = i & 3;
+    const int nrows = B * To;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += nwaves)
+    for (int tr = 0; tr < tpr; ++tr) {
+        const int b = row / To, to = row - b * To;
+        const size_t pix = ((size_t)b * T + 2 * to + (q >> 1)) * F + 2 * (4 * tr + w) + (q & 1);
         const float4 yv = *(const float4*)(y + pix * C + 4 * g);
         const float4 go = *(const float4*)(gout + (((size_t)b * To + to) * Fo + 4 * tr + w) * C + 4 * g);
         float xh[4] = {(yv.x - mu[0]) * istd[0], (yv.y - mu[1]) * istd[1], (yv.z - mu[2]) * istd[2], (yv.w - mu[3]) * istd[3]};
@@ -634,34 +645,40 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < NTW; ++i) { a_dbg[i] = 0.f; a_dgam[i] = 0.f; a_dbet[i] = 0.f; }
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // the next tile's rows are fetched into registers under the current tile's three GEMMs (see glu_fwd_kernel)
+    constexpr int NLD = ROWS * (C / 4) / 256;
+    float4 ld[NLD];
+    auto load_tile = [&](int tile_) {
+        const int b_ = tile_ / tiles_per_clip, o0_ = (tile_ - b_ * tiles_per_clip) * NW;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
+            int o, t, f;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_pixel<PT, PF>(m, o0_, NWC, fsh, o, t, f)) val = *(const float4*)(y + (((size_t)b_ * T + t) * F + f) * C + 4 * v);
+            ld[u] = val;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_clip, o0 = (tile - b * tiles_per_clip) * NW;
         __syncthreads();
-        {   // loads first, LDS stores after (see glu_fwd_kernel)
-            constexpr int NLD = ROWS * (C / 4) / 256;
-            float4 ld[NLD];
 #pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
-                int o, t, f;
-                ld[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) ld[u] = *(const float4*)(y + (((size_t)b * T + t) * F + f) * C + 4 * v);
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
+            int o, t, f;
+            float4 val = ld[u];
+            if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) {
+                const float* mu = sc + 4 * v;
+                val.x = (val.x - mu[0]) * mu[C + 0]; val.y = (val.y - mu[1]) * mu[C + 1];
+                val.z = (val.z - mu[2]) * mu[C + 2]; val.w = (val.w - mu[3]) * mu[C + 3];
             }
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
-                int o, t, f;
-                float4 val = ld[u];
-                if (row_pixel<PT, PF>(m, o0, NWC, fsh, o, t, f)) {
-                    const float* mu = sc + 4 * v;
-                    val.x = (val.x - mu[0]) * mu[C + 0]; val.y = (val.y - mu[1]) * mu[C + 1];
-                    val.z = (val.z - mu[2]) * mu[C + 2]; val.w = (val.w - mu[3]) * mu[C + 3];
-                }
-                float* d = xh + m * CP + 4 * v;
-                d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
-            }
+            float* d = xh + m * CP + 4 * v;
+            d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
         // ---- GEMM1: lin = xn . Wg^T ----
         f32x16 acc[NTW];
 #pragma unroll
