@@ -14,6 +14,12 @@
 // un-pooling are lane-local.
 #include "sed_common.h"
 
+// GLU_ABL: timing-ablation mask for tools/glu_variants.py (0 in the product build): 1 = no MFMA, 2 = no epilogue
+// math, 4 = no global tile loads, 8 = no global stores.
+#ifndef GLU_ABL
+#define GLU_ABL 0
+#endif
+
 template <int C, int PT, int PF>
 struct GluGeom {
     static constexpr int WIN = PT * PF;
@@ -303,11 +309,6 @@ __global__ __launch_bounds__(256) void glu16_bwd_kernel(const float* __restrict_
 // holds only the activation tile (66 KB at C = 128 -> two workgroups per CU instead of one) and the MFMA loop
 // issues one LDS read per MFMA.  The next tile is prefetched into registers under the current tile's MFMAs.
 // ---------------------------------------------------------------------------------------------
-// GLU_ABL: timing-ablation mask for tools/glu_variants.py (0 in the product build): 1 = no MFMA, 2 = no epilogue
-// math, 4 = no global tile loads, 8 = no global stores.
-#ifndef GLU_ABL
-#define GLU_ABL 0
-#endif
 
 // acc += sum_k A[k] * bf(k) over K2 k-steps with the A operand read from LDS at ap[2*ks] in software-pipelined groups
 // of G (one group in flight under the previous group's MFMAs; the fences keep the unrolled chain from hoisting more).
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
             const int idx = tid + 256 * u, m = idx / (C / 4), v = idx - m * (C / 4);
             int o, t, f;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row_pixel<PT, PF>(m, o0_, NWC, fsh, o, t, f)) val = *(const float4*)(y + (((size_t)b_ * T + t) * F + f) * C + 4 * v);
+            if (row_pixel<PT, PF>(m, o0_, NWC, fsh, o, t, f) && !(GLU_ABL & 4)) val = *(const float4*)(y + (((size_t)b_ * T + t) * F + f) * C + 4 * v);
             ld[u] = val;
         }
     };
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
                 for (int nt = 0; nt < NTW; ++nt) {
                     const int n = (wn * NTW + nt) * 32 + lo;
                     const float bv = (C >= 32 || lo < C) ? wg[n * CP + k + hi] : 0.f;
-                    acc[nt] = mfma32(av, bv, acc[nt]);
+                    acc[nt] = (GLU_ABL & 1) ? acc[nt] + av * bv : mfma32(av, bv, acc[nt]);
                 }
             }
         }
@@ -719,7 +720,8 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
                 for (int nt = 0; nt < NTW; ++nt) {
                     const int n = (wn * NTW + nt) * 32 + lo;
                     float dlin = 0.f, e = 0.f;
-                    if (rok && nokv[nt]) {
+                    if (GLU_ABL & 2) { dlin = acc[nt][r]; e = dlin; }
+                    else if (rok && nokv[nt]) {
                         const float xn = fmaf(xh[m * CP + n], gnv[nt], bnv[nt]);
                         const float sg = sed_fast_sigmoid(xn);
                         const float lin = acc[nt][r] + biasv[nt];
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
                 for (int nt = 0; nt < NTW; ++nt) {
                     const int c = (wn * NTW + nt) * 32 + lo;
                     const float bv = (C >= 32 || lo < C) ? wg[(k + hi) * CP + c] : 0.f;
-                    acc[nt] = mfma32(av, bv, acc[nt]);
+                    acc[nt] = (GLU_ABL & 1) ? acc[nt] + av * bv : mfma32(av, bv, acc[nt]);
                 }
             }
         }
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
                         const float dxn = acc[nt][r];
                         a_dgam[nt] += dxn * xh[m * CP + c];
                         a_dbet[nt] += dxn;
-                        dzr[c] = dxn * gam[c];
+                        if (!(GLU_ABL & 8)) dzr[c] = dxn * gam[c];
                     }
                 }
             }
@@ -779,7 +781,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
                 for (int k = 0; k < ROWS; k += 2) {
                     const float av = dl[(k + hi) * CP + mt * 32 + lo];
                     const float bv = fmaf(xh[(k + hi) * CP + c], gc, bc);
-                    P[i] = mfma32(av, bv, P[i]);
+                    P[i] = (GLU_ABL & 1) ? P[i] + av * bv : mfma32(av, bv, P[i]);
                 }
             }
         } else {   // single 32x32 output tile: the 4 waves split K (rows)
@@ -789,7 +791,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ 
             for (int k = 32 * w; k < 32 * w + 32; k += 2) {
                 const float av = cok ? dl[(k + hi) * CP + lo] : 0.f;
                 const float bv = cok ? fmaf(xh[(k + hi) * CP + lo], gc, bc) : 0.f;
-                P[0] = mfma32(av, bv, P[0]);
+                P[0] = (GLU_ABL & 1) ? P[0] + av * bv : mfma32(av, bv, P[0]);
             }
         }
     }

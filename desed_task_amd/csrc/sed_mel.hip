@@ -34,22 +34,40 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
     for (int q = 0; q < 4; ++q) stw[tid + 256 * q] = tw1024[tid + 256 * q];
     __syncthreads();
 
+    // per-thread constants of every frame: its 8 window taps and 4 real-FFT twiddles
+    float2 win[4], tw2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = tid + 256 * q;
+        win[q] = make_float2(window[2 * n], window[2 * n + 1]);
+        tw2[q] = tw2048[n];
+    }
     const int n_frames = B * T;
-    for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
-        const int b = frame / T, t = frame - b * T;
-        const float* clip = audio + (size_t)b * N;
-        const int base = t * hop - MEL_NFFT / 2;
-        // ---- load, reflect-pad, window, pack z[n] = x[2n] + i x[2n+1] ----
+    // the next frame's samples are fetched into registers while the current frame is transformed (a workgroup would
+    // otherwise expose one L2/HBM latency per frame in front of ~10 short barrier-separated phases)
+    float2 smp[4];
+    auto load_frame = [&](int frame_) {
+        const int b_ = frame_ / T, t_ = frame_ - b_ * T;
+        const float* clip = audio + (size_t)b_ * N;
+        const int base = t_ * hop - MEL_NFFT / 2;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int n = tid + 256 * q;
-            int s0 = base + 2 * n, s1 = s0 + 1;
+            int s0 = base + 2 * (tid + 256 * q), s1 = s0 + 1;
             if (s0 < 0) s0 = -s0;
             if (s1 < 0) s1 = -s1;
             if (s0 >= N) s0 = 2 * (N - 1) - s0;
             if (s1 >= N) s1 = 2 * (N - 1) - s1;
-            buf0[n] = make_float2(clip[s0] * window[2 * n], clip[s1] * window[2 * n + 1]);
+            smp[q] = make_float2(clip[s0], clip[s1]);
         }
+    };
+    int frame = blockIdx.x;
+    if (frame < n_frames) load_frame(frame);
+    for (; frame < n_frames; frame += gridDim.x) {
+        const int b = frame / T, t = frame - b * T;
+        // ---- reflect-padded, windowed samples packed as z[n] = x[2n] + i x[2n+1] ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) buf0[tid + 256 * q] = make_float2(smp[q].x * win[q].x, smp[q].y * win[q].y);
+        if (frame + (int)gridDim.x < n_frames) load_frame(frame + gridDim.x);
         __syncthreads();
         // ---- 5 Stockham radix-4 passes, Ns = 1,4,16,64,256; result lands in buf1 ----
         float2* src = buf0;
@@ -93,7 +111,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
                 const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
                 const float dr = zk.x - zm.x, di = zk.y + zm.y;            // zk - conj(zm)
                 const float2 xo = make_float2(0.5f * di, -0.5f * dr);       // -i/2 * (zk - conj(zm))
-                const float2 wx = cmul(tw2048[k], xo);
+                const float2 wx = cmul(tw2[q], xo);
                 const float re = xe.x + wx.x, im = xe.y + wx.y;
                 m = sqrtf(re * re + im * im);
             }

@@ -16,13 +16,13 @@ if not torch.cuda.is_available():
     sys.exit(0)
 P = ctypes.c_void_p
 I = ctypes.c_int
-for (C, T, F) in [(64, 156, 32), (128, 156, 16), (128, 156, 2)]:
+for (C, T, F, PT, PF) in [(32, 313, 64, 2, 2), (64, 156, 32, 1, 2), (128, 156, 16, 1, 2), (128, 156, 2, 1, 2)]:
     B = 48
     y = torch.randn(B, T, F, C, device="cuda")
     stats = torch.cat([torch.zeros(C), torch.ones(C), torch.ones(C), torch.zeros(C)]).cuda()
     gamma, beta = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
     Wg, bg = torch.randn(C, C, device="cuda") * 0.05, torch.zeros(C, device="cuda")
-    out = torch.empty(B, T, F // 2, C, device="cuda")
+    out = torch.empty(B, T // PT, F // PF, C, device="cuda")
     gout = torch.randn_like(out)
     dz = torch.empty_like(y)
     dWg, dbg, dgam, dbet = torch.empty(C, C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
@@ -34,9 +34,9 @@ for (C, T, F) in [(64, 156, 32), (128, 156, 16), (128, 156, 2)]:
         split = int(os.environ.get("GLU_SPLIT", "1"))
         ff.argtypes = [P] * 5 + [I] * 6 + [ctypes.c_uint, ctypes.c_uint, ctypes.c_float, P, I, P]
         fb.argtypes = [P] * 13 + [I] * 6 + [ctypes.c_uint, ctypes.c_uint, ctypes.c_float, P, I, P]
-        fa = (y.data_ptr(), stats.data_ptr(), Wg.data_ptr(), bg.data_ptr(), out.data_ptr(), B, T, F, C, 1, 2, 7, 1 << 23, 2.0, None, split, st)
+        fa = (y.data_ptr(), stats.data_ptr(), Wg.data_ptr(), bg.data_ptr(), out.data_ptr(), B, T, F, C, PT, PF, 7, 1 << 23, 2.0, None, split, st)
         ba = (y.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), Wg.data_ptr(), bg.data_ptr(), gout.data_ptr(), dz.data_ptr(),
-              dWg.data_ptr(), dbg.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), scr.data_ptr(), B, T, F, C, 1, 2, 7, 1 << 23, 2.0, None, split, st)
+              dWg.data_ptr(), dbg.data_ptr(), dgam.data_ptr(), dbet.data_ptr(), scr.data_ptr(), B, T, F, C, PT, PF, 7, 1 << 23, 2.0, None, split, st)
         res = []
         for f, a in ((ff, fa), (fb, ba)):
             for _ in range(3):
