@@ -269,7 +269,7 @@ __global__ __launch_bounds__(CONV_THREADS(COUT)) void conv3x3_kernel(const float
             float v = 0.f;
 #pragma unroll
             for (int ww = 0; ww < WM; ++ww) v += red[(ww * 2 + which) * (NT * 32) + co];
-            partial[(size_t)bid * 2 * COUT + tid] = v;
+            partial[(size_t)tid * gridDim.x + bid] = v;       // [2*COUT][nblocks]: bn_finalize reads one channel's row contiguously
         }
     }
 }
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
         }
         __syncthreads();
         if (tid < 2 * COUT)
-            partial[((size_t)b * gridDim.x + blockIdx.x) * 2 * COUT + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            partial[(size_t)tid * (gridDim.x * gridDim.y) + (size_t)b * gridDim.x + blockIdx.x] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     }
 }
 // x (B,T,F) scaled log-mel; W (16,1,3,3) PyTorch layout; bounds (B,4) int32 or null.
@@ -420,8 +420,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     if (training) {
         double a = 0.0, q = 0.0;
         for (int i = tid; i < nblocks; i += 256) {
-            a += (double)partial[(size_t)i * 2 * C + c];
-            q += (double)partial[(size_t)i * 2 * C + C + c];
+            a += (double)partial[(size_t)c * nblocks + i];
+            q += (double)partial[(size_t)(C + c) * nblocks + i];
         }
         r1[tid] = a; r2[tid] = q;
         __syncthreads();

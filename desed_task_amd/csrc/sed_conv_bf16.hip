@@ -258,7 +258,7 @@ __global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const
             float v = 0.f;
 #pragma unroll
             for (int ww = 0; ww < WM; ++ww) v += red[(ww * 2 + which) * (NT * 32) + co];
-            partial[(size_t)bid * 2 * COUT + tid] = v;
+            partial[(size_t)tid * gridDim.x + bid] = v;       // [2*COUT][nblocks], see bn_finalize_kernel
         }
     }
 }

@@ -64,7 +64,8 @@ int sed_conv_pack_weights(const float* W, float* Wf, float* Wd, int COUT, int CI
 int sed_conv_pack_multi(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout, const int* cin,
                         void* stream);
 
-/* Number of workgroups (= rows of `partial`, 2*COUT floats each) a forward conv launch writes. */
+/* Number of workgroups a forward conv launch writes partial statistics for: `partial` is [2*COUT][nblocks] floats
+ * (row c = per-workgroup sums of channel c, row COUT + c = sums of squares), the layout sed_bn_finalize reads. */
 int sed_conv_fwd_blocks(int B, int T, int F, int CIN, int COUT);
 
 /* Conv2d(k=3,s=1,p=1) (CNN.py:69-72) as implicit GEMM on f32 MFMA.  x (B,T,F,CIN), Wp packed, bias or null,
