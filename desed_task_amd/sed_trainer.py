@@ -221,8 +221,84 @@ class SEDTask4(_Base):
         self.last_outputs = (strong_s, weak_s, strong_t, weak_t)
         return tot_loss
 
-    # ---- outside the hot path -----------------------------------------------------------
-    def validation_step(self, batch, batch_indx):
-        raise NotImplementedError("validation/test scoring is a 'next' row (SURVEY 8f rank 1-2)")
+    # ---- validation forward + decoding ---------------------------------------------
+    class _MacroF1:
+        """Stand-in for torchmetrics MultilabelF1Score(num_labels, average="macro") at threshold 0.5 (sed_trainer.py:106-118):
+        per-class tp / fp / fn counters kept on the device."""
 
-    test_step = validation_step
+        def __init__(self):
+            self.tp = self.fp = self.fn = None
+
+        def __call__(self, preds, target):
+            p, t = preds > 0.5, target > 0
+            tp, fp, fn = (p & t).sum(0), (p & ~t).sum(0), (~p & t).sum(0)
+            if self.tp is None:
+                self.tp, self.fp, self.fn = tp, fp, fn
+            else:
+                self.tp, self.fp, self.fn = self.tp + tp, self.fp + fp, self.fn + fn
+
+        def compute(self):
+            den = 2 * self.tp + self.fp + self.fn
+            return torch.where(den > 0, 2.0 * self.tp / den.clamp(min=1), torch.zeros_like(den, dtype=torch.float32)).mean()
+
+        def reset(self):
+            self.tp = self.fp = self.fn = None
+
+    def _val_state(self):
+        """Buffers of sed_trainer.py:106-135, created on first use (the training-only configurations carry no val keys)."""
+        if not hasattr(self, "val_buffer_student_synth"):
+            import pandas as pd
+            ths = self.hparams["training"].get("val_thresholds", [0.5])
+            self.val_buffer_student_synth = {k: pd.DataFrame() for k in ths}
+            self.val_buffer_teacher_synth = {k: pd.DataFrame() for k in ths}
+            self.val_scores_postprocessed_buffer_student_synth = {}
+            self.val_scores_postprocessed_buffer_teacher_synth = {}
+            self.get_weak_student_f1_seg_macro = SEDTask4._MacroF1()
+            self.get_weak_teacher_f1_seg_macro = SEDTask4._MacroF1()
+
+    def validation_step(self, batch, batch_indx):
+        """sed_trainer.py:367-487 with the per-clip host loop of `batched_decode_preds` replaced by the batched device
+        post-processing (desed_task_amd/postprocess.py).  Same logged keys, same buffers.  The epoch-end metrics
+        (PSDS / intersection / event F1, :489-600) are the next row and are not computed here."""
+        from pathlib import Path
+        import pandas as pd
+        from .postprocess import batched_decode_preds
+        self._val_state()
+        audio, labels, padded_indxs, filenames = batch[0], batch[1], batch[2], batch[3]
+        bce = torch.nn.functional.binary_cross_entropy
+        with torch.no_grad():
+            mels = self.mel_spec(audio)
+            x = self.scaled_logmel(mels)                     # student and teacher see the same features (detect() twice)
+            strong_s, weak_s = self.sed_student(x)
+            strong_t, weak_t = self.sed_teacher(x)
+        data = self.hparams.get("data", {})
+        weak_dir, synth_dir = data.get("weak_folder"), data.get("synth_val_folder")
+        is_weak = [weak_dir is not None and str(Path(f).parent) == str(Path(weak_dir)) for f in filenames]
+        is_synth = [synth_dir is not None and str(Path(f).parent) == str(Path(synth_dir)) for f in filenames]
+        mask_weak = torch.tensor(is_weak, device=audio.device)
+        mask_synth = torch.tensor(is_synth, device=audio.device)
+        if any(is_weak):
+            labels_weak = (torch.sum(labels[mask_weak], -1) >= 1).float()
+            self.log("val/weak/student/loss_weak", bce(weak_s[mask_weak], labels_weak))
+            self.log("val/weak/teacher/loss_weak", bce(weak_t[mask_weak], labels_weak))
+            self.get_weak_student_f1_seg_macro(weak_s[mask_weak], labels_weak.long())
+            self.get_weak_teacher_f1_seg_macro(weak_t[mask_weak], labels_weak.long())
+        if any(is_synth):
+            self.log("val/synth/student/loss_strong", bce(strong_s[mask_synth], labels[mask_synth]))
+            self.log("val/synth/teacher/loss_strong", bce(strong_t[mask_synth], labels[mask_synth]))
+            filenames_synth = [f for f, s in zip(filenames, is_synth) if s]
+            win = self.hparams["training"].get("median_window", 7)
+            for preds, buf, post in ((strong_s, self.val_buffer_student_synth, self.val_scores_postprocessed_buffer_student_synth),
+                                     (strong_t, self.val_buffer_teacher_synth, self.val_scores_postprocessed_buffer_teacher_synth)):
+                _, scores_post, decoded = batched_decode_preds(preds[mask_synth], filenames_synth, self.encoder,
+                                                               median_filter=win, thresholds=list(buf.keys()))
+                post.update(scores_post)
+                for th in buf.keys():
+                    buf[th] = pd.concat([buf[th], decoded[th]], ignore_index=True)
+        return
+
+    def validation_epoch_end(self, outputs):
+        raise NotImplementedError("PSDS / intersection-F1 / event-F1 at epoch end are the next row (SURVEY 8f rank 2)")
+
+    def test_step(self, batch, batch_indx):
+        raise NotImplementedError("test scoring (50 thresholds + PSDS, sed_trainer.py:608-683) is the next row (SURVEY 8f rank 2)")

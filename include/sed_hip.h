@@ -193,6 +193,19 @@ int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_
                 const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
                 int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, void* stream);
 
+/* ---- K13: inference post-processing, recipes/dcase2023_task4_baseline/local/utils.py:16-73 ----- */
+
+/* scipy.ndimage.median_filter(scores (T,NC), size=(win,1)) per clip (utils.py:55): median over time, 'reflect' boundary,
+ * scores / out (B,T,NC) frame-major, 1 <= win <= 15.  Bit-exact (selection). */
+int sed_median_filter(const float* scores, float* out, int B, int T, int NC, int win, void* stream);
+
+/* `scores > thresholds[k]` (utils.py:62) + the contiguous-region search of ManyHotEncoder.decode_strong
+ * (desed_task/utils/encoder.py:189-211): counts (n_thr,B,NC) int32 regions per (threshold, clip, class) and
+ * events (n_thr,B,NC,max_events,2) int32 [onset_frame, offset_frame) pairs; max_events >= (T+1)/2.
+ * true_len (B) int32 or null: frames at or past it are ignored (utils.py:48-50). */
+int sed_threshold_events(const float* scores, const float* thresholds, const int* true_len, int* counts, int* events,
+                         int B, int T, int NC, int n_thr, int max_events, void* stream);
+
 /* ---- K10 + K11: flat parameter arena ------------------------------------------------------------------------- */
 
 /* SEDTask4.update_ema (sed_trainer.py:187-199) over the whole arena: teacher = alpha*teacher + (1-alpha)*student. */

@@ -419,3 +419,35 @@ class OracleTrainer:
         self.step_num += 1
         self.lr = self.max_lr * warmup_factor(self.step_num, self.rampup_len)
         return dict(zip(PARAM_KEYS, grads))
+
+
+# ------------------------------------------------------------------------------------------------
+# inference post-processing: recipes/dcase2023_task4_baseline/local/utils.py:16-73
+# ------------------------------------------------------------------------------------------------
+def median_filter_scores(scores_tc: np.ndarray, win: int = 7) -> np.ndarray:
+    """utils.py:55: scipy.ndimage.median_filter(c_scores, (median_filter, 1)) on a (T, NC) array (scipy is the reference's
+    own dependency here and is importable in this image: this is the reference call, not a restatement)."""
+    import scipy.ndimage
+    return scipy.ndimage.median_filter(scores_tc, (win, 1))
+
+
+def find_contiguous_regions(activity: np.ndarray) -> np.ndarray:
+    """dcase_util.data.DecisionEncoder.find_contiguous_regions (third party, pinned by the reference only as `dcase_util`
+    in requirements; called at desed_task/utils/encoder.py:200).  Published algorithm, restated: parity unpinned."""
+    activity = np.asarray(activity).astype(bool)
+    change = np.logical_xor(activity[1:], activity[:-1]).nonzero()[0] + 1
+    if activity.size and activity[0]:
+        change = np.r_[0, change]
+    if activity.size and activity[-1]:
+        change = np.r_[change, activity.size]
+    return change.reshape((-1, 2))
+
+
+def decode_events(scores_tc: np.ndarray, threshold: float):
+    """utils.py:62-63 + encoder.py:189-211: list of (class index, onset frame, offset frame), class-major."""
+    out = []
+    pred = scores_tc > threshold
+    for c, col in enumerate(pred.T):
+        for on, off in find_contiguous_regions(col):
+            out.append((c, int(on), int(off)))
+    return out

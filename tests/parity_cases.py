@@ -616,3 +616,114 @@ def case_full_size_properties(dev, B=48):
     assert ((after - before)[big] + 1e-3 * torch.sign(grad[big])).abs().max().item() < 5e-7
     t_after = task.sed_teacher.arena.flat.detach()
     assert (t_after - (0.5 * t_before + 0.5 * before)).abs().max().item() < 1e-7                     # P3 (EMA, alpha = 1/2)
+
+
+# ------------------------------------------------------------------------------------------------
+# K13: inference post-processing (median filter + thresholds + event regions), bit-exact vs scipy / the oracle
+# ------------------------------------------------------------------------------------------------
+class _Encoder:
+    """The two members of desed_task.utils.encoder.ManyHotEncoder that batched_decode_preds touches
+    (encoder.py:26-40, :76-78), 2023 recipe values."""
+
+    def __init__(self, labels, audio_len=10, frame_hop=256, net_pooling=4, fs=16000):
+        self.labels, self.audio_len, self.frame_hop, self.net_pooling, self.fs = list(labels), audio_len, frame_hop, net_pooling, fs
+
+    def _frame_to_time(self, frame):
+        frame = frame * self.net_pooling / (self.fs / self.frame_hop)
+        return np.clip(frame, a_min=0, a_max=self.audio_len)
+
+
+def case_postprocess(dev):
+    from desed_task_amd import postprocess as PP
+    g = torch.Generator().manual_seed(11)
+    # ---- median filter: every window length incl. even ones, short clips (T < win: multiple reflections), ties ----
+    for (B, T, NC, win) in ((3, 156, 10, 7), (2, 5, 10, 7), (1, 1, 3, 7), (2, 40, 27, 3), (2, 33, 4, 4), (1, 20, 2, 15), (2, 9, 10, 1)):
+        x = torch.rand(B, T, NC, generator=g)
+        x[:, ::3] = (x[:, ::3] * 4).round() / 4            # ties
+        y = PP.median_filter_scores(to(dev, x), win).cpu().numpy()
+        for b in range(B):
+            ref = O.median_filter_scores(x[b].numpy(), win)
+            assert np.array_equal(y[b], ref), ("median", B, T, NC, win)
+    # ---- thresholds -> regions: saturated, empty, alternating and random columns; padded clips ----
+    B, T, NC = 4, 156, 10
+    x = torch.rand(B, T, NC, generator=g)
+    x[0, :, 0] = 1.0; x[0, :, 1] = 0.0; x[0, ::2, 2] = 1.0; x[0, 1::2, 2] = 0.0; x[1, 100:, 3] = 0.9; x[1, :7, 4] = 0.95
+    thresholds = [0.1, 0.5, 0.5000001, 0.9]
+    for true_len in (None, [156, 100, 1, 0]):
+        counts, events = PP.threshold_events(to(dev, x), thresholds, true_len)
+        for k, th in enumerate(thresholds):
+            for b in range(B):
+                n = T if true_len is None else true_len[b]
+                ref = O.decode_events(x[b, :n].numpy(), np.float32(th))
+                got = [(c, int(events[k, b, c, e, 0]), int(events[k, b, c, e, 1])) for c in range(NC) for e in range(counts[k, b, c])]
+                assert got == ref, ("events", th, b, true_len)
+    # ---- the reference-shaped entry point against the reference's own loop (utils.py:16-73) restated with the oracle ----
+    enc = _Encoder(["c%d" % i for i in range(NC)])
+    strong = x.transpose(1, 2)                                   # (B, NC, T) as the CRNN returns it
+    files = ["/data/synth/clip_%d.wav" % i for i in range(B)]
+    for pad in (None, torch.tensor([1.0, 0.75, 0.5, 1.0])):
+        raw, post, dfs = PP.batched_decode_preds(to(dev, strong), files, enc, thresholds=[0.5, 0.7], median_filter=7, pad_indx=pad)
+        for j in range(B):
+            c_scores = strong[j].transpose(0, 1).numpy()
+            n = T if pad is None else int(T * pad[j].item())
+            c_scores = c_scores[:n]
+            filt = O.median_filter_scores(c_scores, 7)
+            aid = "clip_%d" % j
+            assert np.array_equal(raw[aid].values[:, 2:].astype(np.float32), c_scores), ("raw", j)
+            assert np.array_equal(post[aid].values[:, 2:].astype(np.float32), filt), ("post", j)
+            assert list(post[aid].columns) == ["onset", "offset"] + enc.labels
+            for th in (0.5, 0.7):
+                ref = [(enc.labels[c], float(enc._frame_to_time(on)), float(enc._frame_to_time(off)))
+                       for c, on, off in O.decode_events(filt, np.float32(th))]
+                d = dfs[th][dfs[th]["filename"] == aid + ".wav"]
+                got = [(r.event_label, float(r.onset), float(r.offset)) for r in d.itertuples()]
+                assert got == ref, ("decode", j, th)
+
+
+def case_validation_step(dev):
+    """SEDTask4.validation_step: eval-mode student/teacher forward + batched decoding into the reference's
+    buffers, against the oracle CRNN forward + the reference loop restated with scipy."""
+    import pandas as pd  # noqa: F401
+    bs, n_samp = (2, 2, 4), 16000 * 2 + 1024
+    B = sum(bs)
+    sd = O.make_state_dict(seed=7)
+    audio = O.synth_audio(B, n_samp, seed=21)
+    n_out = (1 + n_samp // 256) // 4
+    labels = O.synth_labels(bs, 10, n_out, seed=5)
+    task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=100)
+    task.hparams["data"] = {"weak_folder": "/d/weak", "synth_val_folder": "/d/synth_val"}
+    task.hparams["training"].update(val_thresholds=[0.3, 0.5], median_window=7)
+    task.encoder = _Encoder(["c%d" % i for i in range(10)], audio_len=n_samp / 16000.0)
+    task.eval()                                                  # Lightning puts the module in eval mode for validation
+    files = ["/d/synth_val/s%d.wav" % i for i in range(3)] + ["/d/weak/w%d.wav" % i for i in range(3)] + ["/d/other/u%d.wav" % i for i in range(2)]
+    task.validation_step((to(dev, audio), to(dev, labels), None, files, None), 0)
+    # oracle: eval-mode forward of the same weights (teacher == student at construction)
+    feats = O.scale_minmax(O.take_log(O.mel_spectrogram(audio)))
+    strong, weak = O.crnn_forward(sd, feats, training=False)
+    lw = (labels[3:6].sum(-1) >= 1).float()
+    ref_w = torch.nn.functional.binary_cross_entropy(weak[3:6], lw).item()
+    ref_s = torch.nn.functional.binary_cross_entropy(strong[:3], labels[:3]).item()
+    for who in ("student", "teacher"):
+        assert abs(float(task.logged["val/weak/%s/loss_weak" % who]) - ref_w) < 2e-5 * max(1.0, ref_w)
+        assert abs(float(task.logged["val/synth/%s/loss_strong" % who]) - ref_s) < 2e-5 * max(1.0, ref_s)
+    enc = task.encoder
+    for j in range(3):
+        filt = O.median_filter_scores(strong[j].transpose(0, 1).numpy(), 7)
+        post = task.val_scores_postprocessed_buffer_student_synth["s%d" % j].values[:, 2:].astype(np.float32)
+        assert np.abs(post - filt).max() < 2e-5                  # posteriors: fp32 rounding vs the oracle forward
+    for th in (0.3, 0.5):
+        for buf in (task.val_buffer_student_synth, task.val_buffer_teacher_synth):
+            df = buf[th]
+            assert list(df.columns) == ["event_label", "onset", "offset", "filename"]
+            assert set(df["filename"]) <= {"s0.wav", "s1.wav", "s2.wav"}
+            # regions recomputed from the task's OWN filtered scores must match the decoded events exactly
+            for j in range(3):
+                own = task.val_scores_postprocessed_buffer_student_synth["s%d" % j].values[:, 2:].astype(np.float32)
+                if buf is task.val_buffer_teacher_synth:
+                    own = task.val_scores_postprocessed_buffer_teacher_synth["s%d" % j].values[:, 2:].astype(np.float32)
+                ref = [(enc.labels[c], float(enc._frame_to_time(on)), float(enc._frame_to_time(off)))
+                       for c, on, off in O.decode_events(own, np.float32(th))]
+                d = df[df["filename"] == "s%d.wav" % j]
+                assert [(r.event_label, float(r.onset), float(r.offset)) for r in d.itertuples()] == ref
+    f1 = float(task.get_weak_student_f1_seg_macro.compute())
+    assert 0.0 <= f1 <= 1.0

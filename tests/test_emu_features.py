@@ -17,3 +17,8 @@ def test_logscale_generic(emu):
 
 def test_mixup_and_specaug(emu):
     P.case_mixup_specaug("cpu")
+
+
+def test_postprocess_median_threshold_events(emu):
+    """K13: batched median filter / thresholds / event regions, bit-exact vs scipy and the oracle."""
+    P.case_postprocess("cpu")

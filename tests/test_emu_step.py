@@ -41,3 +41,8 @@ def test_edge_shapes(emu):
 def test_dyn_args_step_equals_eager(emu):
     """graph.DynArgs: dropout seeds, mixup c/perm, loss weight, EMA factor and Adam factors read from memory."""
     P.case_dyn_args_step("cpu", graph=False, steps=3)
+
+
+def test_validation_step(emu):
+    """SEDTask4.validation_step on the emulator: eval forward + batched decoding vs the oracle."""
+    P.case_validation_step("cpu")

@@ -106,3 +106,12 @@ def test_full_size_step_vs_oracle_c1_batch():
 def test_full_size_properties_bench_batch():
     """Size-independent properties at the bench configuration (48 clips of 10 s)."""
     P.case_full_size_properties("cuda", B=48)
+
+
+def test_postprocess_median_threshold_events():
+    """K13 on the GPU: bit-exact vs scipy / the oracle's restatement of the reference loop."""
+    P.case_postprocess("cuda")
+
+
+def test_validation_step():
+    P.case_validation_step("cuda")
