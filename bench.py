@@ -228,8 +228,18 @@ def main():
 
     # untimed: the W warm-up steps, plus (graph mode) whatever is still missing for the capture to lie outside the timed region
     n_untimed = max(args.warmup, 5) if use_graph else args.warmup
+    graph_note = None
     for i in range(n_untimed):
-        one_step(i)
+        try:
+            one_step(i)
+        except RuntimeError as exc:             # a capture the runtime refuses must not cost the measurement: eager launches
+            if not use_graph or driver.graph is not None and driver.n > driver.warmup + 1:
+                raise
+            graph_note = "hipGraph capture failed (%s): eager launches" % str(exc).splitlines()[0][:120]
+            sys.stderr.write(graph_note + "\n")
+            use_graph = False
+            driver = driver.eager
+            one_step(i)
     timer = KernelTimer({"sed_conv3x3", "sed_conv3x3_bf16x3"})
     if not use_graph:
         timer.wrap(_lib.get())
@@ -302,7 +312,7 @@ def main():
                                "unlabelled), dropout+SpecAugment+mixup on, fp32 accuracy (conv_precision=%s)" % task.sed_student.cnn.conv_precision,
                    "global_batch": sum(BATCH) * world, "parallelism": "dp%d" % world, "last_loss_strong": round(loss_val, 5),
                    "launch": "hipGraph replay of the captured step (3 eager + 1 capture step before the timed region)" if use_graph
-                             else "eager launches", "untimed_steps": n_untimed},
+                             else (graph_note or "eager launches"), "untimed_steps": n_untimed},
         "roofline": roofline,
         # SURVEY 8(d) step-level yardsticks (algorithmic work per clip x measured clips/s, per GPU)
         "step_roofline": {
