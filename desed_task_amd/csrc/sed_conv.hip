@@ -764,11 +764,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_alltaps_kernel(const float* __
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const int wn = w % WN, wk = w / WN;
     const int ftiles = F / TF, ttiles = (T + TR - 1) / TR, ntiles = B * ttiles * ftiles;
-    f32x16 acc[9][NTW];
+    // CIN == 16: the 16x16x4 MFMA (M = 16 input channels exactly; the 32x32x2 tile would run half empty), all waves split K,
+    // every wave owns both 16-wide COUT tiles.  Lane (i = l&15, g = l>>4): A[ci = i][pixel 4ks + g], B[pixel 4ks + g][co = i].
+    constexpr bool M16 = CIN == 16;
+    constexpr int NT16 = COUT / 16, WK16 = 4;
+    f32x16 acc[M16 ? 1 : 9][M16 ? 1 : NTW];
+    f32x4 acc16[M16 ? 9 : 1][M16 ? NT16 : 1];
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
+    for (int tp = 0; tp < (M16 ? 1 : 9); ++tp)
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) acc[tp][n] = f32x16_zero();
+        for (int n = 0; n < (M16 ? 1 : NTW); ++n) acc[tp][n] = f32x16_zero();
+#pragma unroll
+    for (int tp = 0; tp < (M16 ? 9 : 1); ++tp)
+#pragma unroll
+        for (int n = 0; n < (M16 ? NT16 : 1); ++n) acc16[tp][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int ft = tile % ftiles, tt = (tile / ftiles) % ttiles, b = tile / (ftiles * ttiles);
@@ -805,6 +814,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_alltaps_kernel(const float* __
             }
         }
         __syncthreads();
+        if (M16) {
+            constexpr int KS16 = 128 / WK16;
+            const int i16 = lane & 15, g16 = lane >> 4;
+#pragma unroll 2
+            for (int k = w * KS16; k < (w + 1) * KS16; k += 4) {
+                const int p = k + g16;
+                const int pb = (p / TF) * PW + (p % TF);
+                float bv16[NT16];
+#pragma unroll
+                for (int n = 0; n < NT16; ++n) bv16[n] = ds[p * COUT + n * 16 + i16];
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const float av = xs[(pb + (tp / 3) * PW + (tp % 3)) * CIN + i16];
+#pragma unroll
+                    for (int n = 0; n < NT16; ++n) acc16[M16 ? tp : 0][M16 ? n : 0] = mfma16(av, bv16[n], acc16[M16 ? tp : 0][M16 ? n : 0]);
+                }
+            }
+            continue;
+        }
         constexpr int KS = 128 / WK;
 #pragma unroll 2
         for (int k = wk * KS; k < (wk + 1) * KS; k += 2) {
@@ -825,6 +853,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_alltaps_kernel(const float* __
     float* red = (float*)smem;           // [taps in group][CIN][COUT], reuses the staging area
     float* part = dWp + (size_t)blockIdx.x * 9 * CIN * COUT;
     constexpr int TG = 5;
+    if (M16) {            // same tap-group reduction, 16x16 accumulator layout: row = 4g + r (ci), col = i (co within the tile)
+        const int i16 = lane & 15, g16 = lane >> 4;
+#pragma unroll
+        for (int g0 = 0; g0 < 9; g0 += TG) {
+            for (int round = 0; round < WK16; ++round) {
+                __syncthreads();
+                if (w == round) {
+#pragma unroll
+                    for (int tp = g0; tp < g0 + TG && tp < 9; ++tp)
+#pragma unroll
+                        for (int n = 0; n < NT16; ++n)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float* d = red + ((tp - g0) * CIN + 4 * g16 + r) * COUT + n * 16 + i16;
+                                const float v = acc16[M16 ? tp : 0][M16 ? n : 0][r];
+                                *d = (round == 0) ? v : *d + v;
+                            }
+                }
+            }
+            __syncthreads();
+            const int ntp = (9 - g0) < TG ? (9 - g0) : TG;
+            for (int idx = tid; idx < ntp * CIN * COUT; idx += 256) part[(size_t)g0 * CIN * COUT + idx] = red[idx];
+        }
+        return;
+    }
 #pragma unroll
     for (int g0 = 0; g0 < 9; g0 += TG) {
         for (int round = 0; round < WK; ++round) {
