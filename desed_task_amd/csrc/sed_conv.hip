@@ -779,41 +779,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_alltaps_kernel(const float* __
 #pragma unroll
         for (int n = 0; n < (M16 ? NT16 : 1); ++n) acc16[tp][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int ft = tile % ftiles, tt = (tile / ftiles) % ttiles, b = tile / (ftiles * ttiles);
+    // next tile's halo patch and dy tile are fetched into registers under the current tile's MFMAs
+    constexpr int NX = (PP * (CIN / 4) + 255) / 256, ND = 128 * (COUT / 4) / 256;
+    float4 lx[NX], ldy[ND];
+    auto load_tile = [&](int tile_) {
+        const int ft = tile_ % ftiles, tt = (tile_ / ftiles) % ttiles, b = tile_ / (ftiles * ttiles);
         const int t0 = tt * TR, f0 = ft * TF;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int idx = tid + 256 * u, pix = idx / (CIN / 4), v = idx - pix * (CIN / 4);
+            const int i = pix / PW, j = pix - i * PW;
+            const int t = t0 - 1 + i, f = f0 - 1 + j;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < PP * (CIN / 4) && t >= 0 && t < T && f >= 0 && f < F)
+                val = *(const float4*)(x + (((size_t)b * T + t) * F + f) * CIN + 4 * v);
+            lx[u] = val;
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int idx = tid + 256 * u, p = idx / (COUT / 4), v = idx - p * (COUT / 4);
+            const int t = t0 + p / TF, f = f0 + p % TF;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < T) val = *(const float4*)(dy + (((size_t)b * T + t) * F + f) * COUT + 4 * v);
+            ldy[u] = val;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
-        {   // loads first, LDS stores after
-            constexpr int NX = (PP * (CIN / 4) + 255) / 256, ND = 128 * (COUT / 4) / 256;
-            float4 lx[NX], ldy[ND];
 #pragma unroll
-            for (int u = 0; u < NX; ++u) {
-                const int idx = tid + 256 * u, pix = idx / (CIN / 4), v = idx - pix * (CIN / 4);
-                const int i = pix / PW, j = pix - i * PW;
-                const int t = t0 - 1 + i, f = f0 - 1 + j;
-                lx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < PP * (CIN / 4) && t >= 0 && t < T && f >= 0 && f < F)
-                    lx[u] = *(const float4*)(x + (((size_t)b * T + t) * F + f) * CIN + 4 * v);
-            }
+        for (int u = 0; u < NX; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < PP * (CIN / 4)) *(float4*)(xs + (idx / (CIN / 4)) * CIN + 4 * (idx % (CIN / 4))) = lx[u];
+        }
 #pragma unroll
-            for (int u = 0; u < ND; ++u) {
-                const int idx = tid + 256 * u, p = idx / (COUT / 4), v = idx - p * (COUT / 4);
-                const int t = t0 + p / TF, f = f0 + p % TF;
-                ldy[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t < T) ldy[u] = *(const float4*)(dy + (((size_t)b * T + t) * F + f) * COUT + 4 * v);
-            }
-#pragma unroll
-            for (int u = 0; u < NX; ++u) {
-                const int idx = tid + 256 * u;
-                if (idx < PP * (CIN / 4)) *(float4*)(xs + (idx / (CIN / 4)) * CIN + 4 * (idx % (CIN / 4))) = lx[u];
-            }
-#pragma unroll
-            for (int u = 0; u < ND; ++u) {
-                const int idx = tid + 256 * u;
-                *(float4*)(ds + (idx / (COUT / 4)) * COUT + 4 * (idx % (COUT / 4))) = ldy[u];
-            }
+        for (int u = 0; u < ND; ++u) {
+            const int idx = tid + 256 * u;
+            *(float4*)(ds + (idx / (COUT / 4)) * COUT + 4 * (idx % (COUT / 4))) = ldy[u];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
         if (M16) {
             constexpr int KS16 = 128 / WK16;
             const int i16 = lane & 15, g16 = lane >> 4;
