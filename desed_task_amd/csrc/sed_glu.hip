@@ -15,7 +15,7 @@
 #include "sed_common.h"
 
 // GLU_ABL: timing-ablation mask for tools/glu_variants.py (0 in the product build): 1 = no MFMA, 2 = no epilogue
-// math, 4 = no global tile loads, 8 = no global stores.
+// math, 4 = no global tile loads, 8 = no global stores; glu32_bwd_kernel: 16 = no identity-operand MFMAs, 32 = no GEMM3.
 #ifndef GLU_ABL
 #define GLU_ABL 0
 #endif
@@ -224,11 +224,11 @@ __global__ __launch_bounds__(256) void glu16_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ Wg, const float* __restrict__ bg,
                                                         const float* __restrict__ gout, float* __restrict__ dz,
-                                                        float* __restrict__ dWg, float* __restrict__ dbg,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int T, int F,
+                                                        float* __restrict__ part, int B, int T, int F,
                                                         uint32_t seed, uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
     if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
-    constexpr int C = 16;
+    constexpr int C = 16, NP = C * C + 3 * C;
+    __shared__ float red[4][NP];                // per-wave sums -> one partial per workgroup (see glu32_bwd_kernel)
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     float wa1[4], wb2[4], idb[4], mu[4], istd[4], gam4[4], bet4[4], bgr[4];
 #pragma unroll
@@ -295,12 +295,16 @@ __global__ __launch_bounds__(256) void glu16_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int k = 0; k < 4; ++k) P = mfma16(accd[k], xnD[k], P);     // P[n' = 4g+r][c = i] += sum_pixels dlin[p][n'] xn[p][c]
     }
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dWg + (4 * g + r) * C + i, P[r]);
+    for (int r = 0; r < 4; ++r) red[wv][(4 * g + r) * C + i] = P[r];
     a_dgam += __shfl_xor(a_dgam, 16); a_dgam += __shfl_xor(a_dgam, 32);
     a_dbet += __shfl_xor(a_dbet, 16); a_dbet += __shfl_xor(a_dbet, 32);
     a_dbg += __shfl_xor(a_dbg, 16); a_dbg += __shfl_xor(a_dbg, 32);
-    if (g == 0) { atomicAdd(dgamma + i, a_dgam); atomicAdd(dbeta + i, a_dbet); atomicAdd(dbg + i, a_dbg); }
+    if (g == 0) { red[wv][C * C + i] = a_dbg; red[wv][C * C + C + i] = a_dgam; red[wv][C * C + 2 * C + i] = a_dbet; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NP; idx += 256)
+        part[(size_t)blockIdx.x * NP + idx] = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256) void glu32_fwd_kernel(const float* __restrict_
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += nwaves)
     for (int tr = 0; tr < tpr; ++tr) {
         const int b = row / To, to = row - b * To;
-        const size_t pix = ((size_t)b * T + 2 * to + (q >> 1)) * F + 2 * (8 * tr + w) + (q & 1);
+        const size_t pix = ((size_t)b * T + 2 * to) * F + 16 * tr + ((q >> 1) ? F : 0) + 2 * w + (q & 1);
         float xn[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -370,11 +374,11 @@ __global__ __launch_bounds__(256) void glu32_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ Wg, const float* __restrict__ bg,
                                                         const float* __restrict__ gout, float* __restrict__ dz,
-                                                        float* __restrict__ dWg, float* __restrict__ dbg,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int T, int F,
+                                                        float* __restrict__ part, int B, int T, int F,
                                                         uint32_t seed, uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
     if (seed_dev) seed += *seed_dev;
-    constexpr int C = 32;
+    constexpr int C = 32, NP = C * C + 3 * C;
+    __shared__ float red[4][NP];                  // per-wave dWg / dbg / dgamma / dbeta, summed into ONE partial per workgroup
     __shared__ float cst[5 * C];                  // mean | invstd | gamma | beta | bg: read per use, 80 VGPRs would not fit
     const int lane = threadIdx.x & 63, lo = lane & 31, hi = lane >> 5, w = lo >> 2, q = lo & 3;
     if (threadIdx.x < C) {
@@ -398,7 +402,8 @@ __global__ __launch_bounds__(256) void glu32_bwd_kernel(const float* __restrict_
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += nwaves)
     for (int tr = 0; tr < tpr; ++tr) {
         const int b = row / To, to = row - b * To;
-        const size_t pix = ((size_t)b * T + 2 * to + (q >> 1)) * F + 2 * (8 * tr + w) + (q & 1);
+        const size_t pix0 = ((size_t)b * T + 2 * to) * F + 16 * tr;              // first pixel of the tile's upper row
+        const size_t pix = pix0 + ((q >> 1) ? F : 0) + 2 * w + (q & 1);
         const float* gsrc = gout + (((size_t)b * To + to) * Fo + 8 * tr + w) * C + 4 * hi;
         float xh[16], xn[16], dlin[16];
 #pragma unroll
@@ -424,11 +429,12 @@ __global__ __launch_bounds__(256) void glu32_bwd_kernel(const float* __restrict_
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * j + e, c = 8 * j + 4 * hi + e;
                 const float lin = acc1[r] + cst[4 * C + c];
-                const float sg = sed_fast_sigmoid(xn[r]);
-                const float gr = sed_keep((uint32_t)(pix * C + c), seed, thr24) ? gv[e] * 0.25f * dscale : 0.f;
+                const float sg = (GLU_ABL & 2) ? xn[r] : sed_fast_sigmoid(xn[r]);
+                const float gr = ((GLU_ABL & 2) || sed_keep((uint32_t)(pix * C + c), seed, thr24)) ? gv[e] * 0.25f * dscale : 0.f;
                 dlin[r] = gr * sg;
                 const float ev = gr * lin * sg * (1.0f - sg);
-                acc2 = mfma32(ev, (c == lo) ? 1.0f : 0.0f, acc2);                 // + e through an identity operand
+                if (!(GLU_ABL & 16)) acc2 = mfma32(ev, (c == lo) ? 1.0f : 0.0f, acc2);                 // + e through an identity operand
+                else acc2[r] += ev;
             }
         }
         f32x16 accx = f32x16_zero(), accd = f32x16_zero();
@@ -436,27 +442,35 @@ __global__ __launch_bounds__(256) void glu32_bwd_kernel(const float* __restrict_
         for (int ks = 0; ks < 16; ++ks) {
             const float idv = (glu32_ch(ks, hi) == lo) ? 1.0f : 0.0f;
             acc2 = mfma32(dlin[ks], wb2[ks], acc2);                               // dxn[pixel S_hi[r]][c = lo] = dlin . Wg
+            if (!(GLU_ABL & 16)) {
             accx = mfma32(xh[ks], idv, accx);                                     // xhat in accumulator layout
             accd = mfma32(dlin[ks], idv, accd);                                   // dlin in accumulator layout [pixel][n' = lo]
+            } else { accx[ks] = xh[ks]; accd[ks] = dlin[ks]; }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int pi = glu32_ch(r, hi), wp = pi >> 2, qp = pi & 3;             // pixel of accumulator row r
-            const size_t pp = ((size_t)b * T + 2 * to + (qp >> 1)) * F + 2 * (8 * tr + wp) + (qp & 1);
+            // accumulator row r is tile pixel S_hi[r] = 4 wp + qp with qp = r & 3 (compile time) and wp = 2 (r >> 2) + hi
+            const size_t pp = pix0 + (((r & 3) >> 1) ? F : 0) + 2 * (2 * (r >> 2) + hi) + (r & 1);
             const float dxn = acc2[r];
             a_dgam = fmaf(dxn, accx[r], a_dgam);
             a_dbet += dxn;
             a_dbg += accd[r];
-            dz[pp * C + lo] = dxn * gam_lo;
+            if (!(GLU_ABL & 8)) dz[pp * C + lo] = dxn * gam_lo;
             accx[r] = fmaf(accx[r], gam_lo, bet_lo);                              // -> xn in accumulator layout
         }
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) P = mfma32(accd[ks], accx[ks], P);        // P[n' = S_hi[r]][c = lo] += sum_pixels dlin xn
+        for (int ks = 0; ks < 16; ++ks) { if (!(GLU_ABL & 32)) P = mfma32(accd[ks], accx[ks], P); else P[ks] += accd[ks] * accx[ks]; }   // P[n' = S_hi[r]][c = lo] += sum_pixels dlin xn
     }
+    // one partial per workgroup (plain stores), summed in a fixed order by glu_bwd_reduce_kernel: 4096 waves x 1024 device-scope
+    // float atomics on the same 1 K addresses cost tens of microseconds
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) atomicAdd(dWg + glu32_ch(r, hi) * C + lo, P[r]);
+    for (int r = 0; r < 16; ++r) red[wv][glu32_ch(r, hi) * C + lo] = P[r];
     a_dgam += __shfl_xor(a_dgam, 32); a_dbet += __shfl_xor(a_dbet, 32); a_dbg += __shfl_xor(a_dbg, 32);
-    if (hi == 0) { atomicAdd(dgamma + lo, a_dgam); atomicAdd(dbeta + lo, a_dbet); atomicAdd(dbg + lo, a_dbg); }
+    if (hi == 0) { red[wv][C * C + lo] = a_dbg; red[wv][C * C + C + lo] = a_dgam; red[wv][C * C + 2 * C + lo] = a_dbet; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NP; idx += 256)
+        part[(size_t)blockIdx.x * NP + idx] = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1504,6 +1518,7 @@ extern "C" long long sed_glu_bwd_scratch_floats(int B, int T, int F, int C, int 
         const int nt3 = (C / 32) * (C / 32), ks = nt3 >= 8 ? 1 : 8 / nt3, wms = 8 / (C / 32);
         return 256LL * (ks * C * C + wms * 3 * C);
     }
+    if (PT == 2 && PF == 2 && (C == 16 || C == 32)) return 1024LL * (C * C + 3 * C);       // one partial per workgroup
     return 0;
 }
 
@@ -1527,26 +1542,26 @@ extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamm
         if (C == 128) return launch_glu_wide_bwd<128, false>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
         if (C == 64) return launch_glu_wide_bwd<64, false>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
     }
-    sed_zero4(s, dWg, C * C, dbg, C, dgamma, C, dbeta, C);
     if (T % PT != 0) (void)hipMemsetAsync(dz, 0, (size_t)B * T * F * C * 4, s);
-    if (C == 16 && PT == 2 && PF == 2 && F % 8 == 0) {
-        const int ntiles = B * (T / 2) * (F / 8);
-        if (ntiles <= 0) return SED_OK;
-        int grid = (ntiles + 3) / 4;
-        if (grid > 1024) grid = 1024;
-        SED_LAUNCH(glu16_bwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B,
-                   T, F, seed, thr24, dscale, seed_dev);
-        return sed_check_launch();
-    }
-    if (C == 32 && PT == 2 && PF == 2 && F % 16 == 0) {
+    if ((C == 16 && PT == 2 && PF == 2 && F % 8 == 0) || (C == 32 && PT == 2 && PF == 2 && F % 16 == 0)) {
+        // LDS-free MFMA kernels: one row of pooling windows per wave iteration, one partial per workgroup + fixed-order reduce
         const int nrows = B * (T / 2);
-        if (nrows <= 0) return SED_OK;
         int grid = (nrows + 3) / 4;
-        if (grid > 1024) grid = 1024;
-        SED_LAUNCH(glu32_bwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B,
-                   T, F, seed, thr24, dscale, seed_dev);
+        const int cap = C == 32 ? 256 : 1024;      // glu32_bwd needs ~330 registers: one workgroup per CU is all that is resident
+        if (grid > cap) grid = cap;
+        if (grid < 1) { sed_zero4(s, dWg, C * C, dbg, C, dgamma, C, dbeta, C); return SED_OK; }
+        if (!scratch) return SED_ERR_ARG;
+        if (C == 16)
+            SED_LAUNCH(glu16_bwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, gamma, beta, Wg, bg, gout, dz, scratch, B, T, F, seed, thr24,
+                       dscale, seed_dev);
+        else
+            SED_LAUNCH(glu32_bwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, gamma, beta, Wg, bg, gout, dz, scratch, B, T, F, seed, thr24,
+                       dscale, seed_dev);
+        SED_LAUNCH(glu_bwd_reduce_kernel, dim3((C * C + 3 * C + 63) / 64), dim3(256), 0, s, scratch, dWg, dbg, dgamma, dbeta, grid, C, 1, 1,
+                   gamma, beta, 0);
         return sed_check_launch();
     }
+    sed_zero4(s, dWg, C * C, dbg, C, dgamma, C, dbeta, C);
 #define GLU_CASE(c, pt, pf)                                                                                              \
     if (C == c && PT == pt && PF == pf)                                                                                  \
         return launch_glu_bwd<c, pt, pf>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, B, T, F, seed, thr24, \
