@@ -261,7 +261,8 @@ class GraphedStepDriver:
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             with dyn_step(self.dyn, record=True):
-                with torch.cuda.graph(self.graph, stream=self.stream):
+                # thread_local: the RCCL watchdog thread of an initialised process group polls events while we capture
+                with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                     self.loss = self._step_body((self.static[0], self.static[1]) + tuple(batch[2:]))
         else:
             self.static[0].copy_(audio, non_blocking=True)
