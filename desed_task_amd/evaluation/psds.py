@@ -114,9 +114,12 @@ class PSDSEval:
         det = det_t[self.detection_cols].dropna()
         if (det.offset < det.onset).any():
             raise PSDSEvalError("The detection dataframe provided has events with offset before onset")
-        unknown = set(det.event_label) - set(self.class_names[:-1])
-        if unknown:
-            raise PSDSEvalError(f"Detections hold labels that are not in the ground truth: {sorted(unknown)}")
+        known = det.event_label.isin(self.class_names[:-1])
+        if not known.all():
+            # the score is defined over the ground-truth classes; detections of any other label belong to no evaluated class
+            import warnings
+            warnings.warn(f"detections of labels absent from the ground truth are ignored: {sorted(set(det.event_label[~known]))}")
+            det = det[known]
         det = det[det.filename.isin(self._files)]          # a file without metadata has no WORLD event: never counted
         d_file = det.filename.map(self._files).to_numpy(np.int64)
         order = np.argsort(d_file, kind="stable")

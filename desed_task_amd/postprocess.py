@@ -89,18 +89,32 @@ def batched_decode_preds(strong_preds, filenames, encoder, thresholds=[0.5], med
     counts, events = threshold_events(filt, thresholds, true_len)
     raw_np, filt_np = scores.cpu().numpy(), filt.cpu().numpy()
     scores_raw, scores_post = {}, {}
-    rows = {th: [] for th in thresholds}
+    audio_ids = [Path(f).stem for f in filenames]
     for j in range(B):
-        audio_id = Path(filenames[j]).stem
-        filename = audio_id + ".wav"
         n = T if true_len is None else true_len[j]
         ts = encoder._frame_to_time(np.arange(n + 1))
-        scores_raw[audio_id] = create_score_dataframe(raw_np[j, :n], ts, encoder.labels)
-        scores_post[audio_id] = create_score_dataframe(filt_np[j, :n], ts, encoder.labels)
-        for k, th in enumerate(thresholds):
-            for c in range(NC):                                   # decode_strong order: class-major, regions in time order
-                for e in range(counts[k, j, c]):
-                    on, off = events[k, j, c, e]
-                    rows[th].append((encoder.labels[c], encoder._frame_to_time(on), encoder._frame_to_time(off), filename))
-    prediction_dfs = {th: pd.DataFrame(rows[th], columns=["event_label", "onset", "offset", "filename"]) for th in thresholds}
+        scores_raw[audio_ids[j]] = create_score_dataframe(raw_np[j, :n], ts, encoder.labels)
+        scores_post[audio_ids[j]] = create_score_dataframe(filt_np[j, :n], ts, encoder.labels)
+    # all regions of all thresholds at once; np.nonzero walks (threshold, clip, class, region) in C order, which is the
+    # reference's row order per threshold: clip-major, then decode_strong's class-major / time order
+    valid = np.arange(events.shape[3])[None, None, None, :] < counts[..., None]
+    k, j, c, e = np.nonzero(valid)
+    onset = np.asarray(encoder._frame_to_time(events[k, j, c, e, 0]), dtype=np.float64)
+    offset = np.asarray(encoder._frame_to_time(events[k, j, c, e, 1]), dtype=np.float64)
+    label_arr = np.asarray(list(encoder.labels), dtype=object)
+    file_arr = np.asarray([a + ".wav" for a in audio_ids], dtype=object)
+    bounds = np.searchsorted(k, np.arange(len(thresholds) + 1))
+    prediction_dfs = {}
+    for i, th in enumerate(thresholds):
+        sl = slice(bounds[i], bounds[i + 1])
+        prediction_dfs[th] = pd.DataFrame({"event_label": label_arr[c[sl]], "onset": onset[sl], "offset": offset[sl],
+                                           "filename": file_arr[j[sl]]}, columns=["event_label", "onset", "offset", "filename"])
     return scores_raw, scores_post, prediction_dfs
+
+
+def write_sed_scores(scores, storage_path):
+    """sed_scores_eval.io.write_sed_scores: one `<audio_id>.tsv` score table per clip under `storage_path`."""
+    import os
+    os.makedirs(storage_path, exist_ok=True)
+    for audio_id, df in scores.items():
+        df.to_csv(os.path.join(storage_path, audio_id + ".tsv"), sep="\t", index=False)

@@ -297,8 +297,144 @@ class SEDTask4(_Base):
                     buf[th] = pd.concat([buf[th], decoded[th]], ignore_index=True)
         return
 
-    def validation_epoch_end(self, outputs):
-        raise NotImplementedError("PSDS / intersection-F1 / event-F1 at epoch end are the next row (SURVEY 8f rank 2)")
+    def validation_epoch_end(self, outputs=None):
+        """sed_trainer.py:489-600 on this package's evaluator restatements (desed_task_amd/evaluation).
+        The threshold-free `sed_scores_eval` PSDS is not restated, so `training.obj_metric_synth_type` must be "event" or
+        "intersection" (the reference's default, None / "psds", raises) and the key val/synth/student/psds1_sed_scores_eval
+        is not logged."""
+        import pandas as pd
+        from .evaluation.evaluation_measures import compute_per_intersection_macro_f1, log_sedeval_metrics
+        self._val_state()
+        obj_type = self.hparams["training"].get("obj_metric_synth_type")
+        if obj_type in (None, "psds"):
+            raise NotImplementedError("obj_metric_synth_type None / 'psds' needs sed_scores_eval's threshold-free PSDS, which is "
+                                      "not part of this build: set training.obj_metric_synth_type to 'event' or 'intersection'")
+        if obj_type not in ("event", "intersection"):
+            raise NotImplementedError(f"obj_metric_synth_type: {obj_type} not implemented.")
+        data = self.hparams["data"]
+        weak_student_f1_macro = self.get_weak_student_f1_seg_macro.compute()
+        weak_teacher_f1_macro = self.get_weak_teacher_f1_seg_macro.compute()
+        intersection_f1_macro_student = compute_per_intersection_macro_f1(self.val_buffer_student_synth, data["synth_val_tsv"],
+                                                                          data["synth_val_dur"])
+        synth_student_event_macro = log_sedeval_metrics(self.val_buffer_student_synth[0.5], data["synth_val_tsv"])[0]
+        intersection_f1_macro_teacher = compute_per_intersection_macro_f1(self.val_buffer_teacher_synth, data["synth_val_tsv"],
+                                                                          data["synth_val_dur"])
+        synth_teacher_event_macro = log_sedeval_metrics(self.val_buffer_teacher_synth[0.5], data["synth_val_tsv"])[0]
+        synth_metric = synth_student_event_macro if obj_type == "event" else intersection_f1_macro_student
+        obj_metric = torch.tensor(float(weak_student_f1_macro) + float(synth_metric))
+        self.log("val/obj_metric", obj_metric, prog_bar=True)
+        self.log("val/weak/student/macro_F1", weak_student_f1_macro)
+        self.log("val/weak/teacher/macro_F1", weak_teacher_f1_macro)
+        self.log("val/synth/student/intersection_f1_macro", intersection_f1_macro_student)
+        self.log("val/synth/teacher/intersection_f1_macro", intersection_f1_macro_teacher)
+        self.log("val/synth/student/event_f1_macro", synth_student_event_macro)
+        self.log("val/synth/teacher/event_f1_macro", synth_teacher_event_macro)
+        # free the buffers
+        ths = self.hparams["training"].get("val_thresholds", [0.5])
+        self.val_buffer_student_synth = {k: pd.DataFrame() for k in ths}
+        self.val_buffer_teacher_synth = {k: pd.DataFrame() for k in ths}
+        self.val_scores_postprocessed_buffer_student_synth = {}
+        self.val_scores_postprocessed_buffer_teacher_synth = {}
+        self.get_weak_student_f1_seg_macro.reset()
+        self.get_weak_teacher_f1_seg_macro.reset()
+        return obj_metric
+
+    # ---- test scoring (sed_trainer.py:608-911) ----------------------------------------------------------
+    _exp_dir = None
+
+    @property
+    def exp_dir(self):
+        if self._exp_dir is None:
+            self._exp_dir = getattr(getattr(self, "logger", None), "log_dir", None) or self.hparams["log_dir"]
+        return self._exp_dir
+
+    def _test_state(self):
+        """Buffers of sed_trainer.py:139-150, created on first use."""
+        if not hasattr(self, "test_psds_buffer_student"):
+            import numpy as np
+            import pandas as pd
+            n = self.hparams["training"]["n_test_thresholds"]
+            test_thresholds = np.arange(1 / (n * 2), 1, 1 / n)
+            self.test_psds_buffer_student = {k: pd.DataFrame() for k in test_thresholds}
+            self.test_psds_buffer_teacher = {k: pd.DataFrame() for k in test_thresholds}
+            self.decoded_student_05_buffer = pd.DataFrame()
+            self.decoded_teacher_05_buffer = pd.DataFrame()
+            self.test_scores_raw_buffer_student = {}
+            self.test_scores_raw_buffer_teacher = {}
+            self.test_scores_postprocessed_buffer_student = {}
+            self.test_scores_postprocessed_buffer_teacher = {}
 
     def test_step(self, batch, batch_indx):
-        raise NotImplementedError("test scoring (50 thresholds + PSDS, sed_trainer.py:608-683) is the next row (SURVEY 8f rank 2)")
+        """sed_trainer.py:608-683: student and teacher posteriors of one batch, median-filtered and decoded at the
+        n_test_thresholds PSDS thresholds + 0.5 by the device post-processing (two launches and one copy per model instead
+        of the reference's per-clip, per-threshold host loop)."""
+        import pandas as pd
+        from .postprocess import batched_decode_preds
+        self._test_state()
+        audio, labels, padded_indxs, filenames = batch[0], batch[1], batch[2], batch[3]
+        with torch.no_grad():
+            mels = self.mel_spec(audio)
+            x = self.scaled_logmel(mels)
+            strong_s, weak_s = self.sed_student(x)
+            strong_t, weak_t = self.sed_teacher(x)
+        if not self.evaluation:
+            bce = torch.nn.functional.binary_cross_entropy
+            self.log("test/student/loss_strong", bce(strong_s, labels))
+            self.log("test/teacher/loss_strong", bce(strong_t, labels))
+        win = self.hparams["training"].get("median_window", 7)
+        for preds, psds_buf, raw, post, who in (
+                (strong_s, self.test_psds_buffer_student, self.test_scores_raw_buffer_student,
+                 self.test_scores_postprocessed_buffer_student, "student"),
+                (strong_t, self.test_psds_buffer_teacher, self.test_scores_raw_buffer_teacher,
+                 self.test_scores_postprocessed_buffer_teacher, "teacher")):
+            scores_raw, scores_post, decoded = batched_decode_preds(preds, filenames, self.encoder, median_filter=win,
+                                                                    thresholds=list(psds_buf.keys()) + [0.5])
+            raw.update(scores_raw)
+            post.update(scores_post)
+            for th in psds_buf.keys():
+                psds_buf[th] = pd.concat([psds_buf[th], decoded[th]], ignore_index=True)
+            if who == "student":
+                self.decoded_student_05_buffer = pd.concat([self.decoded_student_05_buffer, decoded[0.5]])
+            else:
+                self.decoded_teacher_05_buffer = pd.concat([self.decoded_teacher_05_buffer, decoded[0.5]])
+
+    def on_test_epoch_end(self):
+        """sed_trainer.py:685-911.  `evaluation=True`: only the raw / post-processed score tables are written (one TSV per
+        clip, the sed_scores_eval.io.write_sed_scores layout).  Otherwise PSDS scenario 1 / 2 (psds_eval path), event-based
+        and intersection-based macro F1 for both models.  Not reproduced: the `*_sed_scores_eval` keys (that package's
+        threshold-free PSDS is not restated) and the codecarbon energy keys (trackers are outside the hot path)."""
+        import os
+        from .evaluation.evaluation_measures import (compute_per_intersection_macro_f1, compute_psds_from_operating_points,
+                                                     log_sedeval_metrics)
+        from .postprocess import write_sed_scores
+        self._test_state()
+        save_dir = os.path.join(self.exp_dir, "metrics_test")
+        if self.evaluation:
+            for who, raw, post in (("student", self.test_scores_raw_buffer_student, self.test_scores_postprocessed_buffer_student),
+                                   ("teacher", self.test_scores_raw_buffer_teacher, self.test_scores_postprocessed_buffer_teacher)):
+                write_sed_scores(raw, os.path.join(save_dir, f"{who}_scores", "raw"))
+                write_sed_scores(post, os.path.join(save_dir, f"{who}_scores", "postprocessed"))
+                print(f"\nRaw and postprocessed scores for {who} saved in: {os.path.join(save_dir, who + '_scores')}")
+            results = {}
+        else:
+            data = self.hparams["data"]
+            results = {}
+            for who, buf, buf05 in (("student", self.test_psds_buffer_student, self.decoded_student_05_buffer),
+                                    ("teacher", self.test_psds_buffer_teacher, self.decoded_teacher_05_buffer)):
+                results[f"test/{who}/psds1_psds_eval"] = compute_psds_from_operating_points(
+                    buf, data["test_tsv"], data["test_dur"], dtc_threshold=0.7, gtc_threshold=0.7, alpha_ct=0, alpha_st=1,
+                    save_dir=os.path.join(save_dir, who, "scenario1"))
+                results[f"test/{who}/psds2_psds_eval"] = compute_psds_from_operating_points(
+                    buf, data["test_tsv"], data["test_dur"], dtc_threshold=0.1, gtc_threshold=0.1, cttc_threshold=0.3,
+                    alpha_ct=0.5, alpha_st=1, save_dir=os.path.join(save_dir, who, "scenario2"))
+                results[f"test/{who}/event_f1_macro"] = log_sedeval_metrics(buf05, data["test_tsv"], os.path.join(save_dir, who))[0]
+                results[f"test/{who}/intersection_f1_macro"] = compute_per_intersection_macro_f1(
+                    {"0.5": buf05}, data["test_tsv"], data["test_dur"])
+            results["hp_metric"] = torch.tensor(max(results["test/student/psds1_psds_eval"], results["test/student/psds2_psds_eval"]))
+        logger = getattr(self, "logger", None)
+        if logger is not None:
+            logger.log_metrics(results)
+            logger.log_hyperparams(self.hparams, results)
+        for key in results.keys():
+            self.log(key, results[key], prog_bar=True, logger=True)
+        return results

@@ -727,3 +727,87 @@ def case_validation_step(dev):
                 assert [(r.event_label, float(r.onset), float(r.offset)) for r in d.itertuples()] == ref
     f1 = float(task.get_weak_student_f1_seg_macro.compute())
     assert 0.0 <= f1 <= 1.0
+    # ---- validation_epoch_end: ground truth = the student's own 0.5 decoding -> perfect synth metrics ----
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        d05 = task.val_buffer_student_synth[0.5]
+        assert len(d05) > 0
+        tsv, dur = os.path.join(tmp, "gt.tsv"), os.path.join(tmp, "dur.tsv")
+        d05[["filename", "onset", "offset", "event_label"]].to_csv(tsv, sep="\t", index=False)
+        pd.DataFrame({"filename": ["s%d.wav" % j for j in range(3)], "duration": n_samp / 16000.0}).to_csv(dur, sep="\t", index=False)
+        task.hparams["data"].update(synth_val_tsv=tsv, synth_val_dur=dur)
+        try:
+            task.validation_epoch_end([])
+            raise AssertionError("the sed_scores_eval objective must be refused, not silently replaced")
+        except NotImplementedError:
+            pass
+        task.hparams["training"]["obj_metric_synth_type"] = "event"
+        obj = task.validation_epoch_end([])
+        assert abs(float(obj) - (f1 + 1.0)) < 1e-6
+        assert float(task.logged["val/synth/student/event_f1_macro"]) == 1.0
+        # intersection F1 averages over the val thresholds (0.3 scores worse against the 0.5 ground truth)
+        assert 0.0 < float(task.logged["val/synth/student/intersection_f1_macro"]) <= 1.0
+        assert all(len(v) == 0 for v in task.val_buffer_student_synth.values()) and task.get_weak_student_f1_seg_macro.tp is None
+
+
+def case_test_epoch(dev, out_dir):
+    """SEDTask4.test_step x2 + on_test_epoch_end (SURVEY 8f ranks 1 + 2 end to end): device scoring -> decoded operating points
+    -> PSDS / event / intersection metrics.  The ground truth is the oracle decoding (numpy region search) of the task's own
+    post-processed student scores at 0.5, so the student's 0.5 operating point must score a perfect event-based and
+    intersection-based F1 through the whole chain, and the PSD-ROC must reach TPR 1."""
+    import os
+    import pandas as pd
+    from desed_task_amd.evaluation.psds import PSDSEval
+    bs, n_samp = (2, 2, 4), 16000 * 2 + 1024
+    B = sum(bs)
+    sd = O.make_state_dict(seed=7)
+    n_out = (1 + n_samp // 256) // 4
+    task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=100)
+    task.hparams["training"].update(n_test_thresholds=10, median_window=7)
+    task.hparams["log_dir"] = str(out_dir)
+    task.encoder = _Encoder(["c%d" % i for i in range(10)], audio_len=n_samp / 16000.0)
+    task.eval()
+    files = []
+    for step in range(2):
+        audio = O.synth_audio(B, n_samp, seed=31 + step)
+        labels = O.synth_labels(bs, 10, n_out, seed=5 + step)
+        names = ["/d/test/t%d_%d.wav" % (step, i) for i in range(B)]
+        files += names
+        task.test_step((to(dev, audio), to(dev, labels), None, names, None), step)
+    assert np.allclose(sorted(task.test_psds_buffer_student), np.arange(0.05, 1, 0.1)) and len(task.test_psds_buffer_student) == 10
+    assert len(task.test_scores_raw_buffer_student) == 2 * B and "test/student/loss_strong" in task.logged
+    enc = task.encoder
+    rows = []
+    for f in files:
+        aid = os.path.basename(f)[:-4]
+        own = task.test_scores_postprocessed_buffer_student[aid].values[:, 2:].astype(np.float32)
+        ev = O.decode_events(own, np.float32(0.5))
+        for c, on, off in ev:
+            rows.append((aid + ".wav", float(enc._frame_to_time(on)), float(enc._frame_to_time(off)), enc.labels[c]))
+        if not ev:
+            rows.append((aid + ".wav", np.nan, np.nan, np.nan))
+    gt = pd.DataFrame(rows, columns=["filename", "onset", "offset", "event_label"])
+    assert gt.event_label.notna().sum() > 0, "the random-init posteriors must cross 0.5 somewhere for this case to bite"
+    tsv, dur = os.path.join(str(out_dir), "gt.tsv"), os.path.join(str(out_dir), "dur.tsv")
+    gt.to_csv(tsv, sep="\t", index=False)
+    pd.DataFrame({"filename": [os.path.basename(f) for f in files], "duration": n_samp / 16000.0}).to_csv(dur, sep="\t", index=False)
+    task.hparams["data"] = {"test_tsv": tsv, "test_dur": dur}
+    res = task.on_test_epoch_end()
+    for who in ("student", "teacher"):                           # the teacher is a copy of the student at construction
+        assert res["test/%s/event_f1_macro" % who] == 1.0
+        assert res["test/%s/intersection_f1_macro" % who] == 1.0
+        for k in ("psds1_psds_eval", "psds2_psds_eval"):
+            assert 0.0 < res["test/%s/%s" % (who, k)] <= 1.0
+        assert os.path.exists(os.path.join(str(out_dir), "metrics_test", who, "event_f1.txt"))
+        assert len(os.listdir(os.path.join(str(out_dir), "metrics_test", who, "scenario1", "predictions_dtc0.7_gtc0.7_cttc0.3"))) == 10
+    assert abs(float(res["hp_metric"]) - max(res["test/student/psds1_psds_eval"], res["test/student/psds2_psds_eval"])) < 1e-6
+    # the 0.5 operating point alone is a perfect detector: its PSD-ROC is the unit step
+    ev = PSDSEval(ground_truth=gt, metadata=pd.read_csv(dur, sep="\t"), dtc_threshold=0.7, gtc_threshold=0.7)
+    ev.add_operating_point(task.decoded_student_05_buffer)
+    assert ev.psds(alpha_st=1, max_efpr=100).value == 1.0
+    # evaluation mode: only the score tables are written
+    task.evaluation = True
+    task._exp_dir = os.path.join(str(out_dir), "eval")
+    assert task.on_test_epoch_end() == {}
+    assert len(os.listdir(os.path.join(task._exp_dir, "metrics_test", "student_scores", "postprocessed"))) == 2 * B

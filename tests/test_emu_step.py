@@ -46,3 +46,8 @@ def test_dyn_args_step_equals_eager(emu):
 def test_validation_step(emu):
     """SEDTask4.validation_step on the emulator: eval forward + batched decoding vs the oracle."""
     P.case_validation_step("cpu")
+
+
+def test_test_epoch(emu, tmp_path):
+    """test_step + on_test_epoch_end (SURVEY 8f ranks 1 + 2): device scoring -> operating points -> PSDS / F1 metrics."""
+    P.case_test_epoch("cpu", tmp_path)

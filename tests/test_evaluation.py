@@ -195,8 +195,9 @@ def test_psds_small_cases():
     # GTC: one detection covering less than half of the event is relevant (DTC) but does not make a true positive
     counts, *_ = ev._evaluate_detections(ev._init_det_table(det.iloc[:1]))
     assert counts.tolist() == [[0, 0, 0], [0, 0, 0], [0, 0, 0]]
-    with pytest.raises(PSDSEvalError):
-        ev.add_operating_point(det.assign(event_label="unknown"))
+    with pytest.warns(UserWarning, match="absent from the ground truth"):
+        counts, *_ = ev._evaluate_detections(ev._init_det_table(det.assign(event_label="unknown")))
+    assert counts.sum() == 0
     with pytest.raises(PSDSEvalError):
         PSDSEval(ground_truth=gt, metadata=meta, dtc_threshold=1.5)
     with pytest.raises(PSDSEvalError):

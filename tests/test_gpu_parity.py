@@ -115,3 +115,7 @@ def test_postprocess_median_threshold_events():
 
 def test_validation_step():
     P.case_validation_step("cuda")
+
+
+def test_test_epoch(tmp_path):
+    P.case_test_epoch("cuda", tmp_path)
