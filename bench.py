@@ -183,6 +183,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured hipGraph step")
+    ap.add_argument("--embeddings", action="store_true",
+                    help="secondary workload (SURVEY 8f rank 3): the 2023 'pretrained' step, frozen BEATs-shaped embeddings "
+                         "(768 x 496 per clip) fused into the CRNN (confs/pretrained.yaml); not the headline metric")
     args = ap.parse_args()
 
     from desed_task_amd import _lib
@@ -201,6 +204,10 @@ def main():
     torch.manual_seed(1234 + rank); np.random.seed(1234 + rank); random.seed(1234 + rank)
 
     config = recipe_config()
+    if args.embeddings:
+        from desed_task_amd.sed_trainer_pretrained import SEDTask4      # noqa: F811
+        config["net"].update(use_embeddings=True, embedding_size=768, embedding_type="frame", aggregation_type="pool1d")
+        config["pretrained"] = {"e2e": False, "freezed": True, "model": "beats"}
     student = CRNN(**config["net"]).to(dev)
     if world > 1:                                   # identical initial weights on every rank
         dist.broadcast(student.arena.flat, src=0)
@@ -222,9 +229,12 @@ def main():
     else:
         driver = StepDriver(task, world_size=world)
     audio, labels = synthetic_batch(dev, 1234 + rank)
+    emb = None
+    if args.embeddings:
+        emb = torch.randn(sum(BATCH), 768, 496, device=dev, generator=torch.Generator(device=dev).manual_seed(77 + rank))
 
     def one_step(i):
-        driver.run_step((audio, labels.clone(), None, None), i)
+        driver.run_step((audio, labels.clone(), None, emb), i)
 
     # untimed: the W warm-up steps, plus (graph mode) whatever is still missing for the capture to lie outside the timed region
     n_untimed = max(args.warmup, 5) if use_graph else args.warmup
@@ -260,7 +270,7 @@ def main():
         # same workload right after the timed region (same process, same tensors, same stream)
         timer.wrap(_lib.get())
         for i in range(5):
-            driver.eager.run_step((audio, labels.clone(), None, None), i)
+            driver.eager.run_step((audio, labels.clone(), None, emb), i)
         torch.cuda.synchronize()
     timer.unwrap()
     if world > 1:
@@ -309,7 +319,10 @@ def main():
         "dtype": "f32 (fp32 storage and accumulation; the dense contractions of the wide layers run as split-bf16 MFMA, 3 bf16 "
                  "products per fp32 product, fp32-level accuracy; everything else exact f32)", "data": "synthetic",
         "config": {"workload": "dcase2023 CRNN mean-teacher train step, 128-mel 10s@16kHz, batch 48/GPU (12 strong/12 weak/24 "
-                               "unlabelled), dropout+SpecAugment+mixup on, fp32 accuracy (conv_precision=%s)" % task.sed_student.cnn.conv_precision,
+                               "unlabelled), dropout+SpecAugment+mixup on, fp32 accuracy (conv_precision=%s)%s"
+                               % (task.sed_student.cnn.conv_precision,
+                                  " + frozen 768x496 embeddings per clip fused by pool1d/cat_tf (confs/pretrained.yaml; secondary "
+                                  "workload, SURVEY 8f rank 3)" if args.embeddings else ""),
                    "global_batch": sum(BATCH) * world, "parallelism": "dp%d" % world, "last_loss_strong": round(loss_val, 5),
                    "launch": "hipGraph replay of the captured step (3 eager + 1 capture step before the timed region)" if use_graph
                              else (graph_note or "eager launches"), "untimed_steps": n_untimed},
@@ -323,7 +336,7 @@ def main():
             "note": "6.464 GFLOP/clip = conv1-6 + GLU1-6, student fwd + dgrad + wgrad + teacher fwd; 960 512 B/clip = mel path in+out; "
                     "whole-step clips/s, so both are diluted by the GRU recurrence and the HBM-bound narrow blocks (DESIGN.md 8)"},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.embeddings:
         out["cpu_baseline"] = cpu_baseline_bounded()
     print(json.dumps(out))
 

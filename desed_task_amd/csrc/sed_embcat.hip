@@ -1,0 +1,96 @@
+// K14: embedding fusion in front of the recurrent stage, `aggregation_type: "pool1d"` of
+// desed_task/nnet/CRNN.py:283-296 (the 2023 "pretrained" / BEATs configuration):
+//     reshape_emb = adaptive_avg_pool1d(embeddings (B, E, Te), T).transpose(1, 2)            (B, T, E)
+//     z           = dropout(cat((x (B, T, C), reshape_emb), -1))                             (B, T, C + E)
+//     x           = cat_tf(z)                                                                 Linear(C + E -> C)
+// sed_embcat_fwd builds z in ONE pass over the embeddings (pooling, transposition, concatenation and the dropout mask fused:
+// the (B, T, E) pooled tensor and the undropped concatenation never exist in HBM); the Linear and its weight / input
+// gradients are the split-bf16 GEMMs of K7 (sed_gemm_bf16x3) on z, which is also what the backward needs saved.
+// sed_embcat_bwd applies the same mask to the x-columns of dz (the embeddings are frozen features: no gradient).
+//
+// HBM-bound: algorithmic bytes per clip = read E*Te*4 + C*T*4, write (C + E)*T*4  (768 x 496, 128 x 156: 2.16 MB).
+// Layout: embeddings (B, E, Te) time-contiguous exactly as the reference stores them; a workgroup stages EMB_TILE channel
+// rows of one clip in LDS with coalesced reads along time (row stride Te + 1: the strided pooling reads are conflict-free)
+// and writes 128-byte channel runs of z.
+#include "sed_common.h"
+
+#define EMB_TILE 32
+#define EMB_THREADS 256
+
+__global__ __launch_bounds__(EMB_THREADS) void embcat_fwd_kernel(const float* __restrict__ x, const float* __restrict__ emb,
+                                                                  float* __restrict__ z, int T, int Te, int C, int E,
+                                                                  uint32_t seed, uint32_t thr24, float dscale,
+                                                                  const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
+    SED_DYN_SMEM(smem_raw);
+    float* rows = (float*)smem_raw;             // [EMB_TILE][Te + 1]
+    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int ntile = (E + EMB_TILE - 1) / EMB_TILE, W = C + E, RS = Te + 1;
+    if (tile == ntile) {                        // the x columns of this clip
+        const size_t base = (size_t)b * T;
+        for (int i = tid; i < T * C; i += EMB_THREADS) {
+            const int t = i / C, c = i - t * C;
+            const size_t m = base + t;
+            const float v = x[m * C + c];
+            z[m * W + c] = sed_keep((uint32_t)(m * W + c), seed, thr24) ? v * dscale : 0.f;
+        }
+        return;
+    }
+    const int e0 = tile * EMB_TILE;
+    const float* src = emb + ((size_t)b * E + e0) * Te;
+    const int ne = min(EMB_TILE, E - e0);
+    for (int i = tid; i < ne * Te; i += EMB_THREADS) {          // rows are contiguous in HBM: fully coalesced
+        const int r = i / Te, s = i - r * Te;
+        rows[r * RS + s] = src[i];
+    }
+    __syncthreads();
+    const int e = tid & (EMB_TILE - 1);
+    if (e >= ne) return;
+    for (int t = tid / EMB_TILE; t < T; t += EMB_THREADS / EMB_TILE) {
+        // torch adaptive pooling window: [floor(t * Te / T), ceil((t + 1) * Te / T))
+        const int s0 = (int)(((long long)t * Te) / T), s1 = (int)((((long long)(t + 1)) * Te + T - 1) / T);
+        float acc = 0.f;
+        for (int s = s0; s < s1; ++s) acc += rows[e * RS + s];
+        const float v = acc / (float)(s1 - s0);
+        const size_t m = (size_t)b * T + t;
+        const size_t o = m * W + C + e0 + e;
+        z[o] = sed_keep((uint32_t)o, seed, thr24) ? v * dscale : 0.f;
+    }
+}
+
+// x (B,T,C), emb (B,E,Te) -> z (B,T,C+E).  thr24 = 0 disables the dropout (dscale is then 1).
+extern "C" int sed_embcat_fwd(const float* x, const float* emb, float* z, int B, int T, int Te, int C, int E, unsigned seed,
+                              unsigned thr24, float dscale, const unsigned* seed_dev, void* stream) {
+    if (B <= 0 || T <= 0) return SED_OK;
+    if (Te < 1 || C < 1 || E < 1) return SED_ERR_ARG;
+    const size_t smem = (size_t)EMB_TILE * (Te + 1) * sizeof(float);
+    if (smem > 150 * 1024 || (size_t)B * T * (C + E) >= (1ull << 32)) return SED_ERR_UNSUPPORTED;
+    const int ntile = (E + EMB_TILE - 1) / EMB_TILE;
+    SED_MAX_SMEM(embcat_fwd_kernel, smem);
+    SED_LAUNCH(embcat_fwd_kernel, dim3(ntile + 1, B), dim3(EMB_THREADS), smem, (hipStream_t)stream, x, emb, z, T, Te, C, E, seed,
+               thr24, dscale, seed_dev);
+    return sed_check_launch();
+}
+
+__global__ __launch_bounds__(256) void embcat_bwd_kernel(const float* __restrict__ dzx, float* __restrict__ dx, size_t n, int C,
+                                                          int W, uint32_t seed, uint32_t thr24, float dscale,
+                                                          const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t m = i / C;
+        const int c = (int)(i - m * C);
+        dx[i] = sed_keep((uint32_t)(m * W + c), seed, thr24) ? dzx[i] * dscale : 0.f;
+    }
+}
+
+// dzx (M, C) = the first C columns of dz = dy . W_cat_tf -> dx (M, C) = dzx masked with the forward's dropout mask.
+extern "C" int sed_embcat_bwd(const float* dzx, float* dx, int M, int C, int E, unsigned seed, unsigned thr24, float dscale,
+                              const unsigned* seed_dev, void* stream) {
+    if (M <= 0) return SED_OK;
+    if (C < 1 || E < 1) return SED_ERR_ARG;
+    const size_t n = (size_t)M * C;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    SED_LAUNCH(embcat_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dzx, dx, n, C, C + E, seed, thr24, dscale, seed_dev);
+    return sed_check_launch();
+}

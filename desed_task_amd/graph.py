@@ -251,22 +251,30 @@ class GraphedStepDriver:
         self.n += 1
         if self.n <= self.warmup:
             return self.eager.run_step(batch, batch_idx)
-        audio, labels = batch[0], batch[1]
         if self.graph is None:
             if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
                 torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
             self.dyn = DynArgs(dev)
-            self.static = (torch.empty_like(audio), torch.empty_like(labels))
-            self.static[0].copy_(audio); self.static[1].copy_(labels)
+            # every device tensor of the batch (audio, labels, and e.g. the embeddings of the pretrained recipe) gets a static
+            # input buffer: the graph reads those addresses, each replay copies the new batch into them
+            self.static = tuple(torch.empty_like(t) if torch.is_tensor(t) and t.is_cuda else None for t in batch)
+            for st, t in zip(self.static, batch):
+                if st is not None:
+                    st.copy_(t)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             with dyn_step(self.dyn, record=True):
                 # thread_local: the RCCL watchdog thread of an initialised process group polls events while we capture
                 with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
-                    self.loss = self._step_body((self.static[0], self.static[1]) + tuple(batch[2:]))
+                    self.loss = self._step_body(tuple(st if st is not None else t for st, t in zip(self.static, batch)))
         else:
-            self.static[0].copy_(audio, non_blocking=True)
-            self.static[1].copy_(labels, non_blocking=True)
+            if len(batch) != len(self.static):
+                raise ValueError("batch arity changed after the step was captured")
+            for st, t in zip(self.static, batch):
+                if st is not None:
+                    if not torch.is_tensor(t) or t.shape != st.shape:
+                        raise ValueError("batch tensor shapes changed after the step was captured")
+                    st.copy_(t, non_blocking=True)
             self.dyn.run_host_ops()
         self.dyn.upload()
         self.graph.replay()

@@ -6,7 +6,11 @@ Same constructor keywords, same `forward(x, pad_mask=None, embeddings=None, clas
 parameters are views into one flat arena (arena.py), SpecAugment is folded into the first conv's load, and the
 whole forward/backward is a chain of HIP kernels (ops.py).
 
-Not built yet (SURVEY 8f "next" rows; they raise NotImplementedError): use_embeddings / aggregation, pad_mask,
+Embedding fusion: `use_embeddings=True, aggregation_type="pool1d"` (the 2023 "pretrained" / BEATs
+configuration, CRNN.py:143-144, :283-296) is built: `cat_tf = Linear(C + embedding_size, C)` after the heads in the state
+dict, `forward(x, embeddings=emb (B, embedding_size, Te))`.
+
+Not built (they raise NotImplementedError): the other aggregation types (global / frame / interpolate), pad_mask,
 classes_mask, dropstep_recurrent, cnn_integration, multi-head nclass lists.
 """
 import copy
@@ -16,7 +20,7 @@ import torch.nn as nn
 
 from .. import features
 from ..arena import ParamArena
-from ..ops import HeadFn, new_seed
+from ..ops import EmbCatFn, HeadFn, new_seed
 from .CNN import CNN
 from .RNN import BidirectionalGRU
 
@@ -28,8 +32,10 @@ class CRNN(nn.Module):
                  frame_emb_enc_dim=512, aggregation_type="global", specaugm_t_p=0.2, specaugm_t_l=5, specaugm_f_p=0.2,
                  specaugm_f_l=10, dropstep_recurrent=0.0, dropstep_recurrent_len=5, specaugm_iid_masks=True, **kwargs):
         super().__init__()
-        if cnn_integration or use_embeddings or dropstep_recurrent:
-            raise NotImplementedError("cnn_integration / use_embeddings / dropstep_recurrent: next rows (SURVEY 8f)")
+        if cnn_integration or dropstep_recurrent:
+            raise NotImplementedError("cnn_integration / dropstep_recurrent are not built (SURVEY 8f)")
+        if use_embeddings and aggregation_type != "pool1d":
+            raise NotImplementedError("use_embeddings is built for aggregation_type 'pool1d' only (SURVEY 8f rank 3)")
         if rnn_type != "BGRU":
             raise NotImplementedError("Only BGRU supported for CRNN for now")
         if isinstance(nclass, (tuple, list)):
@@ -62,6 +68,9 @@ class CRNN(nn.Module):
         self.sigmoid = nn.Sigmoid()
         self.dense_softmax = nn.Linear(n_RNN_cell * 2, nclass)
         self.softmax = nn.Softmax(dim=-1)
+        if use_embeddings:                                                # CRNN.py:143-144
+            nb_in = self.cnn.nb_filters[-1]
+            self.cat_tf = nn.Linear(nb_in + embedding_size, nb_in)
         self._arena = None
         self._build_arena()
 
@@ -118,9 +127,20 @@ class CRNN(nn.Module):
             raise NotImplementedError("CNN output keeps %d frequency bins; the recurrent stage expects 1" % freq)
         return h.view(bs, frames, chan)
 
-    def forward_tail(self, h):
-        """Second half of forward(): BiGRU + dropout + attention head.  (B, T', C) -> strong (B,nclass,T'), weak."""
+    def forward_tail(self, h, embeddings=None):
+        """Second half of forward(): [embedding fusion +] BiGRU + dropout + attention head.
+        (B, T', C) -> strong (B,nclass,T'), weak."""
         arena = self.arena
+        if self.use_embeddings:
+            if embeddings is None:
+                raise ValueError("this CRNN was built with use_embeddings=True: forward() needs embeddings")
+            if embeddings.requires_grad:
+                raise NotImplementedError("embeddings are frozen features here (pretrained.e2e / unfrozen extractors are not built)")
+            drop = self.dropout.training and self.dropout_p > 0
+            cfg = dict(dropout_p=self.dropout_p, apply_dropout=drop, seed=new_seed() if drop else 0, arena=arena)
+            h = EmbCatFn.apply(h, embeddings, self.cat_tf.weight, self.cat_tf.bias, cfg)
+        elif embeddings is not None:
+            raise ValueError("embeddings given to a CRNN built with use_embeddings=False")
         h = self.rnn(h, arena=arena)                                      # (B, T', 256)
         drop = self.dropout.training and self.dropout_p > 0
         cfg = dict(dropout_p=self.dropout_p, apply_dropout=drop, seed=new_seed() if drop else 0, arena=arena)
@@ -129,9 +149,9 @@ class CRNN(nn.Module):
         return strong.transpose(1, 2), weak
 
     def forward(self, x, pad_mask=None, embeddings=None, classes_mask=None):
-        if pad_mask is not None or embeddings is not None or classes_mask is not None:
-            raise NotImplementedError("pad_mask / embeddings / classes_mask: next rows (SURVEY 8f)")
-        return self.forward_tail(self.forward_cnn(x))
+        if pad_mask is not None or classes_mask is not None:
+            raise NotImplementedError("pad_mask / classes_mask are not built (SURVEY 8f)")
+        return self.forward_tail(self.forward_cnn(x), embeddings)
 
     def train(self, mode=True):
         """Mirrors CRNN.train (CRNN.py:308-323), including that it returns None."""

@@ -272,6 +272,62 @@ class BiGRULayerFn(torch.autograd.Function):
         return (dx, d_w_ih[0], d_w_hh[0], d_b_ih[0], d_b_hh[0], d_w_ih[1], d_w_hh[1], d_b_ih[1], d_b_hh[1], None)
 
 
+class EmbCatFn(torch.autograd.Function):
+    """Embedding fusion of CRNN.py:283-296 (aggregation_type "pool1d"): cat_tf(dropout(cat(x, pool1d(emb)))).
+    x (B,T,C), emb (B,E,Te) frozen features -> (B,T,C).  One fused pooling/concat/dropout kernel (K14) + the K7 GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, emb, w, b, cfg):
+        lib = _lib.get()
+        x, emb, w = x.contiguous(), emb.contiguous().float(), w.contiguous()
+        _lib.check_tensor(x, "embcat input")
+        _lib.check_tensor(emb, "embeddings")
+        B, T, C = x.shape
+        if emb.dim() != 3 or emb.shape[0] != B:
+            raise ValueError("embeddings must be (batch, embedding_size, frames)")
+        E, Te = emb.shape[1], emb.shape[2]
+        if w.shape != (C, C + E):
+            raise ValueError(f"cat_tf.weight is {tuple(w.shape)}, expected {(C, C + E)}")
+        thr24, dscale = dropout_params(cfg.get("dropout_p", 0.0) if cfg.get("apply_dropout", False) else 0.0)
+        seed = cfg.get("seed", 0)
+        seed = seed if isinstance(seed, _graph.DynSeed) else int(seed)
+        st = _lib.stream_ptr(x)
+        f32 = dict(device=x.device, dtype=torch.float32)
+        z = torch.empty(B, T, C + E, **f32)
+        lib.call("sed_embcat_fwd", x.data_ptr(), emb.data_ptr(), z.data_ptr(), B, T, Te, C, E, int(seed), thr24, dscale,
+                 _graph.seed_dev(seed), st)
+        y = torch.empty(B, T, C, **f32)
+        lib.call(gemm_entry(cfg, pair=False), z.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B * T, C, C + E, C + E, C + E, C,
+                 0, 1, 1, 0, st)
+        ctx.save_for_backward(z, w, b)
+        ctx.meta = (B, T, C, E, seed, thr24, dscale)
+        ctx.cfg = cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.get()
+        z, w, b = ctx.saved_tensors
+        B, T, C, E, seed, thr24, dscale = ctx.meta
+        cfg = ctx.cfg
+        dy = dy.contiguous()
+        st = _lib.stream_ptr(dy)
+        M, W = B * T, C + E
+        entry = gemm_entry(cfg, pair=False)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dzx = torch.empty(B, T, C, device=dy.device, dtype=torch.float32)
+            lib.call(entry, dy.data_ptr(), w.data_ptr(), None, dzx.data_ptr(), M, C, C, C, W, C, 0, 0, 1, 0, st)   # dy . W[:, :C]
+            dx = torch.empty_like(dzx)
+            lib.call("sed_embcat_bwd", dzx.data_ptr(), dx.data_ptr(), M, C, E, int(seed), thr24, dscale, _graph.seed_dev(seed), st)
+        dw, db = _grad_buf(cfg, w), _grad_buf(cfg, b)
+        split = max(1, min(32, M // 256))
+        lib.call("sed_zero_buffers", dw.data_ptr(), dw.numel(), None, 0, None, 0, None, 0, st)             # split-K accumulates
+        lib.call(entry, dy.data_ptr(), z.data_ptr(), None, dw.data_ptr(), C, W, M, C, W, W, 1, 0, split, 0, st)  # dy^T . z
+        lib.call("sed_colsum", dy.data_ptr(), db.data_ptr(), None, C, M, C, C, st)
+        return dx, None, dw, db, None
+
+
 class HeadFn(torch.autograd.Function):
     """Dropout + the two dense layers + class-softmax attention pooling (CRNN.py:152-178, :304).
     x (B,T,256) -> strong (B,T,NC) [caller exposes the (B,NC,T) view], weak (B,NC)."""

@@ -90,8 +90,10 @@ class SEDTask4(_Base):
             return features.minmax_scale(mel_feats, eps=self.scaler.eps, apply_log=True)
         return self.scaler(self.take_log(mel_feats))
 
-    def detect(self, mel_feats, model):
-        return model(self.scaled_logmel(mel_feats))
+    def detect(self, mel_feats, model, embeddings=None):
+        if embeddings is None:
+            return model(self.scaled_logmel(mel_feats))
+        return model(self.scaled_logmel(mel_feats), embeddings=embeddings)      # sed_trainer_pretrained.py:276-280
 
     # ---- optimisation hooks -----------------------------------------------------------------------
     def lr_scheduler_step(self, scheduler, optimizer_idx=None, metric=None):
@@ -143,8 +145,17 @@ class SEDTask4(_Base):
             self._tstream = torch.cuda.Stream(device=device)
         return self._tstream
 
+    def _batch_embeddings(self, batch):
+        """Frozen embeddings of the batch, or None: the plain recipe has none (sed_trainer.py:280 ignores batch[3])."""
+        return None
+
+    def _eval_embeddings(self, batch):
+        """Same for validation / test batches (audio, labels, padded_indxs, filenames[, embeddings])."""
+        return None
+
     def training_step(self, batch, batch_indx):
         audio, labels = batch[0], batch[1]
+        embeddings = self._batch_embeddings(batch)        # NOT mixed up with the features (sed_trainer_pretrained.py:320-330)
         indx_synth, indx_weak, indx_unlabelled = self.hparams["training"]["batch_size"]
         features_ = self.mel_spec(audio)                                  # (B, n_mels, T) view of frame-major HBM
 
@@ -173,9 +184,9 @@ class SEDTask4(_Base):
         x = self.scaled_logmel(features_)                                 # shared by student and teacher
         tstream = self._tail_stream(x.device)
         if tstream is None:
-            strong_s, weak_s = self.sed_student(x)
+            strong_s, weak_s = self.sed_student(x, embeddings=embeddings)
             with torch.no_grad():
-                strong_t, weak_t = self.sed_teacher(x)
+                strong_t, weak_t = self.sed_teacher(x, embeddings=embeddings)
         else:
             # Both CNN encoders first (they fill the GPU), then the two latency-bound tails -- BiGRU recurrence (96
             # workgroups each) + head -- side by side on two HIP streams: they are independent and together still leave
@@ -186,8 +197,8 @@ class SEDTask4(_Base):
             main = torch.cuda.current_stream(x.device)
             tstream.wait_stream(main)
             with torch.cuda.stream(tstream), torch.no_grad():
-                strong_t, weak_t = self.sed_teacher.forward_tail(ht)
-            strong_s, weak_s = self.sed_student.forward_tail(hs)
+                strong_t, weak_t = self.sed_teacher.forward_tail(ht, embeddings)
+            strong_s, weak_s = self.sed_student.forward_tail(hs, embeddings)
             main.wait_stream(tstream)
             ht.record_stream(tstream)
             strong_t.record_stream(main)
@@ -266,11 +277,12 @@ class SEDTask4(_Base):
         self._val_state()
         audio, labels, padded_indxs, filenames = batch[0], batch[1], batch[2], batch[3]
         bce = torch.nn.functional.binary_cross_entropy
+        emb = self._eval_embeddings(batch)
         with torch.no_grad():
             mels = self.mel_spec(audio)
             x = self.scaled_logmel(mels)                     # student and teacher see the same features (detect() twice)
-            strong_s, weak_s = self.sed_student(x)
-            strong_t, weak_t = self.sed_teacher(x)
+            strong_s, weak_s = self.sed_student(x, embeddings=emb)
+            strong_t, weak_t = self.sed_teacher(x, embeddings=emb)
         data = self.hparams.get("data", {})
         weak_dir, synth_dir = data.get("weak_folder"), data.get("synth_val_folder")
         is_weak = [weak_dir is not None and str(Path(f).parent) == str(Path(weak_dir)) for f in filenames]
@@ -372,11 +384,12 @@ class SEDTask4(_Base):
         from .postprocess import batched_decode_preds
         self._test_state()
         audio, labels, padded_indxs, filenames = batch[0], batch[1], batch[2], batch[3]
+        emb = self._eval_embeddings(batch)
         with torch.no_grad():
             mels = self.mel_spec(audio)
             x = self.scaled_logmel(mels)
-            strong_s, weak_s = self.sed_student(x)
-            strong_t, weak_t = self.sed_teacher(x)
+            strong_s, weak_s = self.sed_student(x, embeddings=emb)
+            strong_t, weak_t = self.sed_teacher(x, embeddings=emb)
         if not self.evaluation:
             bce = torch.nn.functional.binary_cross_entropy
             self.log("test/student/loss_strong", bce(strong_s, labels))

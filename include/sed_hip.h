@@ -206,6 +206,17 @@ int sed_median_filter(const float* scores, float* out, int B, int T, int NC, int
 int sed_threshold_events(const float* scores, const float* thresholds, const int* true_len, int* counts, int* events,
                          int B, int T, int NC, int n_thr, int max_events, void* stream);
 
+/* ---- K14: embedding fusion before the recurrent stage, desed_task/nnet/CRNN.py:283-296 -------- */
+
+/* z (B,T,C+E) = dropout(cat(x (B,T,C), adaptive_avg_pool1d(emb (B,E,Te), T)^T)) -- the input of `cat_tf`
+ * (aggregation_type "pool1d"); pooling window of frame t = [floor(t*Te/T), ceil((t+1)*Te/T)).  Dropout mask = sed_keep over
+ * the element index of z (thr24 = 0: off, dscale = 1); seed_dev as everywhere (null or one step-varying word). */
+int sed_embcat_fwd(const float* x, const float* emb, float* z, int B, int T, int Te, int C, int E, unsigned seed,
+                   unsigned thr24, float dscale, const unsigned* seed_dev, void* stream);
+/* dx (M,C) = dzx (M,C) masked/scaled with the forward's dropout mask; dzx = the first C columns of dz = dy . W_cat_tf. */
+int sed_embcat_bwd(const float* dzx, float* dx, int M, int C, int E, unsigned seed, unsigned thr24, float dscale,
+                   const unsigned* seed_dev, void* stream);
+
 /* ---- K10 + K11: flat parameter arena ------------------------------------------------------------------------- */
 
 /* SEDTask4.update_ema (sed_trainer.py:187-199) over the whole arena: teacher = alpha*teacher + (1-alpha)*student. */

@@ -136,12 +136,14 @@ def specaug_apply(x: torch.Tensor, f_bounds, t_bounds) -> torch.Tensor:
 # ----------------------------------------------------------------------------------
 def crnn_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool = False,
                  drop_masks: Optional[Sequence[Optional[torch.Tensor]]] = None, dropout_p: float = 0.5,
-                 update_bn: bool = True, taps: Optional[dict] = None):
+                 update_bn: bool = True, taps: Optional[dict] = None, embeddings: Optional[torch.Tensor] = None):
     """x: (B, n_mels, T) scaled log-mel (SpecAugment, if any, already applied).
     drop_masks: None -> no dropout (even when training); else a list of 8 keep-masks
     (7 CNN blocks in NHWC-agnostic NCHW shape (B,C,T,F) pre-pool, then the post-GRU (B,T',256)),
     applied as x * mask / (1-p) (inverted dropout, CNN.py:90-91, CRNN.py:103,304).
     In training mode BN uses batch stats and (if update_bn) updates running stats in sd in place.
+    embeddings (B, E, Te): the `use_embeddings`, aggregation_type "pool1d" branch (CRNN.py:283-296) with sd["cat_tf.*"];
+    its dropout mask is drop_masks[8] of shape (B, T', C + E).
     Returns strong (B, nclass, T//4), weak (B, nclass).  Follows CRNN.py:221-306, CNN.py:66-98."""
     h = x.transpose(1, 2).unsqueeze(1)                                   # (B,1,T,F)  CRNN.py:224
     for i in range(len(NB_FILTERS)):
@@ -162,6 +164,14 @@ def crnn_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool = 
         if taps is not None:
             taps[f"block{i}"] = h
     h = h.squeeze(-1).permute(0, 2, 1)                                   # (B,T',C)  CRNN.py:244-245
+    if embeddings is not None:
+        reshape_emb = F.adaptive_avg_pool1d(embeddings, h.shape[1]).transpose(1, 2)      # CRNN.py:283-286
+        z = torch.cat((h, reshape_emb), -1)
+        if drop_masks is not None and len(drop_masks) > 8 and drop_masks[8] is not None:
+            z = z * drop_masks[8] / (1.0 - dropout_p)
+        h = F.linear(z, sd["cat_tf.weight"], sd["cat_tf.bias"])          # CRNN.py:296
+        if taps is not None:
+            taps["cat_tf"] = h
     flat = []
     for layer in range(2):
         for sfx in ("", "_reverse"):
@@ -205,7 +215,8 @@ def gru_reference_loop(x, w_ih, w_hh, b_ih, b_hh, reverse=False):
 # ----------------------------------------------------------------------------------
 # parameter initialisation with the reference's (torch default) distributions and key layout
 # ----------------------------------------------------------------------------------
-def crnn_param_shapes(n_in=1, nclass=10, nb_filters=NB_FILTERS, hidden=128):
+def crnn_param_shapes(n_in=1, nclass=10, nb_filters=NB_FILTERS, hidden=128, embedding_size=None):
+    """embedding_size: adds `cat_tf` (CRNN.py:143-144, aggregation_type "pool1d"), registered after the heads."""
     shapes = {}
     cin = n_in
     for i, co in enumerate(nb_filters):
@@ -227,6 +238,9 @@ def crnn_param_shapes(n_in=1, nclass=10, nb_filters=NB_FILTERS, hidden=128):
     shapes["dense.bias"] = (nclass,)
     shapes["dense_softmax.weight"] = (nclass, 2 * hidden)
     shapes["dense_softmax.bias"] = (nclass,)
+    if embedding_size is not None:
+        shapes["cat_tf.weight"] = (nb_filters[-1], nb_filters[-1] + embedding_size)
+        shapes["cat_tf.bias"] = (nb_filters[-1],)
     return shapes
 
 
@@ -244,11 +258,11 @@ def lcg_fill(shape, seed: int, scale: float = 1.0, offset: float = 0.0) -> torch
     return torch.from_numpy(((u * 2 - 1) * scale + offset).astype(np.float32)).reshape(shape)
 
 
-def make_state_dict(seed: int = 7, nclass=10, bn_stats: bool = True) -> Dict[str, torch.Tensor]:
+def make_state_dict(seed: int = 7, nclass=10, bn_stats: bool = True, embedding_size=None) -> Dict[str, torch.Tensor]:
     """LCG-filled CRNN state dict with magnitudes like torch's default init (U(+-1/sqrt(fan_in)))."""
     sd = {}
     k = seed * 1000
-    for name, shp in crnn_param_shapes(nclass=nclass).items():
+    for name, shp in crnn_param_shapes(nclass=nclass, embedding_size=embedding_size).items():
         k += 1
         if "batchnorm" in name:
             sd[name] = lcg_fill(shp, k, 0.25, 1.0) if name.endswith("weight") else lcg_fill(shp, k, 0.1)
@@ -276,6 +290,11 @@ def tap_sample(t: torch.Tensor) -> torch.Tensor:
 
 
 PARAM_KEYS = [k for k in crnn_param_shapes().keys()]   # parameters() order of the reference module
+
+
+def param_keys(sd) -> list:
+    """Parameter keys of a state dict in the reference's parameters() order (cat_tf last when present)."""
+    return PARAM_KEYS + [k for k in ("cat_tf.weight", "cat_tf.bias") if k in sd]
 
 
 def synth_audio(batch: int, n_samples: int = 160000, seed: int = 1234) -> torch.Tensor:
@@ -321,7 +340,7 @@ def warmup_factor(step_num: int, rampup_len: int, exponent: float = -5.0) -> flo
 # ----------------------------------------------------------------------------------
 def ema_update(teacher: Dict[str, torch.Tensor], student: Dict[str, torch.Tensor], alpha: float, global_step: int):
     alpha = min(1 - 1 / (global_step + 1), alpha)
-    for k in PARAM_KEYS:
+    for k in param_keys(student):
         teacher[k].mul_(alpha).add_(student[k], alpha=1 - alpha)
     return alpha
 
@@ -348,7 +367,8 @@ class OracleTrainer:
     def __init__(self, student_sd, batch_sizes=(12, 12, 24), lr=1e-3, rampup_len=5900, const_max=2.0,
                  ema_factor=0.999, dropout_p=0.5, teacher_sd=None):
         self.student = {k: v.clone() for k, v in student_sd.items()}
-        for k in PARAM_KEYS:
+        self.keys = param_keys(student_sd)
+        for k in self.keys:
             self.student[k].requires_grad_(True)
         src = teacher_sd if teacher_sd is not None else student_sd
         self.teacher = {k: v.clone() for k, v in src.items()}          # deepcopy (sed_trainer.py:61-64)
@@ -357,8 +377,8 @@ class OracleTrainer:
         self.dropout_p = dropout_p
         self.step_num = 1                                              # schedulers.py:79
         self.lr = lr
-        self.m = {k: torch.zeros_like(self.student[k]) for k in PARAM_KEYS}
-        self.v = {k: torch.zeros_like(self.student[k]) for k in PARAM_KEYS}
+        self.m = {k: torch.zeros_like(self.student[k]) for k in self.keys}
+        self.v = {k: torch.zeros_like(self.student[k]) for k in self.keys}
         self.adam_steps = 0
 
     def features(self, audio, labels, mix=None):
@@ -371,21 +391,23 @@ class OracleTrainer:
             feats[:ns], labels[:ns] = mixup_apply(feats[:ns], labels[:ns], mix["c_strong"], mix["perm_strong"])
         return feats, labels, labels_weak
 
-    def detect(self, feats, sd, training, aug=None, drop_masks=None, update_bn=True):
+    def detect(self, feats, sd, training, aug=None, drop_masks=None, update_bn=True, embeddings=None):
         x = scale_minmax(take_log(feats))
         if aug is not None:
             x = specaug_apply(x, aug["f"], aug["t"])
         return crnn_forward(sd, x, training=training, drop_masks=drop_masks, dropout_p=self.dropout_p,
-                            update_bn=update_bn)
+                            update_bn=update_bn, embeddings=embeddings)
 
-    def training_step(self, audio, labels, mix=None, aug_s=None, aug_t=None, drop_s=None, drop_t=None):
+    def training_step(self, audio, labels, mix=None, aug_s=None, aug_t=None, drop_s=None, drop_t=None, embeddings=None):
+        """embeddings: the pretrained variant of the step (sed_trainer_pretrained.py:282-400) -- the same embeddings go to
+        the student and the teacher and are NOT mixed up with the features."""
         ns, nw, _ = self.batch_sizes
         feats, labels, labels_weak = self.features(audio, labels, mix)
-        strong_s, weak_s = self.detect(feats, self.student, True, aug_s, drop_s)
+        strong_s, weak_s = self.detect(feats, self.student, True, aug_s, drop_s, embeddings=embeddings)
         loss_strong = F.binary_cross_entropy(strong_s[:ns], labels[:ns])
         loss_weak = F.binary_cross_entropy(weak_s[ns:ns + nw], labels_weak)
         with torch.no_grad():
-            strong_t, weak_t = self.detect(feats, self.teacher, True, aug_t, drop_t)   # teacher in TRAIN mode (Q7)
+            strong_t, weak_t = self.detect(feats, self.teacher, True, aug_t, drop_t, embeddings=embeddings)   # TRAIN mode (Q7)
             loss_strong_t = F.binary_cross_entropy(strong_t[:ns], labels[:ns])
             loss_weak_t = F.binary_cross_entropy(weak_t[ns:ns + nw], labels_weak)
         weight = self.const_max * warmup_factor(self.step_num, self.rampup_len)
@@ -407,18 +429,18 @@ class OracleTrainer:
     def optimizer_step(self, tot_loss):
         """Lightning 1.9 order: on_before_zero_grad(EMA) -> zero_grad -> backward -> Adam -> scheduler."""
         with torch.no_grad():
-            ema_update(self.teacher, {k: self.student[k].detach() for k in PARAM_KEYS}, self.ema_factor, self.step_num)
-        params = [self.student[k] for k in PARAM_KEYS]
+            ema_update(self.teacher, {k: self.student[k].detach() for k in self.keys}, self.ema_factor, self.step_num)
+        params = [self.student[k] for k in self.keys]
         grads = torch.autograd.grad(tot_loss, params, allow_unused=True)
         self.adam_steps += 1
         with torch.no_grad():
-            for k, g in zip(PARAM_KEYS, grads):
+            for k, g in zip(self.keys, grads):
                 if g is None:
                     g = torch.zeros_like(self.student[k])
                 adam_step(self.student[k], g, self.m[k], self.v[k], self.adam_steps, self.lr)
         self.step_num += 1
         self.lr = self.max_lr * warmup_factor(self.step_num, self.rampup_len)
-        return dict(zip(PARAM_KEYS, grads))
+        return dict(zip(self.keys, grads))
 
 
 # ------------------------------------------------------------------------------------------------

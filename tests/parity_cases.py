@@ -1,5 +1,7 @@
 """Parity cases shared by the CPU-emulator tests (small shapes) and the GPU tests (`-m gpu`, through the real
 C-ABI library).  Every case compares the HIP path against the CPU oracle on the same seeded inputs."""
+import math
+
 import numpy as np
 import torch
 
@@ -262,12 +264,17 @@ def recipe_config(batch_sizes=(12, 12, 24)):
     }
 
 
-def build_task(dev, batch_sizes, sd, dropout=None, specaug=True, rampup=100, lr=1e-3):
+def build_task(dev, batch_sizes, sd, dropout=None, specaug=True, rampup=100, lr=1e-3, pretrained=False):
     from desed_task_amd.nnet.CRNN import CRNN
-    from desed_task_amd.sed_trainer import SEDTask4
     from desed_task_amd.arena import FusedAdam
     from desed_task_amd.utils.schedulers import ExponentialWarmup
     config = recipe_config(batch_sizes)
+    if pretrained:          # recipes/dcase2023_task4_baseline/confs/pretrained.yaml: embeddings delivered with the batch
+        from desed_task_amd.sed_trainer_pretrained import SEDTask4
+        config["net"] = pretrained_net_config()
+        config["pretrained"] = {"e2e": False, "freezed": True, "model": "beats"}
+    else:
+        from desed_task_amd.sed_trainer import SEDTask4
     net_cfg = dict(config["net"])
     if dropout is not None:
         net_cfg["dropout"] = dropout
@@ -811,3 +818,179 @@ def case_test_epoch(dev, out_dir):
     task._exp_dir = os.path.join(str(out_dir), "eval")
     assert task.on_test_epoch_end() == {}
     assert len(os.listdir(os.path.join(task._exp_dir, "metrics_test", "student_scores", "postprocessed"))) == 2 * B
+
+
+# ------------------------------------------------------------------------------------------------
+# embedding fusion: K14 + cat_tf, CRNN(use_embeddings=True, aggregation_type="pool1d")
+# ------------------------------------------------------------------------------------------------
+def case_embcat_op(dev):
+    """EmbCatFn forward / backward against torch ops on the same dropout mask: ragged pooling windows (496 -> 156, 51 -> 16),
+    up-sampling (Te < T: repeated windows), E not a multiple of the 32-channel tile, dropout on and off."""
+    from desed_task_amd import ops
+    for (B, T, Te, C, E, p, seed) in ((2, 16, 51, 128, 768, 0.5, 77), (1, 156, 496, 128, 64, 0.5, 5), (3, 16, 10, 32, 40, 0.0, 0),
+                                       (2, 7, 7, 128, 33, 0.25, 123456)):
+        x = O.lcg_fill((B, T, C), 1 + T, 1.0)
+        emb = O.lcg_fill((B, E, Te), 2 + Te, 1.0)
+        w = O.lcg_fill((C, C + E), 3, 1.0 / math.sqrt(C + E))
+        b = O.lcg_fill((C,), 4, 0.1)
+        gy = O.lcg_fill((B, T, C), 5, 1.0)
+        # reference
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        z = torch.cat((xr, torch.nn.functional.adaptive_avg_pool1d(emb, T).transpose(1, 2)), -1)
+        if p > 0:
+            z = z * np_keep_mask((B, T, C + E), seed, p) / (1.0 - p)
+        yr = torch.nn.functional.linear(z, wr, br)
+        yr.backward(gy)
+        # HIP path
+        xd, wd, bd = to(dev, x).requires_grad_(True), to(dev, w).requires_grad_(True), to(dev, b).requires_grad_(True)
+        cfg = dict(dropout_p=p, apply_dropout=p > 0, seed=seed)
+        y = ops.EmbCatFn.apply(xd, to(dev, emb), wd, bd, cfg)
+        y.backward(to(dev, gy))
+        tol = lambda ref: 3e-5 * max(1.0, float(ref.detach().abs().max()))      # noqa: E731
+        assert float((y.detach().cpu() - yr.detach()).abs().max()) < tol(yr), ("y", B, T, Te, C, E)
+        assert float((xd.grad.cpu() - xr.grad).abs().max()) < tol(xr.grad), ("dx", B, T, Te, C, E)
+        assert float((wd.grad.cpu() - wr.grad).abs().max()) < tol(wr.grad), ("dw", B, T, Te, C, E)
+        assert float((bd.grad.cpu() - br.grad).abs().max()) < tol(br.grad), ("db", B, T, Te, C, E)
+    # frozen-CNN variant: no input gradient requested
+    y = ops.EmbCatFn.apply(to(dev, x), to(dev, emb), wd, bd, cfg)
+    wd.grad = None
+    y.sum().backward()
+    assert wd.grad is not None
+
+
+def pretrained_net_config():
+    """`net:` of recipes/dcase2023_task4_baseline/confs/pretrained.yaml (BEATs embeddings, 768 x 496 per clip)."""
+    cfg = dict(recipe_config()["net"])
+    cfg.update(use_embeddings=True, embedding_size=768, embedding_type="frame", aggregation_type="pool1d")
+    return cfg
+
+
+def case_embedding_crnn_vs_reference_golden(dev, golden):
+    """CRNN(**pretrained.yaml net) on the HIP kernels against the reference module's recorded outputs
+    (tests/golden/golden_emb.npz): eval and train-mode posteriors, loss, all parameter gradients incl. cat_tf."""
+    from desed_task_amd.nnet.CRNN import CRNN
+    sd = O.make_state_dict(seed=7, embedding_size=768)
+    xin = O.lcg_fill((2, 128, 64), 41, 0.5, 0.5)
+    emb = O.lcg_fill((2, 768, 51), 42, 1.0)
+    cfg = pretrained_net_config()
+    net = CRNN(**cfg)
+    assert [n for n, _ in net.named_parameters()] == list(golden["param_names"])
+    net.load_state_dict({k: v.clone() for k, v in sd.items()})
+    net = net.to(dev) if dev != "cpu" else net
+    assert net.arena.is_intact()
+    net.eval()
+    with torch.no_grad():
+        strong, weak = net(to(dev, xin), embeddings=to(dev, emb))
+    assert np.abs(strong.cpu().numpy() - golden["eval_strong"]).max() < 2e-5
+    assert np.abs(weak.cpu().numpy() - golden["eval_weak"]).max() < 2e-5
+    try:
+        net(to(dev, xin))
+        raise AssertionError("a use_embeddings CRNN must refuse a call without embeddings")
+    except ValueError:
+        pass
+    cfg["dropout"] = 0.0
+    net = CRNN(**cfg, specaugm_t_p=0.0, specaugm_f_p=0.0)
+    net.load_state_dict({k: v.clone() for k, v in sd.items()})
+    net = net.to(dev) if dev != "cpu" else net
+    net.train()
+    strong, weak = net(to(dev, xin), embeddings=to(dev, emb))
+    assert np.abs(strong.detach().cpu().numpy() - golden["train_strong"]).max() < 2e-5
+    assert np.abs(weak.detach().cpu().numpy() - golden["train_weak"]).max() < 2e-5
+    tgt_s = to(dev, (O.lcg_fill(tuple(strong.shape), 31, 0.5, 0.5) < 0.2).float())
+    tgt_w = to(dev, (O.lcg_fill(tuple(weak.shape), 32, 0.5, 0.5) < 0.3).float())
+    loss = torch.nn.functional.binary_cross_entropy(strong, tgt_s) + torch.nn.functional.binary_cross_entropy(weak, tgt_w)
+    assert abs(loss.item() - float(golden["loss"][0])) < 2e-6
+    loss.backward()
+    params = dict(net.named_parameters())
+    for n, ref in zip(list(golden["param_names"]), golden["grad_norms"]):
+        if n.startswith("cnn.cnn.conv") and n.endswith(".bias"):
+            continue                                  # analytically zero (see case_training_step)
+        assert abs(params[n].grad.norm().item() - ref) <= 2e-3 * ref + 1e-7, n
+    for n, sl in (("cat_tf.bias", lambda g: g), ("cat_tf.weight", lambda g: g[::8, ::7]),
+                  ("cnn.cnn.conv6.weight", lambda g: g.reshape(-1)[:512])):
+        got, ref = sl(params[n].grad.detach().cpu().numpy()), golden["grad__" + n]
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7, n
+
+
+def case_pretrained_training_step(dev):
+    """sed_trainer_pretrained.SEDTask4 (embeddings in the batch, CRNN with cat_tf) x2 steps through the StepDriver against
+    the oracle trainer on the same embeddings: losses, posteriors (1e-3), every gradient incl. cat_tf, EMA'd teacher."""
+    import random
+    from desed_task_amd.launcher import StepDriver
+    bs, n_samp, steps = (1, 1, 2), 16000 + 1024, 2
+    B = sum(bs)
+    sd = O.make_state_dict(seed=7, embedding_size=768)
+    audio = O.synth_audio(B, n_samp, seed=77)
+    n_out = (1 + n_samp // 256) // 4
+    labels = O.synth_labels(bs, 10, n_out, seed=5)
+    emb = O.lcg_fill((B, 768, 53), 9, 1.0)                       # BEATs frame rate: ~3.2 embedding frames per CRNN frame
+    task = build_task(dev, bs, sd, dropout=0.0, specaug=False, rampup=100, pretrained=True)
+    assert "cat_tf.weight" in dict(task.sed_teacher.named_parameters())
+    driver = StepDriver(task, world_size=1)
+    orc = O.OracleTrainer(sd, batch_sizes=bs, lr=1e-3, rampup_len=100)
+    keys = O.param_keys(sd)
+    for step in range(steps):
+        random.seed(4); np.random.seed(100 + step); torch.manual_seed(100 + step)
+        assert random.random() < 0.5
+        cw = np.random.beta(0.2, 0.2); pw = torch.randperm(bs[1]); cs = np.random.beta(0.2, 0.2); ps = torch.randperm(bs[0])
+        mix = dict(c_weak=cw, perm_weak=pw, c_strong=cs, perm_strong=ps)
+        random.seed(4); np.random.seed(100 + step); torch.manual_seed(100 + step)
+        loss = driver.run_step((to(dev, audio.clone()), to(dev, labels.clone()), None, to(dev, emb)), step)
+        tot, logs = orc.training_step(audio, labels, mix=mix, embeddings=emb)
+        ref_grads = orc.optimizer_step(tot)
+        hip_params = dict(task.sed_student.named_parameters())
+        for k in keys:
+            if k.startswith("cnn.cnn.conv") and k.endswith(".bias"):
+                continue
+            g, r = hip_params[k].grad.detach().cpu(), ref_grads[k]
+            rel = 1e-4 if step == 0 else 3e-2
+            assert (g - r).abs().max().item() <= rel * r.abs().max().item() + 5e-8, "step %d grad %s" % (step, k)
+        got = {k: (float(v) if not torch.is_tensor(v) else float(v.detach().cpu())) for k, v in task.logged.items()}
+        got["loss"] = float(loss.detach().cpu())
+        logs["loss"] = tot.item()
+        for k in sorted(logs):
+            assert abs(got[k] - logs[k]) <= 2e-5 + 2e-4 * abs(logs[k]), "step %d %s: hip %.8g oracle %.8g" % (step, k, got[k], logs[k])
+        s_s, w_s, s_t, w_t = [t.detach().cpu() for t in task.last_outputs]
+        assert (s_s - orc.last["strong_s"]).abs().max().item() < 1e-3 and (s_t - orc.last["strong_t"]).abs().max().item() < 1e-3
+        assert (w_s - orc.last["weak_s"]).abs().max().item() < 1e-3 and (w_t - orc.last["weak_t"]).abs().max().item() < 1e-3
+    for k in ("cat_tf.weight", "cat_tf.bias", "dense.weight"):
+        for mine, theirs in ((dict(task.sed_student.named_parameters())[k].detach().cpu(), orc.student[k].detach()),
+                             (dict(task.sed_teacher.named_parameters())[k].detach().cpu(), orc.teacher[k])):
+            upd = (theirs - sd[k]).norm().item()
+            assert (mine - theirs).norm().item() <= 0.15 * upd + 1e-6, k
+    # a batch without embeddings is refused; e2e is refused at construction
+    try:
+        task.training_step((to(dev, audio), to(dev, labels), None), 0)
+        raise AssertionError("missing embeddings must raise")
+    except ValueError:
+        pass
+    from desed_task_amd.sed_trainer_pretrained import SEDTask4
+    try:
+        SEDTask4({"pretrained": {"e2e": True}}, None, None)
+        raise AssertionError("e2e must be refused")
+    except NotImplementedError:
+        pass
+
+
+def case_embcat_full_size(dev):
+    """K14 at the pretrained recipe's full size (B 48, 156 frames, BEATs 768 x 496): against torch ops on the same device with
+    dropout off; with dropout on, the kept elements are the scaled undropped values and the keep rate is 1 - p."""
+    from desed_task_amd import ops
+    B, T, Te, C, E, p = 48, 156, 496, 128, 768, 0.5
+    g = torch.Generator().manual_seed(3)
+    x = to(dev, torch.randn(B, T, C, generator=g))
+    emb = to(dev, torch.randn(B, E, Te, generator=g))
+    w = to(dev, torch.randn(C, C + E, generator=g) / math.sqrt(C + E)).requires_grad_(True)
+    b = to(dev, torch.zeros(C)).requires_grad_(True)
+    z_ref = torch.cat((x, torch.nn.functional.adaptive_avg_pool1d(emb, T).transpose(1, 2)), -1)
+    y = ops.EmbCatFn.apply(x, emb, w, b, dict(apply_dropout=False))
+    y_ref = torch.nn.functional.linear(z_ref, w, b)
+    assert float((y - y_ref).abs().max()) < 3e-5 * float(y_ref.abs().max())
+    lib = _lib.get()
+    z = torch.empty(B, T, C + E, device=x.device)
+    thr24, dscale = ops.dropout_params(p)
+    lib.call("sed_embcat_fwd", x.data_ptr(), emb.data_ptr(), z.data_ptr(), B, T, Te, C, E, 99, thr24, dscale, None, _lib.stream_ptr(x))
+    kept = z != 0
+    rate = float(kept.float().mean())
+    assert abs(rate - (1 - p)) < 2e-3, rate
+    assert float((z[kept] - z_ref[kept] * dscale).abs().max()) < 1e-5 * float(z_ref.abs().max()) * dscale

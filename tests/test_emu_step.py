@@ -51,3 +51,20 @@ def test_validation_step(emu):
 def test_test_epoch(emu, tmp_path):
     """test_step + on_test_epoch_end (SURVEY 8f ranks 1 + 2): device scoring -> operating points -> PSDS / F1 metrics."""
     P.case_test_epoch("cpu", tmp_path)
+
+
+def test_embcat_op(emu):
+    """K14: pooling + concat + dropout kernel and the cat_tf GEMMs vs torch ops."""
+    P.case_embcat_op("cpu")
+
+
+def test_embedding_crnn_matches_reference_golden(emu):
+    import os
+    import numpy as np
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_emb.npz"))
+    P.case_embedding_crnn_vs_reference_golden("cpu", G)
+
+
+def test_pretrained_training_step(emu):
+    """sed_trainer_pretrained.SEDTask4: the mean-teacher step with frozen embeddings in the batch vs the oracle trainer."""
+    P.case_pretrained_training_step("cpu")

@@ -1,4 +1,6 @@
 """GPU parity tests (`pytest -m gpu`): HIP kernels through the real C-ABI library vs the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -119,3 +121,18 @@ def test_validation_step():
 
 def test_test_epoch(tmp_path):
     P.case_test_epoch("cuda", tmp_path)
+
+
+def test_embcat_op():
+    """K14: embedding pooling + concat + dropout kernel and the cat_tf GEMMs."""
+    P.case_embcat_op("cuda")
+    P.case_embcat_full_size("cuda")
+
+
+def test_embedding_crnn_matches_reference_golden():
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_emb.npz"))
+    P.case_embedding_crnn_vs_reference_golden("cuda", G)
+
+
+def test_pretrained_training_step():
+    P.case_pretrained_training_step("cuda")
