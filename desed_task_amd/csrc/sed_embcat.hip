@@ -9,26 +9,32 @@
 // sed_embcat_bwd applies the same mask to the x-columns of dz (the embeddings are frozen features: no gradient).
 //
 // HBM-bound: algorithmic bytes per clip = read E*Te*4 + C*T*4, write (C + E)*T*4  (768 x 496, 128 x 156: 2.16 MB).
-// Layout: embeddings (B, E, Te) time-contiguous exactly as the reference stores them; a workgroup stages EMB_TILE channel
-// rows of one clip in LDS with coalesced reads along time (row stride Te + 1: the strided pooling reads are conflict-free)
-// and writes 128-byte channel runs of z.
+// Layout: embeddings (B, E, Te) time-contiguous exactly as the reference stores them; a workgroup stages the input frames of
+// EMB_TCH output frames x EMB_TILE channel rows in LDS with coalesced reads along time (odd row stride: the strided pooling
+// reads are conflict-free) and writes 256-byte channel runs of z; ~33 KB of LDS, four workgroups per CU.
 #include "sed_common.h"
 
-#define EMB_TILE 32
+#define EMB_TILE 64        // embedding channels per workgroup: 256-byte channel runs of z per output frame
+#define EMB_TCH 40         // output frames per workgroup (bounds the LDS stage: 64 x ~130 floats for 496 -> 156)
 #define EMB_THREADS 256
 
+// first input frame of output frame t's pooling window; the window of t ends where ceil((t + 1) * Te / T) says
+__device__ __forceinline__ int emb_win_lo(int t, int Te, int T) { return (int)(((long long)t * Te) / T); }
+__device__ __forceinline__ int emb_win_hi(int t, int Te, int T) { return (int)((((long long)(t + 1)) * Te + T - 1) / T); }
+
 __global__ __launch_bounds__(EMB_THREADS) void embcat_fwd_kernel(const float* __restrict__ x, const float* __restrict__ emb,
-                                                                  float* __restrict__ z, int T, int Te, int C, int E,
+                                                                  float* __restrict__ z, int T, int Te, int C, int E, int RS,
                                                                   uint32_t seed, uint32_t thr24, float dscale,
                                                                   const unsigned* __restrict__ seed_dev) {
     if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     SED_DYN_SMEM(smem_raw);
-    float* rows = (float*)smem_raw;             // [EMB_TILE][Te + 1]
-    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const int ntile = (E + EMB_TILE - 1) / EMB_TILE, W = C + E, RS = Te + 1;
-    if (tile == ntile) {                        // the x columns of this clip
-        const size_t base = (size_t)b * T;
-        for (int i = tid; i < T * C; i += EMB_THREADS) {
+    float* rows = (float*)smem_raw;             // [EMB_TILE][RS]: the input frames this chunk of output frames pools over
+    const int b = blockIdx.z, tile = blockIdx.x, tid = threadIdx.x;
+    const int t0 = blockIdx.y * EMB_TCH, t1 = min(T, t0 + EMB_TCH);
+    const int ntile = (E + EMB_TILE - 1) / EMB_TILE, W = C + E;
+    if (tile == ntile) {                        // the x columns of these frames
+        const size_t base = (size_t)b * T + t0;
+        for (int i = tid; i < (t1 - t0) * C; i += EMB_THREADS) {
             const int t = i / C, c = i - t * C;
             const size_t m = base + t;
             const float v = x[m * C + c];
@@ -36,24 +42,22 @@ __global__ __launch_bounds__(EMB_THREADS) void embcat_fwd_kernel(const float* __
         }
         return;
     }
-    const int e0 = tile * EMB_TILE;
-    const float* src = emb + ((size_t)b * E + e0) * Te;
-    const int ne = min(EMB_TILE, E - e0);
-    for (int i = tid; i < ne * Te; i += EMB_THREADS) {          // rows are contiguous in HBM: fully coalesced
-        const int r = i / Te, s = i - r * Te;
-        rows[r * RS + s] = src[i];
+    const int e0 = tile * EMB_TILE, ne = min(EMB_TILE, E - e0);
+    const int s_lo = emb_win_lo(t0, Te, T), len = emb_win_hi(t1 - 1, Te, T) - s_lo;
+    const float* src = emb + ((size_t)b * E + e0) * Te + s_lo;
+    for (int i = tid; i < ne * len; i += EMB_THREADS) {         // consecutive lanes read consecutive frames of one row
+        const int r = i / len, s = i - r * len;
+        rows[r * RS + s] = src[(size_t)r * Te + s];
     }
     __syncthreads();
     const int e = tid & (EMB_TILE - 1);
     if (e >= ne) return;
-    for (int t = tid / EMB_TILE; t < T; t += EMB_THREADS / EMB_TILE) {
-        // torch adaptive pooling window: [floor(t * Te / T), ceil((t + 1) * Te / T))
-        const int s0 = (int)(((long long)t * Te) / T), s1 = (int)((((long long)(t + 1)) * Te + T - 1) / T);
+    for (int t = t0 + tid / EMB_TILE; t < t1; t += EMB_THREADS / EMB_TILE) {
+        const int w0 = emb_win_lo(t, Te, T) - s_lo, w1 = emb_win_hi(t, Te, T) - s_lo;
         float acc = 0.f;
-        for (int s = s0; s < s1; ++s) acc += rows[e * RS + s];
-        const float v = acc / (float)(s1 - s0);
-        const size_t m = (size_t)b * T + t;
-        const size_t o = m * W + C + e0 + e;
+        for (int s = w0; s < w1; ++s) acc += rows[e * RS + s];  // RS is odd: the 64 channel rows hit distinct banks
+        const float v = acc / (float)(w1 - w0);
+        const size_t o = ((size_t)b * T + t) * W + C + e0 + e;
         z[o] = sed_keep((uint32_t)o, seed, thr24) ? v * dscale : 0.f;
     }
 }
@@ -63,12 +67,15 @@ extern "C" int sed_embcat_fwd(const float* x, const float* emb, float* z, int B,
                               unsigned thr24, float dscale, const unsigned* seed_dev, void* stream) {
     if (B <= 0 || T <= 0) return SED_OK;
     if (Te < 1 || C < 1 || E < 1) return SED_ERR_ARG;
-    const size_t smem = (size_t)EMB_TILE * (Te + 1) * sizeof(float);
+    // longest input span of one chunk of EMB_TCH output frames (+2: the floor / ceil at either end), odd row stride
+    int RS = (int)(((long long)EMB_TCH * Te + T - 1) / T) + 2;
+    RS |= 1;
+    const size_t smem = (size_t)EMB_TILE * RS * sizeof(float);
     if (smem > 150 * 1024 || (size_t)B * T * (C + E) >= (1ull << 32)) return SED_ERR_UNSUPPORTED;
-    const int ntile = (E + EMB_TILE - 1) / EMB_TILE;
+    const int ntile = (E + EMB_TILE - 1) / EMB_TILE, nchunk = (T + EMB_TCH - 1) / EMB_TCH;
     SED_MAX_SMEM(embcat_fwd_kernel, smem);
-    SED_LAUNCH(embcat_fwd_kernel, dim3(ntile + 1, B), dim3(EMB_THREADS), smem, (hipStream_t)stream, x, emb, z, T, Te, C, E, seed,
-               thr24, dscale, seed_dev);
+    SED_LAUNCH(embcat_fwd_kernel, dim3(ntile + 1, nchunk, B), dim3(EMB_THREADS), smem, (hipStream_t)stream, x, emb, z, T, Te, C, E,
+               RS, seed, thr24, dscale, seed_dev);
     return sed_check_launch();
 }
 

@@ -265,15 +265,24 @@ extern "C" int sed_gemm_kcat(const float* A, const float* B0, const float* B1, f
                          (hipStream_t)stream, B1 - (size_t)ksplit * ldb, ksplit);
 }
 
-// column sums: out[n] = sum_m X[m*ld + n], n < N  (bias gradients); out is zeroed here, atomics across row chunks
+// column sums: out[n] = sum_m X[m*ld + n], n < N  (bias gradients); out is zeroed here, atomics across row chunks.
+// A workgroup covers 64 columns x rows_per_block rows: four row lanes per column (256-byte row reads per wave), combined in
+// LDS, one atomic per column.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ out, float* __restrict__ out1,
                                                      int nsplit, int M, int N, int ld, int rows_per_block) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float part[4][64];
+    const int col = threadIdx.x & 63, lane = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + col;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float acc = 0.f;
-    for (int r = r0; r < r1; ++r) acc += X[(size_t)r * ld + n];
-    atomicAdd(n < nsplit ? out + n : out1 + (n - nsplit), acc);
+    if (n < N)
+        for (int r = r0 + lane; r < r1; r += 4) acc += X[(size_t)r * ld + n];
+    part[lane][col] = acc;
+    __syncthreads();
+    if (lane == 0 && n < N) {
+        acc = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+        atomicAdd(n < nsplit ? out + n : out1 + (n - nsplit), acc);
+    }
 }
 // out[n] = sum_m X[m*ld + n] for n < nsplit, out1[n - nsplit] for nsplit <= n < N (out1 may be null when nsplit == N).
 extern "C" int sed_colsum(const float* X, float* out, float* out1, int nsplit, int M, int N, int ld, void* stream) {
@@ -281,8 +290,8 @@ extern "C" int sed_colsum(const float* X, float* out, float* out1, int nsplit, i
     if (nsplit > N || (nsplit < N && out1 == nullptr)) return SED_ERR_ARG;
     sed_zero4(s, out, nsplit, out1, N - nsplit, nullptr, 0, nullptr, 0);
     if (M <= 0 || N <= 0) return SED_OK;
-    const int rpb = 128;
-    SED_LAUNCH(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, s, X, out, out1, nsplit, M, N, ld, rpb);
+    const int rpb = 32;
+    SED_LAUNCH(colsum_kernel, dim3((N + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, s, X, out, out1, nsplit, M, N, ld, rpb);
     return sed_check_launch();
 }
 
