@@ -18,9 +18,9 @@
 #define EMB_TCH 40         // output frames per workgroup (bounds the LDS stage: 64 x ~130 floats for 496 -> 156)
 #define EMB_THREADS 256
 
-// first input frame of output frame t's pooling window; the window of t ends where ceil((t + 1) * Te / T) says
-__device__ __forceinline__ int emb_win_lo(int t, int Te, int T) { return (int)(((long long)t * Te) / T); }
-__device__ __forceinline__ int emb_win_hi(int t, int Te, int T) { return (int)((((long long)(t + 1)) * Te + T - 1) / T); }
+// pooling window of output frame t: [floor(t * Te / T), ceil((t + 1) * Te / T))  (torch adaptive pooling); T * Te < 2^31
+__device__ __forceinline__ int emb_win_lo(int t, int Te, int T) { return (int)((unsigned)(t * Te) / (unsigned)T); }
+__device__ __forceinline__ int emb_win_hi(int t, int Te, int T) { return (int)((unsigned)((t + 1) * Te + T - 1) / (unsigned)T); }
 
 __global__ __launch_bounds__(EMB_THREADS) void embcat_fwd_kernel(const float* __restrict__ x, const float* __restrict__ emb,
                                                                   float* __restrict__ z, int T, int Te, int C, int E, int RS,
@@ -29,31 +29,40 @@ __global__ __launch_bounds__(EMB_THREADS) void embcat_fwd_kernel(const float* __
     if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     SED_DYN_SMEM(smem_raw);
     float* rows = (float*)smem_raw;             // [EMB_TILE][RS]: the input frames this chunk of output frames pools over
+    __shared__ int win[EMB_TCH + 1][2];         // window bounds per output frame, relative to the staged span
     const int b = blockIdx.z, tile = blockIdx.x, tid = threadIdx.x;
     const int t0 = blockIdx.y * EMB_TCH, t1 = min(T, t0 + EMB_TCH);
     const int ntile = (E + EMB_TILE - 1) / EMB_TILE, W = C + E;
-    if (tile == ntile) {                        // the x columns of these frames
-        const size_t base = (size_t)b * T + t0;
-        for (int i = tid; i < (t1 - t0) * C; i += EMB_THREADS) {
-            const int t = i / C, c = i - t * C;
-            const size_t m = base + t;
-            const float v = x[m * C + c];
-            z[m * W + c] = sed_keep((uint32_t)(m * W + c), seed, thr24) ? v * dscale : 0.f;
+    if (tile == ntile) {                        // the x columns of these frames: rows of x are contiguous, rows of z W apart
+        const size_t m0 = (size_t)b * T + t0;
+        const float* xs = x + m0 * C;
+        const int n = (t1 - t0) * C, dt = EMB_THREADS / C, dc = EMB_THREADS % C;
+        int t = tid / C, c = tid % C;
+        for (int i = tid; i < n; i += EMB_THREADS) {
+            const size_t o = (m0 + t) * W + c;
+            z[o] = sed_keep((uint32_t)o, seed, thr24) ? xs[i] * dscale : 0.f;
+            t += dt; c += dc;
+            if (c >= C) { c -= C; ++t; }
         }
         return;
     }
     const int e0 = tile * EMB_TILE, ne = min(EMB_TILE, E - e0);
     const int s_lo = emb_win_lo(t0, Te, T), len = emb_win_hi(t1 - 1, Te, T) - s_lo;
+    if (tid < t1 - t0) {
+        win[tid][0] = emb_win_lo(t0 + tid, Te, T) - s_lo;
+        win[tid][1] = emb_win_hi(t0 + tid, Te, T) - s_lo;
+    }
     const float* src = emb + ((size_t)b * E + e0) * Te + s_lo;
-    for (int i = tid; i < ne * len; i += EMB_THREADS) {         // consecutive lanes read consecutive frames of one row
-        const int r = i / len, s = i - r * len;
-        rows[r * RS + s] = src[(size_t)r * Te + s];
+    // half a wave per channel row: 32 consecutive frames (128 B) per row and pass, eight rows per workgroup pass
+    for (int r = tid >> 5; r < ne; r += EMB_THREADS / 32) {
+        const float* row = src + (size_t)r * Te;
+        for (int s = tid & 31; s < len; s += 32) rows[r * RS + s] = row[s];
     }
     __syncthreads();
     const int e = tid & (EMB_TILE - 1);
     if (e >= ne) return;
     for (int t = t0 + tid / EMB_TILE; t < t1; t += EMB_THREADS / EMB_TILE) {
-        const int w0 = emb_win_lo(t, Te, T) - s_lo, w1 = emb_win_hi(t, Te, T) - s_lo;
+        const int w0 = win[t - t0][0], w1 = win[t - t0][1];
         float acc = 0.f;
         for (int s = w0; s < w1; ++s) acc += rows[e * RS + s];  // RS is odd: the 64 channel rows hit distinct banks
         const float v = acc / (float)(w1 - w0);
@@ -71,7 +80,8 @@ extern "C" int sed_embcat_fwd(const float* x, const float* emb, float* z, int B,
     int RS = (int)(((long long)EMB_TCH * Te + T - 1) / T) + 2;
     RS |= 1;
     const size_t smem = (size_t)EMB_TILE * RS * sizeof(float);
-    if (smem > 150 * 1024 || (size_t)B * T * (C + E) >= (1ull << 32)) return SED_ERR_UNSUPPORTED;
+    if (smem > 150 * 1024 || (size_t)B * T * (C + E) >= (1ull << 32) || (long long)(T + 1) * Te + T >= (1ll << 31) || C > (1 << 20))
+        return SED_ERR_UNSUPPORTED;
     const int ntile = (E + EMB_TILE - 1) / EMB_TILE, nchunk = (T + EMB_TCH - 1) / EMB_TCH;
     SED_MAX_SMEM(embcat_fwd_kernel, smem);
     SED_LAUNCH(embcat_fwd_kernel, dim3(ntile + 1, nchunk, B), dim3(EMB_THREADS), smem, (hipStream_t)stream, x, emb, z, T, Te, C, E,
