@@ -409,29 +409,34 @@ extern "C" int sed_conv0_fwd(const float* x, const float* W, const float* bias, 
 // BatchNorm statistics finalisation (one workgroup per channel; double accumulation)
 // stats layout: [mean | invstd | scale = gamma*invstd | shift = beta - mean*scale], 4*C floats
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float count,
+#define BNF_THREADS 1024
+__global__ __launch_bounds__(BNF_THREADS) void bn_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           float momentum, float eps, float* __restrict__ stats, int training,
                                                           int update_running) {
-    __shared__ double r1[256], r2[256];
+    __shared__ double r1[BNF_THREADS / 64], r2[BNF_THREADS / 64];
     const int c = blockIdx.x, tid = threadIdx.x;
     float mean, invstd;
     if (training) {
+        // latency-bound launch (a few hundred to ~2000 partials per channel): 1024 threads so that every thread issues its one or
+        // two loads at once instead of walking a dependent chain, then wave butterflies and one barrier
         double a = 0.0, q = 0.0;
-        for (int i = tid; i < nblocks; i += 256) {
+#pragma unroll 2
+        for (int i = tid; i < nblocks; i += BNF_THREADS) {
             a += (double)partial[(size_t)c * nblocks + i];
             q += (double)partial[(size_t)(C + c) * nblocks + i];
         }
-        r1[tid] = a; r2[tid] = q;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); q += __shfl_xor(q, off); }
+        if ((tid & 63) == 0) { r1[tid >> 6] = a; r2[tid >> 6] = q; }
         __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if (tid < st) { r1[tid] += r1[tid + st]; r2[tid] += r2[tid + st]; }
-            __syncthreads();
-        }
         if (tid != 0) return;
-        const double m = r1[0] / (double)count;
-        double var = r2[0] / (double)count - m * m;
+        a = 0.0; q = 0.0;
+#pragma unroll
+        for (int w = 0; w < BNF_THREADS / 64; ++w) { a += r1[w]; q += r2[w]; }
+        const double m = a / (double)count;
+        double var = q / (double)count - m * m;
         if (var < 0.0) var = 0.0;
         mean = (float)m;
         invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -455,7 +460,7 @@ extern "C" int sed_bn_finalize(const float* partial, int nblocks, int C, float c
                                float* running_mean, float* running_var, float momentum, float eps, float* stats, int training,
                                int update_running, void* stream) {
     if (C <= 0) return SED_ERR_ARG;
-    SED_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partial, nblocks, C, count, gamma, beta,
+    SED_LAUNCH(bn_finalize_kernel, dim3(C), dim3(BNF_THREADS), 0, (hipStream_t)stream, partial, nblocks, C, count, gamma, beta,
                running_mean, running_var, momentum, eps, stats, training, update_running);
     return sed_check_launch();
 }

@@ -1425,14 +1425,17 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_b_kernel(const float* __rest
     }
 }
 // sums the nblk per-workgroup partials of glu_wide_bwd_kernel: [KS][C][C] dWg slabs, then [WMS][3][C] (dbg, dgamma, dbeta).
-// One workgroup per 64 consecutive outputs: 16 float4 columns x 16 groups of partials, fixed summation order.
-__global__ __launch_bounds__(256) void glu_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dWg,
+// One workgroup per 64 consecutive outputs: 16 float4 columns x 64 groups of partials, fixed summation order.  1024 threads:
+// the launch is a latency chain of dependent loads (256-1024 partials per output), so the walk per thread must be short.
+#define GBR_THREADS 1024
+#define GBR_GROUPS (GBR_THREADS / 16)
+__global__ __launch_bounds__(GBR_THREADS) void glu_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dWg,
                                                              float* __restrict__ dbg, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int nblk, int C, int KS, int WMS,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int fix) {
     // fix != 0 (split-bf16 kernel): the dWg slabs hold dWg' = dlin^T xhat; dWg[n][c] = gamma_c dWg'[n][c] + beta_c dbg[n]
-    __shared__ float4 red[16][16];
-    __shared__ float sdb[256];
+    __shared__ float4 red[GBR_GROUPS][16];
+    __shared__ float sdb[GBR_THREADS];
     const int tid = threadIdx.x, col = tid & 15, grp = tid >> 4, e = blockIdx.x * 64 + 4 * col;
     const int CC = C * C, PART = KS * CC + WMS * 3 * C;
     // outputs [0, CC) are dWg with KS slabs per partial; [CC, CC + 3C) the three vectors with WMS slabs (C % 4 == 0 keeps
@@ -1442,9 +1445,9 @@ __global__ __launch_bounds__(256) void glu_bwd_reduce_kernel(const float* __rest
     const size_t off = isw ? (size_t)e : (size_t)KS * CC + (e - CC);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < CC + 3 * C) {
-        const int total = nblk * nsl;                                  // (partial, slab) pairs, split over the 16 groups
+        const int total = nblk * nsl;                                  // (partial, slab) pairs, split over the groups
 #pragma unroll 4
-        for (int i = grp; i < total; i += 16) {
+        for (int i = grp; i < total; i += GBR_GROUPS) {
             const int b = i / nsl, k = i - b * nsl;
             const float4 v = *(const float4*)(part + (size_t)b * PART + off + (size_t)k * sstride);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
@@ -1456,13 +1459,13 @@ __global__ __launch_bounds__(256) void glu_bwd_reduce_kernel(const float* __rest
     if (fix && blockIdx.x * 64 < CC) {               // dbg[n] for this block's row n = (blockIdx.x * 64) / C   (C >= 64)
         const int nrow = (blockIdx.x * 64) / C;
         float sacc = 0.f;
-        for (int i = tid; i < nblk * WMS; i += 256) {
+        for (int i = tid; i < nblk * WMS; i += GBR_THREADS) {
             const int b = i / WMS, k = i - b * WMS;
             sacc += part[(size_t)b * PART + (size_t)KS * CC + k * 3 * C + nrow];
         }
         sdb[tid] = sacc;
         __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
+        for (int st = GBR_THREADS / 2; st > 0; st >>= 1) {
             if (tid < st) sdb[tid] += sdb[tid + st];
             __syncthreads();
         }
@@ -1470,7 +1473,7 @@ __global__ __launch_bounds__(256) void glu_bwd_reduce_kernel(const float* __rest
     }
     if (grp == 0 && e < CC + 3 * C) {
 #pragma unroll
-        for (int g = 1; g < 16; ++g) { const float4 v = red[g][col]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        for (int g = 1; g < GBR_GROUPS; ++g) { const float4 v = red[g][col]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
         if (fix && isw) {
             const int c = e % C;
             acc.x = fmaf(gamma[c], acc.x, beta[c] * dbn); acc.y = fmaf(gamma[c + 1], acc.y, beta[c + 1] * dbn);
@@ -1505,7 +1508,7 @@ static int launch_glu_wide_bwd(const float* y, const float* stats, const float* 
         SED_LAUNCH((glu_wide_bwd_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, gamma, beta, Wg, bg, gout, dz, scratch, B, T, F,
                    seed, thr24, dscale, seed_dev);
     }
-    SED_LAUNCH(glu_bwd_reduce_kernel, dim3((C * C + 3 * C + 63) / 64), dim3(256), 0, s, scratch, dWg, dbg, dgamma, dbeta, grid, C, KS, WMS,
+    SED_LAUNCH(glu_bwd_reduce_kernel, dim3((C * C + 3 * C + 63) / 64), dim3(GBR_THREADS), 0, s, scratch, dWg, dbg, dgamma, dbeta, grid, C, KS, WMS,
                gamma, beta, SPLIT ? 1 : 0);
     return sed_check_launch();
 }
@@ -1557,7 +1560,7 @@ extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamm
         else
             SED_LAUNCH(glu32_bwd_kernel, dim3(grid), dim3(256), 0, s, y, stats, gamma, beta, Wg, bg, gout, dz, scratch, B, T, F, seed, thr24,
                        dscale, seed_dev);
-        SED_LAUNCH(glu_bwd_reduce_kernel, dim3((C * C + 3 * C + 63) / 64), dim3(256), 0, s, scratch, dWg, dbg, dgamma, dbeta, grid, C, 1, 1,
+        SED_LAUNCH(glu_bwd_reduce_kernel, dim3((C * C + 3 * C + 63) / 64), dim3(GBR_THREADS), 0, s, scratch, dWg, dbg, dgamma, dbeta, grid, C, 1, 1,
                    gamma, beta, 0);
         return sed_check_launch();
     }

@@ -81,13 +81,17 @@ static inline int emu_wave() { return emu_cur->lin >> 6; }
 
 template <typename T>
 static inline T emu_xchg(T v, int src_lane) {
-    static_assert(sizeof(T) == 4, "32-bit shuffles only");
-    float f; memcpy(&f, &v, 4);
-    emu_wave_xchg[emu_wave()][emu_lane()][0] = f;
-    emu_wave_sync();
-    float r = emu_wave_xchg[emu_wave()][src_lane & 63][0];
-    emu_wave_sync();
-    T out; memcpy(&out, &r, 4);
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- and 64-bit shuffles only (HIP moves a double as two dwords)");
+    float f[2] = {0.f, 0.f}; memcpy(f, &v, sizeof(T));
+    T out;
+    float r[2];
+    for (int w = 0; w < (int)(sizeof(T) / 4); ++w) {
+        emu_wave_xchg[emu_wave()][emu_lane()][0] = f[w];
+        emu_wave_sync();
+        r[w] = emu_wave_xchg[emu_wave()][src_lane & 63][0];
+        emu_wave_sync();
+    }
+    memcpy(&out, r, sizeof(T));
     return out;
 }
 template <typename T> static inline T __shfl_xor(T v, int mask, int = 64) { return emu_xchg(v, emu_lane() ^ mask); }
