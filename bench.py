@@ -108,7 +108,7 @@ def conv_flops(key):
 
 def pmc_traffic(cin, cout, F, split):
     """HBM bytes per launch of the matching conv3x3 kernel from the committed rocprofv3 --pmc passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json" if split else "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_q_pmc_traffic.json" if split else "r01_pmc_traffic.json")
     try:
         kernels = json.load(open(path))["kernels"]
     except Exception:  # noqa: BLE001
@@ -301,7 +301,7 @@ def main():
                     "mfma_issue_frac": round((3.0 if split else 1.0) * achieved / peak, 4),
                     "traffic": pmc_traffic(dom_key[4], dom_key[5], dom_key[3], split),
                     "traffic_note": "HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes on this "
-                                    "kernel (profiles/r01_h_pmc_fetch_write.md, r01_h_pmc_traffic.json); algorithmic in+out+weights = %d "
+                                    "kernel (profiles/r01_q_pmc_fetch_write.md, r01_q_pmc_traffic.json); algorithmic in+out+weights = %d "
                                     "bytes" % (4 * dom_key[1] * dom_key[2] * dom_key[3] * (dom_key[4] + dom_key[5]) + 36 * dom_key[4] * dom_key[5]),
                     "note": "achieved = algorithmic FLOPs (2*B*T*F*9*CIN*COUT) / mean launch time (HIP events; %s); for the "
                             "split-bf16 kernel the MFMA pipe issues 3x that (mfma_issue_frac); f32-equivalent peak would be %.1f"
