@@ -306,13 +306,28 @@ extern "C" int sed_colsum(const float* X, float* out, float* out1, int nsplit, i
 // ---------------------------------------------------------------------------------------------
 #define GRU_CH 8
 #define GRU_THREADS 512
+// GRU_VARIANT: timing-ablation mask for tools/gru_variants.py (1 in the product build = padded hidden-state quarters only):
+// 8 = no hidden-state LDS reads, 16 = no FMAs, 32 = no exp/rcp, 64 = no output staging stores, 128 = no per-step barrier
+// (results are wrong under any of 8..128; numbers in DESIGN.md section 8).
+#ifndef GRU_VARIANT
+#define GRU_VARIANT 1
+#endif
+#define GRU_HPAD (GRU_VARIANT & 1)
+#define GRU_NOREAD ((GRU_VARIANT & 8) != 0)
+#define GRU_NOFMA ((GRU_VARIANT & 16) != 0)
+#define GRU_NOTRANS ((GRU_VARIANT & 32) != 0)
+#define GRU_NOOBUF ((GRU_VARIANT & 64) != 0)
+#define GRU_NOBAR ((GRU_VARIANT & 128) != 0)
 __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh0,
                                                       const float* __restrict__ whh1, const float* __restrict__ bhh0,
                                                       const float* __restrict__ bhh1, float* __restrict__ out,
                                                       float* __restrict__ saved, int B, int T) {
     constexpr int H = GRU_H, KH = H / 4, CH = GRU_CH, NT_ = GRU_THREADS;   // KH: K quarter per thread
     constexpr int GI_F = CH * 3 * H, OB_F = CH * 5 * H;            // floats per chunk buffer
-    __shared__ __attribute__((aligned(16))) float hbuf[2][H];
+    // quarter q of h starts at q * (KH + 4) floats: the four quarters a wave reads with one ds_read_b128 fall into 16
+    // distinct banks (at a 128-byte pitch they would share four)
+    constexpr int HP = GRU_HPAD ? KH + 4 : KH;
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4 * HP];
     SED_DYN_SMEM(smem);
     float* gis = (float*)smem;                 // [2][CH][3H]
     float* obuf = gis + 2 * GI_F;              // [2][CH][5H] = h | r | z | n | hn
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __res
         wn[k] = *(const f32x2*)(W + (size_t)(2 * H + j) * H + half * KH + 2 * k);
     }
     const float br = bhh[j], bz = bhh[H + j], bn = bhh[2 * H + j];
-    if (tid < H) hbuf[0][tid] = 0.f;
+    if (tid < H) hbuf[0][(tid / KH) * HP + tid % KH] = 0.f;
     float hprev = 0.f;
     const int nchunks = (T + CH - 1) / CH;
     constexpr int GV = (GI_F / 4 + NT_ - 1) / NT_;         // float4 of gi per thread per chunk
@@ -378,10 +393,10 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __res
             // all of this thread's h slice first (one LDS latency, not one per read), then the FMAs
             float4 hq[KH / 4];
 #pragma unroll
-            for (int k = 0; k < KH / 4; ++k) hq[k] = *(const float4*)(hbuf[cur] + half * KH + 4 * k);
+            for (int k = 0; k < KH / 4; ++k) hq[k] = GRU_NOREAD ? make_float4(gr, gz, gn, gr) : *(const float4*)(hbuf[cur] + half * HP + 4 * k);
             f32x2 pr = {0.f, 0.f}, pz = {0.f, 0.f}, pn = {0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < KH / 4; ++k) {
+            for (int k = 0; k < (GRU_NOFMA ? 1 : KH / 4); ++k) {
                 const f32x2 lo2 = {hq[k].x, hq[k].y}, hi2 = {hq[k].z, hq[k].w};
                 pr = pk_fma(wr[2 * k], lo2, pr); pz = pk_fma(wz[2 * k], lo2, pz); pn = pk_fma(wn[2 * k], lo2, pn);
                 pr = pk_fma(wr[2 * k + 1], hi2, pr); pz = pk_fma(wz[2 * k + 1], hi2, pz); pn = pk_fma(wn[2 * k + 1], hi2, pn);
@@ -389,19 +404,19 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __res
             float ar = pr.x + pr.y, az = pz.x + pz.y, an = pn.x + pn.y;
             ar += __shfl_xor(ar, 1); az += __shfl_xor(az, 1); an += __shfl_xor(an, 1);
             ar += __shfl_xor(ar, 2); az += __shfl_xor(az, 2); an += __shfl_xor(an, 2);
-            const float r = sed_fast_sigmoid(gr + ar + br);
-            const float z = sed_fast_sigmoid(gz + az + bz);
+            const float r = GRU_NOTRANS ? (gr + ar + br) * 0.01f : sed_fast_sigmoid(gr + ar + br);
+            const float z = GRU_NOTRANS ? (gz + az + bz) * 0.01f : sed_fast_sigmoid(gz + az + bz);
             const float hn = an + bn;
-            const float n = sed_fast_tanh(gn + r * hn);
+            const float n = GRU_NOTRANS ? (gn + r * hn) * 0.01f : sed_fast_tanh(gn + r * hn);
             const float hnew = (1.0f - z) * n + z * hprev;
             hprev = hnew;
             if (half == 0) {
-                hbuf[cur ^ 1][j] = hnew;
+                hbuf[cur ^ 1][(j / KH) * HP + j % KH] = hnew;
                 float* o = och + s * 5 * H;
-                o[j] = hnew; o[H + j] = r; o[2 * H + j] = z; o[3 * H + j] = n; o[4 * H + j] = hn;
+                if (!GRU_NOOBUF) { o[j] = hnew; o[H + j] = r; o[2 * H + j] = z; o[3 * H + j] = n; o[4 * H + j] = hn; }
             }
             cur ^= 1;
-            __syncthreads();
+            if (!GRU_NOBAR) __syncthreads();
         }
         if (c + 1 < nchunks) park_chunk(c + 1);
         __syncthreads();
