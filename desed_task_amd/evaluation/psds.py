@@ -110,6 +110,8 @@ class PSDSEval:
         self.metadata = meta
 
     def _init_det_table(self, det_t):
+        if isinstance(det_t, pd.DataFrame) and det_t.empty:       # a system that detected nothing is a legal operating point
+            det_t = pd.DataFrame({c: [] for c in self.detection_cols})
         self._validate(det_t, "detection", self.detection_cols)
         det = det_t[self.detection_cols].dropna()
         if (det.offset < det.onset).any():

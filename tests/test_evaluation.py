@@ -198,6 +198,16 @@ def test_psds_small_cases():
     with pytest.warns(UserWarning, match="absent from the ground truth"):
         counts, *_ = ev._evaluate_detections(ev._init_det_table(det.assign(event_label="unknown")))
     assert counts.sum() == 0
+    # an operating point without detections (a bare pd.DataFrame(), as the trainer's buffers start out): TPR = 0, no FP
+    counts, tpr, fpr, _ = ev._evaluate_detections(ev._init_det_table(pd.DataFrame()))
+    assert counts.sum() == 0 and tpr.tolist() == [0.0, 0.0] and fpr.tolist() == [0.0, 0.0]
+    ev2 = PSDSEval(ground_truth=gt, metadata=meta)
+    ev2.add_operating_point(pd.DataFrame())
+    ev2.add_operating_point(det)
+    assert 0.0 <= ev2.psds(max_efpr=100).value <= 1.0
+    f_avg, _ = ev2.compute_macro_f_score(pd.DataFrame())
+    assert np.isnan(f_avg)                                   # no true positive anywhere (mapped to 0 by the caller)
+    assert EM.compute_per_intersection_macro_f1({0.5: pd.DataFrame()}, gt, meta) == 0.0
     with pytest.raises(PSDSEvalError):
         PSDSEval(ground_truth=gt, metadata=meta, dtc_threshold=1.5)
     with pytest.raises(PSDSEvalError):
