@@ -8,6 +8,11 @@ with two MI355X-side differences: the EMA kernel runs on a side HIP stream concu
 reads the student parameters that backward also only reads; Adam waits for it), and under data parallelism the
 flat gradient arena is averaged with ONE RCCL all-reduce over xGMI (1,112,420 floats; the 1/world factor is
 folded into the Adam kernel).  BN statistics and mixup stay rank-local, like the single-GPU reference.
+
+State that diverges across ranks: the student's and the teacher's BatchNorm running statistics (each rank
+normalises its own clips; momentum 0.99 makes them ~ the last batch).  Policy: `average_bn_buffers(task)` -- ONE all-reduce of
+the 2 x 1 248 floats -- before every validation / test pass and before `save_checkpoint`, which writes from rank 0 only.
+`RankShardedBatchSampler` gives rank r the batches r, r + world, ... of the recipe's ConcatDatasetBatchSampler.
 """
 import os
 
@@ -85,3 +90,65 @@ class StepDriver:
         self.opt.step()
         task.lr_scheduler_step(self.sched, 0, None)
         return loss
+
+
+def bn_buffers(task):
+    """Running mean / variance tensors of the student and the teacher, in a fixed order."""
+    out = []
+    for model in (task.sed_student, task.sed_teacher):
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                out += [m.running_mean, m.running_var]
+    return out
+
+
+def average_bn_buffers(task, world_size=None):
+    """Replace every BN running statistic by its mean over the ranks (one all-reduce of one flat tensor).  No-op at world 1."""
+    world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+    if world <= 1:
+        return
+    bufs = bn_buffers(task)
+    flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(world)
+    off = 0
+    with torch.no_grad():
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+
+
+def save_checkpoint(task, path, world_size=None):
+    """Averages the BN buffers, then rank 0 writes {"sed_student", "sed_teacher"} state dicts (on_save_checkpoint layout,
+    sed_trainer.py:603-606); every rank returns after the file exists."""
+    average_bn_buffers(task, world_size)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if rank == 0:
+        torch.save(task.on_save_checkpoint({}), path)
+    if dist.is_initialized():
+        dist.barrier()
+
+
+class RankShardedBatchSampler:
+    """Rank-strided view of a batch sampler (desed_task/dataio/sampler.py:69-80 yields whole [synth | weak | unlabelled]
+    batches): rank r iterates batches r, r + world, ...; all ranks get the same number of batches (the tail is dropped)."""
+
+    def __init__(self, batch_sampler, rank, world_size):
+        if not 0 <= rank < world_size:
+            raise ValueError("rank out of range")
+        self.batch_sampler, self.rank, self.world = batch_sampler, rank, world_size
+
+    def set_epoch(self, epoch):
+        if hasattr(self.batch_sampler, "set_epoch"):
+            self.batch_sampler.set_epoch(epoch)
+
+    def __len__(self):
+        return len(self.batch_sampler) // self.world
+
+    def __iter__(self):
+        n = len(self) * self.world
+        for i, batch in enumerate(self.batch_sampler):
+            if i >= n:
+                break
+            if i % self.world == self.rank:
+                yield batch

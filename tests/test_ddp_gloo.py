@@ -63,8 +63,22 @@ def _worker(rank, world, port, out_dir):
     rm = task2.sed_student.cnn.cnn.batchnorm0.running_mean.clone()
     rms = [torch.zeros_like(rm) for _ in range(world)]
     dist.all_gather(rms, rm)
+    # SURVEY 8e policy: BN buffers are averaged before validation / checkpointing, the checkpoint is written by rank 0
+    from desed_task_amd.launcher import average_bn_buffers, bn_buffers, save_checkpoint
+    rv_t = task2.sed_teacher.cnn.cnn.batchnorm3.running_var.clone()
+    rvs_t = [torch.zeros_like(rv_t) for _ in range(world)]
+    dist.all_gather(rvs_t, rv_t)
+    assert len(bn_buffers(task2)) == 2 * 2 * 7 and sum(b.numel() for b in bn_buffers(task2)) == 2 * 1248
+    ckpt = os.path.join(out_dir, "ckpt.pt")
+    save_checkpoint(task2, ckpt)
+    assert os.path.exists(ckpt)                                   # every rank returns after rank 0 wrote it
+    rm_avg = task2.sed_student.cnn.cnn.batchnorm0.running_mean.clone()
+    rv_avg_t = task2.sed_teacher.cnn.cnn.batchnorm3.running_var.clone()
+    avgs = [torch.zeros_like(rm_avg) for _ in range(world)]
+    dist.all_gather(avgs, rm_avg)
     if rank == 0:
-        torch.save(dict(summed=summed, gathered=gathered, flats=flats, rms=rms, init=None), os.path.join(out_dir, "r0.pt"))
+        torch.save(dict(summed=summed, gathered=gathered, flats=flats, rms=rms, avgs=avgs, rvs_t=rvs_t, rv_avg_t=rv_avg_t),
+                   os.path.join(out_dir, "r0.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,4 +94,38 @@ def test_two_rank_gradient_average(tmp_path):
     assert (d["summed"] - ref_sum).abs().max().item() <= 1e-6 * ref_sum.abs().max().item() + 1e-9
     f0, f1 = d["flats"]
     assert torch.equal(f0, f1)                                             # student bit-identical across ranks
-    assert not torch.equal(d["rms"][0], d["rms"][1])                       # BN running stats stay rank-local
+    assert not torch.equal(d["rms"][0], d["rms"][1])                       # BN running stats stay rank-local ...
+    # ... until average_bn_buffers / save_checkpoint: every rank then holds the mean over ranks, student and teacher
+    assert torch.equal(d["avgs"][0], d["avgs"][1])
+    assert (d["avgs"][0] - (d["rms"][0] + d["rms"][1]) / 2).abs().max().item() < 1e-7
+    assert (d["rv_avg_t"] - (d["rvs_t"][0] + d["rvs_t"][1]) / 2).abs().max().item() < 1e-6
+    ck = torch.load(os.path.join(str(tmp_path), "ckpt.pt"))
+    assert set(ck) == {"sed_student", "sed_teacher"}
+    assert torch.equal(ck["sed_student"]["cnn.cnn.batchnorm0.running_mean"], d["avgs"][0])
+
+
+def test_rank_sharded_batch_sampler():
+    from desed_task_amd.launcher import RankShardedBatchSampler
+
+    class Batches:
+        def __init__(self):
+            self.epoch = None
+
+        def set_epoch(self, e):
+            self.epoch = e
+
+        def __len__(self):
+            return 7
+
+        def __iter__(self):
+            return iter([[10 * i, 10 * i + 1] for i in range(7)])
+
+    base = Batches()
+    shards = [RankShardedBatchSampler(base, r, 3) for r in range(3)]
+    got = [list(s) for s in shards]
+    assert [len(s) for s in shards] == [2, 2, 2] and all(len(g) == 2 for g in got)      # 7 // 3: the tail batch is dropped
+    assert got[0] == [[0, 1], [30, 31]] and got[1] == [[10, 11], [40, 41]] and got[2] == [[20, 21], [50, 51]]
+    shards[1].set_epoch(5)
+    assert base.epoch == 5
+    with pytest.raises(ValueError):
+        RankShardedBatchSampler(base, 3, 3)
