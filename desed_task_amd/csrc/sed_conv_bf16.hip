@@ -15,11 +15,11 @@
 
 #define CONVB_THREADS(COUT) ((COUT) >= 64 ? 512 : 256)
 
-template <int CIN, int COUT, int TF, int MP = 128>
+template <int CIN, int COUT, int TF, int MP = 128, int CKT = 32>
 struct ConvBCfg {
     static constexpr int TR = MP / TF;
     static constexpr int PW = TF + 2, PH = TR + 2, PP = PW * PH;
-    static constexpr int CK = CIN < 32 ? CIN : 32;       // channels per chunk (one or two MFMA k-steps of 16)
+    static constexpr int CK = CIN < CKT ? CIN : CKT;     // channels per chunk (CKT = 32: two MFMA k-steps of 16; 16: one)
     static constexpr int RSS = CK + 8;                   // LDS row stride in bf16 elements (80 B / 48 B)
     static constexpr int NCH = CIN / CK;
     static constexpr int NT = (COUT + 31) / 32;
@@ -42,6 +42,7 @@ struct PackBJobs {
     unsigned short* Wf[8];
     unsigned short* Wd[8];
     int cout[8], cin[8], start[9];
+    int ckf[8], ckd[8];                                  // channels per chunk of the forward / data-gradient slabs (convb_ck)
     int n;
 };
 __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(PackBJobs jobs) {
@@ -55,17 +56,26 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(PackBJobs jobs) 
     unsigned short hi, lo;
     bf16_split(jobs.W[j][e], hi, lo);
     {
-        const int CK = CIN < 32 ? CIN : 32, NCH = CIN / CK, tap = a * 3 + b, cc = ci / CK, cl = ci % CK;
+        const int CK = jobs.ckf[j], NCH = CIN / CK, tap = a * 3 + b, cc = ci / CK, cl = ci % CK;
         unsigned short* d = jobs.Wf[j] + ((size_t)(tap * NCH + cc) * 2 * COUT + co) * CK + cl;
         d[0] = hi;
         d[(size_t)COUT * CK] = lo;
     }
     if (jobs.Wd[j]) {
-        const int CK = COUT < 32 ? COUT : 32, NCH = COUT / CK, tap = (2 - a) * 3 + (2 - b), cc = co / CK, cl = co % CK;
+        const int CK = jobs.ckd[j], NCH = COUT / CK, tap = (2 - a) * 3 + (2 - b), cc = co / CK, cl = co % CK;
         unsigned short* d = jobs.Wd[j] + ((size_t)(tap * NCH + cc) * 2 * CIN + ci) * CK + cl;
         d[0] = hi;
         d[(size_t)CIN * CK] = lo;
     }
+}
+// Channels per weight chunk for a (CIN -> COUT) contraction: the packing and the kernel dispatch must agree, so both ask here.
+static inline int convb_ck(int CIN, int COUT) {
+    const char* e = getenv("SED_CONVB_CK");            // tuning override (tools/convb_mp_sweep.py)
+    // 64 <-> 128 channels: 16-channel chunks halve the LDS stage (68 KB at 256 pixels) and fit 128 VGPRs, so two workgroups
+    // share a CU: 72.8 -> 63.0 us (forward) and 63.3 -> 56.8 us (data gradient).  128 -> 128 gains nothing (59.6 vs 60.9 us).
+    int ck = ((CIN == 64 && COUT == 128) || (CIN == 128 && COUT == 64)) ? 16 : 32;
+    if (e && CIN >= 32) ck = atoi(e) == 16 ? 16 : 32;
+    return CIN < ck ? CIN : ck;
 }
 // n <= 8 layers; Wf / Wd buffers of 9*CIN*COUT*4 BYTES each (same size as the fp32 packs).
 extern "C" int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout,
@@ -76,9 +86,10 @@ extern "C" int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const
     for (int j = 0; j < n; ++j) {
         jobs.W[j] = (const float*)W[j]; jobs.Wf[j] = (unsigned short*)Wf[j]; jobs.Wd[j] = Wd ? (unsigned short*)Wd[j] : nullptr;
         jobs.cout[j] = cout[j]; jobs.cin[j] = cin[j]; jobs.start[j] = tot;
+        jobs.ckf[j] = convb_ck(cin[j], cout[j]); jobs.ckd[j] = convb_ck(cout[j], cin[j]);
         tot += cout[j] * cin[j] * 9;
     }
-    for (int j = n; j < 8; ++j) { jobs.W[j] = nullptr; jobs.Wf[j] = nullptr; jobs.Wd[j] = nullptr; jobs.cout[j] = 0; jobs.cin[j] = 0; jobs.start[j] = tot; }
+    for (int j = n; j < 8; ++j) { jobs.W[j] = nullptr; jobs.Wf[j] = nullptr; jobs.Wd[j] = nullptr; jobs.cout[j] = 0; jobs.cin[j] = 0; jobs.start[j] = tot; jobs.ckf[j] = 1; jobs.ckd[j] = 1; }
     jobs.start[n] = tot;
     jobs.start[8] = tot;
     jobs.n = n;
@@ -87,17 +98,18 @@ extern "C" int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const
 }
 
 // CONVB_ABL: timing-ablation mask for tools/convb_variants.py (0 in the product build): 1 = no weight-slab global loads,
-// 2 = no MFMAs, 4 = no patch global loads, 8 = no per-tap barrier (results are wrong under any of them).
+// 2 = no MFMAs, 4 = no patch global loads, 8 = no per-tap barrier, 16 = no LDS fragment reads, 32 = no output stores
+// (results are wrong under any of them).
 #ifndef CONVB_ABL
 #define CONVB_ABL 0
 #endif
 
-template <int CIN, int COUT, int TF, bool STATS, int MP = 128>
+template <int CIN, int COUT, int TF, bool STATS, int MP = 128, int CKT = 32>
 __global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const float* __restrict__ x,
                                                                             const unsigned short* __restrict__ Wp,
                                                                             const float* __restrict__ bias, float* __restrict__ y,
                                                                             float* __restrict__ partial, int B, int T, int F) {
-    using Cfg = ConvBCfg<CIN, COUT, TF, MP>;
+    using Cfg = ConvBCfg<CIN, COUT, TF, MP, CKT>;
     constexpr int TR = Cfg::TR, PW = Cfg::PW, PP = Cfg::PP, CK = Cfg::CK, RSS = Cfg::RSS, NCH = Cfg::NCH, NT = Cfg::NT,
                   NTW = Cfg::NTW, THREADS = Cfg::THREADS, WM = Cfg::WM, NCOL = Cfg::NCOL, SLAB = Cfg::SLAB, WBUF_S = Cfg::WBUF_S;
     SED_DYN_SMEM(smem_raw);
@@ -204,13 +216,15 @@ __global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const
                 const unsigned short* ap = patch + abase + (r * PW + t3) * RSS;
 #pragma unroll
                 for (int ks = 0; ks < CK / 16; ++ks) {
-                    const s16x8 a_hi = *(const s16x8*)(ap + 16 * ks);
-                    const s16x8 a_lo = *(const s16x8*)(ap + PP * RSS + 16 * ks);
+                    s16x8 a_hi, a_lo;
+                    if (CONVB_ABL & 16) { a_hi = (s16x8)(short)(lane + ks); a_lo = (s16x8)(short)(lane + t3); }
+                    else { a_hi = *(const s16x8*)(ap + 16 * ks); a_lo = *(const s16x8*)(ap + PP * RSS + 16 * ks); }
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt) {
                         const unsigned short* bp = wb + ((wn * NTW + nt) * 32 + lo) * RSS + 16 * ks + 8 * hi;
-                        const s16x8 b_hi = *(const s16x8*)bp;
-                        const s16x8 b_lo = *(const s16x8*)(bp + NCOL * RSS);
+                        s16x8 b_hi, b_lo;
+                        if (CONVB_ABL & 16) { b_hi = (s16x8)(short)(lane + nt); b_lo = (s16x8)(short)(lane + r); }
+                        else { b_hi = *(const s16x8*)bp; b_lo = *(const s16x8*)(bp + NCOL * RSS); }
                         if (CONVB_ABL & 2) { acc[nt][0] += (float)(a_lo[0] + b_hi[0] + a_hi[1] + b_lo[1]); continue; }
                         acc[nt] = mfma32_bf16(a_lo, b_hi, acc[nt]);
                         acc[nt] = mfma32_bf16(a_hi, b_lo, acc[nt]);
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const
             const int t = t0 + pp / TF, f = f0 + pp % TF;
             if (t < T && co < COUT) {
                 const float v = acc[nt][r] + bv;
-                y[(((size_t)b * T + t) * F + f) * COUT + co] = v;
+                if (!(CONVB_ABL & 32)) y[(((size_t)b * T + t) * F + f) * COUT + co] = v;
                 s += v;
                 s2 += v * v;
             }
@@ -263,17 +277,17 @@ __global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const
     }
 }
 
-template <int CIN, int COUT, int TF, int MP = 128>
+template <int CIN, int COUT, int TF, int MP = 128, int CKT = 32>
 static int launch_convb(const float* x, const unsigned short* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
                         hipStream_t s) {
-    using Cfg = ConvBCfg<CIN, COUT, TF, MP>;
+    using Cfg = ConvBCfg<CIN, COUT, TF, MP, CKT>;
     const int nblk = B * ((T + Cfg::TR - 1) / Cfg::TR) * (F / TF);
     if (partial) {
-        SED_MAX_SMEM((conv3x3_bf16_kernel<CIN, COUT, TF, true, MP>), Cfg::SMEM);
-        SED_LAUNCH((conv3x3_bf16_kernel<CIN, COUT, TF, true, MP>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
+        SED_MAX_SMEM((conv3x3_bf16_kernel<CIN, COUT, TF, true, MP, CKT>), Cfg::SMEM);
+        SED_LAUNCH((conv3x3_bf16_kernel<CIN, COUT, TF, true, MP, CKT>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
     } else {
-        SED_MAX_SMEM((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP>), Cfg::SMEM);
-        SED_LAUNCH((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
+        SED_MAX_SMEM((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT>), Cfg::SMEM);
+        SED_LAUNCH((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F);
     }
     return sed_check_launch();
 }
@@ -306,6 +320,19 @@ extern "C" int sed_conv3x3_bf16x3(const float* x, const void* Wp, const float* b
     if (F % TF != 0 || (F & (F - 1)) != 0 || F < 2) return SED_ERR_UNSUPPORTED;
     const unsigned short* W = (const unsigned short*)Wp;
     const int MP = convb_mp(F, CIN, COUT);
+    const int CK = CIN >= 32 ? convb_ck(CIN, COUT) : 32;      // narrower inputs are a single chunk either way
+#define CONVB_CASE16(ci, co, tf, mp) \
+    if (CIN == ci && COUT == co && TF == tf && MP == mp && CK == 16) return launch_convb<ci, co, tf, mp, 16>(x, W, bias, y, partial, B, T, F, s);
+    // 16-channel weight chunks (half the LDS per workgroup): the wide production shapes
+    CONVB_CASE16(32, 64, 32, 128) CONVB_CASE16(64, 128, 16, 128) CONVB_CASE16(64, 128, 16, 256)
+    CONVB_CASE16(128, 128, 8, 128) CONVB_CASE16(128, 128, 8, 256) CONVB_CASE16(128, 128, 4, 64) CONVB_CASE16(128, 128, 4, 128)
+    CONVB_CASE16(128, 128, 2, 64) CONVB_CASE16(128, 128, 2, 128) CONVB_CASE16(64, 32, 32, 128)
+    CONVB_CASE16(128, 64, 16, 128) CONVB_CASE16(128, 64, 16, 256)
+    // small-shape variants used by the unit tests / other n_mels
+    CONVB_CASE16(64, 128, 4, 256) CONVB_CASE16(64, 128, 8, 256) CONVB_CASE16(64, 128, 32, 256)
+    CONVB_CASE16(128, 64, 4, 256) CONVB_CASE16(128, 64, 8, 256) CONVB_CASE16(128, 64, 32, 256)
+#undef CONVB_CASE16
+    if (CK == 16) return SED_ERR_UNSUPPORTED;
 #define CONVB_CASE(ci, co, tf, mp) \
     if (CIN == ci && COUT == co && TF == tf && MP == mp) return launch_convb<ci, co, tf, mp>(x, W, bias, y, partial, B, T, F, s);
     // production shapes of the 2023 recipe (forward, then data gradient)

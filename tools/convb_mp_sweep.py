@@ -14,10 +14,11 @@ for (CIN, COUT, T, F) in shapes:
     bias = torch.zeros(COUT, device="cuda")
     y = torch.empty(B, T, F, COUT, device="cuda")
     partial = torch.empty(16384 * 2 * COUT, device="cuda")
-    (wf, wd), = pack_conv_weights([w], True, "bf16x3")
     st = torch.cuda.current_stream().cuda_stream
     res = []
-    for mp in ("default", "64", "128", "256"):
+    for ck, mp in (("32", "default"), ("32", "128"), ("32", "256"), ("16", "64"), ("16", "128"), ("16", "256")):
+        os.environ["SED_CONVB_CK"] = ck                 # the packing and the dispatch both read it
+        (wf, wd), = pack_conv_weights([w], True, "bf16x3")
         if mp == "default":
             os.environ.pop("SED_CONVB_MP", None)
         else:
@@ -25,12 +26,12 @@ for (CIN, COUT, T, F) in shapes:
         def run():
             return lib.value("sed_conv3x3_bf16x3", x.data_ptr(), wf.data_ptr(), bias.data_ptr(), y.data_ptr(), partial.data_ptr(), B, T, F, CIN, COUT, st)
         if run() != 0:
-            res.append("%s: n/a" % mp); continue
+            res.append("ck%s/%s: n/a" % (ck, mp)); continue
         for _ in range(2): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20): run()
         e1.record(); torch.cuda.synchronize()
-        res.append("%s: %.1f" % (mp, e0.elapsed_time(e1) / 20 * 1e3))
+        res.append("ck%s/%s: %.1f" % (ck, mp, e0.elapsed_time(e1) / 20 * 1e3))
     print("conv %3d->%3d T=%d F=%2d  us  " % (CIN, COUT, T, F) + "  ".join(res), flush=True)
