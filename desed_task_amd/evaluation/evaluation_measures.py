@@ -2,6 +2,8 @@
 return values, on top of this package's restatements of the two third-party evaluators (`psds.PSDSEval`,
 `sed_eval_metrics.{EventBasedMetrics,SegmentBasedMetrics}`) instead of the absent `psds_eval` / `sed_eval` packages.
 
+The threshold-free PSDS (`compute_psds_from_scores`, sed_scores_eval's role) is psds_scores.py's own exact algorithm.
+
 Known answers (tests/test_evaluation.py, from the reference's PSDS_Eval/meta golden data): event-based F1 39.83 % macro /
 40.92 % micro, segment-based 69.35 % / 75.47 %, intersection F1 63.74 %, PSDS1 0.334, PSDS2 0.533.
 """
@@ -139,9 +141,20 @@ def compute_psds_from_operating_points(prediction_dfs, ground_truth_file, durati
     return psds_score.value
 
 
-def compute_psds_from_scores(*args, **kwargs):
-    """The threshold-free PSDS of `sed_scores_eval` (evaluation_measures.py:258-304) is not restated: it needs that package's
-    exact all-thresholds PSD-ROC construction.  Use `compute_psds_from_operating_points` on
-    `postprocess.batched_decode_preds` outputs (the psds_eval path the recipe computes beside it, sed_trainer.py:759-790)."""
-    raise NotImplementedError("compute_psds_from_scores (sed_scores_eval) is not part of this build; use "
-                              "compute_psds_from_operating_points")
+def compute_psds_from_scores(scores, ground_truth_file, durations_file, dtc_threshold=0.5, gtc_threshold=0.5,
+                             cttc_threshold=0.3, alpha_ct=0, alpha_st=0, max_efpr=100, num_jobs=4, save_dir=None):
+    """Threshold-free PSDS of the score tables `scores` ({audio_id: DataFrame}) (evaluation_measures.py:258-304).  The ground
+    truth / durations may be the dicts of `read_ground_truth_events` / `read_audio_durations` (as the reference passes them)
+    or TSV paths.  Computed by psds_scores.psds_from_scores -- an exact all-thresholds PSD-ROC with psds.py's criteria, NOT a
+    restatement of sed_scores_eval's code (parity with that package unpinned, see psds_scores.py).  `num_jobs` is accepted and
+    unused; with `save_dir` the score tables and the PSD-ROC are written as TSV files."""
+    from .psds_scores import psds_from_scores, read_audio_durations, read_ground_truth_events, write_psd_roc
+    psds, _, psd_roc, _ = psds_from_scores(scores, read_ground_truth_events(ground_truth_file), read_audio_durations(durations_file),
+                                           dtc_threshold=dtc_threshold, gtc_threshold=gtc_threshold, cttc_threshold=cttc_threshold,
+                                           alpha_ct=alpha_ct, alpha_st=alpha_st, max_efpr=max_efpr)
+    if save_dir is not None:
+        from ..postprocess import write_sed_scores
+        write_sed_scores(scores, os.path.join(save_dir, "scores"))
+        write_psd_roc(os.path.join(save_dir, f"PSDS_dtc{dtc_threshold}_gtc{gtc_threshold}_cttc{cttc_threshold}"
+                                             f"_ct{alpha_ct}_st{alpha_st}_max{max_efpr}_sed_scores_eval.tsv"), psd_roc)
+    return psds

@@ -309,34 +309,53 @@ class SEDTask4(_Base):
                     buf[th] = pd.concat([buf[th], decoded[th]], ignore_index=True)
         return
 
+    def _scored_ground_truth(self, tsv, dur, score_buffer):
+        """Ground-truth / duration dicts for the threshold-free PSDS as the reference prepares them (sed_trainer.py:503-525,
+        :736-758): fast_dev_run keeps the scored clips, otherwise clips without events are dropped."""
+        from .evaluation.psds_scores import read_audio_durations, read_ground_truth_events
+        ground_truth, audio_durations = read_ground_truth_events(tsv), read_audio_durations(dur)
+        if self.fast_dev_run:
+            ground_truth = {a: ground_truth[a] for a in score_buffer}
+        else:
+            ground_truth = {a: gt for a, gt in ground_truth.items() if len(gt) > 0}
+        return ground_truth, {a: audio_durations[a] for a in ground_truth}
+
     def validation_epoch_end(self, outputs=None):
-        """sed_trainer.py:489-600 on this package's evaluator restatements (desed_task_amd/evaluation).
-        The threshold-free `sed_scores_eval` PSDS is not restated, so `training.obj_metric_synth_type` must be "event" or
-        "intersection" (the reference's default, None / "psds", raises) and the key val/synth/student/psds1_sed_scores_eval
-        is not logged."""
+        """sed_trainer.py:489-600 on this package's evaluators (desed_task_amd/evaluation): same objective
+        selection (`training.obj_metric_synth_type`: None / "psds" -> threshold-free PSDS scenario 1, "event", "intersection"),
+        same logged keys, same buffer resets."""
         import pandas as pd
-        from .evaluation.evaluation_measures import compute_per_intersection_macro_f1, log_sedeval_metrics
+        from .evaluation.evaluation_measures import (compute_per_intersection_macro_f1, compute_psds_from_scores,
+                                                     log_sedeval_metrics)
         self._val_state()
         obj_type = self.hparams["training"].get("obj_metric_synth_type")
-        if obj_type in (None, "psds"):
-            raise NotImplementedError("obj_metric_synth_type None / 'psds' needs sed_scores_eval's threshold-free PSDS, which is "
-                                      "not part of this build: set training.obj_metric_synth_type to 'event' or 'intersection'")
-        if obj_type not in ("event", "intersection"):
+        if obj_type not in (None, "psds", "event", "intersection"):
             raise NotImplementedError(f"obj_metric_synth_type: {obj_type} not implemented.")
         data = self.hparams["data"]
         weak_student_f1_macro = self.get_weak_student_f1_seg_macro.compute()
         weak_teacher_f1_macro = self.get_weak_teacher_f1_seg_macro.compute()
+        ground_truth, audio_durations = self._scored_ground_truth(data["synth_val_tsv"], data["synth_val_dur"],
+                                                                  self.val_scores_postprocessed_buffer_student_synth)
+        psds1_student_sed_scores_eval = compute_psds_from_scores(
+            self.val_scores_postprocessed_buffer_student_synth, ground_truth, audio_durations, dtc_threshold=0.7,
+            gtc_threshold=0.7, cttc_threshold=None, alpha_ct=0, alpha_st=1)
         intersection_f1_macro_student = compute_per_intersection_macro_f1(self.val_buffer_student_synth, data["synth_val_tsv"],
                                                                           data["synth_val_dur"])
         synth_student_event_macro = log_sedeval_metrics(self.val_buffer_student_synth[0.5], data["synth_val_tsv"])[0]
         intersection_f1_macro_teacher = compute_per_intersection_macro_f1(self.val_buffer_teacher_synth, data["synth_val_tsv"],
                                                                           data["synth_val_dur"])
         synth_teacher_event_macro = log_sedeval_metrics(self.val_buffer_teacher_synth[0.5], data["synth_val_tsv"])[0]
-        synth_metric = synth_student_event_macro if obj_type == "event" else intersection_f1_macro_student
+        if obj_type in (None, "psds"):
+            synth_metric = psds1_student_sed_scores_eval
+        elif obj_type == "event":
+            synth_metric = synth_student_event_macro
+        else:
+            synth_metric = intersection_f1_macro_student
         obj_metric = torch.tensor(float(weak_student_f1_macro) + float(synth_metric))
         self.log("val/obj_metric", obj_metric, prog_bar=True)
         self.log("val/weak/student/macro_F1", weak_student_f1_macro)
         self.log("val/weak/teacher/macro_F1", weak_teacher_f1_macro)
+        self.log("val/synth/student/psds1_sed_scores_eval", psds1_student_sed_scores_eval)
         self.log("val/synth/student/intersection_f1_macro", intersection_f1_macro_student)
         self.log("val/synth/teacher/intersection_f1_macro", intersection_f1_macro_teacher)
         self.log("val/synth/student/event_f1_macro", synth_student_event_macro)
@@ -413,12 +432,13 @@ class SEDTask4(_Base):
 
     def on_test_epoch_end(self):
         """sed_trainer.py:685-911.  `evaluation=True`: only the raw / post-processed score tables are written (one TSV per
-        clip, the sed_scores_eval.io.write_sed_scores layout).  Otherwise PSDS scenario 1 / 2 (psds_eval path), event-based
-        and intersection-based macro F1 for both models.  Not reproduced: the `*_sed_scores_eval` keys (that package's
-        threshold-free PSDS is not restated) and the codecarbon energy keys (trackers are outside the hot path)."""
+        clip, the sed_scores_eval.io.write_sed_scores layout).  Otherwise PSDS scenario 1 / 2 from the operating points
+        (psds_eval role) and from the score tables (sed_scores_eval role), event-based and intersection-based macro F1, for
+        both models -- the reference's `test/...` keys.  Not reproduced: the codecarbon energy keys (trackers are outside the
+        hot path)."""
         import os
         from .evaluation.evaluation_measures import (compute_per_intersection_macro_f1, compute_psds_from_operating_points,
-                                                     log_sedeval_metrics)
+                                                     compute_psds_from_scores, log_sedeval_metrics)
         from .postprocess import write_sed_scores
         self._test_state()
         save_dir = os.path.join(self.exp_dir, "metrics_test")
@@ -432,14 +452,23 @@ class SEDTask4(_Base):
         else:
             data = self.hparams["data"]
             results = {}
-            for who, buf, buf05 in (("student", self.test_psds_buffer_student, self.decoded_student_05_buffer),
-                                    ("teacher", self.test_psds_buffer_teacher, self.decoded_teacher_05_buffer)):
+            ground_truth, audio_durations = self._scored_ground_truth(data["test_tsv"], data["test_dur"],
+                                                                      self.test_scores_postprocessed_buffer_student)
+            for who, buf, buf05, post in (
+                    ("student", self.test_psds_buffer_student, self.decoded_student_05_buffer, self.test_scores_postprocessed_buffer_student),
+                    ("teacher", self.test_psds_buffer_teacher, self.decoded_teacher_05_buffer, self.test_scores_postprocessed_buffer_teacher)):
                 results[f"test/{who}/psds1_psds_eval"] = compute_psds_from_operating_points(
                     buf, data["test_tsv"], data["test_dur"], dtc_threshold=0.7, gtc_threshold=0.7, alpha_ct=0, alpha_st=1,
                     save_dir=os.path.join(save_dir, who, "scenario1"))
+                results[f"test/{who}/psds1_sed_scores_eval"] = compute_psds_from_scores(
+                    post, ground_truth, audio_durations, dtc_threshold=0.7, gtc_threshold=0.7, cttc_threshold=None, alpha_ct=0,
+                    alpha_st=1, save_dir=os.path.join(save_dir, who, "scenario1"))
                 results[f"test/{who}/psds2_psds_eval"] = compute_psds_from_operating_points(
                     buf, data["test_tsv"], data["test_dur"], dtc_threshold=0.1, gtc_threshold=0.1, cttc_threshold=0.3,
                     alpha_ct=0.5, alpha_st=1, save_dir=os.path.join(save_dir, who, "scenario2"))
+                results[f"test/{who}/psds2_sed_scores_eval"] = compute_psds_from_scores(
+                    post, ground_truth, audio_durations, dtc_threshold=0.1, gtc_threshold=0.1, cttc_threshold=0.3, alpha_ct=0.5,
+                    alpha_st=1, save_dir=os.path.join(save_dir, who, "scenario2"))
                 results[f"test/{who}/event_f1_macro"] = log_sedeval_metrics(buf05, data["test_tsv"], os.path.join(save_dir, who))[0]
                 results[f"test/{who}/intersection_f1_macro"] = compute_per_intersection_macro_f1(
                     {"0.5": buf05}, data["test_tsv"], data["test_dur"])

@@ -744,11 +744,16 @@ def case_validation_step(dev):
         d05[["filename", "onset", "offset", "event_label"]].to_csv(tsv, sep="\t", index=False)
         pd.DataFrame({"filename": ["s%d.wav" % j for j in range(3)], "duration": n_samp / 16000.0}).to_csv(dur, sep="\t", index=False)
         task.hparams["data"].update(synth_val_tsv=tsv, synth_val_dur=dur)
-        try:
-            task.validation_epoch_end([])
-            raise AssertionError("the sed_scores_eval objective must be refused, not silently replaced")
-        except NotImplementedError:
-            pass
+        import copy
+        saved = copy.deepcopy((task.val_buffer_student_synth, task.val_buffer_teacher_synth,
+                               task.val_scores_postprocessed_buffer_student_synth, task.val_scores_postprocessed_buffer_teacher_synth,
+                               task.get_weak_student_f1_seg_macro, task.get_weak_teacher_f1_seg_macro))
+        # default objective (None): weak F1 + threshold-free PSDS1 of the student's score tables
+        obj = task.validation_epoch_end([])
+        psds1 = float(task.logged["val/synth/student/psds1_sed_scores_eval"])
+        assert 0.0 < psds1 <= 1.0 and abs(float(obj) - (f1 + psds1)) < 1e-6
+        (task.val_buffer_student_synth, task.val_buffer_teacher_synth, task.val_scores_postprocessed_buffer_student_synth,
+         task.val_scores_postprocessed_buffer_teacher_synth, task.get_weak_student_f1_seg_macro, task.get_weak_teacher_f1_seg_macro) = saved
         task.hparams["training"]["obj_metric_synth_type"] = "event"
         obj = task.validation_epoch_end([])
         assert abs(float(obj) - (f1 + 1.0)) < 1e-6
@@ -804,7 +809,7 @@ def case_test_epoch(dev, out_dir):
     for who in ("student", "teacher"):                           # the teacher is a copy of the student at construction
         assert res["test/%s/event_f1_macro" % who] == 1.0
         assert res["test/%s/intersection_f1_macro" % who] == 1.0
-        for k in ("psds1_psds_eval", "psds2_psds_eval"):
+        for k in ("psds1_psds_eval", "psds2_psds_eval", "psds1_sed_scores_eval", "psds2_sed_scores_eval"):
             assert 0.0 < res["test/%s/%s" % (who, k)] <= 1.0
         assert os.path.exists(os.path.join(str(out_dir), "metrics_test", who, "event_f1.txt"))
         assert len(os.listdir(os.path.join(str(out_dir), "metrics_test", who, "scenario1", "predictions_dtc0.7_gtc0.7_cttc0.3"))) == 10

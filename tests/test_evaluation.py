@@ -212,8 +212,6 @@ def test_psds_small_cases():
         PSDSEval(ground_truth=gt, metadata=meta, dtc_threshold=1.5)
     with pytest.raises(PSDSEvalError):
         PSDSEval(ground_truth=gt, metadata=meta).psds()
-    with pytest.raises(NotImplementedError):
-        EM.compute_psds_from_scores({}, None, None)
 
 
 def test_event_matching_is_optimal():
@@ -226,3 +224,87 @@ def test_event_matching_is_optimal():
     assert m.overall["Ntp"] == 2 and m.class_wise["x"]["Ntp"] == 2
     m.evaluate([{"filename": "g"}], [dict(filename="g", onset=0.0, offset=1.0, event_label="x")])
     assert m.overall["Nfp"] == 1 and m.evaluated_files == 2
+
+
+def _synthetic_scores(n_clips=12, T=40, classes=("a", "b", "c"), levels=8, seed=0):
+    """Ground truth with irrational-ish boundaries (no exact ties in the intersection criteria) and posteriors that follow it
+    (event evidence + a random walk + some leakage into the next class), quantised to `levels` values."""
+    rng = np.random.default_rng(seed)
+    hop = 0.064
+    ts = np.arange(T + 1) * hop
+    mid = (ts[:-1] + ts[1:]) / 2
+    scores, gt, dur = {}, {}, {}
+    for i in range(n_clips):
+        aid = "clip%02d" % i
+        dur[aid] = float(ts[-1] - 0.013 * (i % 3))
+        ev, act = [], np.zeros((T, len(classes)))
+        for k, c in enumerate(classes):
+            for _ in range(rng.integers(0, 3)):
+                on = rng.uniform(0, ts[-1] - 0.4)
+                on, off = round(on, 5) + 1e-4 / 3, round(min(on + rng.uniform(0.15, 1.2), dur[aid]), 5) - 1e-4 / 7
+                ev.append((on, off, c))
+                inside = (mid >= on - 0.05) & (mid < off + 0.08)
+                act[inside, k] += 0.55
+                act[inside, (k + 1) % len(classes)] += 0.25          # cross-trigger fodder
+        walk = np.cumsum(rng.normal(0, 0.06, (T, len(classes))), 0)
+        s = np.clip(0.2 + act + walk + rng.normal(0, 0.05, act.shape), 0.0, 0.999)
+        s = np.floor(s * levels) / levels
+        scores[aid] = pd.DataFrame(np.concatenate((ts[:-1, None], ts[1:, None], s), 1), columns=["onset", "offset"] + list(classes))
+        gt[aid] = ev
+    return scores, gt, dur, list(classes), levels
+
+
+@pytest.mark.parametrize("dtc,gtc,cttc,alpha_ct,alpha_st", [(0.7, 0.7, None, 0.0, 1.0), (0.1, 0.1, 0.3, 0.5, 1.0), (0.5, 0.5, 0.3, 1.0, 0.0)])
+def test_psds_from_scores_equals_operating_points(dtc, gtc, cttc, alpha_ct, alpha_st):
+    """With scores on a finite grid the all-thresholds PSDS must equal psds_eval-style PSDS with one operating point per distinct
+    threshold: ties the sed_scores_eval-role function to the PSDSEval restatement that the reference's golden numbers pin."""
+    from desed_task_amd.evaluation.psds_scores import psds_from_scores
+    from oracle import sed_oracle as O
+    scores, gt, dur, classes, levels = _synthetic_scores()
+    got, single, roc, rocs = psds_from_scores(scores, gt, dur, dtc_threshold=dtc, gtc_threshold=gtc, cttc_threshold=cttc,
+                                              alpha_ct=alpha_ct, alpha_st=alpha_st, max_efpr=2000.0)
+    gt_df = pd.DataFrame([(a + ".wav", o, f, l) for a, ev in gt.items() for o, f, l in ev] +
+                         [(a + ".wav", np.nan, np.nan, np.nan) for a, ev in gt.items() if not ev],
+                         columns=["filename", "onset", "offset", "event_label"])
+    meta = pd.DataFrame({"filename": [a + ".wav" for a in dur], "duration": list(dur.values())})
+    ev = PSDSEval(ground_truth=gt_df, metadata=meta, dtc_threshold=dtc, gtc_threshold=gtc, cttc_threshold=0.3 if cttc is None else cttc)
+    for j in range(-1, levels + 1):
+        th = np.float64((j + 0.5) / levels)                      # between two grid values: enumerates every distinct detection set
+        rows = []
+        for a, df in scores.items():
+            ts = np.concatenate((df.onset.to_numpy(), df.offset.to_numpy()[-1:]))
+            for c, on, off in O.decode_events(df[classes].to_numpy(np.float32), np.float32(th)):
+                rows.append((a + ".wav", ts[on], ts[off], classes[c]))
+        ev.add_operating_point(pd.DataFrame(rows, columns=["filename", "onset", "offset", "event_label"]))
+    want = ev.psds(alpha_ct=alpha_ct, alpha_st=alpha_st, max_efpr=2000.0).value
+    assert 0.0 < want < 1.0
+    assert got == pytest.approx(want, rel=1e-9, abs=1e-12)
+    assert set(single) <= set(classes) and len(roc[0]) == len(roc[1])
+
+
+def test_psds_from_scores_io_and_wrapper(golden, tmp_path):
+    """TSV readers + the evaluation_measures wrapper; a perfect score table (1 inside every event, 0 elsewhere) scores 1."""
+    from desed_task_amd.evaluation.psds_scores import read_audio_durations, read_ground_truth_events
+    gt_path, dur_path = tmp_path / "gt.tsv", tmp_path / "dur.tsv"
+    sub = golden["gt"][golden["gt"].filename.isin(sorted(set(golden["gt"].filename))[:40])]
+    sub.to_csv(gt_path, sep="\t", index=False)
+    golden["durations"][golden["durations"].filename.isin(set(sub.filename))].to_csv(dur_path, sep="\t", index=False)
+    gt, dur = read_ground_truth_events(str(gt_path)), read_audio_durations(str(dur_path))
+    assert len(gt) == 40 == len(dur) and all(k.endswith(("000", "0")) or True for k in gt)
+    assert sum(len(v) for v in gt.values()) == int(sub.event_label.notna().sum())
+    labels = golden["labels"]
+    hop, scores = 0.016, {}
+    for aid, events in gt.items():
+        T = int(np.ceil(10.0 / hop))
+        ts = np.arange(T + 1) * hop
+        s = np.zeros((T, len(labels)))
+        for o, f, l in events:
+            s[int(np.floor(o / hop)):int(np.ceil(f / hop)), labels.index(l)] = 1.0
+        scores[aid] = pd.DataFrame(np.concatenate((ts[:-1, None], ts[1:, None], s), 1), columns=["onset", "offset"] + labels)
+    gt_events = {k: v for k, v in gt.items() if v}                                   # the reference drops clips without events
+    value = EM.compute_psds_from_scores(scores, gt_events, {k: dur[k] for k in gt_events}, dtc_threshold=0.7, gtc_threshold=0.7,
+                                        cttc_threshold=None, alpha_ct=0, alpha_st=1, save_dir=str(tmp_path / "out"))
+    assert value == pytest.approx(1.0, abs=1e-12)
+    assert len(os.listdir(tmp_path / "out" / "scores")) == len(scores)
+    with pytest.raises(ValueError):
+        EM.compute_psds_from_scores({}, gt_events, dur)
