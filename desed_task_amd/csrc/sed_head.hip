@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
                                                    const float* __restrict__ labels, const float* __restrict__ labels_weak,
                                                    float* __restrict__ scalars, float* __restrict__ g_strong,
                                                    float* __restrict__ g_weak, int B, int T, int NC, int n_strong, int n_weak,
-                                                   float weight, const float* __restrict__ weight_dev) {
+                                                   float weight, const float* __restrict__ weight_dev, int selfsup_bce) {
     if (weight_dev) weight = *weight_dev;       // consistency weight in device memory (hipGraph replays)
     // one workgroup per clip; the six scalars (zeroed by the launcher) collect pre-scaled per-clip sums
     __shared__ float red[4][6];
@@ -254,9 +254,15 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
     for (int j = tid; j < clip_el; j += 256) {
         const int i = b * clip_el + j, c = j % NC, t = j / NC;
         const float s = strong_s[i], q = strong_t[i];
-        float g = weight * 2.0f * (s - q) * inv_all;
-        const float d = s - q;
-        acc[4] += d * d;
+        float g;
+        if (selfsup_bce) {      // self_sup_loss: bce (sed_trainer.py:99-100): BCELoss(student, teacher), teacher as the target
+            g = weight * (s - q) / fmaxf(s * (1.0f - s), 1e-12f) * inv_all;
+            acc[4] += bce_term(s, q);
+        } else {
+            const float d = s - q;
+            g = weight * 2.0f * d * inv_all;
+            acc[4] += d * d;
+        }
         if (b < n_strong) {
             const float y = labels[((size_t)b * NC + c) * T + t];
             acc[0] += bce_term(s, y);
@@ -270,9 +276,15 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
     if (tid < NC) {
         const int c = tid, i = b * NC + c;
         const float s = weak_s[i], q = weak_t[i];
-        float g = weight * 2.0f * (s - q) * inv_allw;
-        const float d = s - q;
-        acc[5] += d * d;
+        float g;
+        if (selfsup_bce) {
+            g = weight * (s - q) / fmaxf(s * (1.0f - s), 1e-12f) * inv_allw;
+            acc[5] += bce_term(s, q);
+        } else {
+            const float d = s - q;
+            g = weight * 2.0f * d * inv_allw;
+            acc[5] += d * d;
+        }
         if (b >= n_strong && b < n_strong + n_weak) {
             const float y = labels_weak[(b - n_strong) * NC + c];
             acc[1] += bce_term(s, y);
@@ -295,10 +307,11 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
 }
 extern "C" int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
                            const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
-                           int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, void* stream) {
+                           int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, int selfsup_bce,
+                           void* stream) {
     if (B <= 0 || T <= 0 || NC <= 0 || NC > 256 || n_strong + n_weak > B) return SED_ERR_ARG;
     sed_zero4((hipStream_t)stream, scalars, 6, nullptr, 0, nullptr, 0, nullptr, 0);
     SED_LAUNCH(loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, strong_s, weak_s, strong_t, weak_t, labels, labels_weak,
-               scalars, g_strong, g_weak, B, T, NC, n_strong, n_weak, weight, weight_dev);
+               scalars, g_strong, g_weak, B, T, NC, n_strong, n_weak, weight, weight_dev, selfsup_bce);
     return sed_check_launch();
 }

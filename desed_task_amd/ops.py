@@ -377,10 +377,11 @@ class HeadFn(torch.autograd.Function):
 class MeanTeacherLossFn(torch.autograd.Function):
     """Fused losses of SEDTask4.training_step (sed_trainer.py:309-342).
     Returns a (7,) tensor: [bce_strong, bce_weak, bce_strong_teacher, bce_weak_teacher, mse_strong, mse_weak, total]
-    with total = bce_strong + bce_weak + weight * (mse_strong + mse_weak).  Only `total` is differentiable."""
+    with total = bce_strong + bce_weak + weight * (mse_strong + mse_weak).  Only `total` is differentiable.
+    selfsup_bce: slots 4 / 5 hold BCELoss(student, teacher) instead (`training.self_sup_loss: bce`)."""
 
     @staticmethod
-    def forward(ctx, strong_s, weak_s, strong_t, weak_t, labels, labels_weak, n_strong, n_weak, weight):
+    def forward(ctx, strong_s, weak_s, strong_t, weak_t, labels, labels_weak, n_strong, n_weak, weight, selfsup_bce=False):
         lib = _lib.get()
         strong_s, weak_s = strong_s.contiguous(), weak_s.contiguous()
         strong_t, weak_t = strong_t.contiguous(), weak_t.contiguous()
@@ -393,7 +394,7 @@ class MeanTeacherLossFn(torch.autograd.Function):
         g_weak = torch.empty(B, NC, **f32)
         lib.call("sed_mt_loss", strong_s.data_ptr(), weak_s.data_ptr(), strong_t.data_ptr(), weak_t.data_ptr(), labels.data_ptr(),
                  labels_weak.data_ptr(), scalars.data_ptr(), g_strong.data_ptr(), g_weak.data_ptr(), B, T, NC, int(n_strong),
-                 int(n_weak), float(weight), getattr(weight, "dev", None), _lib.stream_ptr(strong_s))
+                 int(n_weak), float(weight), getattr(weight, "dev", None), int(bool(selfsup_bce)), _lib.stream_ptr(strong_s))
         w = weight.tensor if isinstance(weight, _graph.DynFloat) else float(weight)
         total = scalars[0] + scalars[1] + w * (scalars[4] + scalars[5])
         ctx.save_for_backward(g_strong, g_weak)
@@ -403,4 +404,4 @@ class MeanTeacherLossFn(torch.autograd.Function):
     def backward(ctx, g):
         g_strong, g_weak = ctx.saved_tensors
         gt = g[6]
-        return g_strong * gt, g_weak * gt, None, None, None, None, None, None, None
+        return g_strong * gt, g_weak * gt, None, None, None, None, None, None, None, None

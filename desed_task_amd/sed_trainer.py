@@ -64,10 +64,9 @@ class SEDTask4(_Base):
             p.detach_()
 
         sup = self.hparams["training"]["self_sup_loss"]
-        if sup == "bce":
-            raise NotImplementedError("self_sup_loss: bce is not built on the HIP loss kernel (the 2023 recipe uses mse)")
-        if sup != "mse":
+        if sup not in ("mse", "bce"):                       # sed_trainer.py:97-103
             raise NotImplementedError
+        self.selfsup_bce = sup == "bce"
         self.scaler = self._init_scaler()
 
     # ---- feature pipeline ------------------------------------------------------------------------
@@ -75,7 +74,25 @@ class SEDTask4(_Base):
         sc = self.hparams["scaler"]
         if sc["statistic"] == "instance":
             return TorchScaler("instance", sc["normtype"], sc["dims"])
-        raise NotImplementedError("dataset-wide scaler statistics need the data loaders (outside the hot path)")
+        if sc["statistic"] != "dataset":
+            raise NotImplementedError
+        # sed_trainer.py:218-250: data-set statistics are loaded from `savepath` when it exists, else fitted on the log-mels of
+        # one pass over the training loader (and saved).  Knowing deviation: the reference forgets to return the freshly fitted
+        # scaler when `savepath` is None (falls off the end -> None); it is returned here.
+        import os
+        scaler = TorchScaler("dataset", sc["normtype"], sc["dims"])
+        path = sc.get("savepath")
+        if path is not None and os.path.exists(path):
+            print("Loaded Scaler from previous checkpoint from {}".format(path))
+            return torch.load(path, weights_only=False)
+        self.train_loader = self.train_dataloader()
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        with torch.no_grad():               # the mel kernel has no host path: the clips go to the GPU for the pass
+            scaler.fit(self.train_loader, transform_func=lambda x: self.take_log(self.mel_spec(x[0].to(dev))))
+        if path is not None:
+            torch.save(scaler, path)
+            print("Saving Scaler from previous checkpoint at {}".format(path))
+        return scaler
 
     def take_log(self, mels):
         return features.take_log(mels)
@@ -210,7 +227,7 @@ class SEDTask4(_Base):
         else:
             weight = const_max * sched._get_scaling_factor()
         out = MeanTeacherLossFn.apply(strong_s.transpose(1, 2), weak_s, strong_t.transpose(1, 2), weak_t, labels, labels_weak,
-                                      indx_synth, indx_weak, weight)
+                                      indx_synth, indx_weak, weight, self.selfsup_bce)
         loss_strong, loss_weak, loss_strong_t, loss_weak_t, strong_self, weak_self, tot_loss = out.unbind(0)
         tot_self_loss = (strong_self + weak_self).detach() * (weight.tensor if dyn is not None else weight)
 

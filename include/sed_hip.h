@@ -188,10 +188,11 @@ int sed_head_bwd(const float* x, const float* W1, const float* W2, const float* 
 
 /* Mean-teacher losses of SEDTask4.training_step (recipes/dcase2023_task4_baseline/local/sed_trainer.py:309-342):
  * scalars[6] = BCE strong/weak (student), BCE strong/weak (teacher), MSE strong/weak; g_strong (B,T,NC), g_weak (B,NC)
- * = d(BCE_s + BCE_w + weight*(MSE_s + MSE_w)) / d(student outputs).  labels (B,NC,T); labels_weak (n_weak,NC). */
+ * = d(BCE_s + BCE_w + weight*(MSE_s + MSE_w)) / d(student outputs).  labels (B,NC,T); labels_weak (n_weak,NC).
+ * selfsup_bce != 0: the two consistency terms are BCELoss(student, teacher) instead of MSELoss (`self_sup_loss: bce`, :99-100). */
 int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
                 const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
-                int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, void* stream);
+                int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, int selfsup_bce, void* stream);
 
 /* ---- K13: inference post-processing, recipes/dcase2023_task4_baseline/local/utils.py:16-73 ----- */
 

@@ -365,7 +365,7 @@ class OracleTrainer:
     are injected through `rng` dicts so the HIP path can be compared on identical draws."""
 
     def __init__(self, student_sd, batch_sizes=(12, 12, 24), lr=1e-3, rampup_len=5900, const_max=2.0,
-                 ema_factor=0.999, dropout_p=0.5, teacher_sd=None):
+                 ema_factor=0.999, dropout_p=0.5, teacher_sd=None, self_sup="mse"):
         self.student = {k: v.clone() for k, v in student_sd.items()}
         self.keys = param_keys(student_sd)
         for k in self.keys:
@@ -375,6 +375,7 @@ class OracleTrainer:
         self.batch_sizes = batch_sizes
         self.max_lr, self.rampup_len, self.const_max, self.ema_factor = lr, rampup_len, const_max, ema_factor
         self.dropout_p = dropout_p
+        self.selfsup_loss = F.mse_loss if self_sup == "mse" else F.binary_cross_entropy      # sed_trainer.py:97-100
         self.step_num = 1                                              # schedulers.py:79
         self.lr = lr
         self.m = {k: torch.zeros_like(self.student[k]) for k in self.keys}
@@ -411,8 +412,8 @@ class OracleTrainer:
             loss_strong_t = F.binary_cross_entropy(strong_t[:ns], labels[:ns])
             loss_weak_t = F.binary_cross_entropy(weak_t[ns:ns + nw], labels_weak)
         weight = self.const_max * warmup_factor(self.step_num, self.rampup_len)
-        strong_self = F.mse_loss(strong_s, strong_t)
-        weak_self = F.mse_loss(weak_s, weak_t)
+        strong_self = self.selfsup_loss(strong_s, strong_t)
+        weak_self = self.selfsup_loss(weak_s, weak_t)
         tot_self = (strong_self + weak_self) * weight
         tot = loss_strong + loss_weak + tot_self
         logs = {

@@ -999,3 +999,71 @@ def case_embcat_full_size(dev):
     rate = float(kept.float().mean())
     assert abs(rate - (1 - p)) < 2e-3, rate
     assert float((z[kept] - z_ref[kept] * dscale).abs().max()) < 1e-5 * float(z_ref.abs().max()) * dscale
+
+
+def case_dataset_scaler(dev, tmp_dir):
+    """SEDTask4._init_scaler with statistic "dataset" (sed_trainer.py:218-250): fitted on the log-mels of the training loader,
+    saved, reloaded; against the oracle's mel + log on the same clips."""
+    import os
+    from desed_task_amd.nnet.CRNN import CRNN
+    from desed_task_amd.sed_trainer import SEDTask4
+    config = recipe_config((1, 1, 2))
+    path = os.path.join(str(tmp_dir), "scaler.ckpt")
+    config["scaler"] = {"statistic": "dataset", "normtype": "standard", "dims": [0, 2], "savepath": path}
+    audio = O.synth_audio(6, 8192 + 1024, seed=3)
+
+    class Clips(torch.utils.data.Dataset):
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            return audio[i], torch.zeros(10, 9), 1.0
+
+    class Enc:
+        labels = list(range(10))
+    sampler = [[0, 1], [2, 3], [4, 5]]
+    task = SEDTask4(config, Enc(), CRNN(**config["net"]), train_data=Clips(), train_sampler=sampler)
+    logm = O.take_log(O.mel_spectrogram(audio))
+    want_mean = torch.stack([logm[2 * i:2 * i + 2].mean((0, 2), keepdim=True).mean(0).unsqueeze(0) for i in range(3)]).mean(0)
+    assert tuple(task.scaler.mean.shape) == (1, 128, 1)
+    assert float((task.scaler.mean.cpu() - want_mean).abs().max()) < 2e-3
+    assert os.path.exists(path)
+    x = to(dev, logm[:2].clone())
+    y = task.scaler.to(x.device)(x)
+    ref = (logm[:2] - task.scaler.mean.cpu()) / (torch.sqrt(task.scaler.mean_squared.cpu() - task.scaler.mean.cpu() ** 2) + 1e-8)
+    assert float((y.cpu() - ref).abs().max()) < 1e-4
+    task2 = SEDTask4(config, Enc(), CRNN(**config["net"]))               # no loader needed: loaded from savepath
+    assert torch.equal(task2.scaler.mean.cpu(), task.scaler.mean.cpu())
+
+
+def case_mt_loss(dev):
+    """MeanTeacherLossFn (K9) against torch losses, both `self_sup_loss` modes (sed_trainer.py:97-103, :309-342): the six
+    scalars, the total and its gradient w.r.t. the student's strong / weak posteriors."""
+    from desed_task_amd import ops
+    B, T, NC, ns, nw = 7, 13, 10, 2, 3
+    g = torch.Generator().manual_seed(5)
+    strong_s = torch.rand(B, T, NC, generator=g) * 0.96 + 0.02
+    weak_s = torch.rand(B, NC, generator=g) * 0.96 + 0.02
+    strong_t = torch.rand(B, T, NC, generator=g) * 0.96 + 0.02
+    weak_t = torch.rand(B, NC, generator=g) * 0.96 + 0.02
+    labels = (torch.rand(B, NC, T, generator=g) < 0.2).float()
+    labels_weak = (torch.rand(nw, NC, generator=g) < 0.3).float()
+    weight = 1.37
+    bce = torch.nn.functional.binary_cross_entropy
+    for mode in ("mse", "bce"):
+        selfsup = torch.nn.functional.mse_loss if mode == "mse" else bce
+        ss, ws = strong_s.detach().clone().requires_grad_(True), weak_s.detach().clone().requires_grad_(True)
+        ref = [bce(ss[:ns], labels[:ns].transpose(1, 2)), bce(ws[ns:ns + nw], labels_weak), bce(strong_t[:ns], labels[:ns].transpose(1, 2)),
+               bce(weak_t[ns:ns + nw], labels_weak), selfsup(ss, strong_t), selfsup(ws, weak_t)]
+        tot = ref[0] + ref[1] + weight * (ref[4] + ref[5])
+        tot.backward()
+        sd, wd = to(dev, strong_s.detach().clone()).requires_grad_(True), to(dev, weak_s.detach().clone()).requires_grad_(True)
+        out = ops.MeanTeacherLossFn.apply(sd, wd, to(dev, strong_t), to(dev, weak_t), to(dev, labels), to(dev, labels_weak), ns, nw,
+                                          weight, mode == "bce")
+        out[6].backward()
+        got = out.detach().cpu()
+        for k in range(6):
+            assert abs(float(got[k]) - float(ref[k])) < 2e-6 * max(1.0, abs(float(ref[k]))), (mode, k)
+        assert abs(float(got[6]) - float(tot)) < 5e-6 * max(1.0, abs(float(tot)))
+        assert float((sd.grad.cpu() - ss.grad).abs().max()) < 1e-6 * max(1.0, float(ss.grad.abs().max())), mode
+        assert float((wd.grad.cpu() - ws.grad).abs().max()) < 1e-6 * max(1.0, float(ws.grad.abs().max())), mode

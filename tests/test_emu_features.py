@@ -22,3 +22,13 @@ def test_mixup_and_specaug(emu):
 def test_postprocess_median_threshold_events(emu):
     """K13: batched median filter / thresholds / event regions, bit-exact vs scipy and the oracle."""
     P.case_postprocess("cpu")
+
+
+def test_dataset_scaler(emu, tmp_path):
+    """statistic "dataset" of SEDTask4._init_scaler: fit over the training loader through the mel kernel, save, reload."""
+    P.case_dataset_scaler("cpu", tmp_path)
+
+
+def test_mt_loss_modes(emu):
+    """K9 losses, self_sup_loss mse and bce, against torch."""
+    P.case_mt_loss("cpu")

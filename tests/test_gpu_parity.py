@@ -136,3 +136,8 @@ def test_embedding_crnn_matches_reference_golden():
 
 def test_pretrained_training_step():
     P.case_pretrained_training_step("cuda")
+
+
+def test_mt_loss_modes_and_dataset_scaler(tmp_path):
+    P.case_mt_loss("cuda")
+    P.case_dataset_scaler("cuda", tmp_path)
