@@ -306,13 +306,17 @@ extern "C" int sed_colsum(const float* X, float* out, float* out1, int nsplit, i
 // ---------------------------------------------------------------------------------------------
 #define GRU_CH 8
 #define GRU_THREADS 512
-// GRU_VARIANT: timing-ablation mask for tools/gru_variants.py (1 in the product build = padded hidden-state quarters only):
-// 8 = no hidden-state LDS reads, 16 = no FMAs, 32 = no exp/rcp, 64 = no output staging stores, 128 = no per-step barrier
-// (results are wrong under any of 8..128; numbers in DESIGN.md section 8).
+// GRU_VARIANT: design / timing-ablation mask for tools/gru_variants.py.  Product build = 5:
+//   1 = padded hidden-state quarters (121 -> 117 us per launch), 4 = quad stores of the step results (-> 112.6 us);
+//   2 = two accumulators per gate (measured slower: 122.5 us, off);
+//   8 = no hidden-state LDS reads, 16 = no FMAs, 32 = no exp/rcp, 64 = no output staging stores, 128 = no per-step barrier
+//   (results are wrong under any of 8..128; numbers in DESIGN.md section 8).
 #ifndef GRU_VARIANT
-#define GRU_VARIANT 1
+#define GRU_VARIANT 5
 #endif
 #define GRU_HPAD (GRU_VARIANT & 1)
+#define GRU_ACC6 ((GRU_VARIANT & 2) != 0)
+#define GRU_QSTORE ((GRU_VARIANT & 4) != 0)
 #define GRU_NOREAD ((GRU_VARIANT & 8) != 0)
 #define GRU_NOFMA ((GRU_VARIANT & 16) != 0)
 #define GRU_NOTRANS ((GRU_VARIANT & 32) != 0)
@@ -323,7 +327,10 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __res
                                                       const float* __restrict__ bhh1, float* __restrict__ out,
                                                       float* __restrict__ saved, int B, int T) {
     constexpr int H = GRU_H, KH = H / 4, CH = GRU_CH, NT_ = GRU_THREADS;   // KH: K quarter per thread
-    constexpr int GI_F = CH * 3 * H, OB_F = CH * 5 * H;            // floats per chunk buffer
+    // result planes of a step sit OBP floats apart: with GRU_QSTORE the four lanes of a quad store to four planes at once, so
+    // the plane pitch is H + 8 (quad lanes 8 banks apart) instead of H (same bank)
+    constexpr int OBP = GRU_QSTORE ? H + 8 : H, OBS = 5 * OBP;
+    constexpr int GI_F = CH * 3 * H, OB_F = CH * OBS;              // floats per chunk buffer
     // quarter q of h starts at q * (KH + 4) floats: the four quarters a wave reads with one ds_read_b128 fall into 16
     // distinct banks (at a 128-byte pitch they would share four)
     constexpr int HP = GRU_HPAD ? KH + 4 : KH;
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __res
             const int step = c * CH + s;
             if (step >= T) break;
             const int t = dir ? T - 1 - step : step;
-            const float4 v = *(const float4*)(ob + s * 5 * H + 4 * q);
+            const float4 v = *(const float4*)(ob + s * OBS + (q / (H / 4)) * OBP + 4 * (q % (H / 4)));
             if (q < H / 4) *(float4*)(out + ((size_t)b * T + t) * 2 * H + dir * H + 4 * q) = v;
             else if (saved) *(float4*)(saved + (((size_t)b * T + t) * 2 + dir) * 4 * H + 4 * (q - H / 4)) = v;
         }
@@ -395,12 +402,15 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < KH / 4; ++k) hq[k] = GRU_NOREAD ? make_float4(gr, gz, gn, gr) : *(const float4*)(hbuf[cur] + half * HP + 4 * k);
             f32x2 pr = {0.f, 0.f}, pz = {0.f, 0.f}, pn = {0.f, 0.f};
+            f32x2 qr = {0.f, 0.f}, qz = {0.f, 0.f}, qn = {0.f, 0.f};      // GRU_ACC6: second accumulator per gate (shorter chains)
 #pragma unroll
             for (int k = 0; k < (GRU_NOFMA ? 1 : KH / 4); ++k) {
                 const f32x2 lo2 = {hq[k].x, hq[k].y}, hi2 = {hq[k].z, hq[k].w};
                 pr = pk_fma(wr[2 * k], lo2, pr); pz = pk_fma(wz[2 * k], lo2, pz); pn = pk_fma(wn[2 * k], lo2, pn);
-                pr = pk_fma(wr[2 * k + 1], hi2, pr); pz = pk_fma(wz[2 * k + 1], hi2, pz); pn = pk_fma(wn[2 * k + 1], hi2, pn);
+                if (GRU_ACC6) { qr = pk_fma(wr[2 * k + 1], hi2, qr); qz = pk_fma(wz[2 * k + 1], hi2, qz); qn = pk_fma(wn[2 * k + 1], hi2, qn); }
+                else { pr = pk_fma(wr[2 * k + 1], hi2, pr); pz = pk_fma(wz[2 * k + 1], hi2, pz); pn = pk_fma(wn[2 * k + 1], hi2, pn); }
             }
+            if (GRU_ACC6) { pr += qr; pz += qz; pn += qn; }
             float ar = pr.x + pr.y, az = pz.x + pz.y, an = pn.x + pn.y;
             ar += __shfl_xor(ar, 1); az += __shfl_xor(az, 1); an += __shfl_xor(an, 1);
             ar += __shfl_xor(ar, 2); az += __shfl_xor(az, 2); an += __shfl_xor(an, 2);
@@ -410,10 +420,19 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __res
             const float n = GRU_NOTRANS ? (gn + r * hn) * 0.01f : sed_fast_tanh(gn + r * hn);
             const float hnew = (1.0f - z) * n + z * hprev;
             hprev = hnew;
-            if (half == 0) {
+            if (GRU_QSTORE) {
+                // every lane of the quad stores one of the five results (all four hold them): two LDS stores on the chain, not five
+                float* o = och + s * OBS;
+                const float v4 = half == 0 ? hnew : half == 1 ? r : half == 2 ? z : n;
+                if (!GRU_NOOBUF) o[half * OBP + j] = v4;
+                if (half == 0) {
+                    hbuf[cur ^ 1][(j / KH) * HP + j % KH] = hnew;
+                    if (!GRU_NOOBUF) o[4 * OBP + j] = hn;
+                }
+            } else if (half == 0) {
                 hbuf[cur ^ 1][(j / KH) * HP + j % KH] = hnew;
-                float* o = och + s * 5 * H;
-                if (!GRU_NOOBUF) { o[j] = hnew; o[H + j] = r; o[2 * H + j] = z; o[3 * H + j] = n; o[4 * H + j] = hn; }
+                float* o = och + s * OBS;
+                if (!GRU_NOOBUF) { o[j] = hnew; o[OBP + j] = r; o[2 * OBP + j] = z; o[3 * OBP + j] = n; o[4 * OBP + j] = hn; }
             }
             cur ^= 1;
             if (!GRU_NOBAR) __syncthreads();
@@ -427,7 +446,7 @@ extern "C" int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1
                            float* out, float* saved, int B, int T, int H, void* stream) {
     if (H != GRU_H) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
-    const int smem = (2 * GRU_CH * 3 * GRU_H + 2 * GRU_CH * 5 * GRU_H) * 4;
+    const int smem = (2 * GRU_CH * 3 * GRU_H + 2 * GRU_CH * 5 * (GRU_QSTORE ? GRU_H + 8 : GRU_H)) * 4;
     SED_MAX_SMEM(gru_fwd_kernel, smem);
     SED_LAUNCH(gru_fwd_kernel, dim3(2 * B), dim3(GRU_THREADS), smem, (hipStream_t)stream, gi, whh0, whh1, bhh0, bhh1, out, saved, B, T);
     return sed_check_launch();
@@ -446,8 +465,14 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __res
                                                       float* __restrict__ dbi0, float* __restrict__ dbi1,
                                                       float* __restrict__ dbh0, float* __restrict__ dbh1, int B, int T) {
     constexpr int H = GRU_H, KH = H / 4, CH = GRU_CH, NT_ = GRU_THREADS;
-    constexpr int IB_F = CH * 6 * H, OB_F = CH * 7 * H;
-    __shared__ __attribute__((aligned(16))) float gbuf[2][3 * H];
+    // gbuf: three planes (da_r, da_z, dhn) of four K-quarters; the quarters start QP floats apart so that the four quarters a
+    // wave reads with one ds_read_b128 hit distinct banks (GRU_HPAD), the planes GP apart so that the quad's three stores do.
+    // obuf: seven result planes per step in the order dgi(r, z, n) | hprev | dgh(r, z, hn), OBP apart (GRU_QSTORE: the four
+    // lanes of a quad store four planes with one instruction, 8 banks apart).
+    constexpr int QP = GRU_HPAD ? KH + 4 : KH, GP = 4 * QP + (GRU_QSTORE ? 8 : 0);
+    constexpr int OBP = GRU_QSTORE ? H + 8 : H, OBS = 7 * OBP;
+    constexpr int IB_F = CH * 6 * H, OB_F = CH * OBS;
+    __shared__ __attribute__((aligned(16))) float gbuf[2][3 * GP];
     SED_DYN_SMEM(smem);
     float* ibuf = (float*)smem;                // [2][CH][6H] = r | z | n | hn | hprev | dout
     float* obuf = ibuf + 2 * IB_F;             // [2][CH][7H] = dgi(3H) | dgh(3H) | hprev(H)
@@ -496,10 +521,11 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __res
             const int step = T - 1 - rs;
             const int t = dir ? T - 1 - step : step;
             const size_t bt = (size_t)b * T + t;
-            const float4 v = *(const float4*)(ob + s * 7 * H + 4 * q);
-            if (q < 3 * H / 4) *(float4*)(dgi + (bt * 2 + dir) * 3 * H + 4 * q) = v;
-            else if (q < 6 * H / 4) *(float4*)(dgh + (bt * 2 + dir) * 3 * H + 4 * (q - 3 * H / 4)) = v;
-            else *(float4*)(hprev_out + (bt * 2 + dir) * H + 4 * (q - 6 * H / 4)) = v;
+            const int pl = q / (H / 4), w4 = 4 * (q - pl * (H / 4));
+            const float4 v = *(const float4*)(ob + s * OBS + pl * OBP + w4);
+            if (pl < 3) *(float4*)(dgi + (bt * 2 + dir) * 3 * H + pl * H + w4) = v;
+            else if (pl == 3) *(float4*)(hprev_out + (bt * 2 + dir) * H + w4) = v;
+            else *(float4*)(dgh + (bt * 2 + dir) * 3 * H + (pl - 4) * H + w4) = v;
         }
     };
     load_chunk(0);
@@ -525,21 +551,27 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __res
             const float da_r = da_n * hn * r * (1.0f - r);
             const float dhn = da_n * r;
             sb_r += da_r; sb_z += da_z; sb_n += da_n; sb_hn += dhn;
-            if (half == 0) {
-                gbuf[cur][k] = da_r; gbuf[cur][H + k] = da_z; gbuf[cur][2 * H + k] = dhn;
-                float* o = och + s * 7 * H;
-                o[k] = da_r; o[H + k] = da_z; o[2 * H + k] = da_n;
-                o[3 * H + k] = da_r; o[4 * H + k] = da_z; o[5 * H + k] = dhn;
-                o[6 * H + k] = hp;
+            const int gk = (k / KH) * QP + k % KH;
+            float* o = och + s * OBS;
+            if (GRU_QSTORE) {
+                // all four lanes of the quad hold the same values: three store instructions on the chain instead of ten
+                const float g3 = half == 0 ? da_r : half == 1 ? da_z : dhn;
+                if (half < 3) gbuf[cur][half * GP + gk] = g3;
+                o[half * OBP + k] = half == 0 ? da_r : half == 1 ? da_z : half == 2 ? da_n : hp;
+                if (half < 3) o[(4 + half) * OBP + k] = g3;
+            } else if (half == 0) {
+                gbuf[cur][gk] = da_r; gbuf[cur][GP + gk] = da_z; gbuf[cur][2 * GP + gk] = dhn;
+                o[k] = da_r; o[OBP + k] = da_z; o[2 * OBP + k] = da_n; o[3 * OBP + k] = hp;
+                o[4 * OBP + k] = da_r; o[5 * OBP + k] = da_z; o[6 * OBP + k] = dhn;
             }
             __syncthreads();
-            const float* gv = gbuf[cur] + half * KH;
+            const float* gv = gbuf[cur] + half * QP;
             float4 ga[KH / 4], gc[KH / 4], gd[KH / 4];
 #pragma unroll
             for (int q4 = 0; q4 < KH / 4; ++q4) {
                 ga[q4] = *(const float4*)(gv + 4 * q4);
-                gc[q4] = *(const float4*)(gv + H + 4 * q4);
-                gd[q4] = *(const float4*)(gv + 2 * H + 4 * q4);
+                gc[q4] = *(const float4*)(gv + GP + 4 * q4);
+                gd[q4] = *(const float4*)(gv + 2 * GP + 4 * q4);
             }
             f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f};     // three independent packed chains
 #pragma unroll
@@ -574,7 +606,7 @@ extern "C" int sed_gru_bwd(const float* dout, const float* out, const float* sav
     if ((dbi0 == nullptr) != (dbi1 == nullptr) || (dbh0 == nullptr) != (dbh1 == nullptr)) return SED_ERR_ARG;
     if (dbi0 || dbh0) sed_zero4((hipStream_t)stream, dbi0, dbi0 ? 3 * H : 0, dbi1, dbi1 ? 3 * H : 0, dbh0, dbh0 ? 3 * H : 0, dbh1, dbh1 ? 3 * H : 0);
     if (B <= 0 || T <= 0) return SED_OK;
-    const int smem = (2 * GRU_CH * 6 * GRU_H + 2 * GRU_CH * 7 * GRU_H) * 4;
+    const int smem = (2 * GRU_CH * 6 * GRU_H + 2 * GRU_CH * 7 * (GRU_QSTORE ? GRU_H + 8 : GRU_H)) * 4;
     SED_MAX_SMEM(gru_bwd_kernel, smem);
     SED_LAUNCH(gru_bwd_kernel, dim3(2 * B), dim3(GRU_THREADS), smem, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh, hprev,
                dbi0, dbi1, dbh0, dbh1, B, T);
