@@ -8,12 +8,18 @@
 // The Python side hands the reference's (B, n_mels, T) shape out as a transposed view.
 //
 // One 256-thread workgroup per frame (grid-stride over B*T frames).  LDS: two 8 KB ping-pong
-// buffers + 8 KB twiddles + 4.1 KB magnitudes.  HBM: 4*N bytes in (each sample is re-read 8x by
+// buffers (XOR-swizzled indices) + 8 KB per-pass twiddle tables + 4.1 KB magnitudes.  HBM: 4*N bytes in (each sample is re-read 8x by
 // overlapping frames, served by L2) + 4*T*n_mels out per clip = 960,512 B/clip at the 2023 config.
 #include "sed_common.h"
 
 #define MEL_NFFT 2048
 #define MEL_M 1024   // packed complex length
+
+// LDS index swizzle of the two FFT buffers.  The Stockham passes read consecutive elements but WRITE with strides 4 and 16
+// (Ns = 1, 4): as plain indices those ds_write_b64 hit every bank pair four times (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+// = 0.42 for the kernel).  XOR-ing bits 2..5 into bits 0..3 keeps the reads at 1.14x and makes every write conflict-free
+// under the gfx950 lane groups (modelled over all five passes: 992 -> 640 LDS cycles per frame for the data buffers).
+__device__ __forceinline__ int mel_sw(int i) { return i ^ ((i >> 2) & 15); }
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -27,11 +33,17 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
                                                   const int* __restrict__ fb_len, const float* __restrict__ fb_w, int fb_stride) {
     __shared__ float2 buf0[MEL_M];
     __shared__ float2 buf1[MEL_M];
-    __shared__ float2 stw[MEL_M];
+    // per-pass twiddle tables [pass 1..4][j = 1..3][k < Ns]: w^(j k 256/Ns), contiguous in k.  (Indexing one 1024-entry table
+    // with the stride 256/Ns put the 4 / 16 / 64 distinct twiddles of passes 1-3 on one, two and eight bank pairs.)
+    __shared__ float2 stw[3 * (4 + 16 + 64 + 256)];
     __shared__ float mag[MEL_M + 8];
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) stw[tid + 256 * q] = tw1024[tid + 256 * q];
+    for (int i = tid; i < 3 * (4 + 16 + 64 + 256); i += 256) {
+        int pass = 1, base = 0;
+        while (i >= base + 3 * (1 << (2 * pass))) { base += 3 * (1 << (2 * pass)); ++pass; }
+        const int Ns = 1 << (2 * pass), j = (i - base) / Ns, k = (i - base) - j * Ns;
+        stw[i] = tw1024[((j + 1) * (256 / Ns) * k) & (MEL_M - 1)];
+    }
     __syncthreads();
 
     // per-thread constants of every frame: its 8 window taps and 4 real-FFT twiddles
@@ -66,7 +78,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
         const int b = frame / T, t = frame - b * T;
         // ---- reflect-padded, windowed samples packed as z[n] = x[2n] + i x[2n+1] ----
 #pragma unroll
-        for (int q = 0; q < 4; ++q) buf0[tid + 256 * q] = make_float2(smp[q].x * win[q].x, smp[q].y * win[q].y);
+        for (int q = 0; q < 4; ++q) buf0[mel_sw(tid + 256 * q)] = make_float2(smp[q].x * win[q].x, smp[q].y * win[q].y);
         if (frame + (int)gridDim.x < n_frames) load_frame(frame + gridDim.x);
         __syncthreads();
         // ---- 5 Stockham radix-4 passes, Ns = 1,4,16,64,256; result lands in buf1 ----
@@ -76,12 +88,12 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
         for (int pass = 0; pass < 5; ++pass) {
             const int Ns = 1 << (2 * pass);
             const int k = tid & (Ns - 1);
-            const int tstep = (256 / Ns) * k;           // twiddle index of exp(-2 pi i k / (4 Ns))
-            float2 v0 = src[tid], v1 = src[tid + 256], v2 = src[tid + 512], v3 = src[tid + 768];
-            if (pass > 0) {
-                v1 = cmul(v1, stw[tstep]);
-                v2 = cmul(v2, stw[2 * tstep]);
-                v3 = cmul(v3, stw[3 * tstep]);
+            float2 v0 = src[mel_sw(tid)], v1 = src[mel_sw(tid + 256)], v2 = src[mel_sw(tid + 512)], v3 = src[mel_sw(tid + 768)];
+            if (pass > 0) {                              // twiddles exp(-2 pi i j k / (4 Ns)), j = 1, 2, 3
+                const float2* tw = stw + (Ns - 4) + k;   // 3 * (4 + 16 + ... + Ns / 4) = Ns - 4
+                v1 = cmul(v1, tw[0]);
+                v2 = cmul(v2, tw[Ns]);
+                v3 = cmul(v3, tw[2 * Ns]);
             }
             // DFT-4 (forward, e^{-i pi/2} = -i)
             const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
@@ -89,10 +101,10 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
             const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
             const float2 a3 = make_float2(v1.x - v3.x, v1.y - v3.y);   // (v1 - v3)
             const int d = ((tid - k) << 2) + k;
-            dst[d] = make_float2(a0.x + a2.x, a0.y + a2.y);
-            dst[d + Ns] = make_float2(a1.x + a3.y, a1.y - a3.x);      // a1 - i a3
-            dst[d + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
-            dst[d + 3 * Ns] = make_float2(a1.x - a3.y, a1.y + a3.x);  // a1 + i a3
+            dst[mel_sw(d)] = make_float2(a0.x + a2.x, a0.y + a2.y);
+            dst[mel_sw(d + Ns)] = make_float2(a1.x + a3.y, a1.y - a3.x);      // a1 - i a3
+            dst[mel_sw(d + 2 * Ns)] = make_float2(a0.x - a2.x, a0.y - a2.y);
+            dst[mel_sw(d + 3 * Ns)] = make_float2(a1.x - a3.y, a1.y + a3.x);  // a1 + i a3
             __syncthreads();
             float2* tmp = src; src = dst; dst = tmp;
         }
@@ -103,11 +115,11 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
             const int k = tid + 256 * q;
             float m;
             if (k == 0) {
-                const float2 z0 = Z[0];
+                const float2 z0 = Z[mel_sw(0)];
                 m = fabsf(z0.x + z0.y);
                 mag[MEL_M] = fabsf(z0.x - z0.y);
             } else {
-                const float2 zk = Z[k], zm = Z[MEL_M - k];
+                const float2 zk = Z[mel_sw(k)], zm = Z[mel_sw(MEL_M - k)];
                 const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
                 const float dr = zk.x - zm.x, di = zk.y + zm.y;            // zk - conj(zm)
                 const float2 xo = make_float2(0.5f * di, -0.5f * dr);       // -i/2 * (zk - conj(zm))
