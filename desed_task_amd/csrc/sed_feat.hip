@@ -148,3 +148,56 @@ extern "C" int sed_specaug(const float* x, float* y, const int* bounds, int B, i
     SED_LAUNCH(specaug_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, y, bounds, T, Fq);
     return sed_check_launch();
 }
+
+// ---- SpecAugment mask draws (CRNN.apply_specaugment, desed_task/nnet/CRNN.py:207-219 = torchaudio mask_along_axis[_iid]) ----
+// u_f / u_t: (2, n) uniform draws per axis (row 0 -> mask length, row 1 -> start) or null when that axis is off; n = B
+// (per-clip masks) or 1 (one mask for the batch).  bounds (B, 4) int32 = [f0, f1, t0, t1).  Same float32 arithmetic as the
+// reference: value = u0 * mask_param, min_value = u1 * (axis_len - value), start = trunc(min_value), end = start + trunc(value).
+// One launch instead of ~25 single-element torch kernels per model call.
+__global__ __launch_bounds__(256) void specaug_bounds_kernel(const float* __restrict__ u_f, const float* __restrict__ u_t,
+                                                             int* __restrict__ bounds, int B, int n, int f_param, int n_freq,
+                                                             int t_param, int n_time) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const int i = n == 1 ? 0 : b;
+    int f0 = 0, f1 = 0, t0 = 0, t1 = 0;
+    if (u_f != nullptr) {
+        const float value = u_f[i] * (float)f_param;
+        const float min_value = u_f[n + i] * ((float)n_freq - value);
+        f0 = (int)min_value;
+        f1 = f0 + (int)value;
+    }
+    if (u_t != nullptr) {
+        const float value = u_t[i] * (float)t_param;
+        const float min_value = u_t[n + i] * ((float)n_time - value);
+        t0 = (int)min_value;
+        t1 = t0 + (int)value;
+    }
+    bounds[4 * b] = f0; bounds[4 * b + 1] = f1; bounds[4 * b + 2] = t0; bounds[4 * b + 3] = t1;
+}
+extern "C" int sed_specaug_bounds(const float* u_f, const float* u_t, int* bounds, int B, int n, int f_param, int n_freq,
+                                  int t_param, int n_time, void* stream) {
+    if (B <= 0) return SED_OK;
+    if (n != 1 && n != B) return SED_ERR_ARG;
+    SED_LAUNCH(specaug_bounds_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, u_f, u_t, bounds, B, n, f_param,
+               n_freq, t_param, n_time);
+    return sed_check_launch();
+}
+
+// ---- weak labels of the weakly annotated clips: (sum_t labels[b, c, :] > 0) as float (sed_trainer.py:292) ----
+// labels (n, NC, T) -> out (n, NC); one wave per (clip, class) row (a thread per row would walk 156 dependent loads)
+__global__ __launch_bounds__(256) void weak_labels_kernel(const float* __restrict__ labels, float* __restrict__ out, int rows, int T) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float* p = labels + (size_t)r * T;
+    float acc = 0.f;
+    for (int t = lane; t < T; t += 64) acc += p[t];
+    acc = wave_sum(acc);
+    if (lane == 0) out[r] = acc > 0.f ? 1.0f : 0.0f;
+}
+extern "C" int sed_weak_labels(const float* labels, float* out, int n, int NC, int T, void* stream) {
+    if (n <= 0 || NC <= 0) return SED_OK;
+    if (T <= 0) return SED_ERR_ARG;
+    SED_LAUNCH(weak_labels_kernel, dim3((n * NC + 3) / 4), dim3(256), 0, (hipStream_t)stream, labels, out, n * NC, T);
+    return sed_check_launch();
+}

@@ -723,6 +723,14 @@ __global__ __launch_bounds__(512, 4) void glu_wide_fwd_b_kernel(const float* __r
 }
 
 // persistent-grid cap; SED_GLU_GRID_CAP (tests) forces several tiles per workgroup on small problems
+// zero the gradient rows of the frames that floor-mode time pooling drops: dz (B, T, F*C), rows [t0, T) of every clip
+__global__ __launch_bounds__(256) void glu_zero_tail_kernel(float* __restrict__ dz, long long n4, int T, int t0, int tail4,
+                                                            long long clip4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const long long b = i / tail4, r = i - b * tail4;
+        ((float4*)dz)[b * clip4 + (long long)t0 * (clip4 / T) + r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
 static inline int glu_grid_cap(int dflt) {
     const char* e = getenv("SED_GLU_GRID_CAP");
     return e ? atoi(e) : dflt;
@@ -1545,7 +1553,15 @@ extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamm
         if (C == 128) return launch_glu_wide_bwd<128, false>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
         if (C == 64) return launch_glu_wide_bwd<64, false>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
     }
-    if (T % PT != 0) (void)hipMemsetAsync(dz, 0, (size_t)B * T * F * C * 4, s);
+    if (T % PT != 0) {
+        // frames the floor-mode pooling drops get no gradient: zero just those rows (zeroing all of dz was a 123 MB memset
+        // per step for block 1)
+        const int tail = T % PT, rowf4 = F * C / 4;
+        const long long n4 = (long long)B * tail * rowf4;
+        int grid = (int)((n4 + 255) / 256);
+        if (grid > 2048) grid = 2048;
+        SED_LAUNCH(glu_zero_tail_kernel, dim3(grid), dim3(256), 0, s, dz, n4, T, T - tail, tail * rowf4, (long long)T * rowf4);
+    }
     if ((C == 16 && PT == 2 && PF == 2 && F % 8 == 0) || (C == 32 && PT == 2 && PF == 2 && F % 16 == 0)) {
         // LDS-free MFMA kernels: one row of pooling windows per wave iteration, one partial per workgroup + fixed-order reduce
         const int nrows = B * (T / 2);

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
                                                    float* __restrict__ g_weak, int B, int T, int NC, int n_strong, int n_weak,
                                                    float weight, const float* __restrict__ weight_dev, int selfsup_bce) {
     if (weight_dev) weight = *weight_dev;       // consistency weight in device memory (hipGraph replays)
-    // one workgroup per clip; the six scalars (zeroed by the launcher) collect pre-scaled per-clip sums
+    // one workgroup per clip; the eight scalars (zeroed by the launcher) collect pre-scaled per-clip sums
     __shared__ float red[4][6];
     const int tid = threadIdx.x, b = blockIdx.x;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -299,10 +299,17 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
         if ((tid & 63) == 0) red[tid >> 6][k] = v;
     }
     __syncthreads();
-    if (tid < 6) {
-        const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-        const float sc = tid == 0 || tid == 2 ? inv_bs : (tid == 1 || tid == 3 ? inv_bw : (tid == 4 ? inv_all : inv_allw));
-        atomicAdd(scalars + tid, v * sc);
+    if (tid < 8) {
+        // slots 0..5: the six means; 6: weight * (self_strong + self_weak) (logged as tot_self_loss); 7: the total loss
+        float part[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float sc = k == 0 || k == 2 ? inv_bs : (k == 1 || k == 3 ? inv_bw : (k == 4 ? inv_all : inv_allw));
+            part[k] = ((red[0][k] + red[1][k]) + (red[2][k] + red[3][k])) * sc;
+        }
+        const float self_tot = weight * (part[4] + part[5]);
+        const float v = tid < 6 ? part[tid] : (tid == 6 ? self_tot : part[0] + part[1] + self_tot);
+        atomicAdd(scalars + tid, v);
     }
 }
 extern "C" int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
@@ -310,7 +317,7 @@ extern "C" int sed_mt_loss(const float* strong_s, const float* weak_s, const flo
                            int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, int selfsup_bce,
                            void* stream) {
     if (B <= 0 || T <= 0 || NC <= 0 || NC > 256 || n_strong + n_weak > B) return SED_ERR_ARG;
-    sed_zero4((hipStream_t)stream, scalars, 6, nullptr, 0, nullptr, 0, nullptr, 0);
+    sed_zero4((hipStream_t)stream, scalars, 8, nullptr, 0, nullptr, 0, nullptr, 0);
     SED_LAUNCH(loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, strong_s, weak_s, strong_t, weak_t, labels, labels_weak,
                scalars, g_strong, g_weak, B, T, NC, n_strong, n_weak, weight, weight_dev, selfsup_bce);
     return sed_check_launch();

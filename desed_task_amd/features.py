@@ -163,20 +163,34 @@ def mixup_(data, perm, c, mode=0, c_dev=None, perm_dev=None):
 
 
 def specaug_bounds(batch, n_freq, n_time, f_l, f_p, t_l, t_p, device, iid_masks=True, generator=None):
-    """Draws of torchaudio's mask_along_axis(_iid) for CRNN.apply_specaugment -> (B,4) int32 [f0,f1,t0,t1)."""
-    out = torch.zeros(batch, 4, dtype=torch.int32, device=device)
+    """Draws of torchaudio's mask_along_axis(_iid) for CRNN.apply_specaugment -> (B,4) int32 [f0,f1,t0,t1).
+    Two torch.rand calls (frequency axis first, as in the reference) feed ONE kernel that does the reference's float32
+    arithmetic; the tensor-op version of this function cost ~25 single-element launches per model call."""
     n = batch if iid_masks else 1
-    for col, (cap, p, axis_len) in enumerate(((f_l, f_p, n_freq), (t_l, t_p, n_time))):
+    params, us = [], []
+    for cap, p, axis_len in ((f_l, f_p, n_freq), (t_l, t_p, n_time)):
         mask_param = min(cap, int(axis_len * p))
-        if mask_param < 1:
-            continue
-        u = torch.rand(2, n, device=device, generator=generator)
-        value = u[0] * mask_param
-        min_value = u[1] * (axis_len - value)
-        start = min_value.long()
-        end = start + value.long()
-        out[:, 2 * col] = start.to(torch.int32)
-        out[:, 2 * col + 1] = end.to(torch.int32)
+        params.append(mask_param)
+        us.append(torch.rand(2, n, device=device, generator=generator) if mask_param >= 1 else None)
+    out = torch.empty(batch, 4, dtype=torch.int32, device=device)
+    if batch == 0:
+        return out
+    _lib.check_tensor(out, "specaug bounds")
+    _lib.get().call("sed_specaug_bounds", us[0].data_ptr() if us[0] is not None else None,
+                    us[1].data_ptr() if us[1] is not None else None, out.data_ptr(), batch, n, params[0], n_freq, params[1], n_time,
+                    _lib.stream_ptr(out))
+    return out
+
+
+def weak_labels(labels):
+    """(labels (n, NC, T).sum(-1) > 0).float() in one launch (sed_trainer.py:292)."""
+    labels = labels.contiguous().float()
+    n, NC, T = labels.shape
+    out = torch.empty(n, NC, dtype=torch.float32, device=labels.device)
+    if n == 0:
+        return out
+    _lib.check_tensor(labels, "labels")
+    _lib.get().call("sed_weak_labels", labels.data_ptr(), out.data_ptr(), n, NC, T, _lib.stream_ptr(labels))
     return out
 
 

@@ -206,6 +206,13 @@ class GraphedStepDriver:
     def _device(self):
         return next(self.task.sed_student.parameters()).device
 
+    def input_buffers(self):
+        """The static device tensors the captured graph reads (one per tensor of the batch tuple, None elsewhere), available
+        after the capture step.  A data pipeline that writes its batches straight into them (e.g. as the target of its
+        host-to-device copies) and passes them to run_step() saves the per-step device-to-device staging copy; tensors the step
+        modifies in place (the labels under mixup) must of course be rewritten every step."""
+        return self.static
+
     def _step_body(self, batch):
         """One step in Lightning's order; under world_size > 1 it stops after backward."""
         d = self.eager
@@ -274,7 +281,8 @@ class GraphedStepDriver:
                 if st is not None:
                     if not torch.is_tensor(t) or t.shape != st.shape:
                         raise ValueError("batch tensor shapes changed after the step was captured")
-                    st.copy_(t, non_blocking=True)
+                    if t.data_ptr() != st.data_ptr():       # a loader may fill the static buffers directly (input_buffers())
+                        st.copy_(t, non_blocking=True)
             self.dyn.run_host_ops()
         self.dyn.upload()
         self.graph.replay()

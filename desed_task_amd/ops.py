@@ -376,8 +376,9 @@ class HeadFn(torch.autograd.Function):
 
 class MeanTeacherLossFn(torch.autograd.Function):
     """Fused losses of SEDTask4.training_step (sed_trainer.py:309-342).
-    Returns a (7,) tensor: [bce_strong, bce_weak, bce_strong_teacher, bce_weak_teacher, mse_strong, mse_weak, total]
-    with total = bce_strong + bce_weak + weight * (mse_strong + mse_weak).  Only `total` is differentiable.
+    Returns (scalars, total): scalars (8,) = [bce_strong, bce_weak, bce_strong_teacher, bce_weak_teacher, mse_strong, mse_weak,
+    weight * (mse_strong + mse_weak), total] (not differentiable) and total = bce_strong + bce_weak + weight * (mse_strong +
+    mse_weak) as a 0-d differentiable tensor -- all computed by the kernel (no scalar tensor arithmetic on the host side).
     selfsup_bce: slots 4 / 5 hold BCELoss(student, teacher) instead (`training.self_sup_loss: bce`)."""
 
     @staticmethod
@@ -389,19 +390,17 @@ class MeanTeacherLossFn(torch.autograd.Function):
         _lib.check_tensor(strong_s, "strong preds")
         B, T, NC = strong_s.shape
         f32 = dict(device=strong_s.device, dtype=torch.float32)
-        scalars = torch.empty(6, **f32)
+        scalars = torch.empty(8, **f32)
         g_strong = torch.empty(B, T, NC, **f32)
         g_weak = torch.empty(B, NC, **f32)
         lib.call("sed_mt_loss", strong_s.data_ptr(), weak_s.data_ptr(), strong_t.data_ptr(), weak_t.data_ptr(), labels.data_ptr(),
                  labels_weak.data_ptr(), scalars.data_ptr(), g_strong.data_ptr(), g_weak.data_ptr(), B, T, NC, int(n_strong),
                  int(n_weak), float(weight), getattr(weight, "dev", None), int(bool(selfsup_bce)), _lib.stream_ptr(strong_s))
-        w = weight.tensor if isinstance(weight, _graph.DynFloat) else float(weight)
-        total = scalars[0] + scalars[1] + w * (scalars[4] + scalars[5])
         ctx.save_for_backward(g_strong, g_weak)
-        return torch.cat([scalars, total.reshape(1)])
+        ctx.mark_non_differentiable(scalars)
+        return scalars, scalars[7].clone()
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, _g_scalars, g_total):
         g_strong, g_weak = ctx.saved_tensors
-        gt = g[6]
-        return g_strong * gt, g_weak * gt, None, None, None, None, None, None, None, None
+        return g_strong * g_total, g_weak * g_total, None, None, None, None, None, None, None, None

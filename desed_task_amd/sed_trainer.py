@@ -181,7 +181,7 @@ class SEDTask4(_Base):
             raise ValueError("batch smaller than the configured strong+weak sizes")
         weak_sl = slice(indx_synth, indx_synth + indx_weak)
         strong_sl = slice(0, indx_synth)
-        labels_weak = (torch.sum(labels[weak_sl], -1) > 0).float()
+        labels_weak = features.weak_labels(labels[weak_sl])             # (sum over frames > 0).float(), one launch
 
         mixup_type = self.hparams["training"].get("mixup")
         dyn = _graph.active()
@@ -226,10 +226,9 @@ class SEDTask4(_Base):
             weight = dyn.scalar(dyn.F_LOSS_W, lambda: const_max * sched._get_scaling_factor())
         else:
             weight = const_max * sched._get_scaling_factor()
-        out = MeanTeacherLossFn.apply(strong_s.transpose(1, 2), weak_s, strong_t.transpose(1, 2), weak_t, labels, labels_weak,
-                                      indx_synth, indx_weak, weight, self.selfsup_bce)
-        loss_strong, loss_weak, loss_strong_t, loss_weak_t, strong_self, weak_self, tot_loss = out.unbind(0)
-        tot_self_loss = (strong_self + weak_self).detach() * (weight.tensor if dyn is not None else weight)
+        scalars, tot_loss = MeanTeacherLossFn.apply(strong_s.transpose(1, 2), weak_s, strong_t.transpose(1, 2), weak_t, labels,
+                                                    labels_weak, indx_synth, indx_weak, weight, self.selfsup_bce)
+        loss_strong, loss_weak, loss_strong_t, loss_weak_t, strong_self, weak_self, tot_self_loss, _ = scalars.unbind(0)
 
         self.log("train/student/loss_strong", loss_strong.detach())
         self.log("train/student/loss_weak", loss_weak.detach())

@@ -54,6 +54,15 @@ int sed_mixup(float* data, float* tmp, const int* perm, float c, float one_minus
  * bounds (B,4) int32 = [f0,f1,t0,t1). */
 int sed_specaug(const float* x, float* y, const int* bounds, int B, int T, int Fq, void* stream);
 
+/* The mask draws of CRNN.apply_specaugment (desed_task/nnet/CRNN.py:207-219, torchaudio mask_along_axis[_iid]) from uniform
+ * numbers: u_f / u_t (2, n) per axis (row 0 -> length, row 1 -> start; null = axis off), n = B (per-clip masks) or 1;
+ * bounds (B,4) int32 = [f0, f1, t0, t1).  float32 arithmetic identical to the reference's tensor ops. */
+int sed_specaug_bounds(const float* u_f, const float* u_t, int* bounds, int B, int n, int f_param, int n_freq, int t_param,
+                       int n_time, void* stream);
+
+/* labels_weak = (sum over frames of labels (n,NC,T) > 0) as float (n,NC) (sed_trainer.py:292). */
+int sed_weak_labels(const float* labels, float* out, int n, int NC, int T, void* stream);
+
 /* ---- K6: CNN block (desed_task/nnet/CNN.py:66-98), channels-last (B,T,F,C) ---------------------------------- */
 
 /* nn.Conv2d weight (COUT,CIN,3,3) -> packed Wf[9][CIN][COUT] (forward) and Wd[9][COUT][CIN] (data gradient:
@@ -187,7 +196,8 @@ int sed_head_bwd(const float* x, const float* W1, const float* W2, const float* 
                  float dscale, const unsigned* seed_dev, void* stream);
 
 /* Mean-teacher losses of SEDTask4.training_step (recipes/dcase2023_task4_baseline/local/sed_trainer.py:309-342):
- * scalars[6] = BCE strong/weak (student), BCE strong/weak (teacher), MSE strong/weak; g_strong (B,T,NC), g_weak (B,NC)
+ * scalars[8] = BCE strong/weak (student), BCE strong/weak (teacher), MSE strong/weak, weight*(MSE_s + MSE_w), total;
+ * g_strong (B,T,NC), g_weak (B,NC)
  * = d(BCE_s + BCE_w + weight*(MSE_s + MSE_w)) / d(student outputs).  labels (B,NC,T); labels_weak (n_weak,NC).
  * selfsup_bce != 0: the two consistency terms are BCELoss(student, teacher) instead of MSELoss (`self_sup_loss: bce`, :99-100). */
 int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,

@@ -94,6 +94,29 @@ def case_mixup_specaug(dev):
     ref = O.specaug_apply(xin, (bounds[:, 0].long(), bounds[:, 1].long()), (bounds[:, 2].long(), bounds[:, 3].long()))
     got = Fh.specaug_apply(to(dev, xin), to(dev, bounds))
     assert torch.equal(got.cpu(), ref)
+    # the mask draws: one kernel on two torch.rand calls == the reference's tensor arithmetic on the same draws, bit for bit
+    device = torch.device(dev)
+    for (B, n_freq, n_time, f_l, f_p, t_l, t_p, iid) in ((48, 128, 626, 10, 0.2, 5, 0.2, True), (5, 128, 626, 10, 0.2, 5, 0.2, False),
+                                                          (7, 64, 40, 10, 0.2, 5, 0.0, True), (3, 16, 9, 0, 0.2, 3, 0.5, True)):
+        torch.manual_seed(123)
+        got_b = Fh.specaug_bounds(B, n_freq, n_time, f_l, f_p, t_l, t_p, device, iid_masks=iid).cpu()
+        torch.manual_seed(123)
+        want = torch.zeros(B, 4, dtype=torch.int32)
+        n = B if iid else 1
+        for col, (cap, p, axis_len) in enumerate(((f_l, f_p, n_freq), (t_l, t_p, n_time))):
+            mask_param = min(cap, int(axis_len * p))
+            if mask_param < 1:
+                continue
+            u = torch.rand(2, n, device=device).cpu()
+            value = u[0] * mask_param                                  # torchaudio mask_along_axis_iid arithmetic
+            start = (u[1] * (axis_len - value)).long()
+            want[:, 2 * col] = start.to(torch.int32)
+            want[:, 2 * col + 1] = (start + value.long()).to(torch.int32)
+        assert torch.equal(got_b, want), (B, n_freq, n_time, iid)
+    # weak labels of the weakly annotated clips
+    lab = (O.lcg_fill((5, 10, 17), 3, 0.5, 0.5) < 0.1).float()
+    lab[1] = 0
+    assert torch.equal(Fh.weak_labels(to(dev, lab)).cpu(), (lab.sum(-1) > 0).float())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1058,12 +1081,14 @@ def case_mt_loss(dev):
         tot = ref[0] + ref[1] + weight * (ref[4] + ref[5])
         tot.backward()
         sd, wd = to(dev, strong_s.detach().clone()).requires_grad_(True), to(dev, weak_s.detach().clone()).requires_grad_(True)
-        out = ops.MeanTeacherLossFn.apply(sd, wd, to(dev, strong_t), to(dev, weak_t), to(dev, labels), to(dev, labels_weak), ns, nw,
-                                          weight, mode == "bce")
-        out[6].backward()
-        got = out.detach().cpu()
+        scalars, total = ops.MeanTeacherLossFn.apply(sd, wd, to(dev, strong_t), to(dev, weak_t), to(dev, labels), to(dev, labels_weak),
+                                                     ns, nw, weight, mode == "bce")
+        assert total.dim() == 0 and total.requires_grad and not scalars.requires_grad
+        total.backward()
+        got = scalars.detach().cpu()
         for k in range(6):
             assert abs(float(got[k]) - float(ref[k])) < 2e-6 * max(1.0, abs(float(ref[k]))), (mode, k)
-        assert abs(float(got[6]) - float(tot)) < 5e-6 * max(1.0, abs(float(tot)))
+        assert abs(float(got[6]) - weight * float(ref[4] + ref[5])) < 5e-6 * max(1.0, abs(float(tot)))
+        assert abs(float(got[7]) - float(tot)) < 5e-6 * max(1.0, abs(float(tot))) and float(total) == float(got[7])
         assert float((sd.grad.cpu() - ss.grad).abs().max()) < 1e-6 * max(1.0, float(ss.grad.abs().max())), mode
         assert float((wd.grad.cpu() - ws.grad).abs().max()) < 1e-6 * max(1.0, float(ws.grad.abs().max())), mode
