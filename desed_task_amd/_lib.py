@@ -43,6 +43,8 @@ class _Lib:
     def __init__(self, path, is_emulator=False):
         self.path = path
         self.is_emulator = is_emulator
+        import torch  # noqa: F401  -- first: libsed_hip.so must resolve libamdhip64 to the runtime torch already loaded;
+        # dlopen-ing it before torch brings in a second HIP runtime and every launch on a torch stream then fails
         self._dll = ctypes.CDLL(path)
         self.protos = parse_header()
         for name, argtypes in self.protos.items():
