@@ -10,10 +10,12 @@ with dropout + SpecAugment -> BCE/MSE losses) + EMA + backward + [gradient all-r
 on one batch of 48 synthetic 10 s / 16 kHz clips per GPU (12 strong / 12 weak / 24 unlabelled), already resident in
 HBM.  Weak scaling: every rank runs the reference's single-GPU step on its own clips; gradients are averaged.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the kernel that dominates the step (the 3x3 convolution as
-implicit GEMM on the f32 MFMA): algorithmic FLOPs per launch / the mean launch time measured with HIP events inside
-the timed region.  `cpu_baseline` times the CPU oracle (oracle/sed_oracle.py, the unfused torch restatement of the
-reference step) on this host's cores, rank 0, N=1 only.
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel that dominates the step -- the launch shape with the largest
+total time per step over ALL C-ABI entry points, every launch bracketed by HIP events on its stream over 5 eager steps right
+after the timed region -- as algorithmic work per launch / mean launch time against the roof that bounds it;
+`roofline_families` is the same accounting per kernel family (mel, block0, conv, glu, wgrad, gru, gemm, head+loss, optim).
+`cpu_baseline` times the CPU oracle (oracle/sed_oracle.py, the unfused torch restatement of the reference step) on this
+host's cores at the same batch of 48 clips, rank 0, N=1 only.
 """
 import argparse
 import json
@@ -66,10 +68,11 @@ def synthetic_batch(device, seed):
 
 
 class KernelTimer:
-    """HIP-event timing of selected C-ABI entry points on torch's current stream (the stream they launch on)."""
+    """HIP-event timing of C-ABI entry points on the stream they launch on (torch's current stream at the call: every
+    ops.py / features.py wrapper passes exactly that stream to the library).  names = None: every entry point."""
 
-    def __init__(self, names):
-        self.names = set(names)
+    def __init__(self, names=None):
+        self.names = None if names is None else set(names)
         self.records = {}
 
     def wrap(self, lib):
@@ -77,14 +80,15 @@ class KernelTimer:
         timer = self
 
         def timed_call(name, *args):
-            if name not in timer.names:
+            if timer.names is not None and name not in timer.names:
                 return orig(name, *args)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             orig(name, *args)
             e1.record()
-            key = (name,) + tuple(a for a in args if isinstance(a, int) and 0 < a < 100000 and not isinstance(a, bool))[:6]
+            nd = ENTRIES[name][2] if name in ENTRIES else 0        # leading shape arguments (pointers are > 2^31, flags come later)
+            key = (name,) + tuple(a for a in args if isinstance(a, int) and 0 < a < 2 ** 31 and not isinstance(a, bool))[:nd]
             timer.records.setdefault(key, []).append((e0, e1))
         lib.call = timed_call
         self._undo = lambda: setattr(lib, "call", orig)
@@ -100,38 +104,142 @@ class KernelTimer:
         return out
 
 
-def conv_flops(key):
-    """Algorithmic FLOPs of one sed_conv3x3 launch: 2 * B*T*F * 9*CIN * COUT (key = (name, B, T, F, CIN, COUT))."""
-    _, B, T, F, CIN, COUT = key[:6]
-    return 2.0 * B * T * F * 9 * CIN * COUT
+PEAK_HBM_GBS = 8000.0             # same guide: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
+
+# entry point -> (kernel that does the work, family, number of leading shape arguments, algorithmic work of ONE call).
+# key = (name, the leading shape arguments in call order); work in FLOP for mfma / valu, in bytes for hbm.
+# "valu": the recurrence runs on the f32 vector pipes, whose peak equals the exact-f32 MFMA peak (157.3 TFLOP/s).
+def _conv_fl(k): return 2.0 * k[1] * k[2] * k[3] * 9 * k[4] * k[5]            # (B,T,F,CIN,COUT)
+def _glu_shape(k): return k[1] * k[2] * k[3], k[4], k[5] * k[6]               # (B,T,F,C,PT,PF) -> pixels, C, pool
+def _gemm_fl(k): return 2.0 * k[1] * k[2] * k[3]                              # (M,N,K)
 
 
-def pmc_traffic(cin, cout, F, split):
-    """HBM bytes per launch of the matching conv3x3 kernel from the committed rocprofv3 --pmc passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_q_pmc_traffic.json" if split else "r01_pmc_traffic.json")
-    try:
-        kernels = json.load(open(path))["kernels"]
-    except Exception:  # noqa: BLE001
-        return None
-    tf = min(F, 32)
-    for name, rec in kernels.items():
-        if name.startswith("%s<%d, %d, %d, true" % ("conv3x3_bf16_kernel" if split else "conv3x3_kernel", cin, cout, tf)):
-            return rec["hbm_bytes"]
+def _glu_fwd_work(k):
+    npx, C, pool = _glu_shape(k)
+    return ("hbm", 4.0 * npx * C * (1 + 1.0 / pool)) if C <= 32 else ("mfma", 2.0 * npx * C * C)
+
+
+def _glu_bwd_work(k):
+    npx, C, pool = _glu_shape(k)
+    return ("hbm", 4.0 * npx * C * (2 + 1.0 / pool)) if C <= 32 else ("mfma", 6.0 * npx * C * C)
+
+
+ENTRIES = {
+    "sed_mel_fwd": ("mel_kernel", "mel", 6, lambda k: ("hbm", 4.0 * k[1] * (k[2] + k[3] * k[6]))),      # (B,N,T,n_fft,hop,n_mels)
+    "sed_logscale_fwd": ("minmax_partial/apply_kernel", "mel", 2, lambda k: ("hbm", 8.0 * k[1] * k[2])),
+    "sed_conv0_fwd": ("conv0_kernel", "block0", 4, lambda k: ("hbm", 4.0 * k[1] * k[2] * k[3] * (1 + k[4]))),
+    "sed_conv0_wgrad": ("conv0_wgrad_kernel", "block0", 4, lambda k: ("hbm", 4.0 * k[1] * k[2] * k[3] * (1 + 2 * k[4]))),
+    "sed_conv3x3": ("conv3x3_kernel", "conv", 5, lambda k: ("mfma", _conv_fl(k))),
+    "sed_conv3x3_bf16x3": ("conv3x3_bf16_kernel", "conv", 5, lambda k: ("mfma", _conv_fl(k))),
+    "sed_conv_wgrad": ("conv_wgrad_kernel", "wgrad", 5, lambda k: ("mfma", _conv_fl(k))),
+    "sed_conv_wgrad_bf16x3": ("conv_wgrad_bf16_kernel", "wgrad", 5, lambda k: ("mfma", _conv_fl(k))),
+    "sed_glu_fwd": ("glu*_fwd_kernel", "glu", 6, _glu_fwd_work),
+    "sed_glu_bwd": ("glu*_bwd_kernel", "glu", 6, _glu_bwd_work),
+    "sed_bn_bwd_apply": ("bn_bwd_apply_kernel", "glu", 2, lambda k: ("hbm", 12.0 * k[1] * k[2])),              # (npix, C)
+    "sed_gru_fwd": ("gru_fwd_kernel", "gru", 3, lambda k: ("valu", 2.0 * k[1] * k[2] * 2 * 3 * k[3] * k[3])),          # (B,T,H)
+    "sed_gru_bwd": ("gru_bwd_kernel", "gru", 3, lambda k: ("valu", 2.0 * k[1] * k[2] * 2 * 3 * k[3] * k[3])),
+    "sed_gemm": ("gemm_vec_kernel", "gemm", 3, lambda k: ("mfma", _gemm_fl(k))),
+    "sed_gemm_bf16x3": ("gemm_bf16x3_kernel", "gemm", 3, lambda k: ("mfma", _gemm_fl(k))),
+    "sed_gemm_pair": ("gemm_vec_kernel", "gemm", 3, lambda k: ("mfma", 2 * _gemm_fl(k))),
+    "sed_gemm_pair_bf16x3": ("gemm_bf16x3_kernel", "gemm", 3, lambda k: ("mfma", 2 * _gemm_fl(k))),
+    "sed_gemm_kcat": ("gemm_vec_kernel", "gemm", 3, lambda k: ("mfma", _gemm_fl(k))),
+    "sed_gemm_kcat_bf16x3": ("gemm_bf16x3_kernel", "gemm", 3, lambda k: ("mfma", _gemm_fl(k))),
+    "sed_head_fwd": ("head_fwd_kernel", "head+loss", 4, lambda k: ("hbm", 4.0 * k[1] * k[2] * (k[3] + 2 * k[4]))),   # (B,T,D,NC)
+    "sed_head_bwd": ("head_bwd_kernel", "head+loss", 4, lambda k: ("hbm", 4.0 * k[1] * k[2] * (2 * k[3] + 4 * k[4]))),
+    "sed_mt_loss": ("loss_kernel", "head+loss", 3, lambda k: ("hbm", 4.0 * k[1] * k[2] * k[3] * 4)),
+    "sed_adam_step": ("adam_kernel", "optim", 1, lambda k: ("hbm", 28.0 * k[1])),
+    "sed_ema_update": ("ema_kernel", "optim", 1, lambda k: ("hbm", 12.0 * k[1])),
+}
+
+
+def entry_peak(name, bound, precision):
+    if bound == "hbm":
+        return PEAK_HBM_GBS, "GB/s"
+    if bound == "valu":
+        return PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+    split = name.endswith("bf16x3") or (name in ("sed_glu_fwd", "sed_glu_bwd") and precision == "bf16x3")
+    return (PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS), "TFLOP/s"
+
+
+def roofline_tables(summ, n_steps, step_ms, precision):
+    """Per-launch-shape rows and per-family totals from the event timings of `n_steps` eager steps."""
+    rows, fam = [], {}
+    for key, (n, mean_ms, tot_ms) in summ.items():
+        name = key[0]
+        ent = ENTRIES.get(name)
+        per_step_us = tot_ms * 1e3 / n_steps
+        if ent is None:
+            f = fam.setdefault("other", {"us_per_step": 0.0})
+            f["us_per_step"] += per_step_us
+            continue
+        kernel, family, _nd, work_fn = ent
+        try:
+            bound, work = work_fn(key)
+        except IndexError:
+            bound, work = "hbm", 0.0
+        peak, unit = entry_peak(name, bound, precision)
+        achieved = work / (mean_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
+        rows.append({"entry": name, "kernel": kernel, "family": family, "shape": list(key[1:]), "bound": bound,
+                     "launches_per_step": round(n / n_steps, 2), "avg_us": round(mean_ms * 1e3, 2),
+                     "us_per_step": round(per_step_us, 1), "work": work, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                     "frac": round(achieved / peak, 4)})
+        f = fam.setdefault(family, {"us_per_step": 0.0, "work": {}})
+        f["us_per_step"] += per_step_us
+        f["work"].setdefault((bound, peak, unit), [0.0, 0.0])
+        f["work"][(bound, peak, unit)][0] += work * n / n_steps
+        f["work"][(bound, peak, unit)][1] += per_step_us
+    families = {}
+    for name, f in fam.items():
+        e = {"us_per_step": round(f["us_per_step"], 1), "share_of_step": round(f["us_per_step"] / (step_ms * 1e3), 4)}
+        for (bound, peak, unit), (work, us) in f.get("work", {}).items():
+            ach = work / (us * 1e-6) / (1e9 if bound == "hbm" else 1e12) if us > 0 else 0.0
+            e[bound] = {"achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "us_per_step": round(us, 1)}
+        families[name] = e
+    rows.sort(key=lambda r: -r["us_per_step"])
+    return rows, families
+
+
+def kernel_name(row):
+    """rocprof kernel name (prefix) of a roofline row, for the PMC lookup."""
+    e, k = row["entry"], row["shape"]
+    if e in ("sed_conv3x3", "sed_conv3x3_bf16x3", "sed_conv_wgrad", "sed_conv_wgrad_bf16x3") and len(k) >= 5:
+        return "%s<%d, %d" % (row["kernel"], k[3], k[4])
+    return row["kernel"]
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` (name prefix) from the newest committed rocprofv3 --pmc summary in profiles/, or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            kernels = json.load(open(path))["kernels"]
+        except Exception:  # noqa: BLE001
+            continue
+        hits = [rec["hbm_bytes"] for name, rec in kernels.items() if name and name.startswith(kernel.split("*")[0])]
+        if hits:
+            return max(hits)
     return None
 
 
-def cpu_baseline():
-    """One full oracle training step (training_step + EMA + backward + Adam) on a 12-clip batch of 10 s clips."""
+def cpu_baseline(budget_s=200.0):
+    """SURVEY 8(d) / BASELINE.md 3: the oracle's full training step (training_step + EMA + backward + Adam) at B = 48
+    (12/12/24 clips of 10 s, dropout + SpecAugment + mixup on), fp32 torch CPU, 3 warm-up + 5 timed steps, median.
+    Thread count: the three warm-up steps run at os.cpu_count(), 64 and 32 threads; the timed steps use the fastest of the
+    three (torch's CPU convolutions stop scaling, and on a loaded 256-core host can collapse, far below the core count) -- all
+    three timings are reported.  Dropout keep-masks are drawn outside the timed region (the reference draws them inside: this
+    baseline is, if anything, faster than the reference).  A time budget bounds the leg: if the steps are slower than
+    budget/8, fewer timed steps are run and the sample says so."""
     from oracle import sed_oracle as O
-    threads = min(os.cpu_count() or 1, 32)      # torch CPU convs stop scaling (and can collapse) far below 256 threads
-    torch.set_num_threads(threads)
-    bs = (2, 2, 4)
+    ncpu = os.cpu_count() or 1
+    bs = BATCH
     B = sum(bs)
     sd = O.make_state_dict(seed=7)
     g = torch.Generator().manual_seed(0)
     audio = 0.1 * torch.randn(B, N_SAMPLES, generator=g)
     labels = O.synth_labels(bs, 10, N_FRAMES_OUT, seed=5)
     tr = O.OracleTrainer(sd, batch_sizes=bs)
+    shapes = [(B, 16, 626, 128), (B, 32, 313, 64), (B, 64, 156, 32), (B, 128, 156, 16), (B, 128, 156, 8),
+              (B, 128, 156, 4), (B, 128, 156, 2), (B, 156, 256)]
 
     def draws():
         mix = dict(c_weak=float(np.random.beta(0.2, 0.2)), perm_weak=torch.randperm(bs[1]),
@@ -141,27 +249,36 @@ def cpu_baseline():
             fb = O.specaug_bounds(torch.rand(B), torch.rand(B), 10, 128)
             tb = O.specaug_bounds(torch.rand(B), torch.rand(B), 5, 626)
             augs.append(dict(f=fb, t=tb))
-            shapes = [(B, 16, 626, 128), (B, 32, 313, 64), (B, 64, 156, 32), (B, 128, 156, 16), (B, 128, 156, 8),
-                      (B, 128, 156, 4), (B, 128, 156, 2), (B, 156, 256)]
             drops.append([(torch.rand(s) >= 0.5).float() for s in shapes])
         return mix, augs, drops
 
-    # tiny warm-up (thread pool, allocator), not timed
-    warm = O.OracleTrainer(sd, batch_sizes=(1, 1, 2))
-    tot, _ = warm.training_step(audio[:4, :16000], O.synth_labels((1, 1, 2), 10, 15, seed=1))
-    warm.optimizer_step(tot)
-    t0 = time.perf_counter()
-    mix, augs, drops = draws()
-    tot, _ = tr.training_step(audio, labels, mix=mix, aug_s=augs[0], aug_t=augs[1], drop_s=drops[0], drop_t=drops[1])
-    tr.optimizer_step(tot)
-    dt = time.perf_counter() - t0
-    return {"value": B / dt, "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": "1 full oracle training step (mel+mixup+student/teacher fwd+losses+EMA+bwd+Adam), batch %d (%d/%d/%d) of "
-                      "10 s clips, dropout+SpecAugment on, fp32 torch CPU, %d threads of %d host cores, %.2f s wall"
-                      % (B, bs[0], bs[1], bs[2], threads, os.cpu_count() or 1, dt)}
+    def one_step():
+        mix, augs, drops = draws()
+        t0 = time.perf_counter()
+        tot, _ = tr.training_step(audio, labels, mix=mix, aug_s=augs[0], aug_t=augs[1], drop_s=drops[0], drop_t=drops[1])
+        tr.optimizer_step(tot)
+        return time.perf_counter() - t0
+
+    t_start = time.perf_counter()
+    probe = {}
+    for threads in sorted({ncpu, min(ncpu, 64), min(ncpu, 32)}, reverse=True):          # the 3 warm-up steps
+        torch.set_num_threads(threads)
+        probe[threads] = one_step()
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
+    times = []
+    while len(times) < 5 and (len(times) < 1 or time.perf_counter() - t_start + probe[best] < budget_s):
+        times.append(one_step())
+    med = float(np.median(times))
+    return {"value": round(B / med, 3), "unit": "clips/s", "cores": best, "kind": "port",
+            "sample": "oracle (unfused fp32 torch-CPU restatement of the reference step: mel+mixup+student/teacher fwd+losses+EMA+bwd+"
+                      "Adam), batch %d (%d/%d/%d) of 10 s clips, dropout+SpecAugment+mixup on; %d warm-up steps at %s threads took %s s; "
+                      "%d timed steps at %d threads of %d host cores: median %.2f s (min %.2f, max %.2f)"
+                      % (B, bs[0], bs[1], bs[2], len(probe), "/".join(str(t) for t in probe),
+                         "/".join("%.1f" % probe[t] for t in probe), len(times), best, ncpu, med, min(times), max(times))}
 
 
-def cpu_baseline_bounded(timeout_s=150):
+def cpu_baseline_bounded(timeout_s=330):
     """Run cpu_baseline() in a child process with a hard wall-clock bound (a pathological host must not stall the bench)."""
     import subprocess
     code = "import json, bench; print('CPU_BASELINE ' + json.dumps(bench.cpu_baseline()))"
@@ -173,7 +290,7 @@ def cpu_baseline_bounded(timeout_s=150):
         return {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: " + r.stderr[-200:]}
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "clips/s", "cores": os.cpu_count(), "kind": "port",
-                "sample": "oracle step on 8 clips did not finish within %d s on this host" % timeout_s}
+                "sample": "oracle steps at batch 48 did not finish within %d s on this host" % timeout_s}
 
 
 def main():
@@ -263,9 +380,6 @@ def main():
         inputs["audio"] = bufs[0]
         if emb is not None:
             inputs["emb"] = bufs[3]
-    timer = KernelTimer({"sed_conv3x3", "sed_conv3x3_bf16x3"})
-    if not use_graph:
-        timer.wrap(_lib.get())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -278,13 +392,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if use_graph:
-        # per-launch HIP events cannot be placed inside a graph replay: time the roofline kernel over eager steps of the
-        # same workload right after the timed region (same process, same tensors, same stream)
-        timer.wrap(_lib.get())
-        for i in range(5):
-            driver.eager.run_step((audio, labels.clone(), None, emb), i)     # (eager: works on the tensors it is given)
-        torch.cuda.synchronize()
+    # Per-launch HIP events cannot be placed inside a graph replay, and bracketing all ~330 launches of a step with events
+    # would perturb the timed region: the kernels are timed over EAGER_STEPS eager steps of the same workload right after the
+    # timed region (same process, same tensors, every launch bracketed by events on the stream it is launched on).
+    EAGER_STEPS = 5
+    timer = KernelTimer(None)
+    eager = driver.eager if use_graph else driver
+    timer.wrap(_lib.get())
+    for i in range(EAGER_STEPS):
+        eager.run_step((audio, labels.clone(), None, emb), i)
+    torch.cuda.synchronize()
     timer.unwrap()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -294,36 +411,39 @@ def main():
     if rank != 0:
         return
 
-    summ = timer.summary()
-    dom_key, dom = None, None
-    for key, (n, mean_ms, tot_ms) in summ.items():
-        if dom is None or tot_ms > dom[2]:
-            dom_key, dom = key, (n, mean_ms, tot_ms)
+    step_ms = dt / args.steps * 1e3
+    precision = task.sed_student.cnn.conv_precision
+    rows, families = roofline_tables(timer.summary(), EAGER_STEPS, step_ms, precision)
     roofline = None
-    if dom_key is not None:
-        fl = conv_flops(dom_key)
-        achieved = fl / (dom[1] * 1e-3) / 1e12
-        split = dom_key[0] == "sed_conv3x3_bf16x3"
-        peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        roofline = {"bound": "mfma",
-                    "kernel": "%s<CIN=%d,COUT=%d> (B,T,F)=(%d,%d,%d), %s" %
-                              ("conv3x3_bf16_kernel" if split else "conv3x3_kernel", dom_key[4], dom_key[5], dom_key[1], dom_key[2],
-                               dom_key[3], "split-bf16: 3 x v_mfma_f32_32x32x16_bf16 per product, fp32-level accuracy" if split
-                               else "v_mfma_f32_32x32x2_f32"),
-                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "mfma_issue_frac": round((3.0 if split else 1.0) * achieved / peak, 4),
-                    "traffic": pmc_traffic(dom_key[4], dom_key[5], dom_key[3], split),
-                    "traffic_note": "HBM bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes on this "
-                                    "kernel (profiles/r01_q_pmc_fetch_write.md, r01_q_pmc_traffic.json); algorithmic in+out+weights = %d "
-                                    "bytes" % (4 * dom_key[1] * dom_key[2] * dom_key[3] * (dom_key[4] + dom_key[5]) + 36 * dom_key[4] * dom_key[5]),
-                    "note": "achieved = algorithmic FLOPs (2*B*T*F*9*CIN*COUT) / mean launch time (HIP events; %s); for the "
-                            "split-bf16 kernel the MFMA pipe issues 3x that (mfma_issue_frac); f32-equivalent peak would be %.1f"
-                            % ("5 eager steps right after the timed region, whose steps are hipGraph replays" if use_graph
-                               else "timed region", PEAK_F32_MFMA_TFLOPS),
-                    "launches_timed": dom[0], "avg_launch_ms": round(dom[1], 4),
-                    "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
-                    "conv_share_of_step": round(sum(v[2] for v in summ.values()) / (5 if use_graph else args.steps)
-                                                    / (dt * 1e3 / args.steps), 3)}
+    if rows:
+        # the dominant kernel = the launch shape with the largest total time per step in the whole-step event trace
+        dom = rows[0]
+        kname = kernel_name(dom)
+        issue = 3.0 if (dom["bound"] == "mfma" and dom["peak"] == PEAK_BF16_MFMA_TFLOPS) else 1.0
+        roofline = {"bound": "mfma" if dom["bound"] == "valu" else dom["bound"], "kernel": kname, "entry": dom["entry"], "shape": dom["shape"],
+                    "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
+                    "traffic": pmc_traffic(kname),
+                    "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_us"],
+                    "share_of_step": round(dom["us_per_step"] / (step_ms * 1e3), 4),
+                    "algorithmic_work_per_launch": dom["work"],
+                    "note": "dominant = largest total time per step over ALL entry points (HIP events around every launch, %d eager steps "
+                            "right after the timed region); achieved = algorithmic %s per launch / mean launch time.%s%s"
+                            % (EAGER_STEPS, "bytes" if dom["bound"] == "hbm" else "FLOPs",
+                               " Split-bf16 kernel: the MFMA pipe issues 3 bf16 MFMAs per algorithmic product (mfma_issue_frac)."
+                               if issue == 3.0 else "",
+                               " The GRU recurrence runs on the f32 vector pipes (packed FMA), whose peak equals the exact-f32 MFMA peak "
+                               "of 157.3 TFLOP/s; it is bound by the latency of 156 dependent steps, not by a throughput roof."
+                               if dom["bound"] == "valu" else ""),
+                    "traffic_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
+                                    "(profiles/*_pmc_traffic.json, gfx950 FETCH_SIZE half-count correction), or null"}
+        if issue == 3.0:
+            roofline["mfma_issue_frac"] = round(3.0 * dom["frac"], 4)
+        # kept from round 1: the heaviest 3x3 convolution launch as its own entry
+        convs = [r for r in rows if r["family"] == "conv"]
+        if convs:
+            c = max(convs, key=lambda r: r["work"])
+            roofline["conv_entry"] = {k: c[k] for k in ("entry", "shape", "avg_us", "achieved", "peak", "unit", "frac")}
+            roofline["conv_entry"]["traffic"] = pmc_traffic(kernel_name(c))
     clips = sum(BATCH) * world * args.steps
     out = {
         "metric": "10s-clips/sec CRNN mean-teacher train @batch48",
@@ -340,6 +460,11 @@ def main():
                    "launch": "hipGraph replay of the captured step (3 eager + 1 capture step before the timed region)" if use_graph
                              else (graph_note or "eager launches"), "untimed_steps": n_untimed},
         "roofline": roofline,
+        # every kernel family of the step: time per step (events, eager launches), share of the replayed step, and achieved
+        # / peak of its algorithmic work against the roof that bounds it
+        "roofline_families": families,
+        "roofline_top_launches": [{k: r[k] for k in ("entry", "shape", "bound", "launches_per_step", "avg_us", "us_per_step", "achieved",
+                                                       "peak", "unit", "frac")} for r in rows[:12]],
         # SURVEY 8(d) step-level yardsticks (algorithmic work per clip x measured clips/s, per GPU)
         "step_roofline": {
             "mfma_tflops": round(6.464e9 * clips / dt / world / 1e12, 2),

@@ -27,6 +27,7 @@ class ParamArena:
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        self.successor = None           # set by the owner when it replaces this arena (e.g. after a device move)
         self._index = {}
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
@@ -104,15 +105,95 @@ def ema_update_(teacher_params, student_params, alpha, teacher_arena=None, stude
 
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(lr, betas, eps) semantics (no weight decay / amsgrad) on the HIP kernel.
-    With an arena whose gradients are flat the step is ONE launch; otherwise one launch per tensor."""
+    With an arena whose gradients are flat the step is ONE launch; otherwise one launch per tensor.
+
+    State: the moments live in two flat buffers shaped like the arena; `self.state[p]` holds, per parameter, views into
+    them under torch.optim.Adam's own keys (`step`, `exp_avg`, `exp_avg_sq`), so `state_dict()` / `load_state_dict()` carry the
+    full optimizer state in Adam's layout (what Lightning writes into a checkpoint's `optimizer_states` and reads back on
+    resume, train_sed.py:293) and the per-tensor path continues from the same moments.  `arena` may be the ParamArena or
+    the model that owns it (`model.arena` is then looked up at every step, so a `.to()` that rebuilt the arena is followed)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, arena=None, grad_scale=1.0):
         defaults = dict(lr=lr, betas=betas, eps=eps)
         super().__init__(params, defaults)
-        self.arena = arena
+        self._arena_src = arena
         self.grad_scale = grad_scale
         self._flat_state = None
 
+    # ---- arena lookup ---------------------------------------------------------------------------------
+    @property
+    def arena(self):
+        src = self._arena_src
+        if src is None or isinstance(src, ParamArena):
+            while isinstance(src, ParamArena) and src.successor is not None:     # the owner rebuilt it (device move)
+                src = self._arena_src = src.successor
+            return src
+        return src.arena
+
+    @arena.setter
+    def arena(self, value):
+        self._arena_src = value
+
+    def _group_params(self):
+        return [p for g in self.param_groups for p in g["params"]]
+
+    def _flat_ok(self, arena):
+        gp = self._group_params()
+        return (arena is not None and len(self.param_groups) == 1 and len(gp) == len(arena.params)
+                and all(a is b for a, b in zip(gp, arena.params)) and arena.is_intact())
+
+    def _flat(self, arena):
+        """The flat moment buffers for `arena` (created on first use; moved when the arena moved; seeded from per-tensor state
+        when that is where the moments currently live, e.g. right after load_state_dict)."""
+        st = self._flat_state
+        if st is None:
+            st = self._flat_state = dict(step=0, m=torch.zeros_like(arena.flat), v=torch.zeros_like(arena.flat))
+            for p, o in zip(arena.params, arena.offsets):
+                ps = self.state.get(p)
+                if ps and "exp_avg" in ps:
+                    st["m"][o:o + p.numel()].view(p.shape).copy_(ps["exp_avg"])
+                    st["v"][o:o + p.numel()].view(p.shape).copy_(ps["exp_avg_sq"])
+                    st["step"] = int(ps["step"])
+            self._bind_views(arena)
+        elif st["m"].device != arena.flat.device or st["m"].numel() != arena.flat.numel():
+            if st["m"].numel() != arena.flat.numel():
+                raise RuntimeError("FusedAdam: the parameter arena changed size")
+            st["m"], st["v"] = st["m"].to(arena.flat.device), st["v"].to(arena.flat.device)
+            self._bind_views(arena)
+        return st
+
+    def _bind_views(self, arena):
+        st = self._flat_state
+        for p, o in zip(arena.params, arena.offsets):
+            self.state[p] = {"step": st["step"], "exp_avg": st["m"][o:o + p.numel()].view(p.shape),
+                             "exp_avg_sq": st["v"][o:o + p.numel()].view(p.shape)}
+
+    # ---- (de)serialisation in torch.optim.Adam's layout -------------------------------------------------------
+    def state_dict(self):
+        st = self._flat_state
+        if st is not None:
+            for ps in self.state.values():
+                ps["step"] = torch.tensor(float(st["step"]))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)         # fills self.state[p] with fresh tensors on each parameter's device
+        steps = [int(ps["step"]) for ps in self.state.values() if "step" in ps]
+        arena = self.arena
+        if self._flat_state is not None and self._flat_ok(arena):
+            # keep the flat buffers (a captured hipGraph holds their addresses): copy the loaded moments in place
+            st = self._flat_state
+            for p, o in zip(arena.params, arena.offsets):
+                ps = self.state.get(p)
+                if ps and "exp_avg" in ps:
+                    st["m"][o:o + p.numel()].view(p.shape).copy_(ps["exp_avg"])
+                    st["v"][o:o + p.numel()].view(p.shape).copy_(ps["exp_avg_sq"])
+            st["step"] = steps[0] if steps else 0
+            self._bind_views(arena)
+        else:
+            self._flat_state = None                 # rebuilt from self.state at the next flat step
+
+    # ---- the step -------------------------------------------------------------------------------------------
     def _launch(self, p, g, m, v, n, group, step, hyper_dev=None):
         b1, b2 = group["betas"]
         bc1 = 1.0 - b1 ** step
@@ -128,12 +209,8 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         arena = self.arena
-        group_params = [p for g in self.param_groups for p in g["params"]]
-        if (arena is not None and len(self.param_groups) == 1 and len(group_params) == len(arena.params)
-                and all(a is b for a, b in zip(group_params, arena.params)) and arena.is_intact() and arena.grads_are_flat()):
-            if self._flat_state is None:
-                self._flat_state = dict(step=0, m=torch.zeros_like(arena.flat), v=torch.zeros_like(arena.flat))
-            st = self._flat_state
+        if self._flat_ok(arena) and arena.grads_are_flat():
+            st = self._flat(arena)
             dyn = _graph.active()
             if dyn is not None:
                 # hipGraph replay: step counter and the two step-dependent factors are host logic re-run every step
@@ -152,16 +229,23 @@ class FusedAdam(torch.optim.Optimizer):
             st["step"] += 1
             self._launch(arena.flat, arena.flat_grad, st["m"], st["v"], arena.numel, self.param_groups[0], st["step"])
             return loss
+        # per-tensor path: continues from whatever moments exist (the flat buffers' views, a loaded state dict, or zeros)
+        flat_step = self._flat_state["step"] if self._flat_state is not None else None
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 st = self.state[p]
-                if not st:
-                    st["step"] = 0 if self._flat_state is None else self._flat_state["step"]
-                    st["m"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["v"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] += 1
+                if "exp_avg" not in st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                step = int(flat_step if flat_step is not None else st["step"]) + 1
+                st["step"] = step
+                if st["exp_avg"].device != p.device:
+                    st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].to(p.device), st["exp_avg_sq"].to(p.device)
                 g = p.grad.contiguous()
-                self._launch(p.data, g, st["m"], st["v"], p.numel(), group, st["step"])
+                self._launch(p.data, g, st["exp_avg"], st["exp_avg_sq"], p.numel(), group, step)
+        if flat_step is not None:
+            self._flat_state["step"] = flat_step + 1
         return loss

@@ -99,10 +99,10 @@ extern "C" int sed_take_log(const float* x, float* y, long long n, void* stream)
 __global__ __launch_bounds__(256) void mixup_kernel(float* __restrict__ data, const float* __restrict__ src,
                                                     const int* __restrict__ perm, float c, float omc, int L, int mode,
                                                     const float* __restrict__ c_dev) {
-    if (c_dev) {                                // coefficient in device memory (hipGraph replays); 1 = "no mixup this step"
+    if (c_dev) {                                // coefficient in device memory (hipGraph replays)
         c = c_dev[0]; omc = c_dev[1];           // {c, 1-c} exactly as the host would have passed them by value
-        if (c == 1.0f) return;
-    }
+        if (c > 1.5f) return;                   // sentinel 2 = "no mixup this step" (a Beta(0.2,0.2) draw can round to exactly 1.0f,
+    }                                           // and hard labels are still clamp(t + t[perm]) then)
     const int i = blockIdx.y;
     const int j = perm[i];
     const float* a = src + (size_t)i * L;

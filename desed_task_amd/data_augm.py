@@ -25,7 +25,7 @@ def mixup_inplace_(data, target, alpha=0.2, beta=0.2, mixup_label_type="soft", d
     """Same draws, but mixes `data` and `target` (batch-major slices) in place: no gather/scatter copies.
 
     dyn (graph.DynArgs): the launches are issued unconditionally and read c / perm from device memory; `gate()` tells,
-    each step, whether mixup applies (if not: c = 1, which turns the kernels into no-ops)."""
+    each step, whether mixup applies (if not: the sentinel c = 2 turns the kernels into no-ops)."""
     if dyn is not None:
         n = data.size(0)
 

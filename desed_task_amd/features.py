@@ -76,6 +76,21 @@ class MelSpectrogram(torch.nn.Module):
         self.register_buffer("fb_start", start, persistent=False)
         self.register_buffer("fb_len", length, persistent=False)
         self.register_buffer("fb_w", w.contiguous(), persistent=False)
+        self.register_buffer("fb_dense", fb.contiguous(), persistent=False)     # (n_freqs, n_mels): checkpoint compatibility only
+
+    # Checkpoint compatibility with the reference's SEDTask4 state dict: torchaudio's MelSpectrogram owns two persistent buffers,
+    # `spectrogram.window` and `mel_scale.fb`, which therefore sit in every Lightning checkpoint of the recipe under
+    # `mel_spec.*` (train_sed.py:302 loads them strictly).  They are emitted on save and accepted (and ignored: both are functions
+    # of the constructor arguments) on load.
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        destination[prefix + "spectrogram.window"] = self.window if keep_vars else self.window.detach()
+        destination[prefix + "mel_scale.fb"] = self.fb_dense if keep_vars else self.fb_dense.detach()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for k in ("spectrogram.window", "mel_scale.fb"):
+            state_dict.pop(prefix + k, None)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def _tables_to(self, device):
         if self.window.device != device:

@@ -128,7 +128,7 @@ class DynArgs:
         return v
 
     def mix_site(self, n, draw):
-        """One mixup group of n clips: `draw()` -> (c, perm) or None (= no mixup this step: c = 1, identity)."""
+        """One mixup group of n clips: `draw()` -> (c, perm) or None (= no mixup this step: sentinel c = 2, identity)."""
         g = self._sites["mix"]
         if g >= self.N_PERMS or n > self.PERM_LEN:
             raise RuntimeError("DynArgs: mixup group does not fit the permutation slots")
@@ -140,7 +140,7 @@ class DynArgs:
         def fill():
             r = draw()
             if r is None:
-                hf[cslot] = 1.0
+                hf[cslot] = 2.0                 # sentinel outside [0, 1]: the mixup launches of this replay return at once
                 hf[cslot + 1] = 0.0
                 host[pslot:pslot + n] = ident
             else:
@@ -187,8 +187,10 @@ class GraphedStepDriver:
     stream cannot take part in a capture (hipStreamEndCapture faults).  The caller's current stream is joined on entry
     and exit, so callers need no extra synchronisation.
 
-    world_size > 1: the graph ends after backward; the RCCL all-reduce of the flat gradient arena and the Adam launch
-    stay eager (one collective + one kernel), so no collective is ever captured."""
+    world_size > 1: no collective is ever captured.  The step is TWO graphs -- [forwards, losses, EMA, backward of the heads and
+    the BiGRU] and [backward of the CNN] -- with the asynchronous all-reduce of gradient bucket A issued between them (it runs on
+    RCCL's stream under the second graph), then bucket B's all-reduce and the Adam launch, eager.  With SED_DDP_OVERLAP=0: one
+    graph up to the end of backward, one blocking all-reduce over the arena, Adam."""
 
     def __init__(self, task, world_size=1, warmup=3, ema_side_stream=True):
         from .launcher import StepDriver
@@ -198,6 +200,7 @@ class GraphedStepDriver:
         self.warmup = warmup
         self.n = 0
         self.graph = None
+        self.graph_cnn = None       # world_size > 1, overlapped exchange: the CNN half of backward is its own graph
         self.dyn = None
         self.static = None
         self.loss = None
@@ -214,9 +217,11 @@ class GraphedStepDriver:
         return self.static
 
     def _step_body(self, batch):
-        """One step in Lightning's order; under world_size > 1 it stops after backward."""
+        """One step in Lightning's order.  world_size 1: the whole step.  world_size > 1: up to and including loss.backward() --
+        which, with the overlapped gradient exchange, ends at the cut behind the student's CNN (launcher.StepDriver)."""
         d = self.eager
         task = self.task
+        d.arm_overlap()
         loss = task.training_step(batch, 0)
         if d.side is not None:
             main = torch.cuda.current_stream()
@@ -235,9 +240,15 @@ class GraphedStepDriver:
         return loss
 
     def _finish_multi(self):
-        """Eager tail under data parallelism: gradient all-reduce + Adam + scheduler (by-value arguments)."""
+        """Tail of a data-parallel step around the second graph: [bucket A all-reduce, async] -> replay of the CNN backward ->
+        bucket B all-reduce -> Adam + scheduler (eager, by-value arguments).  No collective is ever captured."""
         d = self.eager
-        d.allreduce_grads()
+        if self.graph_cnn is not None:
+            d.launch_bucket_a()
+            self.graph_cnn.replay()
+            d.finish_buckets()
+        else:
+            d.allreduce_grads()
         d.opt.step()
         self.task.lr_scheduler_step(d.sched, 0, None)
 
@@ -274,6 +285,13 @@ class GraphedStepDriver:
                 # thread_local: the RCCL watchdog thread of an initialised process group polls events while we capture
                 with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                     self.loss = self._step_body(tuple(st if st is not None else t for st, t in zip(self.static, batch)))
+                student = self.task.sed_student
+                if self.world > 1 and getattr(student, "_cnn_boundary", None) is not None:
+                    # the cut left the CNN half of backward undone: it becomes a second graph (same memory pool), replayed
+                    # after bucket A has been handed to RCCL
+                    self.graph_cnn = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph_cnn, pool=self.graph.pool(), stream=self.stream, capture_error_mode="thread_local"):
+                        student.backward_cnn()
         else:
             if len(batch) != len(self.static):
                 raise ValueError("batch arity changed after the step was captured")

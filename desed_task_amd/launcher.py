@@ -6,8 +6,8 @@ recipes/dcase2023_task4_baseline/train_sed.py:269-276).
     -> scheduler.step
 with two MI355X-side differences: the EMA kernel runs on a side HIP stream concurrently with backward (it only
 reads the student parameters that backward also only reads; Adam waits for it), and under data parallelism the
-flat gradient arena is averaged with ONE RCCL all-reduce over xGMI (1,112,420 floats; the 1/world factor is
-folded into the Adam kernel).  BN statistics and mixup stay rank-local, like the single-GPU reference.
+flat gradient arena is summed over the ranks in two buckets (heads + BiGRU launched under the CNN backward, then the
+CNN) with RCCL all-reduces over xGMI (1,112,420 floats in total; the 1/world factor is folded into the Adam kernel).  BN statistics and mixup stay rank-local, like the single-GPU reference.
 
 State that diverges across ranks: the student's and the teacher's BatchNorm running statistics (each rank
 normalises its own clips; momentum 0.99 makes them ~ the last batch).  Policy: `average_bn_buffers(task)` -- ONE all-reduce of
@@ -41,7 +41,20 @@ def init_distributed(backend=None):
 
 
 class StepDriver:
-    def __init__(self, task, world_size=1, ema_side_stream=True):
+    """One mean-teacher step in Lightning 1.9's order, optionally data-parallel.
+
+    Gradient exchange (world_size > 1), as BASELINE.json's north_star states it: the flat gradient arena is exchanged in TWO
+    buckets that follow the order in which backward produces them --
+      bucket A = everything behind the CNN in parameters() order (BiGRU, the two dense heads, cat_tf): complete as soon as the
+                 recurrent stage's backward has run.  The student's autograd graph is cut at the CNN output, loss.backward()
+                 therefore returns right there, the all-reduce of A is handed to RCCL as an asynchronous collective (its own
+                 stream) and runs UNDER the CNN backward, which is enqueued next;
+      bucket B = the CNN parameters, reduced after backward.
+    Adam waits for both (and for the EMA side stream).  The sum / world_size average is folded into the Adam kernel.
+    `overlap_allreduce=False` gives the single blocking all-reduce over the whole arena (same result, bit for bit: a sum over
+    ranks per element either way)."""
+
+    def __init__(self, task, world_size=1, ema_side_stream=True, overlap_allreduce=None, broadcast_init=True):
         self.task = task
         self.world = world_size
         self.opt = task.opt
@@ -51,29 +64,134 @@ class StepDriver:
         self.side = torch.cuda.Stream(device=dev) if (ema_side_stream and dev.type == "cuda") else None
         if hasattr(self.opt, "grad_scale"):
             self.opt.grad_scale = 1.0 / world_size
+        if overlap_allreduce is None:
+            overlap_allreduce = os.environ.get("SED_DDP_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap_allreduce) and world_size > 1 and self.arena is not None
+        self.bucket_log = []            # [(tag, first float, number of floats)] of the collectives of the last step (tests)
+        self._work_a = None
+        if world_size > 1 and broadcast_init and dist.is_initialized():
+            self.broadcast_state()
+
+    # ---- start-up: every rank continues from rank 0's weights and BatchNorm buffers --------------------------------
+    def broadcast_state(self):
+        """Ranks must not depend on having been seeded alike: parameters (student and teacher) and BN buffers come from rank 0."""
+        for model in (self.task.sed_student, self.task.sed_teacher):
+            arena = getattr(model, "arena", None)
+            if arena is not None:
+                dist.broadcast(arena.flat, src=0)
+            else:
+                for p in model.parameters():
+                    dist.broadcast(p.data, src=0)
+        bufs = bn_buffers(self.task)
+        if bufs:
+            flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+            dist.broadcast(flat, src=0)
+            off = 0
+            with torch.no_grad():
+                for b_ in bufs:
+                    b_.copy_(flat[off:off + b_.numel()].view_as(b_))
+                    off += b_.numel()
+
+    # ---- gradient buckets -------------------------------------------------------------------------------------
+    def bucket_bounds(self):
+        """(split, numel): bucket B = arena floats [0, split) (the CNN, first in parameters() order), bucket A = [split, numel)."""
+        arena = self.task.sed_student.arena
+        cnn = getattr(self.task.sed_student, "cnn", None)
+        n_cnn = len(list(cnn.parameters())) if cnn is not None else 0
+        split = arena.offsets[n_cnn] if n_cnn < len(arena.offsets) else arena.numel
+        return split, arena.numel
+
+    def _reduce_bucket(self, tag, lo, hi, async_op):
+        flat = self.task.sed_student.arena.flat_grad
+        self.bucket_log.append((tag, lo, hi - lo))
+        if hi <= lo:
+            return None
+        return dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=async_op)
+
+    def backward(self, loss):
+        """loss.backward() with the gradient exchange.  Overlap mode: the student's autograd graph is cut at the CNN output
+        (CRNN.split_backward), so loss.backward() ends after the recurrent stage; bucket A is handed to RCCL there as an
+        asynchronous collective and the CNN backward is enqueued behind it on the compute stream."""
+        student = self.task.sed_student
+        if not (self.overlap and getattr(student, "_cnn_boundary", None) is not None):
+            loss.backward()
+            if hasattr(student, "backward_cnn"):
+                student.backward_cnn()
+            self.allreduce_grads()
+            return
+        loss.backward()
+        self.launch_bucket_a()
+        student.backward_cnn()
+        self.finish_buckets()
+
+    def launch_bucket_a(self):
+        arena = self.task.sed_student.arena
+        split, n = self.bucket_bounds()
+        base = arena.flat_grad.data_ptr()
+        flat_a = all(p.grad is None or p.grad.data_ptr() == base + 4 * o
+                     for p, o in zip(arena.params, arena.offsets) if o >= split)
+        self._work_a = (self._reduce_bucket("A", split, n, async_op=True) or True) if flat_a else None
+
+    def finish_buckets(self):
+        arena = self.task.sed_student.arena
+        split, n = self.bucket_bounds()
+        if self._work_a is None or not arena.grads_are_flat():
+            # some gradient lives outside the arena: the blocking whole-arena path (bucket A, if in flight, first completes and
+            # is excluded so that nothing is summed twice)
+            if self._work_a is not None and self._work_a is not True:
+                self._work_a.wait()
+            done_a = self._work_a is not None
+            self._work_a = None
+            flat = arena.gather_grads()
+            self.bucket_log.append(("B" if done_a else "AB", 0, split if done_a else n))
+            dist.all_reduce(flat[:split] if done_a else flat, op=dist.ReduceOp.SUM)
+            self._finish_scale(arena)
+            return
+        wb = self._reduce_bucket("B", 0, split, async_op=True)
+        for w in (self._work_a, wb):
+            if w is not None and w is not True:
+                w.wait()
+        self._work_a = None
+        self._finish_scale(arena)
+
+    def _finish_scale(self, arena):
+        flat = arena.flat_grad
+        if not hasattr(self.opt, "grad_scale"):
+            flat.div_(self.world)
+        if not arena.grads_are_flat():        # gradients lived elsewhere: scatter the averaged values back
+            with torch.no_grad():
+                for p, o in zip(arena.params, arena.offsets):
+                    if p.grad is not None:
+                        p.grad.copy_(flat[o:o + p.numel()].view(p.shape))
 
     def allreduce_grads(self):
+        """The blocking exchange: ONE all-reduce over the whole flat gradient arena."""
         if self.world <= 1:
             return
-        arena = self.arena
+        arena = self.task.sed_student.arena if self.arena is not None else None
         if arena is not None:
             flat = arena.gather_grads()
+            self.bucket_log.append(("AB", 0, arena.numel))
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            if not hasattr(self.opt, "grad_scale"):
-                flat.div_(self.world)
-            if not arena.grads_are_flat():        # gradients lived elsewhere: scatter the averaged values back
-                with torch.no_grad():
-                    for p, o in zip(arena.params, arena.offsets):
-                        if p.grad is not None:
-                            p.grad.copy_(flat[o:o + p.numel()].view(p.shape))
+            self._finish_scale(arena)
         else:
             for p in self.task.sed_student.parameters():
                 if p.grad is not None:
                     dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
-                    p.grad.div_(self.world)
+                    if not hasattr(self.opt, "grad_scale"):
+                        p.grad.div_(self.world)
+
+    def arm_overlap(self):
+        """Cut the student's autograd graph at the CNN output for this step when the overlapped exchange is on."""
+        self.bucket_log = []
+        self._work_a = None
+        student = self.task.sed_student
+        if hasattr(student, "split_backward"):
+            student.split_backward = bool(self.overlap)
 
     def run_step(self, batch, batch_idx=0):
         task = self.task
+        self.arm_overlap()
         loss = task.training_step(batch, batch_idx)
         if self.side is not None:
             main = torch.cuda.current_stream()
@@ -83,8 +201,7 @@ class StepDriver:
         else:
             task.on_before_zero_grad()
         self.opt.zero_grad(set_to_none=True)
-        loss.backward()
-        self.allreduce_grads()
+        self.backward(loss)
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)   # Adam overwrites theta_s that the EMA reads
         self.opt.step()
@@ -118,27 +235,62 @@ def average_bn_buffers(task, world_size=None):
             off += b.numel()
 
 
-def save_checkpoint(task, path, world_size=None):
-    """Averages the BN buffers, then rank 0 writes {"sed_student", "sed_teacher"} state dicts (on_save_checkpoint layout,
-    sed_trainer.py:603-606); every rank returns after the file exists."""
+def checkpoint_dict(task, epoch=0):
+    """A Lightning-1.9-shaped checkpoint of the run: what `train_sed.py` reads back -- `state_dict` (`sed_student.*` /
+    `sed_teacher.*` keys, :302 and --test_from_checkpoint :367-374), `hyper_parameters`, `epoch` -- plus what a resume needs
+    (`optimizer_states` in torch.optim.Adam's layout, `lr_schedulers` with `step_num`, `global_step`) and the
+    `on_save_checkpoint` extras (sed_trainer.py:603-606)."""
+    sched = task.scheduler["scheduler"] if task.scheduler is not None else None
+    ckpt = {
+        "epoch": int(epoch),
+        "global_step": int(sched.step_num - 1) if sched is not None else 0,
+        "pytorch-lightning_version": "1.9.0",
+        "state_dict": {k: v.detach().cpu().clone() for k, v in task.state_dict().items()},
+        "optimizer_states": [task.opt.state_dict()] if task.opt is not None else [],
+        "lr_schedulers": [sched.state_dict()] if sched is not None else [],
+        "hyper_parameters": dict(task.hparams),
+    }
+    task.on_save_checkpoint(ckpt)
+    return ckpt
+
+
+def save_checkpoint(task, path, world_size=None, epoch=0):
+    """Averages the BN buffers over the ranks, then rank 0 writes `checkpoint_dict(task)`; every rank returns after the file
+    exists."""
     average_bn_buffers(task, world_size)
     rank = dist.get_rank() if dist.is_initialized() else 0
     if rank == 0:
-        torch.save(task.on_save_checkpoint({}), path)
+        torch.save(checkpoint_dict(task, epoch), path)
     if dist.is_initialized():
         dist.barrier()
+
+
+def load_checkpoint(task, path_or_dict, resume=True):
+    """Inverse of save_checkpoint on every rank: weights + BN buffers of both models; with resume=True also Adam's moments / step
+    and the scheduler's step_num (which drives lr, the consistency ramp-up and the EMA factor).  Also accepts the reference's
+    own Lightning checkpoints (same keys)."""
+    ckpt = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu", weights_only=False)
+    task.load_state_dict(ckpt["state_dict"])
+    if resume:
+        if ckpt.get("optimizer_states") and task.opt is not None:
+            task.opt.load_state_dict(ckpt["optimizer_states"][0])
+        if ckpt.get("lr_schedulers") and task.scheduler is not None:
+            task.scheduler["scheduler"].load_state_dict(ckpt["lr_schedulers"][0])
+    return ckpt
 
 
 class RankShardedBatchSampler:
     """Rank-strided view of a batch sampler (desed_task/dataio/sampler.py:69-80 yields whole [synth | weak | unlabelled]
     batches): rank r iterates batches r, r + world, ...; all ranks get the same number of batches (the tail is dropped)."""
 
-    def __init__(self, batch_sampler, rank, world_size):
+    def __init__(self, batch_sampler, rank, world_size, seed=0):
         if not 0 <= rank < world_size:
             raise ValueError("rank out of range")
         self.batch_sampler, self.rank, self.world = batch_sampler, rank, world_size
+        self.seed, self.epoch = int(seed), 0
 
     def set_epoch(self, epoch):
+        self.epoch = int(epoch)
         if hasattr(self.batch_sampler, "set_epoch"):
             self.batch_sampler.set_epoch(epoch)
 
@@ -146,9 +298,18 @@ class RankShardedBatchSampler:
         return len(self.batch_sampler) // self.world
 
     def __iter__(self):
+        # Every rank must walk the SAME sequence of batches and keep its own share.  The recipe's samplers draw from torch's
+        # global CPU generator, whose state differs across ranks as soon as anything rank-local consumed it (mixup permutations,
+        # a rank-dependent seed): the epoch's batches are therefore drawn under a forked generator seeded with (seed, epoch)
+        # only, and the caller's generator state is left untouched.
         n = len(self) * self.world
-        for i, batch in enumerate(self.batch_sampler):
-            if i >= n:
-                break
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(self.seed + self.epoch)
+            batches = []
+            for i, batch in enumerate(self.batch_sampler):
+                if i >= n:
+                    break
+                batches.append(list(batch))
+        for i, batch in enumerate(batches):
             if i % self.world == self.rank:
                 yield batch

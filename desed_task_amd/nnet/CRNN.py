@@ -73,10 +73,18 @@ class CRNN(nn.Module):
             self.cat_tf = nn.Linear(nb_in + embedding_size, nb_in)
         self._arena = None
         self._build_arena()
+        # data parallelism (launcher.StepDriver): with split_backward the autograd graph is cut at the CNN output, so that
+        # loss.backward() stops after the recurrent stage -- the point where the all-reduce of the BiGRU / head gradients can start
+        # -- and backward_cnn() runs the CNN's backward under it
+        self.split_backward = False
+        self._cnn_boundary = None
 
     # ---- flat parameter arena -------------------------------------------------------------------
     def _build_arena(self):
+        old = self._arena
         self._arena = ParamArena(list(self.parameters()))
+        if old is not None:
+            old.successor = self._arena         # an optimizer built on the old arena follows the chain (arena.FusedAdam)
 
     @property
     def arena(self):
@@ -85,8 +93,13 @@ class CRNN(nn.Module):
         return self._arena
 
     def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() go through here.  When nothing moved (Lightning calls model.to(device) at the start of fit
+        # and test on a module that is already there) the parameters are still the arena's views: keep it, so that an
+        # optimizer / captured graph holding its buffers stays valid.  Otherwise rebuild on the new storage.
         out = super()._apply(fn, *args, **kwargs)
-        self._build_arena()
+        a = self._arena
+        if a is None or not a.is_intact() or a.flat.device != a.params[0].device:
+            self._build_arena()
         return out
 
     def __deepcopy__(self, memo):
@@ -94,10 +107,11 @@ class CRNN(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k == "_arena":
+            if k in ("_arena", "_cnn_boundary"):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         new._arena = None
+        new._cnn_boundary = None
         new._build_arena()
         return new
 
@@ -131,6 +145,10 @@ class CRNN(nn.Module):
         """Second half of forward(): [embedding fusion +] BiGRU + dropout + attention head.
         (B, T', C) -> strong (B,nclass,T'), weak."""
         arena = self.arena
+        if self.split_backward and h.requires_grad and torch.is_grad_enabled():
+            cut = h.detach().requires_grad_(True)
+            self._cnn_boundary = (h, cut)
+            h = cut
         if self.use_embeddings:
             if embeddings is None:
                 raise ValueError("this CRNN was built with use_embeddings=True: forward() needs embeddings")
@@ -147,6 +165,13 @@ class CRNN(nn.Module):
         strong, weak = HeadFn.apply(h, self.dense.weight, self.dense.bias, self.dense_softmax.weight,
                                     self.dense_softmax.bias, cfg)
         return strong.transpose(1, 2), weak
+
+    def backward_cnn(self):
+        """Second half of a split backward (split_backward = True): the CNN's backward from the gradient that loss.backward()
+        left at the cut.  No-op when the last forward was not cut."""
+        b, self._cnn_boundary = self._cnn_boundary, None
+        if b is not None and b[1].grad is not None:
+            b[0].backward(b[1].grad)
 
     def forward(self, x, pad_mask=None, embeddings=None, classes_mask=None):
         if pad_mask is not None or classes_mask is not None:

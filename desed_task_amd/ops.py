@@ -38,11 +38,30 @@ def dropout_params(p):
     return int(round(p * (1 << 24))), 1.0 / (1.0 - p)
 
 
+_seed_gen = None
+_seed_gen_src = None
+
+
+def seed_generator():
+    """The private CPU generator the dropout seeds are drawn from.  It is derived from torch's seed (re-derived whenever
+    torch.manual_seed() was called since, so a seeded run is reproducible) and from RANK, but it CONSUMES nothing from the global
+    generator: the global CPU stream then sees exactly what the reference's step draws from it (the mixup permutations), and
+    ranks seeded alike stay in lock-step whatever their dropout call sites do."""
+    global _seed_gen, _seed_gen_src
+    src = (torch.initial_seed(), os.environ.get("RANK", "0"))
+    if _seed_gen is None or src != _seed_gen_src:
+        _seed_gen = torch.Generator()
+        _seed_gen.manual_seed((src[0] * 6364136223846793005 + 1442695040888963407 + 7919 * int(src[1] or 0)) % (2 ** 63))
+        _seed_gen_src = src
+    return _seed_gen
+
+
 def new_seed(generator=None):
-    """A fresh 31-bit dropout seed from torch's CPU generator (host side, no device sync).
+    """A fresh 31-bit dropout seed (host side, no device sync) from `generator` or the private seed generator above.
     Under a graph.DynArgs step the draw is repeated every replay and the seed travels through device memory."""
     def draw():
-        return int(torch.randint(0, 2 ** 31 - 1, (1,), generator=generator).item())
+        g = generator if generator is not None else seed_generator()
+        return int(torch.randint(0, 2 ** 31 - 1, (1,), generator=g).item())
     dyn = _graph.active()
     if dyn is not None:
         return dyn.new_seed(draw)

@@ -1,16 +1,12 @@
 """Step-wise schedulers with the reference's interface (desed_task/utils/schedulers.py:8-104): the same object
 scales the learning rate and the mean-teacher consistency weight (sed_trainer.py:329-332).  Host-side scalars."""
 import numpy as np
-import torch
 
 
 class BaseScheduler(object):
     def __init__(self, optimizer):
         self.optimizer = optimizer
         self.step_num = 0
-
-    def zero_grad(self):
-        self.optimizer.zero_grad()
 
     def _get_lr(self):
         raise NotImplementedError
@@ -28,14 +24,6 @@ class BaseScheduler(object):
 
     def state_dict(self):
         return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
-
-    def as_tensor(self, start=0, stop=100_000):
-        values = []
-        for _ in range(start, stop):
-            self.step_num += 1
-            values.append(self._get_lr())
-        self.step_num = 0
-        return torch.tensor(values)
 
 
 class ExponentialWarmup(BaseScheduler):

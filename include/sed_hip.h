@@ -39,7 +39,7 @@ int sed_take_log(const float* x, float* y, long long n, void* stream);
  * A captured training step freezes every by-value launch argument.  The entry points whose arguments change from
  * step to step therefore take one extra, NULLABLE device pointer that overrides the by-value argument when set:
  *   seed_dev   (sed_glu_*, sed_head_*) : *seed_dev is added to `seed` (wrapping) -- the dropout entropy of this step;
- *   c_dev      (sed_mixup)             : {c, 1-c} (c == 1 makes the launch a no-op);
+ *   c_dev      (sed_mixup)             : {c, 1-c} (the sentinel c = 2 makes the launch a no-op);
  *   weight_dev (sed_mt_loss)           : consistency-loss weight;
  *   alpha_dev  (sed_ema_update)        : {alpha, 1-alpha};
  *   hyper_dev  (sed_adam_step)         : {step_size, inv_bc2_sqrt}.

@@ -123,14 +123,18 @@ def case_mixup_specaug(dev):
 # CNN block (K6)
 # ------------------------------------------------------------------------------------------------
 def np_keep_mask(shape, seed, p):
-    """numpy replica of sed_keep() over a (B,T,F,C) channels-last element index."""
+    """Host replica of sed_keep() (csrc/sed_common.h) over a (B,T,F,C) channels-last element index -> float 0/1 mask.
+    64-bit integer tensor arithmetic with explicit 32-bit wrap-around (torch: multi-threaded; the 60 M-element masks of the
+    full-size cases take a second instead of several)."""
     n = int(np.prod(shape))
     thr = int(round(p * (1 << 24))) if p > 0 else 0
-    x = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B1) + np.uint64(seed)) & np.uint64(0xFFFFFFFF)
-    x ^= x >> np.uint64(16); x = (x * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
-    x ^= x >> np.uint64(13); x = (x * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
-    x ^= x >> np.uint64(16)
-    return torch.from_numpy(((x >> np.uint64(8)) >= thr).astype(np.float32)).reshape(shape)
+    M = 0xFFFFFFFF
+    x = torch.arange(n, dtype=torch.int64)
+    x = (x * 0x9E3779B1 + int(seed)) & M
+    x ^= x >> 16; x = (x * 0x85EBCA6B) & M
+    x ^= x >> 13; x = (x * 0xC2B2AE35) & M
+    x ^= x >> 16
+    return ((x >> 8) >= thr).to(torch.float32).reshape(shape)
 
 
 def case_cnn_block(dev, layer, B, T, F, training=True, dropout_p=0.5, seed=1234, tol=2e-5, precision="f32"):
@@ -352,6 +356,11 @@ def case_training_step(dev, small=False, golden=None):
             # Adam sign-of-near-zero-gradient divergence of a few parameter elements (see the comment below).
             rel = 1e-4 if step == 0 else 3e-2
             assert (g - r).abs().max().item() <= rel * r.abs().max().item() + 5e-8, "step %d grad %s" % (step, k)
+            # ... and the bulk of every tensor agrees far tighter than its worst element: median elementwise error
+            emax, emed = grad_error_stats(g, r)
+            if DIAG is not None:
+                DIAG.append(("grad", step, k, emax, emed))
+            assert emed <= (1e-5 if step == 0 else 2e-3), "step %d grad %s: median error %.3e" % (step, k, emed)
         got = {k: (float(v) if not torch.is_tensor(v) else float(v.detach().cpu())) for k, v in task.logged.items()}
         got["loss"] = float(loss.detach().cpu())
         logs["loss"] = tot.item()
@@ -388,6 +397,12 @@ def case_training_step(dev, small=False, golden=None):
             upd = (theirs - sd[k]).norm().item()
             err = (mine - theirs).norm().item()
             assert err <= 0.15 * upd + 1e-6, "%s %s: |err| %.3e vs |update| %.3e" % (what, k, err, upd)
+            # the L2 bound above is dominated by the few sign-flipped elements; the typical element agrees much tighter
+            med_err = (mine - theirs).abs().median().item()
+            med_upd = (theirs - sd[k]).abs().median().item()
+            if DIAG is not None:
+                DIAG.append(("param", what, k, err / max(upd, 1e-30), med_err / max(med_upd, 1e-30)))
+            assert med_err <= 0.01 * med_upd + 1e-8, "%s %s: median |err| %.3e vs median |update| %.3e" % (what, k, med_err, med_upd)
     # teacher BN buffers (updated under no_grad in train mode, never EMA'd).  running_var, not running_mean: the mean
     # contains the conv bias, whose reference value random-walks (see above).
     for i in (0, 3, 6):
@@ -1092,3 +1107,242 @@ def case_mt_loss(dev):
         assert abs(float(got[7]) - float(tot)) < 5e-6 * max(1.0, abs(float(tot))) and float(total) == float(got[7])
         assert float((sd.grad.cpu() - ss.grad).abs().max()) < 1e-6 * max(1.0, float(ss.grad.abs().max())), mode
         assert float((wd.grad.cpu() - ws.grad).abs().max()) < 1e-6 * max(1.0, float(ws.grad.abs().max())), mode
+
+
+# ------------------------------------------------------------------------------------------------
+# the BENCHMARKED configuration: dropout + SpecAugment + mixup ON, compared as a whole with the oracle
+# ------------------------------------------------------------------------------------------------
+class StochasticRecorder:
+    """Records what the HIP path drew in one training step so the oracle can be run on identical draws: the dropout seed of
+    every call site (7 CNN blocks + post-GRU head [+ embcat] per model) and the SpecAugment bounds per model.  The draws
+    themselves are untouched -- `ops.new_seed` and `features.specaug_bounds` still produce them; the recorder only listens and
+    tags each draw with the model (student / teacher) whose forward asked for it (the two tails run in swapped order when they
+    are overlapped on two HIP streams)."""
+
+    def __init__(self, task):
+        import importlib
+        cnn_mod = importlib.import_module("desed_task_amd.nnet.CNN")
+        crnn_mod = importlib.import_module("desed_task_amd.nnet.CRNN")      # (the package re-exports the class under that name)
+        self.rec = {"student": {"seeds": [], "bounds": None}, "teacher": {"seeds": [], "bounds": None}}
+        self._cur = [None]
+        self._mods = (cnn_mod, crnn_mod)
+        self._orig_seed = cnn_mod.new_seed
+        self._orig_bounds = Fh.specaug_bounds
+        rec, cur = self.rec, self._cur
+
+        def new_seed(generator=None, _o=self._orig_seed):
+            s = _o(generator)
+            rec[cur[0]]["seeds"].append(int(s))
+            return s
+
+        def specaug_bounds(*a, _o=self._orig_bounds, **k):
+            b = _o(*a, **k)
+            rec[cur[0]]["bounds"] = b
+            return b
+
+        cnn_mod.new_seed = new_seed
+        crnn_mod.new_seed = new_seed
+        Fh.specaug_bounds = specaug_bounds
+        self._models = []
+        for name, model in (("student", task.sed_student), ("teacher", task.sed_teacher)):
+            for meth in ("forward_cnn", "forward_tail"):
+                orig = getattr(model, meth)
+
+                def wrapped(*a, _o=orig, _n=name, **k):
+                    prev, cur[0] = cur[0], _n
+                    try:
+                        return _o(*a, **k)
+                    finally:
+                        cur[0] = prev
+                object.__setattr__(model, meth, wrapped)
+                self._models.append((model, meth))
+
+    def reset(self):
+        for v in self.rec.values():
+            v["seeds"], v["bounds"] = [], None
+
+    def close(self):
+        for m in self._mods:
+            m.new_seed = self._orig_seed
+        Fh.specaug_bounds = self._orig_bounds
+        for model, meth in self._models:
+            object.__delattr__(model, meth)
+
+    def oracle_draws(self, who, B, n_frames, p=0.5, embedding_size=None):
+        """-> (aug, drop_masks) in the oracle's conventions (masks NCHW for the CNN blocks, (B,T',256) for the head)."""
+        r = self.rec[who]
+        b = r["bounds"].cpu().long()
+        aug = dict(f=(b[:, 0], b[:, 1]), t=(b[:, 2], b[:, 3]))
+        seeds = list(r["seeds"])
+        assert len(seeds) == (8 if embedding_size is None else 9), (who, len(seeds))
+        masks = []
+        T, Fq = n_frames, 128
+        for i, co in enumerate(O.NB_FILTERS):
+            masks.append(np_keep_mask((B, T, Fq, co), seeds[i], p).permute(0, 3, 1, 2))
+            T, Fq = T // O.POOLING[i][0], Fq // O.POOLING[i][1]
+        if embedding_size is None:
+            masks.append(np_keep_mask((B, T, 256), seeds[7], p))
+        else:           # forward_tail order: embcat seed first, then the head's
+            masks.append(np_keep_mask((B, T, 256), seeds[8], p))
+            masks.append(np_keep_mask((B, T, 128 + embedding_size), seeds[7], p))
+        return aug, masks
+
+
+def _mixup_draws(bs, seeds):
+    """The draws SEDTask4.training_step will make after seeding (coin, beta, randperm weak, beta, randperm strong)."""
+    import random
+    random.seed(seeds[0]); np.random.seed(seeds[1]); torch.manual_seed(seeds[2])
+    mix = None
+    if 0.5 > random.random():
+        cw = np.random.beta(0.2, 0.2); pw = torch.randperm(bs[1]); cs = np.random.beta(0.2, 0.2); ps = torch.randperm(bs[0])
+        mix = dict(c_weak=cw, perm_weak=pw, c_strong=cs, perm_strong=ps)
+    random.seed(seeds[0]); np.random.seed(seeds[1]); torch.manual_seed(seeds[2])
+    return mix
+
+
+DIAG = None      # a list here collects the error statistics of case_training_step (diagnostics)
+STATS = None     # a list here collects (name, max, median) of every step-0 gradient comparison (diagnostics)
+
+
+def grad_error_stats(g, r):
+    """(max, median) over the elements of max(|g - r| - 5e-8, 0) / max |r| for one gradient tensor."""
+    d = ((g - r).abs().reshape(-1) - 5e-8).clamp(min=0)        # 5e-8 absolute: gradients that are themselves rounding residue
+    s = max(r.abs().max().item(), 1e-30)
+    return d.max().item() / s, d.median().item() / s
+
+
+def case_stochastic_training_step(dev, bs=(2, 2, 4), n_samp=16000 * 2 + 1024, steps=2, grads=True):
+    """`steps` full mean-teacher steps with dropout (all 8 sites per model, the head's included), SpecAugment and mixup ON --
+    the configuration bench.py times -- against OracleTrainer.training_step(..., aug_s, aug_t, drop_s, drop_t) on the draws the
+    HIP path made (reference: local/sed_trainer.py:304-342, desed_task/nnet/CRNN.py:207-219,303-306, CNN.py:90-91).
+    Done = posteriors <= 1e-3 abs, logged scalars <= 2e-4 rel, step-0 gradients <= 1e-4 of the per-tensor maximum."""
+    from desed_task_amd.launcher import StepDriver
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    B = sum(bs)
+    sd = O.make_state_dict(seed=7)
+    audio = O.synth_audio(B, n_samp, seed=78)
+    n_frames = 1 + n_samp // 256
+    n_out = n_frames // 4
+    labels = O.synth_labels(bs, 10, n_out, seed=5)
+    task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=100)
+    driver = StepDriver(task, world_size=1)
+    orc = O.OracleTrainer(sd, batch_sizes=bs, lr=1e-3, rampup_len=100)
+    rec = StochasticRecorder(task)
+    worst = {"post": 0.0, "scalar": 0.0, "grad_max": 0.0, "grad_med": 0.0}
+    try:
+        mixed = []
+        for step in range(steps):
+            mix = _mixup_draws(bs, (4 + step, 100 + step, 100 + step))       # seeds 4 -> mixup on, 5 -> off
+            mixed.append(mix is not None)
+            rec.reset()
+            loss = driver.run_step((to(dev, audio.clone()), to(dev, labels.clone()), None, None), step)
+            aug_s, drop_s = rec.oracle_draws("student", B, n_frames)
+            aug_t, drop_t = rec.oracle_draws("teacher", B, n_frames)
+            assert rec.rec["student"]["seeds"] != rec.rec["teacher"]["seeds"]
+            tot, logs = orc.training_step(audio, labels, mix=mix, aug_s=aug_s, aug_t=aug_t, drop_s=drop_s, drop_t=drop_t)
+            ref_grads = orc.optimizer_step(tot) if grads else None
+            got = {k: (float(v) if not torch.is_tensor(v) else float(v.detach().cpu())) for k, v in task.logged.items()}
+            got["loss"] = float(loss.detach().cpu()); logs["loss"] = tot.item()
+            for k in sorted(logs):
+                a, b = got[k], logs[k]
+                worst["scalar"] = max(worst["scalar"], abs(a - b) / max(abs(b), 1e-1))
+                assert abs(a - b) <= 2e-5 + 2e-4 * abs(b), "step %d %s: hip %.8g oracle %.8g" % (step, k, a, b)
+            for a, name in zip([t.detach().cpu() for t in task.last_outputs], ("strong_s", "weak_s", "strong_t", "weak_t")):
+                err = (a - orc.last[name]).abs().max().item()
+                worst["post"] = max(worst["post"], err)
+                assert err < 1e-3, "step %d %s: %.3e" % (step, name, err)
+            if grads:
+                hip_params = dict(task.sed_student.named_parameters())
+                for k in O.PARAM_KEYS:
+                    if k.startswith("cnn.cnn.conv") and k.endswith(".bias"):
+                        continue                                   # analytically zero (see case_training_step)
+                    emax, emed = grad_error_stats(hip_params[k].grad.detach().cpu(), ref_grads[k])
+                    if step == 0:
+                        worst["grad_max"], worst["grad_med"] = max(worst["grad_max"], emax), max(worst["grad_med"], emed)
+                        if STATS is not None:
+                            STATS.append((k, emax, emed))
+                        assert emax <= 1e-4 and emed <= 1e-5, "step 0 grad %s: max %.3e median %.3e" % (k, emax, emed)
+                    else:
+                        # later steps inherit Adam's sign flips of near-zero gradient elements (a few parameter elements move by
+                        # +-lr instead of -+lr): the bulk must still agree -- median error -- while single elements may not
+                        assert emed <= 2e-3 and emax <= 6e-2, "step %d grad %s: max %.3e median %.3e" % (step, k, emax, emed)
+        assert any(mixed) or steps < 2
+    finally:
+        rec.close()
+    return worst
+
+
+def case_head_dropout(dev, B=3, T=39, p=0.5, seed=4242):
+    """HeadFn (post-GRU Dropout(0.5) + dense + dense_softmax + class-softmax attention pooling, CRNN.py:152-178,:304) forward
+    and backward against torch ops on the same keep mask."""
+    from desed_task_amd.ops import HeadFn
+    D, NC = 256, 10
+    x = O.lcg_fill((B, T, D), 61, 1.0)
+    w1 = O.lcg_fill((NC, D), 62, 1.0 / 16); b1 = O.lcg_fill((NC,), 63, 0.1)
+    w2 = O.lcg_fill((NC, D), 64, 1.0 / 16); b2 = O.lcg_fill((NC,), 65, 0.1)
+    gs = O.lcg_fill((B, T, NC), 66, 1.0); gw = O.lcg_fill((B, NC), 67, 1.0)
+    ref_in = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    h = ref_in[0] * np_keep_mask((B, T, D), seed, p) / (1.0 - p)
+    strong = torch.sigmoid(torch.nn.functional.linear(h, ref_in[1], ref_in[2]))
+    sof = torch.softmax(torch.nn.functional.linear(h, ref_in[3], ref_in[4]), dim=-1).clamp(min=1e-7, max=1)
+    weak = (strong * sof).sum(1) / sof.sum(1)
+    ((strong * gs).sum() + (weak * gw).sum()).backward()
+    hip_in = [to(dev, t).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    s_h, w_h = HeadFn.apply(*hip_in, dict(dropout_p=p, apply_dropout=p > 0, seed=seed))
+    ((s_h * to(dev, gs)).sum() + (w_h * to(dev, gw)).sum()).backward()
+    assert (s_h.detach().cpu() - strong.detach()).abs().max().item() < 2e-6
+    assert (w_h.detach().cpu() - weak.detach()).abs().max().item() < 2e-6
+    for nm, a, b in zip(("dx", "dW1", "db1", "dW2", "db2"), hip_in, ref_in):
+        emax, _ = grad_error_stats(a.grad.detach().cpu(), b.grad)
+        assert emax < 2e-5, "%s: %.3e" % (nm, emax)
+    kept = (hip_in[0].grad.detach().cpu() != 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 0.05 if p > 0 else kept > 0.99
+
+
+def case_b48_forward_vs_oracle(dev, bs=(12, 12, 24)):
+    """BASELINE config C2 itself -- 48 clips (12/12/24) of 10 s, dropout + SpecAugment + mixup ON, student != teacher weights --
+    compared with the oracle, forward pass: student and teacher posteriors (1e-3 abs), the six loss scalars, all 7 + 7
+    BatchNorm running statistics (batch-size dependent reductions) and the per-clip min/max of the scaler."""
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    B, n_samp = sum(bs), 160000
+    n_frames = 1 + n_samp // 256
+    sd, sd_t = O.make_state_dict(seed=13), O.make_state_dict(seed=14)
+    audio = O.synth_audio(B, n_samp, seed=5)
+    labels = O.synth_labels(bs, 10, 156, seed=6)
+    task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=100)
+    task.sed_teacher.load_state_dict({k: v.clone() for k, v in sd_t.items()})
+    assert task.sed_teacher.arena.is_intact()
+    orc = O.OracleTrainer(sd, batch_sizes=bs, lr=1e-3, rampup_len=100, teacher_sd=sd_t)
+    rec = StochasticRecorder(task)
+    try:
+        mix = _mixup_draws(bs, (4, 100, 100))
+        assert mix is not None
+        audio_d = to(dev, audio)
+        with torch.no_grad():
+            _, mm = Fh.minmax_scale(task.mel_spec(audio_d), apply_log=True, return_minmax=True)
+            loss = task.training_step((audio_d, to(dev, labels.clone()), None, None), 0)
+        aug_s, drop_s = rec.oracle_draws("student", B, n_frames)
+        aug_t, drop_t = rec.oracle_draws("teacher", B, n_frames)
+    finally:
+        rec.close()
+    with torch.no_grad():
+        logm = O.take_log(O.mel_spectrogram(audio))
+        tot, logs = orc.training_step(audio, labels, mix=mix, aug_s=aug_s, aug_t=aug_t, drop_s=drop_s, drop_t=drop_t)
+    mm = mm.cpu()
+    assert (mm[:, 0] - logm.amin((1, 2))).abs().max().item() < 2e-3 and (mm[:, 1] - logm.amax((1, 2))).abs().max().item() < 2e-3   # dB
+    out = {}
+    for a, name in zip([t.detach().cpu() for t in task.last_outputs], ("strong_s", "weak_s", "strong_t", "weak_t")):
+        out[name] = (a - orc.last[name]).abs().max().item()
+        assert out[name] < 1e-3, "%s: %.3e" % (name, out[name])
+    got = {k: (float(v) if not torch.is_tensor(v) else float(v.detach().cpu())) for k, v in task.logged.items()}
+    got["loss"] = float(loss.detach().cpu()); logs["loss"] = tot.item()
+    for k in sorted(logs):
+        assert abs(got[k] - logs[k]) <= 2e-5 + 2e-4 * abs(logs[k]), "%s: hip %.8g oracle %.8g" % (k, got[k], logs[k])
+    for who, model, ref in (("student", task.sed_student, orc.student), ("teacher", task.sed_teacher, orc.teacher)):
+        for i in range(7):
+            bn = getattr(model.cnn.cnn, "batchnorm%d" % i)
+            for nm, a in (("running_mean", bn.running_mean), ("running_var", bn.running_var)):
+                b = ref["cnn.cnn.batchnorm%d.%s" % (i, nm)].detach()
+                err = (a.cpu() - b).abs().max().item()
+                assert err <= 2e-5 * max(1.0, b.abs().max().item()), "%s bn%d %s: %.3e" % (who, i, nm, err)
+    return out

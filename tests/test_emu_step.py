@@ -68,3 +68,14 @@ def test_embedding_crnn_matches_reference_golden(emu):
 def test_pretrained_training_step(emu):
     """sed_trainer_pretrained.SEDTask4: the mean-teacher step with frozen embeddings in the batch vs the oracle trainer."""
     P.case_pretrained_training_step("cpu")
+
+
+def test_stochastic_step_matches_oracle(emu):
+    """The benchmarked configuration (dropout on all 8 sites per model incl. the head, SpecAugment, mixup) as a whole against
+    the oracle on the recorded draws: 2 steps, posteriors / scalars / every gradient."""
+    P.case_stochastic_training_step("cpu", bs=(1, 1, 2), n_samp=16000 + 1024, steps=2)
+
+
+def test_head_dropout(emu):
+    P.case_head_dropout("cpu")
+    P.case_head_dropout("cpu", B=2, T=5, p=0.25, seed=7)

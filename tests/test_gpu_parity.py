@@ -141,3 +141,29 @@ def test_pretrained_training_step():
 def test_mt_loss_modes_and_dataset_scaler(tmp_path):
     P.case_mt_loss("cuda")
     P.case_dataset_scaler("cuda", tmp_path)
+
+
+def test_head_dropout_production_shape():
+    """head_fwd/bwd_kernel with the post-GRU Dropout(0.5) on (CRNN.py:304) vs torch ops on the same keep mask."""
+    P.case_head_dropout("cuda", B=4, T=156)
+    P.case_head_dropout("cuda", B=2, T=5, p=0.25, seed=7)
+
+
+def test_stochastic_steps_vs_oracle():
+    """3 full steps in the configuration bench.py times (dropout on all 8 sites per model, SpecAugment, mixup) vs the oracle
+    on the draws the HIP path made."""
+    w = P.case_stochastic_training_step("cuda", bs=(2, 2, 4), n_samp=16000 * 2 + 1024, steps=3)
+    print("stochastic step worst errors:", w)
+
+
+def test_full_size_stochastic_step_c1_batch():
+    """The same at full clip length: 16 clips = [4,4,8] of 10 s (config C1), one step incl. all gradients."""
+    w = P.case_stochastic_training_step("cuda", bs=(4, 4, 8), n_samp=160000, steps=1)
+    print("full-size stochastic step worst errors:", w)
+
+
+def test_b48_forward_vs_oracle():
+    """Config C2 itself (48 clips of 10 s, dropout + SpecAugment + mixup on) against the oracle: posteriors, losses, all BN
+    running statistics, per-clip min/max."""
+    w = P.case_b48_forward_vs_oracle("cuda")
+    print("B=48 posterior errors:", w)
