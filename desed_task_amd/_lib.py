@@ -83,6 +83,14 @@ def use_library(path, is_emulator=True):
     return _lib
 
 
+TUNING_KEYS = {"glu_grid_cap": 0, "glu_bwd128_split": 1, "convb_ck": 2, "convb_mp": 3}
+
+
+def set_tuning(key, value):
+    """Tests / sweep tools: override a kernel tuning choice of the bound library (0 = built-in choice).  See sed_set_tuning."""
+    get().call("sed_set_tuning", TUNING_KEYS[key], int(value))
+
+
 def check_tensor(t, name="tensor"):
     """Device policy: CUDA (ROCm) tensors only -- unless the emulator build was injected by the tests."""
     lib = get()

@@ -1,0 +1,412 @@
+// K6, first block, WITHOUT its pre-BatchNorm tensor in HBM.
+//
+// Block 0 of the CNN (desed_task/nnet/CNN.py:66-98 with n_in_channel = 1, 16 filters, pooling (2,2)) turns a 15 MB input
+// (B,T,F) into a 246 MB conv output y (B,T,F,16) that the unfused path wrote once and read three times (BN+GLU forward, GLU
+// backward, weight gradient) and whose gradient dz it wrote and read once more: ~2.2 GB of HBM traffic per step for a K = 9
+// convolution that costs 36 FMAs per lane to recompute.  Here y only ever exists in registers:
+//
+//   forward  (training): sed_conv0_fwd(y = NULL)  conv0 in registers -> per-workgroup (sum, sum^2) for BatchNorm   [reads x]
+//                        sed_bn_finalize          batch statistics, running-stat update (momentum 0.99, eps 1e-3)
+//                        sed_block0_fwd           conv0 + BN + GLU + Dropout + AvgPool(2,2) -> pooled output        [reads x, writes out]
+//   forward  (eval)    : sed_bn_finalize (running stats) + sed_block0_fwd
+//   backward (training): sed_block0_bwd           recompute conv0/BN/GLU, GLU + BN backward, ALL six parameter gradients
+//                                                 (conv weight/bias, BN gamma/beta, GLU weight/bias)               [reads x, gout]
+//
+// The conv weight gradient needs dy = invstd (dz - mean(dz) - xhat mean(dz xhat)), i.e. two batch-wide means that are only
+// complete when the pass is over.  It is linear in dy, so the pass accumulates the three raw correlations
+//      S1[c][tap] = sum_p x_tap(p) dz_c(p),   S2[c][tap] = sum_p x_tap(p) xhat_c(p),   Sx[tap] = sum_p x_tap(p)
+// and a tiny second kernel forms  dW[c][tap] = invstd_c (S1 - m1_c Sx - m2_c S2),  m1 = gamma dbeta / N, m2 = gamma dgamma / N
+// in double.  S1 and m1 Sx cancel down to N cov(x_tap, dz_c): to keep that difference out of fp32 rounding each workgroup
+// accumulates against x - k (k = a local estimate of the input mean, any constant is algebraically exact) and the reduction
+// adds k sum(dz_c), k sum(xhat_c), k n back in double.
+//
+// Lane layout = the glu16 kernels' (sed_glu.hip): one wave per 16-pixel tile = 4 pooling windows along F on the 16x16x4 f32
+// MFMA; operand lane (i = pixel = 4 w + q, g = channel quad) computes its own four conv outputs (36 FMAs from a 16 x F LDS
+// tile of the input, SpecAugment predicate applied while staging), which are directly the MFMA operand.
+#include "sed_common.h"
+
+#define B0_TR 16            // input rows per workgroup tile (8 pooled rows, two per wave)
+#define B0_MAXF 128
+
+// stage the (B0_TR + 2) x (F + 2) halo tile of clip b, rows t0 - 1 .. t0 + B0_TR, minus `center` (zero padding and
+// SpecAugment-masked bins hold 0 - center)
+__device__ __forceinline__ void b0_stage(float* tile, const float* __restrict__ x, const int* __restrict__ bounds, int b, int t0, int T,
+                                         int F, float center) {
+    const int PW = F + 2;
+    int mf0 = 0, mf1 = 0, mt0 = 0, mt1 = 0;
+    if (bounds) { mf0 = bounds[4 * b]; mf1 = bounds[4 * b + 1]; mt0 = bounds[4 * b + 2]; mt1 = bounds[4 * b + 3]; }
+    for (int idx = threadIdx.x; idx < (B0_TR + 2) * PW; idx += 256) {
+        const int i = idx / PW, j = idx - i * PW;
+        const int t = t0 - 1 + i, f = j - 1;
+        float v = 0.f;
+        if (t >= 0 && t < T && f >= 0 && f < F) {
+            v = x[((size_t)b * T + t) * F + f];
+            if ((f >= mf0 && f < mf1) || (t >= mt0 && t < mt1)) v = 0.f;
+        }
+        tile[idx] = v - center;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: x (B,T,F) -> out (B,T/2,F/2,16).  grid = (ceil(T/16), B), 256 threads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void block0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, const int* __restrict__ bounds,
+                                                         const float* __restrict__ stats, const float* __restrict__ Wg,
+                                                         const float* __restrict__ bg, float* __restrict__ out, int B, int T, int F,
+                                                         uint32_t seed, uint32_t thr24, float dscale,
+                                                         const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
+    constexpr int C = 16;
+    __shared__ float tile[(B0_TR + 2) * (B0_MAXF + 2)];
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y, t0 = blockIdx.x * B0_TR, PW = F + 2;
+    float wreg[4][9], breg[4], wa[4], sc[4], sh[4], bgr[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        breg[c] = bias ? bias[4 * g + c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wreg[c][k] = W[(4 * g + c) * 9 + k];
+        wa[c] = Wg[i * C + 4 * g + c];
+        sc[c] = stats[2 * C + 4 * g + c];
+        sh[c] = stats[3 * C + 4 * g + c];
+        bgr[c] = bg[4 * g + c];
+    }
+    b0_stage(tile, x, bounds, b, t0, T, F, 0.f);
+    __syncthreads();
+    const int To = T / 2, Fo = F / 2, tpr = Fo / 4;
+    const int w = i >> 2, q = i & 3;
+    for (int pr = wv; pr < B0_TR / 2; pr += 4) {
+        const int to = (t0 >> 1) + pr;
+        if (to >= To) break;
+        const int lr = 2 * pr + (q >> 1);                       // tile-local row of this lane's pixel
+        for (int tr = 0; tr < tpr; ++tr) {
+            const int col = 2 * (4 * tr + w) + (q & 1);
+            float in[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) in[a * 3 + bb] = tile[(lr + a) * PW + col + bb];
+            float xn[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc = fmaf(in[k], wreg[c][k], acc);
+                acc += breg[c];                                 // == conv0_kernel's y, bit for bit (same operation order)
+                xn[c] = fmaf(acc, sc[c], sh[c]);
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = mfma16(wa[k], xn[k], acc);      // D[n = 4g+r][pixel i]
+            const size_t pix = ((size_t)b * T + t0 + lr) * F + col;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float o = (acc[r] + bgr[r]) * sed_fast_sigmoid(xn[r]);
+                const uint32_t e = (uint32_t)(pix * C + 4 * g + r);
+                o = sed_keep(e, seed, thr24) ? o * dscale : 0.f;
+                o += __shfl_xor(o, 1);
+                o += __shfl_xor(o, 2);
+                v[r] = 0.25f * o;
+            }
+            if (q == 0)
+                *(float4*)(out + (((size_t)b * To + to) * Fo + 4 * tr + w) * C + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+extern "C" int sed_block0_fwd(const float* x, const float* W, const float* bias, const int* bounds, const float* stats,
+                              const float* Wg, const float* bg, float* out, int B, int T, int F, unsigned seed, unsigned thr24,
+                              float dscale, const unsigned* seed_dev, void* stream) {
+    if (F > B0_MAXF || F < 8 || F % 8 != 0) return SED_ERR_UNSUPPORTED;
+    if (B <= 0 || T < 2) return SED_OK;
+    SED_LAUNCH(block0_fwd_kernel, dim3((T + B0_TR - 1) / B0_TR, B), dim3(256), 0, (hipStream_t)stream, x, W, bias, bounds, stats, Wg,
+               bg, out, B, T, F, seed, thr24, dscale, seed_dev);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward (training-mode BatchNorm).  Persistent workgroups over the (clip, 16-row tile) pairs; per workgroup ONE
+// partial record, reduced in a fixed order (double) by block0_bwd_reduce_kernel.
+// ---------------------------------------------------------------------------------------------
+// partial record (floats): P = dWg (256) | dbg (16) | dgamma (16) | dbeta (16) | S1 (16 x 9) | S2 (16 x 9) | sum xhat (16) |
+//                          Sx (9) | k | pixel count | pad
+#define B0_O_DBG 256
+#define B0_O_DGAM 272
+#define B0_O_DBET 288
+#define B0_O_S1 304
+#define B0_O_S2 448
+#define B0_O_XH 592
+#define B0_O_SX 608
+#define B0_O_K 617
+#define B0_O_CNT 618
+#define B0_NP 624
+#define B0_NSUM 617         // entries [0, 617) are sums over the workgroup's pixels
+
+__global__ __launch_bounds__(256) void block0_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, const int* __restrict__ bounds,
+                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ Wg,
+                                                         const float* __restrict__ bg, const float* __restrict__ gout,
+                                                         float* __restrict__ part, int B, int T, int F, int tiles_t, uint32_t seed,
+                                                         uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;
+    constexpr int C = 16;
+    __shared__ float tile[(B0_TR + 2) * (B0_MAXF + 2)];
+    __shared__ float red[4][B0_NP];
+    __shared__ float kred[4];
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int PW = F + 2, ntiles = B * tiles_t;
+    const int To = T / 2, Fo = F / 2, tpr = Fo / 4;
+    // ---- centring constant: mean of a sample of this workgroup's first tile (any value is exact; a good one keeps S1 small) ----
+    float k;
+    {
+        const int tl = blockIdx.x, b = tl / tiles_t, t0 = (tl - b * tiles_t) * B0_TR;
+        float s = 0.f;
+        int n = 0;
+        for (int idx = threadIdx.x; idx < B0_TR * F; idx += 256 * 2) {
+            const int r = idx / F, f = idx - r * F, t = t0 + r;
+            if (t < T) { s += x[((size_t)b * T + t) * F + f]; ++n; }
+        }
+        float nf = (float)n;
+        s = wave_sum(s); nf = wave_sum(nf);
+        if (lane == 0) { kred[wv] = s; red[wv][0] = nf; }
+        __syncthreads();
+        const float tot = (kred[0] + kred[1]) + (kred[2] + kred[3]), cnt = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        k = cnt > 0.f ? tot / cnt : 0.f;
+        __syncthreads();
+    }
+    float wreg[4][9], breg[4], wa1[4], wb2[4], idb[4], mu[4], istd[4], gam4[4], bet4[4], bgr[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = 4 * g + c;
+        float ws = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 9; ++kk) { wreg[c][kk] = W[ch * 9 + kk]; ws += wreg[c][kk]; }
+        breg[c] = (bias ? bias[ch] : 0.f) + k * ws;             // conv over (x - k) + k sum(w) = conv over x
+        wa1[c] = Wg[i * C + ch];
+        wb2[c] = Wg[ch * C + i];
+        idb[c] = (ch == i) ? 1.0f : 0.0f;
+        mu[c] = stats[ch]; istd[c] = stats[C + ch];
+        gam4[c] = gamma[ch]; bet4[c] = beta[ch];
+        bgr[c] = bg[ch];
+    }
+    const float gam_i = gamma[i], bet_i = beta[i];
+    f32x4 P = {0.f, 0.f, 0.f, 0.f};
+    float a_dgam = 0.f, a_dbet = 0.f, a_dbg = 0.f, a_xh = 0.f, a_sx = 0.f, a_cnt = 0.f;
+    float S1[9], S2[9];
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) { S1[kk] = 0.f; S2[kk] = 0.f; }
+    const int w = i >> 2, q = i & 3;
+    const int ta = i < 9 ? i / 3 : 0, tb = i < 9 ? i - 3 * (i / 3) : 0;          // the tap whose Sx this lane accumulates (i < 9)
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int b = tl / tiles_t, t0 = (tl - b * tiles_t) * B0_TR;
+        __syncthreads();                                          // previous tile fully consumed
+        b0_stage(tile, x, bounds, b, t0, T, F, k);
+        __syncthreads();
+        for (int pr = wv; pr < B0_TR / 2; pr += 4) {
+            const int to = (t0 >> 1) + pr;
+            // T odd: floor-mode pooling drops frame T - 1.  It gets no gradient from above (dz = 0) but its dy is not zero -- the
+            // two batch means of the BatchNorm backward reach every pixel -- so it still enters Sx, S2 and sum(xhat).  It is
+            // walked as the top row of a window whose bottom row (frame T, outside the clip) is masked out.
+            const bool tail = (to == To) && (T & 1);
+            if (to >= To && !tail) break;
+            const int lr = 2 * pr + (q >> 1);
+            for (int tr = 0; tr < tpr; ++tr) {
+                const int col = 2 * (4 * tr + w) + (q & 1);
+                // ---- operand layout: lane = (pixel i, channel quad g) ----
+                float in[9];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 3; ++bb) in[a * 3 + bb] = tile[(lr + a) * PW + col + bb];
+                float xh[4], xn[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < 9; ++kk) acc = fmaf(in[kk], wreg[c][kk], acc);
+                    acc += breg[c];
+                    xh[c] = (acc - mu[c]) * istd[c];
+                    xn[c] = fmaf(xh[c], gam4[c], bet4[c]);
+                }
+                float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!tail) go = *(const float4*)(gout + (((size_t)b * To + to) * Fo + 4 * tr + w) * C + 4 * g);
+                f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc1 = mfma16(wa1[kk], xn[kk], acc1);   // lin^T: D[n = 4g+r][pixel i]
+                const float gv[4] = {go.x, go.y, go.z, go.w};
+                const size_t pix = ((size_t)b * T + t0 + lr) * F + col;
+                float dlin[4], e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float lin = acc1[r] + bgr[r];
+                    const float sg = sed_fast_sigmoid(xn[r]);
+                    const uint32_t ei = (uint32_t)(pix * C + 4 * g + r);
+                    const float gr = sed_keep(ei, seed, thr24) ? gv[r] * 0.25f * dscale : 0.f;
+                    dlin[r] = gr * sg;
+                    e[r] = gr * lin * sg * (1.0f - sg);
+                }
+                f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, accx = {0.f, 0.f, 0.f, 0.f}, accd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    acc2 = mfma16(dlin[kk], wb2[kk], acc2);       // dxn[pixel 4g+r][c = i] = dlin . Wg
+                    acc2 = mfma16(e[kk], idb[kk], acc2);          //                         + e
+                    accx = mfma16(xh[kk], idb[kk], accx);         // xhat  in accumulator layout
+                    accd = mfma16(dlin[kk], idb[kk], accd);       // dlin  in accumulator layout  [pixel 4g+r][n' = i]
+                }
+                // ---- accumulator layout: lane = (channel i, window g), r = pixel of the 2x2 window ----
+                // the window's four 3x3 neighbourhoods live in one 4x4 patch of the (centred) input tile
+                const float* prow = tile + (2 * pr) * PW + 2 * (4 * tr + g);
+                float patch[4][4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) patch[rr][cc] = prow[rr * PW + cc];
+                if (tail) { accx[2] = 0.f; accx[3] = 0.f; }      // pixels of frame T do not exist
+                float xnD[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dxn = acc2[r];
+                    a_dgam += dxn * accx[r];
+                    a_dbet += dxn;
+                    a_dbg += accd[r];
+                    a_xh += accx[r];
+                    const float dzr = dxn * gam_i;               // dL/d xhat of (pixel r of window g, channel i)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int bb = 0; bb < 3; ++bb) {
+                            const float xv = patch[(r >> 1) + a][(r & 1) + bb];
+                            S1[a * 3 + bb] = fmaf(xv, dzr, S1[a * 3 + bb]);
+                            S2[a * 3 + bb] = fmaf(xv, accx[r], S2[a * 3 + bb]);
+                        }
+                    xnD[r] = fmaf(accx[r], gam_i, bet_i);
+                }
+                // Sx: lanes i < 9 own tap (ta, tb); every lane group g covers its own window
+                a_sx += prow[ta * PW + tb] + prow[ta * PW + tb + 1];
+                if (!tail) a_sx += prow[(ta + 1) * PW + tb] + prow[(ta + 1) * PW + tb + 1];
+                a_cnt += tail ? 2.0f : 4.0f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) P = mfma16(accd[kk], xnD[kk], P);   // P[n' = 4g+r][c = i] += dlin[p][n'] xn[p][c]
+            }
+        }
+    }
+    // ---- per-workgroup partial record ----
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv][(4 * g + r) * C + i] = P[r];
+    a_dgam += __shfl_xor(a_dgam, 16); a_dgam += __shfl_xor(a_dgam, 32);
+    a_dbet += __shfl_xor(a_dbet, 16); a_dbet += __shfl_xor(a_dbet, 32);
+    a_dbg += __shfl_xor(a_dbg, 16); a_dbg += __shfl_xor(a_dbg, 32);
+    a_xh += __shfl_xor(a_xh, 16); a_xh += __shfl_xor(a_xh, 32);
+    a_sx += __shfl_xor(a_sx, 16); a_sx += __shfl_xor(a_sx, 32);
+    a_cnt += __shfl_xor(a_cnt, 16); a_cnt += __shfl_xor(a_cnt, 32);
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) {
+        float v1 = S1[kk], v2 = S2[kk];
+        v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
+        v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
+        if (g == 0) { red[wv][B0_O_S1 + i * 9 + kk] = v1; red[wv][B0_O_S2 + i * 9 + kk] = v2; }
+    }
+    if (g == 0) {
+        red[wv][B0_O_DBG + i] = a_dbg; red[wv][B0_O_DGAM + i] = a_dgam; red[wv][B0_O_DBET + i] = a_dbet; red[wv][B0_O_XH + i] = a_xh;
+        if (i < 9) red[wv][B0_O_SX + i] = a_sx;
+        if (i == 0) { red[wv][B0_O_CNT] = a_cnt; red[wv][B0_O_K] = 0.f; }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < B0_NP; idx += 256) {
+        float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+        if (idx == B0_O_K) v = k;
+        if (idx > B0_O_CNT) v = 0.f;
+        part[(size_t)blockIdx.x * B0_NP + idx] = v;
+    }
+}
+
+// sums[o] (double) = sum over the partial records, un-centred: S1 += k gamma_c dbeta_c, S2 += k sum(xhat_c), Sx += k n.
+// grid = ceil(B0_NSUM+2 / 64) workgroups of 1024 threads = 64 outputs x 16 walkers; fixed summation order.
+__global__ __launch_bounds__(1024) void block0_bwd_reduce_kernel(const float* __restrict__ part, int nparts,
+                                                                 const float* __restrict__ gamma, double* __restrict__ sums) {
+    __shared__ double red[16][64];
+    const int tid = threadIdx.x, col = tid & 63, grp = tid >> 6, o = blockIdx.x * 64 + col;
+    double acc = 0.0;
+    if (o < B0_NP) {
+        int o2 = -1;                                            // the companion column multiplied by k
+        float scale = 1.0f;
+        if (o >= B0_O_S1 && o < B0_O_S2) { const int c = (o - B0_O_S1) / 9; o2 = B0_O_DBET + c; scale = gamma[c]; }
+        else if (o >= B0_O_S2 && o < B0_O_XH) { const int c = (o - B0_O_S2) / 9; o2 = B0_O_XH + c; }
+        else if (o >= B0_O_SX && o < B0_O_K) o2 = B0_O_CNT;
+        for (int p = grp; p < nparts; p += 16) {
+            const float* rec = part + (size_t)p * B0_NP;
+            double v = (double)rec[o];
+            if (o2 >= 0) v += (double)rec[B0_O_K] * (double)scale * (double)rec[o2];
+            acc += v;
+        }
+    }
+    red[grp][col] = acc;
+    __syncthreads();
+    if (grp == 0 && o < B0_NP) {
+#pragma unroll
+        for (int gq = 1; gq < 16; ++gq) acc += red[gq][col];
+        sums[o] = acc;
+    }
+}
+
+// the six parameter gradients from the reduced sums
+__global__ __launch_bounds__(256) void block0_bwd_final_kernel(const double* __restrict__ sums, const float* __restrict__ stats,
+                                                               const float* __restrict__ gamma, float* __restrict__ dW,
+                                                               float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ dWg,
+                                                               float* __restrict__ dbg, double count) {
+    constexpr int C = 16;
+    const int tid = threadIdx.x;
+    dWg[tid] = (float)sums[tid];                                  // 256 threads = the 16 x 16 GLU weight gradient
+    if (tid < C) {
+        dbg[tid] = (float)sums[B0_O_DBG + tid];
+        dgamma[tid] = (float)sums[B0_O_DGAM + tid];
+        dbeta[tid] = (float)sums[B0_O_DBET + tid];
+        if (dbias) dbias[tid] = 0.f;                              // analytically zero under training-mode BatchNorm
+    }
+    if (tid < C * 9) {
+        const int c = tid / 9, tap = tid - 9 * c;
+        const double g = (double)gamma[c], is = (double)stats[C + c];
+        const double m1 = g * sums[B0_O_DBET + c] / count, m2 = g * sums[B0_O_DGAM + c] / count;
+        dW[tid] = (float)(is * (sums[B0_O_S1 + tid] - m1 * sums[B0_O_SX + tap] - m2 * sums[B0_O_S2 + tid]));
+    }
+}
+
+static inline int block0_bwd_grid(int B, int T) {
+    const int ntiles = B * ((T + B0_TR - 1) / B0_TR);
+    return ntiles < 1024 ? ntiles : 1024;
+}
+// floats of scratch: one partial record per workgroup + the reduced sums (doubles)
+extern "C" long long sed_block0_bwd_scratch_floats(int B, int T, int F) {
+    (void)F;
+    return (long long)block0_bwd_grid(B, T) * B0_NP + 2 * B0_NP + 2;
+}
+
+extern "C" int sed_block0_bwd(const float* x, const float* W, const float* bias, const int* bounds, const float* stats,
+                              const float* gamma, const float* beta, const float* Wg, const float* bg, const float* gout,
+                              float* dW, float* dbias, float* dgamma, float* dbeta, float* dWg, float* dbg, float* scratch, int B,
+                              int T, int F, unsigned seed, unsigned thr24, float dscale, const unsigned* seed_dev, void* stream) {
+    if (F > B0_MAXF || F < 8 || F % 8 != 0) return SED_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = block0_bwd_grid(B, T);
+    if (grid < 1 || T < 2) {
+        sed_zero4(s, dWg, 256, dW, 144, dgamma, 16, dbeta, 16);
+        sed_zero4(s, dbg, 16, dbias, dbias ? 16 : 0, nullptr, 0, nullptr, 0);
+        return sed_check_launch();
+    }
+    if (!scratch) return SED_ERR_ARG;
+    const int tiles_t = (T + B0_TR - 1) / B0_TR;
+    float* part = scratch;
+    size_t off = (size_t)grid * B0_NP;
+    off += off & 1;                                               // 8-byte alignment of the doubles
+    double* sums = (double*)(scratch + off);
+    SED_LAUNCH(block0_bwd_kernel, dim3(grid), dim3(256), 0, s, x, W, bias, bounds, stats, gamma, beta, Wg, bg, gout, part, B, T, F,
+               tiles_t, seed, thr24, dscale, seed_dev);
+    SED_LAUNCH(block0_bwd_reduce_kernel, dim3((B0_NP + 63) / 64), dim3(1024), 0, s, (const float*)part, grid, gamma, sums);
+    SED_LAUNCH(block0_bwd_final_kernel, dim3(1), dim3(256), 0, s, (const double*)sums, stats, gamma, dW, dbias, dgamma, dbeta, dWg, dbg,
+               (double)B * (double)T * (double)F);
+    return sed_check_launch();
+}

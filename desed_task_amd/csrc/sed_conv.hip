@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
                 s[c] += acc;
                 s2[c] += acc * acc;
             }
-            *(float4*)(y + (((size_t)b * T + t) * F + pc) * COUT + 4 * cq) = make_float4(o[0], o[1], o[2], o[3]);
+            if (y) *(float4*)(y + (((size_t)b * T + t) * F + pc) * COUT + 4 * cq) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
     if (partial) {
@@ -395,7 +395,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
             partial[(size_t)tid * (gridDim.x * gridDim.y) + (size_t)b * gridDim.x + blockIdx.x] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     }
 }
-// x (B,T,F) scaled log-mel; W (16,1,3,3) PyTorch layout; bounds (B,4) int32 or null.
+// x (B,T,F) scaled log-mel; W (16,1,3,3) PyTorch layout; bounds (B,4) int32 or null.  y null = statistics pass only (the
+// conv output stays in registers: first half of the fused first block, sed_block0.hip).
 extern "C" int sed_conv0_fwd(const float* x, const float* W, const float* bias, const int* bounds, float* y, float* partial,
                              int B, int T, int F, int COUT, void* stream) {
     if (COUT != 16 || F > 128 || F < 1) return SED_ERR_UNSUPPORTED;

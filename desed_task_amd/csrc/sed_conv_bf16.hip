@@ -70,11 +70,11 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(PackBJobs jobs) 
 }
 // Channels per weight chunk for a (CIN -> COUT) contraction: the packing and the kernel dispatch must agree, so both ask here.
 static inline int convb_ck(int CIN, int COUT) {
-    const char* e = getenv("SED_CONVB_CK");            // tuning override (tools/convb_mp_sweep.py)
+    const int e = sed_tuning[SED_TUNE_CONVB_CK];       // tuning override (tools/convb_mp_sweep.py)
     // 64 <-> 128 channels: 16-channel chunks halve the LDS stage (68 KB at 256 pixels) and fit 128 VGPRs, so two workgroups
     // share a CU: 72.8 -> 63.0 us (forward) and 63.3 -> 56.8 us (data gradient).  128 -> 128 gains nothing (59.6 vs 60.9 us).
     int ck = ((CIN == 64 && COUT == 128) || (CIN == 128 && COUT == 64)) ? 16 : 32;
-    if (e && CIN >= 32) ck = atoi(e) == 16 ? 16 : 32;
+    if (e && CIN >= 32) ck = e == 16 ? 16 : 32;
     return CIN < ck ? CIN : ck;
 }
 // n <= 8 layers; Wf / Wd buffers of 9*CIN*COUT*4 BYTES each (same size as the fp32 packs).
@@ -296,8 +296,8 @@ static int launch_convb(const float* x, const unsigned short* Wp, const float* b
 // kernel, so the per-step costs (weight-slab streaming, barrier) must be amortised over more pixels: 256-pixel tiles
 // (each wave 32 px x all couts) wherever that still leaves >= ~230 workgroups.
 static inline int convb_mp(int F, int CIN, int COUT) {
-    const char* e = getenv("SED_CONVB_MP");            // tuning override (tools/convb_mp_sweep.py)
-    if (e && COUT >= 64) return atoi(e);
+    const int e = sed_tuning[SED_TUNE_CONVB_MP];       // tuning override (tools/convb_mp_sweep.py)
+    if (e && COUT >= 64) return e;
     if (COUT < 64) return 128;
     if (CIN <= 32) return 128;          // one cin chunk: a 256-px patch + the 3-tap weight row leaves one workgroup per CU (44 vs 57 us)
     if (CIN == 128 && COUT == 128 && F <= 2) return 64;

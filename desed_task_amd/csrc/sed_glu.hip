@@ -722,7 +722,7 @@ __global__ __launch_bounds__(512, 4) void glu_wide_fwd_b_kernel(const float* __r
     }
 }
 
-// persistent-grid cap; SED_GLU_GRID_CAP (tests) forces several tiles per workgroup on small problems
+// persistent-grid cap; sed_set_tuning(SED_TUNE_GLU_GRID_CAP, n) (tests) forces several tiles per workgroup on small problems
 // zero the gradient rows of the frames that floor-mode time pooling drops: dz (B, T, F*C), rows [t0, T) of every clip
 __global__ __launch_bounds__(256) void glu_zero_tail_kernel(float* __restrict__ dz, long long n4, int T, int t0, int tail4,
                                                             long long clip4) {
@@ -732,8 +732,8 @@ __global__ __launch_bounds__(256) void glu_zero_tail_kernel(float* __restrict__ 
     }
 }
 static inline int glu_grid_cap(int dflt) {
-    const char* e = getenv("SED_GLU_GRID_CAP");
-    return e ? atoi(e) : dflt;
+    const int e = sed_tuning[SED_TUNE_GLU_GRID_CAP];
+    return e > 0 ? e : dflt;
 }
 template <int C, bool SPLIT>
 static int launch_glu_wide_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
@@ -1544,10 +1544,10 @@ extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamm
     if (F % PF != 0) return SED_ERR_UNSUPPORTED;
     if (PT == 1 && PF == 2) {
         // C = 128 stays on the exact-f32 kernel.  Both bf16 fragment sets of Wg are 128 VGPRs per wave with 32x32 tiles and the
-        // split kernel spills (208 vs 170 us at F = 16; SED_GLU_BWD128_SPLIT=1 selects it for A/B runs); a variant on the
+        // split kernel spills (208 vs 170 us at F = 16; sed_set_tuning(SED_TUNE_GLU_BWD128_SPLIT, 1) selects it for A/B runs); a variant on the
         // 16x16x32 MFMA (wave = 16 columns x all rows: 64 VGPRs of fragments) was measured too and lost as well (197 us):
         // the allocator still parked one fragment set in scratch and every wave re-reads the whole A tile from LDS.
-        if (C == 128 && split_bf16 && getenv("SED_GLU_BWD128_SPLIT") != nullptr)
+        if (C == 128 && split_bf16 && sed_tuning[SED_TUNE_GLU_BWD128_SPLIT] != 0)
             return launch_glu_wide_bwd<128, true>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
         if (C == 64 && split_bf16) return launch_glu_wide_bwd<64, true>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
         if (C == 128) return launch_glu_wide_bwd<128, false>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);

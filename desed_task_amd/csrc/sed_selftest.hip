@@ -2,6 +2,13 @@
 // C[32][32] = A[32][K] * B[K][32] via v_mfma_f32_32x32x2_f32, and the 16x16x4 analogue.
 #include "sed_common.h"
 
+int sed_tuning[SED_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int sed_set_tuning(int key, int value) {
+    if (key < 0 || key >= SED_TUNE_COUNT) return SED_ERR_ARG;
+    sed_tuning[key] = value;
+    return SED_OK;
+}
+
 __global__ __launch_bounds__(64) void selftest_mfma32_kernel(const float* A, const float* Bm, float* C, int K) {
     const int lane = threadIdx.x;
     f32x16 acc = f32x16_zero();

@@ -12,6 +12,7 @@ from . import graph as _graph
 
 BN_EPS = 1e-3        # desed_task/nnet/CNN.py:76
 BN_MOMENTUM = 0.99
+BLOCK0_FUSED = os.environ.get("SED_BLOCK0_FUSED", "1") != "0"     # first block without its pre-BN tensor in HBM (A/B switch)
 
 
 def gemm_entry(cfg, pair=True):
@@ -130,6 +131,33 @@ class ConvBlockFn(torch.autograd.Function):
         bounds = cfg.get("bounds") if first else None
         st = _lib.stream_ptr(x)
         dev = x.device
+        # First block, fused: its pre-BN tensor y (246 MB at B = 48) never exists in HBM -- statistics pass, then one kernel for
+        # conv + BN + GLU + dropout + pooling; the backward recomputes y from x (csrc/sed_block0.hip).  The unfused kernels stay
+        # for what the fused ones do not cover (other widths / poolings, gradients through eval-mode BatchNorm).
+        need_grad = any(ctx.needs_input_grad)
+        if (first and COUT == 16 and (PT, PF) == (2, 2) and F % 8 == 0 and 8 <= F <= 128 and cfg.get("block0_fused", BLOCK0_FUSED)
+                and (training or not need_grad)):
+            conv_w = conv_w.contiguous()
+            stats = torch.empty(4 * COUT, device=dev, dtype=torch.float32)
+            nblk, partial = 0, None
+            if training:
+                nblk = lib.value("sed_conv_fwd_blocks", B, T, F, CIN, COUT)
+                partial = torch.empty(nblk * 2 * COUT, device=dev, dtype=torch.float32)
+                lib.call("sed_conv0_fwd", x.data_ptr(), conv_w.data_ptr(), _p(conv_b), _p(bounds), None, partial.data_ptr(),
+                         B, T, F, COUT, st)
+            lib.call("sed_bn_finalize", _p(partial), nblk, COUT, float(B * T * F), bn_w.data_ptr(), bn_b.data_ptr(),
+                     running_mean.data_ptr(), running_var.data_ptr(), BN_MOMENTUM, BN_EPS, stats.data_ptr(), int(training),
+                     int(training and cfg.get("update_running", True)), st)
+            out = torch.empty(B, T // PT, F // PF, COUT, device=dev, dtype=torch.float32)
+            glu_w = glu_w.contiguous()
+            lib.call("sed_block0_fwd", x.data_ptr(), conv_w.data_ptr(), _p(conv_b), _p(bounds), stats.data_ptr(), glu_w.data_ptr(),
+                     glu_b.data_ptr(), out.data_ptr(), B, T, F, int(seed), thr24, dscale, _graph.seed_dev(seed), st)
+            ctx.save_for_backward(x, stats, conv_w, bn_w, bn_b, glu_w, glu_b, conv_b)
+            ctx.meta = (first, B, T, F, CIN, COUT, PT, PF, training, seed, thr24, dscale, bounds)
+            ctx.cfg = cfg
+            ctx.fused0 = True
+            return out
+        ctx.fused0 = False
         y = torch.empty(B, T, F, COUT, device=dev, dtype=torch.float32)
         bf16x3 = (not first) and cfg.get("conv_precision", "f32") == "bf16x3" and cfg.get("packed") is not None
         nblk = lib.value("sed_conv_fwd_blocks_bf16" if bf16x3 else "sed_conv_fwd_blocks", B, T, F, CIN, COUT)
@@ -162,6 +190,21 @@ class ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         lib = _lib.get()
+        if ctx.fused0:
+            x, stats, conv_w, bn_w, bn_b, glu_w, glu_b, conv_b = ctx.saved_tensors
+            first, B, T, F, CIN, COUT, PT, PF, training, seed, thr24, dscale, bounds = ctx.meta
+            cfg = ctx.cfg
+            gout = gout.contiguous()
+            st = _lib.stream_ptr(x)
+            d_w, d_bias = _grad_buf(cfg, conv_w), _grad_buf(cfg, conv_b)
+            d_gamma, d_beta = _grad_buf(cfg, bn_w), _grad_buf(cfg, bn_b)
+            d_glu_w, d_glu_b = _grad_buf(cfg, glu_w), _grad_buf(cfg, glu_b)
+            scratch = torch.empty(int(lib.value("sed_block0_bwd_scratch_floats", B, T, F)), device=x.device, dtype=torch.float32)
+            lib.call("sed_block0_bwd", x.data_ptr(), conv_w.data_ptr(), _p(conv_b), _p(bounds), stats.data_ptr(), bn_w.data_ptr(),
+                     bn_b.data_ptr(), glu_w.data_ptr(), glu_b.data_ptr(), gout.data_ptr(), d_w.data_ptr(), d_bias.data_ptr(),
+                     d_gamma.data_ptr(), d_beta.data_ptr(), d_glu_w.data_ptr(), d_glu_b.data_ptr(), scratch.data_ptr(), B, T, F,
+                     int(seed), thr24, dscale, _graph.seed_dev(seed), st)
+            return None, d_w, d_bias, d_gamma, d_beta, d_glu_w, d_glu_b, None, None, None
         x, y, stats, conv_w, bn_w, bn_b, glu_w, glu_b, conv_b = ctx.saved_tensors
         first, B, T, F, CIN, COUT, PT, PF, training, seed, thr24, dscale, bounds = ctx.meta
         gout = gout.contiguous()

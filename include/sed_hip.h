@@ -8,7 +8,8 @@
  * Conventions: every function returns 0 (SED_OK) or a negative error code, never throws, never
  * allocates or frees -- the caller (PyTorch) owns all buffers, including workspaces -- and is
  * asynchronous on `stream` (a hipStream_t passed as void*).  Pointers are device pointers.
- * Re-entrant across streams; no global mutable state.
+ * Re-entrant across streams; no global mutable state and no reads of the process environment (the only process-wide
+ * setting is the explicit tuning override of sed_set_tuning, used by tests and sweep tools).
  * Activation layout is channels-last: (B, T, F, C) fp32, T = time frames, F = mel bins.
  */
 #ifndef SED_HIP_H
@@ -93,9 +94,31 @@ int sed_conv3x3_bf16x3(const float* x, const void* Wp, const float* bias, float*
 int sed_conv_fwd_blocks_bf16(int B, int T, int F, int CIN, int COUT);   /* rows of `partial` for the bf16x3 forward */
 
 /* Layer 0 (CIN=1): direct conv with the SpecAugment predicate (CRNN.py:207-219) fused into the load.
- * x (B,T,F) scaled log-mel; W (16,1,3,3) PyTorch layout; bounds (B,4) int32 [f0,f1,t0,t1) or null. */
+ * x (B,T,F) scaled log-mel; W (16,1,3,3) PyTorch layout; bounds (B,4) int32 [f0,f1,t0,t1) or null.  y may be null: only the
+ * BatchNorm partial statistics are produced (first pass of the fused first block below). */
 int sed_conv0_fwd(const float* x, const float* W, const float* bias, const int* bounds, float* y, float* partial,
                   int B, int T, int F, int COUT, void* stream);
+
+/* ---- First block without its pre-BatchNorm tensor in HBM (CNN.py:66-98 for n_in_channel = 1, 16 filters, pooling (2,2)) ----
+ * The 246 MB conv output of block 0 (B = 48) is never written: it is recomputed from the 15 MB input wherever it is needed.
+ *   training forward : sed_conv0_fwd(y = NULL, partial) -> sed_bn_finalize -> sed_block0_fwd
+ *   eval forward     : sed_bn_finalize(training = 0)    -> sed_block0_fwd
+ *   training backward: sed_block0_bwd (all six parameter gradients of the block in one pass over x and gout)
+ * sed_block0_fwd: conv0 (SpecAugment predicate fused, as sed_conv0_fwd) + BN-apply + GLU + Dropout + AvgPool(2,2):
+ * x (B,T,F), W (16,1,3,3), stats from sed_bn_finalize -> out (B,T/2,F/2,16).  F % 8 == 0, F <= 128.  Dropout as sed_glu_fwd
+ * (element index of the (B,T,F,16) tensor: identical masks to the unfused path). */
+int sed_block0_fwd(const float* x, const float* W, const float* bias, const int* bounds, const float* stats, const float* Wg,
+                   const float* bg, float* out, int B, int T, int F, unsigned seed, unsigned thr24, float dscale,
+                   const unsigned* seed_dev, void* stream);
+/* Floats of scratch sed_block0_bwd needs (one partial record per workgroup + the reduced sums). */
+long long sed_block0_bwd_scratch_floats(int B, int T, int F);
+/* Backward of the whole first block under training-mode BatchNorm: gout (B,T/2,F/2,16) -> dW (16,1,3,3), dbias (16; analytically
+ * zero), dgamma, dbeta (16), dWg (16,16), dbg (16), all overwritten.  The weight gradient is assembled from raw correlations
+ * accumulated in the same pass (see sed_block0.hip); nothing of size B*T*F*16 is read or written. */
+int sed_block0_bwd(const float* x, const float* W, const float* bias, const int* bounds, const float* stats, const float* gamma,
+                   const float* beta, const float* Wg, const float* bg, const float* gout, float* dW, float* dbias, float* dgamma,
+                   float* dbeta, float* dWg, float* dbg, float* scratch, int B, int T, int F, unsigned seed, unsigned thr24,
+                   float dscale, const unsigned* seed_dev, void* stream);
 
 /* BatchNorm2d(eps=1e-3, momentum=0.99) statistics (CNN.py:76): reduce the partials (training) or read the
  * running stats (eval); stats = [mean | invstd | scale | shift] (4*C); updates running stats when asked. */
@@ -241,6 +264,12 @@ int sed_adam_step(float* p, const float* g, float* m, float* v, long long n, flo
 /* Zero up to four small accumulator buffers in one launch (null / 0 entries are skipped). */
 int sed_zero_buffers(float* p0, long long n0, float* p1, long long n1, float* p2, long long n2, float* p3, long long n3,
                      void* stream);
+
+/* Tuning overrides for tests / sweep tools (no reference counterpart): key 0 = persistent-grid cap of the wide GLU kernels,
+ * 1 = split-bf16 variant of the 128-channel GLU backward, 2 = channels per weight chunk of the split-bf16 conv (16|32),
+ * 3 = pixels per workgroup of the split-bf16 conv.  value 0 restores the built-in choice.  Not for use while kernels are in
+ * flight on other threads. */
+int sed_set_tuning(int key, int value);
 
 /* Hardware self-test of the MFMA lane maps (no reference counterpart): C = A[M][K] * B[K][M], M = shape (32|16). */
 int sed_selftest_mfma(const float* A, const float* Bm, float* C, int K, int shape, void* stream);

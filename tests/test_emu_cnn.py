@@ -26,7 +26,25 @@ def test_block_train_split_bf16(emu, layer, B, T, F):
 
 
 @pytest.mark.parametrize("layer,B,T,F", [(2, 2, 6, 32), (6, 2, 35, 2)])
-def test_block_persistent_tiles(emu, layer, B, T, F, monkeypatch):
+def test_block_persistent_tiles(emu, layer, B, T, F):
     """Wide GLU kernels with several tiles per workgroup: exercises the register prefetch of the next tile."""
-    monkeypatch.setenv("SED_GLU_GRID_CAP", "3")
-    P.case_cnn_block("cpu", layer, B, T, F, training=True, dropout_p=0.5)
+    from desed_task_amd import _lib
+    _lib.set_tuning("glu_grid_cap", 3)
+    try:
+        P.case_cnn_block("cpu", layer, B, T, F, training=True, dropout_p=0.5)
+    finally:
+        _lib.set_tuning("glu_grid_cap", 0)
+
+
+@pytest.mark.parametrize("B,T,F,fused", [(2, 37, 32, True), (1, 18, 8, True), (2, 6, 16, False), (3, 33, 16, True)])
+def test_first_block_fused_and_unfused(emu, B, T, F, fused):
+    """Block 0 through sed_block0_fwd / sed_block0_bwd (conv output recomputed, never stored) and through the unfused kernels:
+    odd frame counts, several 16-row tiles per clip, tiles shared by persistent workgroups."""
+    P.case_cnn_block("cpu", 0, B, T, F, training=True, dropout_p=0.5, block0_fused=fused)
+
+
+def test_first_block_fused_eval(emu):
+    import torch
+    with torch.no_grad():
+        pass
+    P.case_cnn_block("cpu", 0, 2, 21, 16, training=False, dropout_p=0.0)          # gradients through eval-mode BN: unfused path

@@ -1,4 +1,4 @@
-"""Tile-size sweep of the split-bf16 3x3 conv (SED_CONVB_MP override) over every forward / data-gradient shape of the recipe."""
+"""Tile-size sweep of the split-bf16 3x3 conv (sed_set_tuning overrides) over every forward / data-gradient shape of the recipe."""
 import os, sys
 sys.path.insert(0, '.')
 import torch
@@ -17,12 +17,12 @@ for (CIN, COUT, T, F) in shapes:
     st = torch.cuda.current_stream().cuda_stream
     res = []
     for ck, mp in (("32", "default"), ("32", "128"), ("32", "256"), ("16", "64"), ("16", "128"), ("16", "256")):
-        os.environ["SED_CONVB_CK"] = ck                 # the packing and the dispatch both read it
+        _lib.set_tuning("convb_ck", int(ck))            # the packing and the dispatch both read it
         (wf, wd), = pack_conv_weights([w], True, "bf16x3")
         if mp == "default":
-            os.environ.pop("SED_CONVB_MP", None)
+            _lib.set_tuning("convb_mp", 0)
         else:
-            os.environ["SED_CONVB_MP"] = mp
+            _lib.set_tuning("convb_mp", int(mp))
         def run():
             return lib.value("sed_conv3x3_bf16x3", x.data_ptr(), wf.data_ptr(), bias.data_ptr(), y.data_ptr(), partial.data_ptr(), B, T, F, CIN, COUT, st)
         if run() != 0:
