@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void block0_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ beta, const float* __restrict__ Wg,
                                                          const float* __restrict__ bg, const float* __restrict__ gout,
                                                          float* __restrict__ part, int B, int T, int F, int tiles_t, uint32_t seed,
-                                                         uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+                                                         uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev,
+                                                         int center) {
     if (seed_dev) seed += *seed_dev;
     constexpr int C = 16;
     __shared__ float tile[(B0_TR + 2) * (B0_MAXF + 2)];
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void block0_bwd_kernel(const float* __restrict
         if (lane == 0) { kred[wv] = s; red[wv][0] = nf; }
         __syncthreads();
         const float tot = (kred[0] + kred[1]) + (kred[2] + kred[3]), cnt = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-        k = cnt > 0.f ? tot / cnt : 0.f;
+        k = (center && cnt > 0.f) ? tot / cnt : 0.f;
         __syncthreads();
     }
     float wreg[4][9], breg[4], wa1[4], wb2[4], idb[4], mu[4], istd[4], gam4[4], bet4[4], bgr[4];
@@ -404,7 +405,7 @@ extern "C" int sed_block0_bwd(const float* x, const float* W, const float* bias,
     off += off & 1;                                               // 8-byte alignment of the doubles
     double* sums = (double*)(scratch + off);
     SED_LAUNCH(block0_bwd_kernel, dim3(grid), dim3(256), 0, s, x, W, bias, bounds, stats, gamma, beta, Wg, bg, gout, part, B, T, F,
-               tiles_t, seed, thr24, dscale, seed_dev);
+               tiles_t, seed, thr24, dscale, seed_dev, sed_tuning[SED_TUNE_B0_NOCENTER] ? 0 : 1);
     SED_LAUNCH(block0_bwd_reduce_kernel, dim3((B0_NP + 63) / 64), dim3(1024), 0, s, (const float*)part, grid, gamma, sums);
     SED_LAUNCH(block0_bwd_final_kernel, dim3(1), dim3(256), 0, s, (const double*)sums, stats, gamma, dW, dbias, dgamma, dbeta, dWg, dbg,
                (double)B * (double)T * (double)F);

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 for w in $what; do
 case $w in
-tests) timeout 1200 python -m pytest tests -m gpu -x -q -s 2>&1 | grep -v "^$" | tail -25 | cut -c1-400 | tee gpurun_out/tests_$tag.log ;;
+tests) timeout 1200 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "^$" | tail -25 | cut -c1-400 | tee gpurun_out/tests_$tag.log ;;
 bench) timeout 600 python bench.py 2>gpurun_out/bench_$tag.err | tail -1 > gpurun_out/bench_$tag.json; cut -c1-600 gpurun_out/bench_$tag.json; tail -3 gpurun_out/bench_$tag.err ;;
 benchq) timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>gpurun_out/bench_$tag.err | tail -1 > gpurun_out/bench_$tag.json; cut -c1-400 gpurun_out/bench_$tag.json; tail -3 gpurun_out/bench_$tag.err ;;
 trace) timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_$tag -o $tag -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_$tag.log 2>&1
