@@ -106,9 +106,7 @@ __global__ __launch_bounds__(256) void block0_fwd_kernel(const float* __restrict
                 float o = (acc[r] + bgr[r]) * sed_fast_sigmoid(xn[r]);
                 const uint32_t e = (uint32_t)(pix * C + 4 * g + r);
                 o = sed_keep(e, seed, thr24) ? o * dscale : 0.f;
-                o += __shfl_xor(o, 1);
-                o += __shfl_xor(o, 2);
-                v[r] = 0.25f * o;
+                v[r] = 0.25f * sed_quad_sum(o);
             }
             if (q == 0)
                 *(float4*)(out + (((size_t)b * To + to) * Fo + 4 * tr + w) * C + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
@@ -144,6 +142,8 @@ extern "C" int sed_block0_fwd(const float* x, const float* W, const float* bias,
 #define B0_NP 624
 #define B0_NSUM 617         // entries [0, 617) are sums over the workgroup's pixels
 
+#define B0_TS 20            // row pitch (floats) of the wave-private 16 x 16 transposition buffers: 16-byte rows, and the
+                            // strided reads of a lane group (rows 4g + kk, column i) fall into 16 distinct banks per group
 __global__ __launch_bounds__(256) void block0_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                          const float* __restrict__ bias, const int* __restrict__ bounds,
                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void block0_bwd_kernel(const float* __restrict
     constexpr int C = 16;
     __shared__ float tile[(B0_TR + 2) * (B0_MAXF + 2)];
     __shared__ float red[4][B0_NP];
+    __shared__ __attribute__((aligned(16))) float tbuf[4][2][16 * B0_TS];
     __shared__ float kred[4];
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     const int PW = F + 2, ntiles = B * tiles_t;
@@ -178,7 +179,12 @@ __global__ __launch_bounds__(256) void block0_bwd_kernel(const float* __restrict
         k = (center && cnt > 0.f) ? tot / cnt : 0.f;
         __syncthreads();
     }
-    float wreg[4][9], breg[4], wa1[4], wb2[4], idb[4], mu[4], istd[4], gam4[4], bet4[4], bgr[4];
+    // Everything up to the weight gradient stays in the OPERAND layout -- lane = (pixel i = 4 w + q, channel quad g), registers =
+    // the quad's four channels: conv0, BN, GEMM1 (lin^T = Wg xn^T), the gate epilogue, GEMM2 computed transposed (dxn^T = Wg^T dlin^T,
+    // so that it lands on the lane that holds xhat and e for the same pixel and channels), the BN reductions and the raw
+    // correlations S1 / S2 against the nine taps this lane already loaded for its convolution.  Only GEMM3 (dWg += dlin^T xn)
+    // contracts over pixels and needs channel-indexed lanes: dlin and xn go through a wave-private 16 x 16 LDS transposition.
+    float wreg[4][9], breg[4], wa1[4], wb2[4], mu[4], istd[4], gam4[4], bet4[4], bgr[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int ch = 4 * g + c;
@@ -186,21 +192,26 @@ __global__ __launch_bounds__(256) void block0_bwd_kernel(const float* __restrict
 #pragma unroll
         for (int kk = 0; kk < 9; ++kk) { wreg[c][kk] = W[ch * 9 + kk]; ws += wreg[c][kk]; }
         breg[c] = (bias ? bias[ch] : 0.f) + k * ws;             // conv over (x - k) + k sum(w) = conv over x
-        wa1[c] = Wg[i * C + ch];
-        wb2[c] = Wg[ch * C + i];
-        idb[c] = (ch == i) ? 1.0f : 0.0f;
+        wa1[c] = Wg[i * C + ch];                                // GEMM1:  A[n = i][c = 4g + kk]
+        wb2[c] = Wg[ch * C + i];                                // GEMM2^T: A[c = i][n = 4g + kk]
         mu[c] = stats[ch]; istd[c] = stats[C + ch];
         gam4[c] = gamma[ch]; bet4[c] = beta[ch];
         bgr[c] = bg[ch];
     }
-    const float gam_i = gamma[i], bet_i = beta[i];
     f32x4 P = {0.f, 0.f, 0.f, 0.f};
-    float a_dgam = 0.f, a_dbet = 0.f, a_dbg = 0.f, a_xh = 0.f, a_sx = 0.f, a_cnt = 0.f;
-    float S1[9], S2[9];
+    float a_dgam[4], a_dbet[4], a_dbg[4], a_xh[4], a_sx[9], a_cnt = 0.f;
+    float S1[4][9], S2[4][9];
 #pragma unroll
-    for (int kk = 0; kk < 9; ++kk) { S1[kk] = 0.f; S2[kk] = 0.f; }
+    for (int c = 0; c < 4; ++c) {
+        a_dgam[c] = 0.f; a_dbet[c] = 0.f; a_dbg[c] = 0.f; a_xh[c] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 9; ++kk) { S1[c][kk] = 0.f; S2[c][kk] = 0.f; }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 9; ++kk) a_sx[kk] = 0.f;
     const int w = i >> 2, q = i & 3;
-    const int ta = i < 9 ? i / 3 : 0, tb = i < 9 ? i - 3 * (i / 3) : 0;          // the tap whose Sx this lane accumulates (i < 9)
+    float* t1 = tbuf[wv][0];
+    float* t2 = tbuf[wv][1];
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const int b = tl / tiles_t, t0 = (tl - b * tiles_t) * B0_TR;
         __syncthreads();                                          // previous tile fully consumed
@@ -214,9 +225,9 @@ __global__ __launch_bounds__(256) void block0_bwd_kernel(const float* __restrict
             const bool tail = (to == To) && (T & 1);
             if (to >= To && !tail) break;
             const int lr = 2 * pr + (q >> 1);
+            const float vm = (tail && (q >> 1)) ? 0.f : 1.f;      // this lane's pixel exists
             for (int tr = 0; tr < tpr; ++tr) {
                 const int col = 2 * (4 * tr + w) + (q & 1);
-                // ---- operand layout: lane = (pixel i, channel quad g) ----
                 float in[9];
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(256) void block0_bwd_kernel(const float* __restrict
 #pragma unroll
                     for (int kk = 0; kk < 9; ++kk) acc = fmaf(in[kk], wreg[c][kk], acc);
                     acc += breg[c];
-                    xh[c] = (acc - mu[c]) * istd[c];
+                    xh[c] = (acc - mu[c]) * istd[c] * vm;
                     xn[c] = fmaf(xh[c], gam4[c], bet4[c]);
                 }
                 float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -249,71 +260,69 @@ __global__ __launch_bounds__(256) void block0_bwd_kernel(const float* __restrict
                     dlin[r] = gr * sg;
                     e[r] = gr * lin * sg * (1.0f - sg);
                 }
-                f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, accx = {0.f, 0.f, 0.f, 0.f}, accd = {0.f, 0.f, 0.f, 0.f};
+                // wave-private transposition of dlin and xn for GEMM3 (written now, read after GEMM2)
+                sed_wave_sync();                                  // the previous iteration's reads are done
+                *(float4*)(t1 + i * B0_TS + 4 * g) = make_float4(dlin[0], dlin[1], dlin[2], dlin[3]);
+                *(float4*)(t2 + i * B0_TS + 4 * g) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+                f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    acc2 = mfma16(dlin[kk], wb2[kk], acc2);       // dxn[pixel 4g+r][c = i] = dlin . Wg
-                    acc2 = mfma16(e[kk], idb[kk], acc2);          //                         + e
-                    accx = mfma16(xh[kk], idb[kk], accx);         // xhat  in accumulator layout
-                    accd = mfma16(dlin[kk], idb[kk], accd);       // dlin  in accumulator layout  [pixel 4g+r][n' = i]
-                }
-                // ---- accumulator layout: lane = (channel i, window g), r = pixel of the 2x2 window ----
-                // the window's four 3x3 neighbourhoods live in one 4x4 patch of the (centred) input tile
-                const float* prow = tile + (2 * pr) * PW + 2 * (4 * tr + g);
-                float patch[4][4];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) patch[rr][cc] = prow[rr * PW + cc];
-                if (tail) { accx[2] = 0.f; accx[3] = 0.f; }      // pixels of frame T do not exist
-                float xnD[4];
+                for (int kk = 0; kk < 4; ++kk) acc2 = mfma16(wb2[kk], dlin[kk], acc2);  // dxn^T: D[c = 4g+r][pixel i]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float dxn = acc2[r];
-                    a_dgam += dxn * accx[r];
-                    a_dbet += dxn;
-                    a_dbg += accd[r];
-                    a_xh += accx[r];
-                    const float dzr = dxn * gam_i;               // dL/d xhat of (pixel r of window g, channel i)
+                    const float dxn = acc2[r] + e[r];
+                    a_dgam[r] = fmaf(dxn, xh[r], a_dgam[r]);
+                    a_dbet[r] += dxn;
+                    a_dbg[r] += dlin[r];
+                    a_xh[r] += xh[r];
+                    const float dzr = dxn * gam4[r];              // dL/d xhat of (pixel i, channel 4g + r)
 #pragma unroll
-                    for (int a = 0; a < 3; ++a)
-#pragma unroll
-                        for (int bb = 0; bb < 3; ++bb) {
-                            const float xv = patch[(r >> 1) + a][(r & 1) + bb];
-                            S1[a * 3 + bb] = fmaf(xv, dzr, S1[a * 3 + bb]);
-                            S2[a * 3 + bb] = fmaf(xv, accx[r], S2[a * 3 + bb]);
-                        }
-                    xnD[r] = fmaf(accx[r], gam_i, bet_i);
+                    for (int kk = 0; kk < 9; ++kk) {
+                        S1[r][kk] = fmaf(in[kk], dzr, S1[r][kk]);
+                        S2[r][kk] = fmaf(in[kk], xh[r], S2[r][kk]);
+                    }
                 }
-                // Sx: lanes i < 9 own tap (ta, tb); every lane group g covers its own window
-                a_sx += prow[ta * PW + tb] + prow[ta * PW + tb + 1];
-                if (!tail) a_sx += prow[(ta + 1) * PW + tb] + prow[(ta + 1) * PW + tb + 1];
-                a_cnt += tail ? 2.0f : 4.0f;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) P = mfma16(accd[kk], xnD[kk], P);   // P[n' = 4g+r][c = i] += dlin[p][n'] xn[p][c]
+                for (int kk = 0; kk < 9; ++kk) a_sx[kk] = fmaf(in[kk], vm, a_sx[kk]);
+                a_cnt += vm;
+                sed_wave_sync();
+                float dT[4], xT[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { dT[kk] = t1[(4 * g + kk) * B0_TS + i]; xT[kk] = t2[(4 * g + kk) * B0_TS + i]; }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) P = mfma16(dT[kk], xT[kk], P);   // P[n' = 4g+r][c = i] += dlin[p][n'] xn[p][c]
             }
         }
     }
-    // ---- per-workgroup partial record ----
+    // ---- per-workgroup partial record: sum the 16 pixel lanes of every channel quad, then the four waves ----
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wv][(4 * g + r) * C + i] = P[r];
-    a_dgam += __shfl_xor(a_dgam, 16); a_dgam += __shfl_xor(a_dgam, 32);
-    a_dbet += __shfl_xor(a_dbet, 16); a_dbet += __shfl_xor(a_dbet, 32);
-    a_dbg += __shfl_xor(a_dbg, 16); a_dbg += __shfl_xor(a_dbg, 32);
-    a_xh += __shfl_xor(a_xh, 16); a_xh += __shfl_xor(a_xh, 32);
-    a_sx += __shfl_xor(a_sx, 16); a_sx += __shfl_xor(a_sx, 32);
-    a_cnt += __shfl_xor(a_cnt, 16); a_cnt += __shfl_xor(a_cnt, 32);
 #pragma unroll
-    for (int kk = 0; kk < 9; ++kk) {
-        float v1 = S1[kk], v2 = S2[kk];
-        v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
-        v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
-        if (g == 0) { red[wv][B0_O_S1 + i * 9 + kk] = v1; red[wv][B0_O_S2 + i * 9 + kk] = v2; }
+    for (int m = 1; m <= 8; m <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            a_dgam[c] += __shfl_xor(a_dgam[c], m); a_dbet[c] += __shfl_xor(a_dbet[c], m);
+            a_dbg[c] += __shfl_xor(a_dbg[c], m); a_xh[c] += __shfl_xor(a_xh[c], m);
+#pragma unroll
+            for (int kk = 0; kk < 9; ++kk) { S1[c][kk] += __shfl_xor(S1[c][kk], m); S2[c][kk] += __shfl_xor(S2[c][kk], m); }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 9; ++kk) a_sx[kk] += __shfl_xor(a_sx[kk], m);
+        a_cnt += __shfl_xor(a_cnt, m);
     }
-    if (g == 0) {
-        red[wv][B0_O_DBG + i] = a_dbg; red[wv][B0_O_DGAM + i] = a_dgam; red[wv][B0_O_DBET + i] = a_dbet; red[wv][B0_O_XH + i] = a_xh;
-        if (i < 9) red[wv][B0_O_SX + i] = a_sx;
-        if (i == 0) { red[wv][B0_O_CNT] = a_cnt; red[wv][B0_O_K] = 0.f; }
+    if (i == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ch = 4 * g + c;
+            red[wv][B0_O_DBG + ch] = a_dbg[c]; red[wv][B0_O_DGAM + ch] = a_dgam[c]; red[wv][B0_O_DBET + ch] = a_dbet[c];
+            red[wv][B0_O_XH + ch] = a_xh[c];
+#pragma unroll
+            for (int kk = 0; kk < 9; ++kk) { red[wv][B0_O_S1 + ch * 9 + kk] = S1[c][kk]; red[wv][B0_O_S2 + ch * 9 + kk] = S2[c][kk]; }
+        }
+        if (g == 0) {                                             // every channel quad saw the same pixels: count them once
+#pragma unroll
+            for (int kk = 0; kk < 9; ++kk) red[wv][B0_O_SX + kk] = a_sx[kk];
+            red[wv][B0_O_CNT] = a_cnt; red[wv][B0_O_K] = 0.f;
+        }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < B0_NP; idx += 256) {
@@ -325,11 +334,12 @@ __global__ __launch_bounds__(256) void block0_bwd_kernel(const float* __restrict
 }
 
 // sums[o] (double) = sum over the partial records, un-centred: S1 += k gamma_c dbeta_c, S2 += k sum(xhat_c), Sx += k n.
-// grid = ceil(B0_NSUM+2 / 64) workgroups of 1024 threads = 64 outputs x 16 walkers; fixed summation order.
+// One workgroup per 32 outputs, 32 walkers per output (the launch is a latency chain of dependent loads: keep the walks short);
+// fixed summation order.
 __global__ __launch_bounds__(1024) void block0_bwd_reduce_kernel(const float* __restrict__ part, int nparts,
                                                                  const float* __restrict__ gamma, double* __restrict__ sums) {
-    __shared__ double red[16][64];
-    const int tid = threadIdx.x, col = tid & 63, grp = tid >> 6, o = blockIdx.x * 64 + col;
+    __shared__ double red[32][33];
+    const int tid = threadIdx.x, col = tid & 31, grp = tid >> 5, o = blockIdx.x * 32 + col;
     double acc = 0.0;
     if (o < B0_NP) {
         int o2 = -1;                                            // the companion column multiplied by k
@@ -337,18 +347,22 @@ __global__ __launch_bounds__(1024) void block0_bwd_reduce_kernel(const float* __
         if (o >= B0_O_S1 && o < B0_O_S2) { const int c = (o - B0_O_S1) / 9; o2 = B0_O_DBET + c; scale = gamma[c]; }
         else if (o >= B0_O_S2 && o < B0_O_XH) { const int c = (o - B0_O_S2) / 9; o2 = B0_O_XH + c; }
         else if (o >= B0_O_SX && o < B0_O_K) o2 = B0_O_CNT;
-        for (int p = grp; p < nparts; p += 16) {
-            const float* rec = part + (size_t)p * B0_NP;
-            double v = (double)rec[o];
-            if (o2 >= 0) v += (double)rec[B0_O_K] * (double)scale * (double)rec[o2];
-            acc += v;
+        if (o2 >= 0) {
+#pragma unroll 4
+            for (int p = grp; p < nparts; p += 32) {
+                const float* rec = part + (size_t)p * B0_NP;
+                acc += (double)rec[o] + (double)rec[B0_O_K] * (double)scale * (double)rec[o2];
+            }
+        } else {
+#pragma unroll 4
+            for (int p = grp; p < nparts; p += 32) acc += (double)part[(size_t)p * B0_NP + o];
         }
     }
     red[grp][col] = acc;
     __syncthreads();
     if (grp == 0 && o < B0_NP) {
 #pragma unroll
-        for (int gq = 1; gq < 16; ++gq) acc += red[gq][col];
+        for (int gq = 1; gq < 32; ++gq) acc += red[gq][col];
         sums[o] = acc;
     }
 }
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(256) void block0_bwd_final_kernel(const double* __r
 
 static inline int block0_bwd_grid(int B, int T) {
     const int ntiles = B * ((T + B0_TR - 1) / B0_TR);
-    return ntiles < 1024 ? ntiles : 1024;
+    return ntiles < 512 ? ntiles : 512;              // two workgroups per CU are resident (register-bound)
 }
 // floats of scratch: one partial record per workgroup + the reduced sums (doubles)
 extern "C" long long sed_block0_bwd_scratch_floats(int B, int T, int F) {
@@ -406,7 +420,7 @@ extern "C" int sed_block0_bwd(const float* x, const float* W, const float* bias,
     double* sums = (double*)(scratch + off);
     SED_LAUNCH(block0_bwd_kernel, dim3(grid), dim3(256), 0, s, x, W, bias, bounds, stats, gamma, beta, Wg, bg, gout, part, B, T, F,
                tiles_t, seed, thr24, dscale, seed_dev, sed_tuning[SED_TUNE_B0_NOCENTER] ? 0 : 1);
-    SED_LAUNCH(block0_bwd_reduce_kernel, dim3((B0_NP + 63) / 64), dim3(1024), 0, s, (const float*)part, grid, gamma, sums);
+    SED_LAUNCH(block0_bwd_reduce_kernel, dim3((B0_NP + 31) / 32), dim3(1024), 0, s, (const float*)part, grid, gamma, sums);
     SED_LAUNCH(block0_bwd_final_kernel, dim3(1), dim3(256), 0, s, (const double*)sums, stats, gamma, dW, dbias, dgamma, dbeta, dWg, dbg,
                (double)B * (double)T * (double)F);
     return sed_check_launch();

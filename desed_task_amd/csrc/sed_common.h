@@ -115,6 +115,19 @@ __device__ __forceinline__ void sed_sched_fence() {
 #endif
 }
 
+// Rendezvous of the 64 lanes of ONE wave around an exchange through wave-private LDS (a lane reads what another lane of its
+// own wave wrote).  The LDS pipeline executes a wave's DS instructions in issue order, so no hardware barrier is needed: the
+// fence only keeps the compiler from moving the accesses across it.  (A workgroup barrier cannot be used where waves run
+// different trip counts.)
+__device__ __forceinline__ void sed_wave_sync() {
+#ifdef SED_EMU
+    emu_wave_sync();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+
 // Two values at once -> packed bf16 pairs (low half = a): hi = (bf16(a), bf16(b)), lo = bf16 of the exact remainders.
 // gfx950 converts a pair with one v_cvt_pk_bf16_f32 (RNE, same rounding as f32_to_bf16): 5 VALU ops per pair instead of ~24.
 __device__ __forceinline__ void bf16_split2(float a, float b, unsigned& hi, unsigned& lo) {
@@ -139,6 +152,31 @@ __device__ __forceinline__ f32x16 f32x16_zero() {
 #pragma unroll
     for (int i = 0; i < 16; ++i) z[i] = 0.f;
     return z;
+}
+
+// ---- quad exchanges on the DPP path ------------------------------------------------------------------
+// __shfl_xor(v, 1 | 2) compiles to ds_bpermute_b32 -- a round trip through the LDS crossbar (~100+ cycles of latency, LDS issue
+// slots) -- even though the partner sits in the same quad.  quad_perm DPP moves the value inside the VALU: [1,0,3,2] = 0xB1 for
+// lane ^ 1, [2,3,0,1] = 0x4E for lane ^ 2.  These sit on the dependent chain of every GRU step.
+__device__ __forceinline__ float sed_quad_xor1(float v) {
+#ifdef SED_EMU
+    return __shfl_xor(v, 1);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+#endif
+}
+__device__ __forceinline__ float sed_quad_xor2(float v) {
+#ifdef SED_EMU
+    return __shfl_xor(v, 2);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+#endif
+}
+// sum over the four lanes of a quad, result in all four
+__device__ __forceinline__ float sed_quad_sum(float v) {
+    v += sed_quad_xor1(v);
+    v += sed_quad_xor2(v);
+    return v;
 }
 
 // ---- wave / block reductions -------------------------------------------------------------------

@@ -208,9 +208,7 @@ __global__ __launch_bounds__(256) void glu16_fwd_kernel(const float* __restrict_
             float o = (acc[r] + bgr[r]) * sed_fast_sigmoid(xn[r]);
             const uint32_t e = (uint32_t)(pix * C + 4 * g + r);
             o = sed_keep(e, seed, thr24) ? o * dscale : 0.f;
-            o += __shfl_xor(o, 1);
-            o += __shfl_xor(o, 2);
-            v[r] = 0.25f * o;
+            v[r] = 0.25f * sed_quad_sum(o);
         }
         if (q == 0)
             *(float4*)(out + (((size_t)b * To + to) * Fo + 4 * tr + w) * C + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
@@ -358,9 +356,7 @@ __global__ __launch_bounds__(256) void glu32_fwd_kernel(const float* __restrict_
             float o = (acc[r] + bgr[r]) * sed_fast_sigmoid(xn[r]);
             const uint32_t e = (uint32_t)(pix * C + glu32_ch(r, hi));
             o = sed_keep(e, seed, thr24) ? o * dscale : 0.f;
-            o += __shfl_xor(o, 1);
-            o += __shfl_xor(o, 2);
-            v[r] = 0.25f * o;
+            v[r] = 0.25f * sed_quad_sum(o);
         }
         if (q == 0) {
             float* dst = out + (((size_t)b * To + to) * Fo + 8 * tr + w) * C + 4 * hi;

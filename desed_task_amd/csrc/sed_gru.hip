@@ -412,8 +412,7 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __res
             }
             if (GRU_ACC6) { pr += qr; pz += qz; pn += qn; }
             float ar = pr.x + pr.y, az = pz.x + pz.y, an = pn.x + pn.y;
-            ar += __shfl_xor(ar, 1); az += __shfl_xor(az, 1); an += __shfl_xor(an, 1);
-            ar += __shfl_xor(ar, 2); az += __shfl_xor(az, 2); an += __shfl_xor(an, 2);
+            ar = sed_quad_sum(ar); az = sed_quad_sum(az); an = sed_quad_sum(an);      // the four K-quarters (DPP, not ds_bpermute)
             const float r = GRU_NOTRANS ? (gr + ar + br) * 0.01f : sed_fast_sigmoid(gr + ar + br);
             const float z = GRU_NOTRANS ? (gz + az + bz) * 0.01f : sed_fast_sigmoid(gz + az + bz);
             const float hn = an + bn;
@@ -583,8 +582,7 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __res
                 p0 = pk_fma(wr[2 * q4 + 1], a1, p0); p1 = pk_fma(wz[2 * q4 + 1], c1, p1); p2 = pk_fma(wn[2 * q4 + 1], d1, p2);
             }
             float acc = ((p0.x + p0.y) + (p1.x + p1.y)) + (p2.x + p2.y);
-            acc += __shfl_xor(acc, 1);
-            acc += __shfl_xor(acc, 2);
+            acc = sed_quad_sum(acc);
             dh_carry = dh * z + acc;
             cur ^= 1;
         }

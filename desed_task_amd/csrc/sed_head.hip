@@ -60,8 +60,8 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            l1[c] += __shfl_xor(l1[c], 1); l1[c] += __shfl_xor(l1[c], 2);
-            l2[c] += __shfl_xor(l2[c], 1); l2[c] += __shfl_xor(l2[c], 2);
+            l1[c] = sed_quad_sum(l1[c]);
+            l2[c] = sed_quad_sum(l2[c]);
         }
         if (live && q == 0) {
 #pragma unroll

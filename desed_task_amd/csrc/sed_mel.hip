@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
                 const float* w = fb_w + (size_t)m * fb_stride;
                 for (int i = half; i < ln; i += 2) acc = fmaf(w[i], mag[st + i], acc);
             }
-            acc += __shfl_xor(acc, 1);
+            acc += sed_quad_xor1(acc);
             if (m < n_mels && half == 0) {
                 float v = acc;
                 if (LOG) {
