@@ -201,3 +201,28 @@ extern "C" int sed_weak_labels(const float* labels, float* out, int n, int NC, i
     SED_LAUNCH(weak_labels_kernel, dim3((n * NC + 3) / 4), dim3(256), 0, (hipStream_t)stream, labels, out, n * NC, T);
     return sed_check_launch();
 }
+
+// ---- dropstep_recurrent without embeddings (desed_task/nnet/CRNN.py:296-301) -------------------------------------------------
+// y = dropout(time_mask(x)) on (B,T,C): frames [t0, t1) of clip b are zeroed (bounds (B,2) int32 or null), then the usual
+// counter-hash dropout over the element index.  The operator is diagonal: the backward is the same launch on the gradient.
+__global__ __launch_bounds__(256) void dropstep_kernel(const float* __restrict__ x, float* __restrict__ y, const int* __restrict__ tb,
+                                                       int T, int C, size_t n, uint32_t seed, uint32_t thr24, float dscale,
+                                                       const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t m = i / C;
+        const int b = (int)(m / T), t = (int)(m - (size_t)b * T);
+        const bool gone = tb && t >= tb[2 * b] && t < tb[2 * b + 1];
+        y[i] = (!gone && sed_keep((uint32_t)i, seed, thr24)) ? x[i] * dscale : 0.f;
+    }
+}
+extern "C" int sed_dropstep(const float* x, float* y, const int* bounds, int B, int T, int C, unsigned seed, unsigned thr24,
+                            float dscale, const unsigned* seed_dev, void* stream) {
+    if (B <= 0 || T <= 0 || C <= 0) return SED_OK;
+    const size_t n = (size_t)B * T * C;
+    if (n >= (1ull << 32)) return SED_ERR_UNSUPPORTED;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    SED_LAUNCH(dropstep_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, bounds, T, C, n, seed, thr24, dscale, seed_dev);
+    return sed_check_launch();
+}

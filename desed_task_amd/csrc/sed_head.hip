@@ -20,7 +20,9 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
                                                                 const float* __restrict__ b2, float* __restrict__ strong,
                                                                 float* __restrict__ psoft, float* __restrict__ weak,
                                                                 float* __restrict__ den, int T, uint32_t seed, uint32_t thr24,
-                                                                float dscale, const unsigned* __restrict__ seed_dev) {
+                                                                float dscale, const unsigned* __restrict__ seed_dev,
+                                                                const unsigned char* __restrict__ cvalid,
+                                                                const unsigned char* __restrict__ pad) {
     if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     constexpr int D = HEAD_D, FPP = HEAD_THREADS / 4;          // frames per pass
     __shared__ __attribute__((aligned(16))) float w1[NC * D];
@@ -66,6 +68,12 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
         if (live && q == 0) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) { l1[c] += b1[c]; l2[c] += b2[c]; }
+            // CRNN.py:160-166: padded frames and the classes a clip's data set does not annotate cannot be attended to
+            // (masked_fill(-1e30) before the class softmax; a fully masked frame therefore attends uniformly)
+            const bool padded = pad && pad[(size_t)b * T + t];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (padded || (cvalid && !cvalid[b * NC + c])) l2[c] = -1e30f;
             float mx = l2[0];
 #pragma unroll
             for (int c = 1; c < NC; ++c) mx = fmaxf(mx, l2[c]);
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
                 const float s = sed_sigmoid(l1[c]);
                 const float p = l2[c] * inv;
                 const float a = fminf(fmaxf(p, 1e-7f), 1.0f);
-                so[c] = s;
+                so[c] = (cvalid && !cvalid[b * NC + c]) ? 0.f : s;        // CRNN.py:173-175 (after the pooling below)
                 po[c] = p;
                 num[c] += s * a;
                 dn[c] += a;
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
         float n = 0.f, d = 0.f;
 #pragma unroll
         for (int w = 0; w < HEAD_THREADS / 64; ++w) { n += red[w][tid]; d += red[w][NC + tid]; }
-        weak[b * NC + tid] = n / d;
+        weak[b * NC + tid] = (cvalid && !cvalid[b * NC + tid]) ? 0.f : n / d;
         den[b * NC + tid] = d;
     }
 }
@@ -114,7 +122,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ den, const float* __restrict__ d_strong,
                                                        const float* __restrict__ d_weak, float* __restrict__ dx,
                                                        float* __restrict__ dW1, float* __restrict__ dW2, float* __restrict__ db1,
-                                                       float* __restrict__ db2, int T, uint32_t seed, uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+                                                       float* __restrict__ db2, int T, uint32_t seed, uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev,
+                                                       const unsigned char* __restrict__ cvalid, const unsigned char* __restrict__ pad) {
     if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     constexpr int D = HEAD_D, TS = HEAD_TS;
     SED_DYN_SMEM(smem);
@@ -132,12 +141,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             const size_t bt = (size_t)b * T + t;
             float g1[NC], g2[NC];
             float dot = 0.f;
+            const bool padded = pad && pad[bt];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
+                // masked outputs (strong and weak of an invalid class are constants 0) pass no gradient; the stored `strong`
+                // of such a class is the masked 0, its sigmoid is not needed: every term below carries a zero factor
+                const bool ok = !(cvalid && !cvalid[b * NC + c]);
                 const float s = strong[bt * NC + c], p = psoft[bt * NC + c];
                 const float a = fminf(fmaxf(p, 1e-7f), 1.0f);
-                const float dw = d_weak[b * NC + c], dd = den[b * NC + c], wk = weak[b * NC + c];
-                const float ds = d_strong[bt * NC + c] + dw * a / dd;
+                const float dw = ok ? d_weak[b * NC + c] : 0.f, dd = den[b * NC + c], wk = weak[b * NC + c];
+                const float ds = (ok ? d_strong[bt * NC + c] : 0.f) + dw * a / dd;
                 g1[c] = ds * s * (1.0f - s);
                 const float da = dw * (s - wk) / dd;
                 const float dp = (p >= 1e-7f && p <= 1.0f) ? da : 0.f;
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                g2[c] = psoft[bt * NC + c] * (g2[c] - dot);
+                g2[c] = padded ? 0.f : psoft[bt * NC + c] * (g2[c] - dot);     // filled logits are constants
                 if (q == 0) { dl[tl * 2 * NC + c] = g1[c]; dl[tl * 2 * NC + NC + c] = g2[c]; }
             }
             float* dr = dx + bt * D;
@@ -201,12 +214,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 
 extern "C" int sed_head_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, float* strong,
                             float* psoft, float* weak, float* den, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
-                            float dscale, const unsigned* seed_dev, void* stream) {
+                            float dscale, const unsigned* seed_dev, const unsigned char* classes_valid, const unsigned char* pad_mask,
+                            void* stream) {
     if (D != HEAD_D) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
     hipStream_t s = (hipStream_t)stream;
 #define HEAD_CASE(nc) \
-    if (NC == nc) { SED_LAUNCH((head_fwd_kernel<nc>), dim3(B), dim3(HEAD_THREADS), 0, s, x, W1, b1, W2, b2, strong, psoft, weak, den, T, seed, thr24, dscale, seed_dev); return sed_check_launch(); }
+    if (NC == nc) { SED_LAUNCH((head_fwd_kernel<nc>), dim3(B), dim3(HEAD_THREADS), 0, s, x, W1, b1, W2, b2, strong, psoft, weak, den, T, seed, thr24, dscale, seed_dev, classes_valid, pad_mask); return sed_check_launch(); }
     HEAD_CASE(10) HEAD_CASE(27)
 #undef HEAD_CASE
     return SED_ERR_UNSUPPORTED;
@@ -215,14 +229,15 @@ extern "C" int sed_head_fwd(const float* x, const float* W1, const float* b1, co
 extern "C" int sed_head_bwd(const float* x, const float* W1, const float* W2, const float* strong, const float* psoft,
                             const float* weak, const float* den, const float* d_strong, const float* d_weak, float* dx, float* dW1,
                             float* dW2, float* db1, float* db2, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
-                            float dscale, const unsigned* seed_dev, void* stream) {
+                            float dscale, const unsigned* seed_dev, const unsigned char* classes_valid, const unsigned char* pad_mask,
+                            void* stream) {
     if (D != HEAD_D) return SED_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     sed_zero4(s, dW1, NC * D, dW2, NC * D, db1, NC, db2, NC);
     if (B <= 0 || T <= 0) return SED_OK;
     const int smem = (2 * NC * D + HEAD_TS * 2 * NC) * 4;
 #define HEAD_CASE(nc) \
-    if (NC == nc) { SED_MAX_SMEM((head_bwd_kernel<nc>), smem); SED_LAUNCH((head_bwd_kernel<nc>), dim3((T + HEAD_TS - 1) / HEAD_TS, B), dim3(256), smem, s, x, W1, W2, strong, psoft, weak, den, d_strong, d_weak, dx, dW1, dW2, db1, db2, T, seed, thr24, dscale, seed_dev); return sed_check_launch(); }
+    if (NC == nc) { SED_MAX_SMEM((head_bwd_kernel<nc>), smem); SED_LAUNCH((head_bwd_kernel<nc>), dim3((T + HEAD_TS - 1) / HEAD_TS, B), dim3(256), smem, s, x, W1, W2, strong, psoft, weak, den, d_strong, d_weak, dx, dW1, dW2, db1, db2, T, seed, thr24, dscale, seed_dev, classes_valid, pad_mask); return sed_check_launch(); }
     HEAD_CASE(10) HEAD_CASE(27)
 #undef HEAD_CASE
     return SED_ERR_UNSUPPORTED;
@@ -243,19 +258,25 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
                                                    const float* __restrict__ labels, const float* __restrict__ labels_weak,
                                                    float* __restrict__ scalars, float* __restrict__ g_strong,
                                                    float* __restrict__ g_weak, int B, int T, int NC, int n_strong, int n_weak,
-                                                   float weight, const float* __restrict__ weight_dev, int selfsup_bce) {
+                                                   float weight, const float* __restrict__ weight_dev, int selfsup_bce,
+                                                   int selfsup_from, const unsigned char* __restrict__ valid) {
     if (weight_dev) weight = *weight_dev;       // consistency weight in device memory (hipGraph replays)
     // one workgroup per clip; the eight scalars (zeroed by the launcher) collect pre-scaled per-clip sums
     __shared__ float red[4][6];
     const int tid = threadIdx.x, b = blockIdx.x;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int ns_el = n_strong * T * NC, all_el = B * T * NC, clip_el = T * NC;
-    const float inv_bs = ns_el > 0 ? 1.0f / (float)ns_el : 0.f, inv_all = 1.0f / (float)all_el;
+    // selfsup_from: the consistency terms average over clips [selfsup_from, B) only (2024 recipe: everything but MAESTRO,
+    // dcase2024 sed_trainer_pretrained.py:337,399-406); valid (B,NC): labels of classes a clip's data set does not annotate
+    // count as 0 (:352-356)
+    const int ns_el = n_strong * T * NC, all_el = (B - selfsup_from) * T * NC, clip_el = T * NC;
+    const float inv_bs = ns_el > 0 ? 1.0f / (float)ns_el : 0.f, inv_all = all_el > 0 ? 1.0f / (float)all_el : 0.f;
+    const bool selfsup = b >= selfsup_from;
     for (int j = tid; j < clip_el; j += 256) {
         const int i = b * clip_el + j, c = j % NC, t = j / NC;
         const float s = strong_s[i], q = strong_t[i];
-        float g;
-        if (selfsup_bce) {      // self_sup_loss: bce (sed_trainer.py:99-100): BCELoss(student, teacher), teacher as the target
+        float g = 0.f;
+        if (!selfsup) {
+        } else if (selfsup_bce) {      // self_sup_loss: bce (sed_trainer.py:99-100): BCELoss(student, teacher), teacher as the target
             g = weight * (s - q) / fmaxf(s * (1.0f - s), 1e-12f) * inv_all;
             acc[4] += bce_term(s, q);
         } else {
@@ -264,20 +285,22 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
             acc[4] += d * d;
         }
         if (b < n_strong) {
-            const float y = labels[((size_t)b * NC + c) * T + t];
+            float y = labels[((size_t)b * NC + c) * T + t];
+            if (valid && !valid[b * NC + c]) y = 0.f;
             acc[0] += bce_term(s, y);
             acc[2] += bce_term(q, y);
             g += (s - y) / fmaxf(s * (1.0f - s), 1e-12f) * inv_bs;
         }
         g_strong[i] = g;
     }
-    const int nw_el = n_weak * NC, allw = B * NC;
-    const float inv_bw = nw_el > 0 ? 1.0f / (float)nw_el : 0.f, inv_allw = 1.0f / (float)allw;
+    const int nw_el = n_weak * NC, allw = (B - selfsup_from) * NC;
+    const float inv_bw = nw_el > 0 ? 1.0f / (float)nw_el : 0.f, inv_allw = allw > 0 ? 1.0f / (float)allw : 0.f;
     if (tid < NC) {
         const int c = tid, i = b * NC + c;
         const float s = weak_s[i], q = weak_t[i];
-        float g;
-        if (selfsup_bce) {
+        float g = 0.f;
+        if (!selfsup) {
+        } else if (selfsup_bce) {
             g = weight * (s - q) / fmaxf(s * (1.0f - s), 1e-12f) * inv_allw;
             acc[5] += bce_term(s, q);
         } else {
@@ -286,7 +309,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
             acc[5] += d * d;
         }
         if (b >= n_strong && b < n_strong + n_weak) {
-            const float y = labels_weak[(b - n_strong) * NC + c];
+            float y = labels_weak[(b - n_strong) * NC + c];
+            if (valid && !valid[b * NC + c]) y = 0.f;
             acc[1] += bce_term(s, y);
             acc[3] += bce_term(q, y);
             g += (s - y) / fmaxf(s * (1.0f - s), 1e-12f) * inv_bw;
@@ -315,10 +339,10 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
 extern "C" int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
                            const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
                            int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, int selfsup_bce,
-                           void* stream) {
-    if (B <= 0 || T <= 0 || NC <= 0 || NC > 256 || n_strong + n_weak > B) return SED_ERR_ARG;
+                           int selfsup_from, const unsigned char* valid, void* stream) {
+    if (B <= 0 || T <= 0 || NC <= 0 || NC > 256 || n_strong + n_weak > B || selfsup_from < 0 || selfsup_from > B) return SED_ERR_ARG;
     sed_zero4((hipStream_t)stream, scalars, 8, nullptr, 0, nullptr, 0, nullptr, 0);
     SED_LAUNCH(loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, strong_s, weak_s, strong_t, weak_t, labels, labels_weak,
-               scalars, g_strong, g_weak, B, T, NC, n_strong, n_weak, weight, weight_dev, selfsup_bce);
+               scalars, g_strong, g_weak, B, T, NC, n_strong, n_weak, weight, weight_dev, selfsup_bce, selfsup_from, valid);
     return sed_check_launch();
 }

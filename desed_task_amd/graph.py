@@ -45,8 +45,8 @@ def seed_dev(seed):
 
 class DynArgs:
     F_LOSS_W, F_EMA_ALPHA, F_EMA_OMA, F_ADAM_STEP, F_ADAM_IBC2, F_MIX_C0 = 0, 1, 2, 3, 4, 5   # float slots; {c, 1-c} per group
-    SEED0, N_SEEDS = 16, 32
-    PERM0, PERM_LEN, N_PERMS = 48, 64, 4
+    SEED0, N_SEEDS = 24, 40
+    PERM0, PERM_LEN, N_PERMS = 64, 64, 8            # 8 mixup sites: the 2024 step mixes 3 data sets x (features, embeddings)
 
     def __init__(self, device):
         n = self.PERM0 + self.PERM_LEN * self.N_PERMS

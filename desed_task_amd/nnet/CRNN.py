@@ -10,8 +10,13 @@ Embedding fusion: `use_embeddings=True, aggregation_type="poo
 configuration, CRNN.py:143-144, :283-296) is built: `cat_tf = Linear(C + embedding_size, C)` after the heads in the state
 dict, `forward(x, embeddings=emb (B, embedding_size, Te))`.
 
-Not built (they raise NotImplementedError): the other aggregation types (global / frame / interpolate), pad_mask,
-classes_mask, dropstep_recurrent, cnn_integration, multi-head nclass lists.
+Also built: `aggregation_type="interpolate"` (nearest-exact, CRNN.py:271-279, the same fused kernel), `dropstep_recurrent`
+(CRNN.py:288-301: per-clip time spans of the recurrent stage's input zeroed, independently for the CNN features and the
+embeddings), `classes_mask` / `pad_mask` of the multi-data-set recipes (CRNN.py:157-176) inside the head kernels.
+
+Not built (they raise NotImplementedError): aggregation_type "frame" (a 512-unit BiGRU encoder over the embedding frames, used by
+no recipe configuration) and "global" (in the reference itself this branch ends in an undefined `reshape_emb`, CRNN.py:249-262 +
+:295), cnn_integration, multi-head nclass lists.
 """
 import copy
 
@@ -20,7 +25,7 @@ import torch.nn as nn
 
 from .. import features
 from ..arena import ParamArena
-from ..ops import EmbCatFn, HeadFn, new_seed
+from ..ops import DropStepFn, EmbCatFn, HeadFn, new_seed
 from .CNN import CNN
 from .RNN import BidirectionalGRU
 
@@ -32,10 +37,11 @@ class CRNN(nn.Module):
                  frame_emb_enc_dim=512, aggregation_type="global", specaugm_t_p=0.2, specaugm_t_l=5, specaugm_f_p=0.2,
                  specaugm_f_l=10, dropstep_recurrent=0.0, dropstep_recurrent_len=5, specaugm_iid_masks=True, **kwargs):
         super().__init__()
-        if cnn_integration or dropstep_recurrent:
-            raise NotImplementedError("cnn_integration / dropstep_recurrent are not built (SURVEY 8f)")
-        if use_embeddings and aggregation_type != "pool1d":
-            raise NotImplementedError("use_embeddings is built for aggregation_type 'pool1d' only (SURVEY 8f rank 3)")
+        if cnn_integration:
+            raise NotImplementedError("cnn_integration is not built (SURVEY 8f)")
+        if use_embeddings and aggregation_type not in ("pool1d", "interpolate"):
+            raise NotImplementedError("use_embeddings is built for aggregation_type 'pool1d' and 'interpolate' ('frame' needs a "
+                                      "512-unit BiGRU encoder no recipe uses; 'global' is broken in the reference itself)")
         if rnn_type != "BGRU":
             raise NotImplementedError("Only BGRU supported for CRNN for now")
         if isinstance(nclass, (tuple, list)):
@@ -141,30 +147,67 @@ class CRNN(nn.Module):
             raise NotImplementedError("CNN output keeps %d frequency bins; the recurrent stage expects 1" % freq)
         return h.view(bs, frames, chan)
 
-    def forward_tail(self, h, embeddings=None):
-        """Second half of forward(): [embedding fusion +] BiGRU + dropout + attention head.
+    def forward_tail(self, h, embeddings=None, pad_mask=None, classes_mask=None):
+        """Second half of forward(): [dropstep / embedding fusion +] BiGRU + dropout + attention head.
         (B, T', C) -> strong (B,nclass,T'), weak."""
         arena = self.arena
         if self.split_backward and h.requires_grad and torch.is_grad_enabled():
             cut = h.detach().requires_grad_(True)
             self._cnn_boundary = (h, cut)
             h = cut
+        B, Tp = h.shape[0], h.shape[1]
+        dropstep = bool(self.dropstep_recurrent) and self.training                 # CRNN.py:288, :296
         if self.use_embeddings:
             if embeddings is None:
                 raise ValueError("this CRNN was built with use_embeddings=True: forward() needs embeddings")
             if embeddings.requires_grad:
                 raise NotImplementedError("embeddings are frozen features here (pretrained.e2e / unfrozen extractors are not built)")
+            tmask = None
+            if dropstep:        # two independent TimeMasking draws: the CNN features first, then the embeddings (:292-293)
+                bx, be = self._dropstep_bounds(B, Tp, h.device), self._dropstep_bounds(B, Tp, h.device)
+                tmask = torch.cat((bx, be), 1).contiguous() if bx is not None else None
             drop = self.dropout.training and self.dropout_p > 0
-            cfg = dict(dropout_p=self.dropout_p, apply_dropout=drop, seed=new_seed() if drop else 0, arena=arena)
+            cfg = dict(dropout_p=self.dropout_p, apply_dropout=drop, seed=new_seed() if drop else 0, arena=arena, tmask=tmask,
+                       mode=1 if self.aggregation_type == "interpolate" else 0)
             h = EmbCatFn.apply(h, embeddings, self.cat_tf.weight, self.cat_tf.bias, cfg)
         elif embeddings is not None:
             raise ValueError("embeddings given to a CRNN built with use_embeddings=False")
+        elif dropstep:          # x = dropout(dropstep(x)) -- this branch of the reference drops out the GRU input too (:296-301)
+            drop = self.dropout.training and self.dropout_p > 0
+            cfg = dict(dropout_p=self.dropout_p, apply_dropout=drop, seed=new_seed() if drop else 0)
+            h = DropStepFn.apply(h, self._dropstep_bounds(B, Tp, h.device), cfg)
         h = self.rnn(h, arena=arena)                                      # (B, T', 256)
         drop = self.dropout.training and self.dropout_p > 0
-        cfg = dict(dropout_p=self.dropout_p, apply_dropout=drop, seed=new_seed() if drop else 0, arena=arena)
+        cfg = dict(dropout_p=self.dropout_p, apply_dropout=drop, seed=new_seed() if drop else 0, arena=arena,
+                   classes_valid=self._byte_mask(classes_mask, (B, self.nclass), "classes_mask"),
+                   pad_mask=self._byte_mask(pad_mask, (B, Tp), "pad_mask"))
         strong, weak = HeadFn.apply(h, self.dense.weight, self.dense.bias, self.dense_softmax.weight,
                                     self.dense_softmax.bias, cfg)
         return strong.transpose(1, 2), weak
+
+    def _dropstep_bounds(self, B, n_time, device):
+        """One torchaudio TimeMasking(dropstep_recurrent_len, iid_masks=True, p=dropstep_recurrent) draw over the frame axis
+        (CRNN.py:289-291) -> (B,2) int32 [t0, t1), or None when the mask cannot be longer than 0."""
+        if min(self.dropstep_recurrent_len, int(n_time * self.dropstep_recurrent)) < 1:
+            return None
+        b = features.specaug_bounds(B, 1, n_time, 0, 0.0, self.dropstep_recurrent_len, self.dropstep_recurrent, device,
+                                    iid_masks=self.specaugm_iid_masks)
+        return b[:, 2:4].contiguous()
+
+    @staticmethod
+    def _byte_mask(mask, shape, name):
+        """bool / 0-1 mask of the reference call (`classes_mask` (B,nclass): True = class annotated in the clip's data set;
+        `pad_mask` (B,1,T') or (B,T'): True = padded frame) -> contiguous uint8 tensor for the head kernels."""
+        if mask is None:
+            return None
+        m = mask
+        if name == "pad_mask" and m.dim() == 3:
+            if m.shape[1] != 1:
+                raise NotImplementedError("pad_mask must be (batch, 1, frames) or (batch, frames)")
+            m = m[:, 0]
+        if tuple(m.shape) != tuple(shape):
+            raise ValueError("%s has shape %s, expected %s" % (name, tuple(mask.shape), tuple(shape)))
+        return (m != 0).to(torch.uint8).contiguous()
 
     def backward_cnn(self):
         """Second half of a split backward (split_backward = True): the CNN's backward from the gradient that loss.backward()
@@ -174,9 +217,7 @@ class CRNN(nn.Module):
             b[0].backward(b[1].grad)
 
     def forward(self, x, pad_mask=None, embeddings=None, classes_mask=None):
-        if pad_mask is not None or classes_mask is not None:
-            raise NotImplementedError("pad_mask / classes_mask are not built (SURVEY 8f)")
-        return self.forward_tail(self.forward_cnn(x), embeddings)
+        return self.forward_tail(self.forward_cnn(x), embeddings, pad_mask, classes_mask)
 
     def train(self, mode=True):
         """Mirrors CRNN.train (CRNN.py:308-323), including that it returns None."""

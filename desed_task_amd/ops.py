@@ -356,12 +356,14 @@ class EmbCatFn(torch.autograd.Function):
         st = _lib.stream_ptr(x)
         f32 = dict(device=x.device, dtype=torch.float32)
         z = torch.empty(B, T, C + E, **f32)
+        tmask, mode = cfg.get("tmask"), int(cfg.get("mode", 0))       # dropstep_recurrent bounds (B,4) int32; 1 = "interpolate"
         lib.call("sed_embcat_fwd", x.data_ptr(), emb.data_ptr(), z.data_ptr(), B, T, Te, C, E, int(seed), thr24, dscale,
-                 _graph.seed_dev(seed), st)
+                 _graph.seed_dev(seed), _p(tmask), mode, st)
         y = torch.empty(B, T, C, **f32)
         lib.call(gemm_entry(cfg, pair=False), z.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B * T, C, C + E, C + E, C + E, C,
                  0, 1, 1, 0, st)
         ctx.save_for_backward(z, w, b)
+        ctx.tmask = tmask
         ctx.meta = (B, T, C, E, seed, thr24, dscale)
         ctx.cfg = cfg
         return y
@@ -381,13 +383,43 @@ class EmbCatFn(torch.autograd.Function):
             dzx = torch.empty(B, T, C, device=dy.device, dtype=torch.float32)
             lib.call(entry, dy.data_ptr(), w.data_ptr(), None, dzx.data_ptr(), M, C, C, C, W, C, 0, 0, 1, 0, st)   # dy . W[:, :C]
             dx = torch.empty_like(dzx)
-            lib.call("sed_embcat_bwd", dzx.data_ptr(), dx.data_ptr(), M, C, E, int(seed), thr24, dscale, _graph.seed_dev(seed), st)
+            lib.call("sed_embcat_bwd", dzx.data_ptr(), dx.data_ptr(), M, C, E, int(seed), thr24, dscale, _graph.seed_dev(seed),
+                     _p(ctx.tmask), T, st)
         dw, db = _grad_buf(cfg, w), _grad_buf(cfg, b)
         split = max(1, min(32, M // 256))
         lib.call("sed_zero_buffers", dw.data_ptr(), dw.numel(), None, 0, None, 0, None, 0, st)             # split-K accumulates
         lib.call(entry, dy.data_ptr(), z.data_ptr(), None, dw.data_ptr(), C, W, M, C, W, W, 1, 0, split, 0, st)  # dy^T . z
         lib.call("sed_colsum", dy.data_ptr(), db.data_ptr(), None, C, M, C, C, st)
         return dx, None, dw, db, None
+
+
+class DropStepFn(torch.autograd.Function):
+    """`dropstep_recurrent` of a CRNN without embeddings (CRNN.py:296-301): dropout(time_mask(x)) on (B,T,C) in one kernel.
+    bounds (B,2) int32 [t0, t1) or None."""
+
+    @staticmethod
+    def forward(ctx, x, bounds, cfg):
+        x = x.contiguous()
+        _lib.check_tensor(x, "dropstep input")
+        B, T, C = x.shape
+        thr24, dscale = dropout_params(cfg.get("dropout_p", 0.0) if cfg.get("apply_dropout", False) else 0.0)
+        seed = cfg.get("seed", 0)
+        seed = seed if isinstance(seed, _graph.DynSeed) else int(seed)
+        y = torch.empty_like(x)
+        _lib.get().call("sed_dropstep", x.data_ptr(), y.data_ptr(), _p(bounds), B, T, C, int(seed), thr24, dscale, _graph.seed_dev(seed),
+                        _lib.stream_ptr(x))
+        ctx.bounds = bounds
+        ctx.meta = (B, T, C, seed, thr24, dscale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, C, seed, thr24, dscale = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.get().call("sed_dropstep", dy.data_ptr(), dx.data_ptr(), _p(ctx.bounds), B, T, C, int(seed), thr24, dscale,
+                        _graph.seed_dev(seed), _lib.stream_ptr(dy))
+        return dx, None, None
 
 
 class HeadFn(torch.autograd.Function):
@@ -410,9 +442,11 @@ class HeadFn(torch.autograd.Function):
         weak = torch.empty(B, NC, **f32)
         den = torch.empty(B, NC, **f32)
         w1, w2 = w1.contiguous(), w2.contiguous()
+        cvalid, pad = cfg.get("classes_valid"), cfg.get("pad_mask")     # (B,NC) / (B,T) uint8 or None (CRNN.py:157-176)
         lib.call("sed_head_fwd", x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), strong.data_ptr(),
                  psoft.data_ptr(), weak.data_ptr(), den.data_ptr(), B, T, D, NC, int(seed), thr24, dscale, _graph.seed_dev(seed),
-                 _lib.stream_ptr(x))
+                 _p(cvalid), _p(pad), _lib.stream_ptr(x))
+        ctx.masks = (cvalid, pad)
         ctx.save_for_backward(x, w1, w2, strong, psoft, weak, den, b1, b2)
         ctx.meta = (B, T, D, NC, seed, thr24, dscale)
         ctx.cfg = cfg
@@ -432,7 +466,8 @@ class HeadFn(torch.autograd.Function):
         db1, db2 = _grad_buf(cfg, b1), _grad_buf(cfg, b2)
         lib.call("sed_head_bwd", x.data_ptr(), w1.data_ptr(), w2.data_ptr(), strong.data_ptr(), psoft.data_ptr(), weak.data_ptr(),
                  den.data_ptr(), d_strong.data_ptr(), d_weak.data_ptr(), dx.data_ptr(), dw1.data_ptr(), dw2.data_ptr(),
-                 db1.data_ptr(), db2.data_ptr(), B, T, D, NC, int(seed), thr24, dscale, _graph.seed_dev(seed), _lib.stream_ptr(x))
+                 db1.data_ptr(), db2.data_ptr(), B, T, D, NC, int(seed), thr24, dscale, _graph.seed_dev(seed), _p(ctx.masks[0]),
+                 _p(ctx.masks[1]), _lib.stream_ptr(x))
         return dx, dw1, db1, dw2, db2, None
 
 
@@ -441,10 +476,13 @@ class MeanTeacherLossFn(torch.autograd.Function):
     Returns (scalars, total): scalars (8,) = [bce_strong, bce_weak, bce_strong_teacher, bce_weak_teacher, mse_strong, mse_weak,
     weight * (mse_strong + mse_weak), total] (not differentiable) and total = bce_strong + bce_weak + weight * (mse_strong +
     mse_weak) as a 0-d differentiable tensor -- all computed by the kernel (no scalar tensor arithmetic on the host side).
-    selfsup_bce: slots 4 / 5 hold BCELoss(student, teacher) instead (`training.self_sup_loss: bce`)."""
+    selfsup_bce: slots 4 / 5 hold BCELoss(student, teacher) instead (`training.self_sup_loss: bce`).
+    selfsup_from / valid: the 2024 multi-data-set step -- consistency terms over clips [selfsup_from, B), labels of classes
+    outside a clip's data set (valid (B,NC) uint8 == 0) count as 0."""
 
     @staticmethod
-    def forward(ctx, strong_s, weak_s, strong_t, weak_t, labels, labels_weak, n_strong, n_weak, weight, selfsup_bce=False):
+    def forward(ctx, strong_s, weak_s, strong_t, weak_t, labels, labels_weak, n_strong, n_weak, weight, selfsup_bce=False,
+                selfsup_from=0, valid=None):
         lib = _lib.get()
         strong_s, weak_s = strong_s.contiguous(), weak_s.contiguous()
         strong_t, weak_t = strong_t.contiguous(), weak_t.contiguous()
@@ -457,7 +495,8 @@ class MeanTeacherLossFn(torch.autograd.Function):
         g_weak = torch.empty(B, NC, **f32)
         lib.call("sed_mt_loss", strong_s.data_ptr(), weak_s.data_ptr(), strong_t.data_ptr(), weak_t.data_ptr(), labels.data_ptr(),
                  labels_weak.data_ptr(), scalars.data_ptr(), g_strong.data_ptr(), g_weak.data_ptr(), B, T, NC, int(n_strong),
-                 int(n_weak), float(weight), getattr(weight, "dev", None), int(bool(selfsup_bce)), _lib.stream_ptr(strong_s))
+                 int(n_weak), float(weight), getattr(weight, "dev", None), int(bool(selfsup_bce)), int(selfsup_from), _p(valid),
+                 _lib.stream_ptr(strong_s))
         ctx.save_for_backward(g_strong, g_weak)
         ctx.mark_non_differentiable(scalars)
         return scalars, scalars[7].clone()
@@ -465,4 +504,4 @@ class MeanTeacherLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _g_scalars, g_total):
         g_strong, g_weak = ctx.saved_tensors
-        return g_strong * g_total, g_weak * g_total, None, None, None, None, None, None, None, None
+        return g_strong * g_total, g_weak * g_total, None, None, None, None, None, None, None, None, None, None

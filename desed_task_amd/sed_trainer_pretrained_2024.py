@@ -1,0 +1,118 @@
+"""Drop-in for the training step of the 2024 recipe's trainer, recipes/dcase2024_task4_baseline/local/sed_trainer_pretrained.py
+(SURVEY 8f rank 3): the mean-teacher step over FIVE data sets per batch -- [MAESTRO | synthetic | strong real | weak |
+unlabelled] -- with frozen embeddings, per-clip `valid_class_mask`, mixup inside each data set and consistency losses on
+everything but MAESTRO (:318-430).
+
+Same surface as the reference class for the step: constructor (with `pretrained_model`), `mel_spec`, `scaler`, `take_log`,
+`detect(mel_feats, model, embeddings=None, **kwargs)`, `apply_mixup`, `training_step`, the EMA / scheduler hooks and the nine
+logged keys.  Batches are `(audio, labels, padded_indxs, embeddings, valid_class_mask)` (:333-335).
+
+Reference behaviours kept on purpose: the labels of a data-set group are mixed TWICE when embeddings are present -- once with
+the features' (c, perm), once more with the embeddings' own draw (:283-301); the weak labels are derived after mixup (:354);
+`train/student/tot_supervised` logs the strong consistency loss (:415); the consistency weight stops ramping at
+`training.epoch_decay` (:393-396).
+
+Not built from this file: validation / test of the 2024 recipe (MAESTRO segment metrics, class-wise median filters, mpAUC) and
+`pretrained.e2e`; the recipe's `net.n_RNN_cell: 192` is outside what the HIP GRU kernel is built for (128 units) -- the CRNN
+constructor refuses it.
+"""
+import random
+
+import numpy as np
+import torch
+
+from . import features
+from . import graph as _graph
+from .data_augm import mixup_inplace_
+from .ops import MeanTeacherLossFn
+from .sed_trainer_pretrained import SEDTask4 as _SEDTask4
+
+
+class SEDTask4(_SEDTask4):
+    current_epoch = 0           # Lightning sets it on the real LightningModule; the stand-in base leaves it at 0
+
+    def detect(self, mel_feats, model, embeddings=None, **kwargs):
+        x = self.scaled_logmel(mel_feats)
+        if embeddings is None:
+            return model(x, **kwargs)
+        return model(x, embeddings=embeddings, **kwargs)
+
+    def _unpack_batch(self, batch):
+        if self.hparams["pretrained"]["e2e"]:
+            raise NotImplementedError                       # as the reference (:306-316)
+        if len(batch) != 5:
+            raise ValueError("the 2024 step expects batches (audio, labels, padded_indxs, embeddings, valid_class_mask)")
+        return batch
+
+    def apply_mixup(self, features_, embeddings, labels, start_indx, stop_indx, dyn=None, gate=None):
+        """Mixup inside one data set, in place (:283-301): features + labels, then embeddings + labels again (second draw)."""
+        mixup_type = self.hparams["training"].get("mixup")
+        sl = slice(start_indx, stop_indx)
+        if stop_indx <= start_indx:
+            return features_, embeddings, labels
+        mixup_inplace_(features_[sl], labels[sl], mixup_label_type=mixup_type, dyn=dyn, gate=gate)
+        if embeddings is not None:
+            mixup_inplace_(embeddings[sl], labels[sl], mixup_label_type=mixup_type, dyn=dyn, gate=gate)
+        return features_, embeddings, labels
+
+    def training_step(self, batch, batch_indx):
+        audio, labels, padded_indxs, embeddings, valid_class_mask = self._unpack_batch(batch)
+        features_ = self.mel_spec(audio)
+        indx_maestro, indx_synth, indx_strong, indx_weak, indx_unlabelled = (int(v) for v in np.cumsum(self.hparams["training"]["batch_size"]))
+        if indx_weak > features_.shape[0]:
+            raise ValueError("batch smaller than the configured data-set sizes")
+        embeddings = embeddings.float()
+        if not embeddings.is_contiguous():
+            embeddings = embeddings.contiguous()
+        valid = (valid_class_mask != 0).to(torch.uint8).contiguous()
+
+        mixup_type = self.hparams["training"].get("mixup")
+        groups = ((indx_strong, indx_weak), (indx_maestro, indx_strong), (0, indx_maestro))          # :341-351, in this order
+        dyn = _graph.active()
+        if dyn is not None and mixup_type is not None:
+            def flip():
+                dyn.state["mixup"] = self.hparams["training"]["mixup_prob"] > random.random()
+            dyn.host(flip)
+            gate = lambda: dyn.state["mixup"]       # noqa: E731
+            for a, b in groups:
+                self.apply_mixup(features_, embeddings, labels, a, b, dyn=dyn, gate=gate)
+        elif mixup_type is not None and self.hparams["training"]["mixup_prob"] > random.random():
+            for a, b in groups:
+                self.apply_mixup(features_, embeddings, labels, a, b)
+
+        labels_weak = features.weak_labels(labels[indx_strong:indx_weak])       # after mixup (:354); class masking: loss kernel
+        x = self.scaled_logmel(features_)
+        strong_s, weak_s = self.sed_student(x, embeddings=embeddings, classes_mask=valid)
+        with torch.no_grad():
+            strong_t, weak_t = self.sed_teacher(x, embeddings=embeddings, classes_mask=valid)
+
+        sched = self.scheduler["scheduler"]
+        const_max = self.hparams["training"]["const_max"]
+        decay = self.hparams["training"].get("epoch_decay", float("inf"))
+
+        def weight_now():
+            return const_max * sched._get_scaling_factor() if self.current_epoch < decay else const_max
+        weight = dyn.scalar(dyn.F_LOSS_W, weight_now) if dyn is not None else weight_now()
+        scalars, tot_loss = MeanTeacherLossFn.apply(strong_s.transpose(1, 2), weak_s, strong_t.transpose(1, 2), weak_t, labels,
+                                                    labels_weak, indx_strong, indx_weak - indx_strong, weight, self.selfsup_bce,
+                                                    indx_maestro, valid)
+        loss_strong, loss_weak, _, _, strong_self, weak_self, tot_self_loss, _ = scalars.unbind(0)
+        lr = lambda: self.opt.param_groups[-1]["lr"] if self.opt is not None else 0.0      # noqa: E731
+        self.log("train/student/loss_strong", loss_strong.detach())
+        self.log("train/student/loss_weak", loss_weak.detach())
+        if dyn is not None:
+            dyn.host(lambda: (self.log("train/step", sched.step_num, prog_bar=True), self.log("train/lr", lr(), prog_bar=True)))
+        self.log("train/step", sched.step_num, prog_bar=True)
+        self.log("train/student/tot_self_loss", tot_self_loss, prog_bar=True)
+        self.log("train/weight", weight.tensor if dyn is not None else weight)
+        self.log("train/student/tot_supervised", strong_self.detach(), prog_bar=True)      # sic (reference :415)
+        self.log("train/student/weak_self_sup_loss", weak_self.detach())
+        self.log("train/student/strong_self_sup_loss", strong_self.detach())
+        self.log("train/lr", lr(), prog_bar=True)
+        self.last_outputs = (strong_s, weak_s, strong_t, weak_t)
+        return tot_loss
+
+    def validation_step(self, batch, batch_indx):
+        raise NotImplementedError("validation / test of the 2024 recipe (MAESTRO metrics, class-wise median filters) are not built")
+
+    test_step = validation_step

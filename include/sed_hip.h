@@ -208,24 +208,33 @@ int sed_gru_bwd(const float* dout, const float* out, const float* saved, const f
 /* ---- K8 + K9: attention-pooling head (desed_task/nnet/CRNN.py:152-178, dropout :304) and losses ---------------- */
 
 /* x (B,T,256) -> strong (B,T,NC) = sigmoid(dense), psoft (B,T,NC) = softmax over classes of dense_softmax,
- * weak (B,NC) = sum_t(strong*clamp(psoft)) / sum_t(clamp(psoft)), den (B,NC) = the denominators. */
+ * weak (B,NC) = sum_t(strong*clamp(psoft)) / sum_t(clamp(psoft)), den (B,NC) = the denominators.
+ * classes_valid (B,NC) bytes or null: the `classes_mask` of the multi-data-set recipes (CRNN.py:157-176; non-zero = the clip's
+ * data set annotates the class): other classes cannot be attended to and their strong / weak outputs are 0.  pad_mask (B,T)
+ * bytes or null (non-zero = padded frame): its attention logits are filled with -1e30 (CRNN.py:161-162). */
 int sed_head_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, float* strong,
                  float* psoft, float* weak, float* den, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
-                 float dscale, const unsigned* seed_dev, void* stream);
+                 float dscale, const unsigned* seed_dev, const unsigned char* classes_valid, const unsigned char* pad_mask,
+                 void* stream);
 
 int sed_head_bwd(const float* x, const float* W1, const float* W2, const float* strong, const float* psoft,
                  const float* weak, const float* den, const float* d_strong, const float* d_weak, float* dx, float* dW1,
                  float* dW2, float* db1, float* db2, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
-                 float dscale, const unsigned* seed_dev, void* stream);
+                 float dscale, const unsigned* seed_dev, const unsigned char* classes_valid, const unsigned char* pad_mask,
+                 void* stream);
 
 /* Mean-teacher losses of SEDTask4.training_step (recipes/dcase2023_task4_baseline/local/sed_trainer.py:309-342):
  * scalars[8] = BCE strong/weak (student), BCE strong/weak (teacher), MSE strong/weak, weight*(MSE_s + MSE_w), total;
  * g_strong (B,T,NC), g_weak (B,NC)
  * = d(BCE_s + BCE_w + weight*(MSE_s + MSE_w)) / d(student outputs).  labels (B,NC,T); labels_weak (n_weak,NC).
- * selfsup_bce != 0: the two consistency terms are BCELoss(student, teacher) instead of MSELoss (`self_sup_loss: bce`, :99-100). */
+ * selfsup_bce != 0: the two consistency terms are BCELoss(student, teacher) instead of MSELoss (`self_sup_loss: bce`, :99-100).
+ * selfsup_from: the consistency terms average over clips [selfsup_from, B) (0 in the 2023 recipe; the 2024 recipe leaves its
+ * MAESTRO clips out, dcase2024 local/sed_trainer_pretrained.py:337,399-406).  valid (B,NC) bytes or null: labels of classes a
+ * clip's data set does not annotate count as 0 (:352-356). */
 int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
                 const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
-                int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, int selfsup_bce, void* stream);
+                int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, int selfsup_bce,
+                int selfsup_from, const unsigned char* valid, void* stream);
 
 /* ---- K13: inference post-processing, recipes/dcase2023_task4_baseline/local/utils.py:16-73 ----- */
 
@@ -244,12 +253,20 @@ int sed_threshold_events(const float* scores, const float* thresholds, const int
 
 /* z (B,T,C+E) = dropout(cat(x (B,T,C), adaptive_avg_pool1d(emb (B,E,Te), T)^T)) -- the input of `cat_tf`
  * (aggregation_type "pool1d"); pooling window of frame t = [floor(t*Te/T), ceil((t+1)*Te/T)).  Dropout mask = sed_keep over
- * the element index of z (thr24 = 0: off, dscale = 1); seed_dev as everywhere (null or one step-varying word). */
+ * the element index of z (thr24 = 0: off, dscale = 1); seed_dev as everywhere (null or one step-varying word).
+ * tmask (B,4) int32 [x0, x1, e0, e1) or null: `dropstep_recurrent` (CRNN.py:288-294) -- output frames [x0, x1) of the CNN columns
+ * and, independently, [e0, e1) of the embedding columns are zeroed before the dropout.  mode 0 = adaptive_avg_pool1d
+ * (aggregation_type "pool1d"), 1 = nearest-exact interpolation (aggregation_type "interpolate", :271-279). */
 int sed_embcat_fwd(const float* x, const float* emb, float* z, int B, int T, int Te, int C, int E, unsigned seed,
-                   unsigned thr24, float dscale, const unsigned* seed_dev, void* stream);
+                   unsigned thr24, float dscale, const unsigned* seed_dev, const int* tmask, int mode, void* stream);
 /* dx (M,C) = dzx (M,C) masked/scaled with the forward's dropout mask; dzx = the first C columns of dz = dy . W_cat_tf. */
 int sed_embcat_bwd(const float* dzx, float* dx, int M, int C, int E, unsigned seed, unsigned thr24, float dscale,
-                   const unsigned* seed_dev, void* stream);
+                   const unsigned* seed_dev, const int* tmask, int T, void* stream);
+
+/* `dropstep_recurrent` of a CRNN WITHOUT embeddings (CRNN.py:296-301): y = dropout(time_mask(x)) on (B,T,C); bounds (B,2) int32
+ * [t0, t1) or null.  Diagonal operator: the backward is the same call on the gradient. */
+int sed_dropstep(const float* x, float* y, const int* bounds, int B, int T, int C, unsigned seed, unsigned thr24, float dscale,
+                 const unsigned* seed_dev, void* stream);
 
 /* ---- K10 + K11: flat parameter arena ------------------------------------------------------------------------- */
 

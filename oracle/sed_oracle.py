@@ -134,16 +134,33 @@ def specaug_apply(x: torch.Tensor, f_bounds, t_bounds) -> torch.Tensor:
 # ----------------------------------------------------------------------------------
 # a8-a10: CRNN forward, functional over a reference-layout state dict
 # ----------------------------------------------------------------------------------
+def time_mask(x: torch.Tensor, bounds) -> torch.Tensor:
+    """torchaudio TimeMasking on the frame axis of a (B, T, C) tensor with the draws injected: frames [start, end) of clip b are
+    zeroed (`dropstep_recurrent`, CRNN.py:288-301).  bounds = (start, end) int tensors of shape (B,) or None."""
+    if bounds is None:
+        return x
+    ti = torch.arange(x.shape[1]).view(1, -1, 1)
+    s, e = [b.view(-1, 1, 1) for b in bounds]
+    return x.masked_fill((ti >= s) & (ti < e), 0.0)
+
+
 def crnn_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool = False,
                  drop_masks: Optional[Sequence[Optional[torch.Tensor]]] = None, dropout_p: float = 0.5,
-                 update_bn: bool = True, taps: Optional[dict] = None, embeddings: Optional[torch.Tensor] = None):
+                 update_bn: bool = True, taps: Optional[dict] = None, embeddings: Optional[torch.Tensor] = None,
+                 classes_mask: Optional[torch.Tensor] = None, pad_mask: Optional[torch.Tensor] = None,
+                 dropstep=None, aggregation_type: str = "pool1d"):
     """x: (B, n_mels, T) scaled log-mel (SpecAugment, if any, already applied).
     drop_masks: None -> no dropout (even when training); else a list of 8 keep-masks
     (7 CNN blocks in NHWC-agnostic NCHW shape (B,C,T,F) pre-pool, then the post-GRU (B,T',256)),
     applied as x * mask / (1-p) (inverted dropout, CNN.py:90-91, CRNN.py:103,304).
     In training mode BN uses batch stats and (if update_bn) updates running stats in sd in place.
-    embeddings (B, E, Te): the `use_embeddings`, aggregation_type "pool1d" branch (CRNN.py:283-296) with sd["cat_tf.*"];
-    its dropout mask is drop_masks[8] of shape (B, T', C + E).
+    embeddings (B, E, Te): the `use_embeddings` branch, aggregation_type "pool1d" (CRNN.py:283-296) or "interpolate" (:271-279),
+    with sd["cat_tf.*"]; its dropout mask is drop_masks[8] of shape (B, T', C + E).
+    dropstep: `dropstep_recurrent` draws (training only): with embeddings a pair ((sx, ex), (se, ee)) -- the CNN features' span
+    and, drawn second, the embeddings' (:292-293); without, one (s, e) pair, and the GRU input is then ALSO dropped out
+    (:296-301) with mask drop_masks[8] of shape (B, T', C).
+    classes_mask (B, nclass) bool, True = class annotated in the clip's data set; pad_mask (B, 1, T') bool, True = padded
+    frame: CRNN.py:157-176.
     Returns strong (B, nclass, T//4), weak (B, nclass).  Follows CRNN.py:221-306, CNN.py:66-98."""
     h = x.transpose(1, 2).unsqueeze(1)                                   # (B,1,T,F)  CRNN.py:224
     for i in range(len(NB_FILTERS)):
@@ -165,13 +182,24 @@ def crnn_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool = 
             taps[f"block{i}"] = h
     h = h.squeeze(-1).permute(0, 2, 1)                                   # (B,T',C)  CRNN.py:244-245
     if embeddings is not None:
-        reshape_emb = F.adaptive_avg_pool1d(embeddings, h.shape[1]).transpose(1, 2)      # CRNN.py:283-286
+        if aggregation_type == "interpolate":                                            # CRNN.py:271-279
+            reshape_emb = F.interpolate(embeddings.unsqueeze(1), size=(embeddings.shape[1], h.shape[1]),
+                                        mode="nearest-exact").squeeze(1).transpose(1, 2)
+        else:
+            reshape_emb = F.adaptive_avg_pool1d(embeddings, h.shape[1]).transpose(1, 2)  # CRNN.py:283-286
+        if dropstep is not None and training:                                            # CRNN.py:288-294
+            h = time_mask(h, dropstep[0])
+            reshape_emb = time_mask(reshape_emb, dropstep[1])
         z = torch.cat((h, reshape_emb), -1)
         if drop_masks is not None and len(drop_masks) > 8 and drop_masks[8] is not None:
             z = z * drop_masks[8] / (1.0 - dropout_p)
         h = F.linear(z, sd["cat_tf.weight"], sd["cat_tf.bias"])          # CRNN.py:296
         if taps is not None:
             taps["cat_tf"] = h
+    elif dropstep is not None and training:                                              # CRNN.py:296-301
+        h = time_mask(h, dropstep)
+        if drop_masks is not None and len(drop_masks) > 8 and drop_masks[8] is not None:
+            h = h * drop_masks[8] / (1.0 - dropout_p)
     flat = []
     for layer in range(2):
         for sfx in ("", "_reverse"):
@@ -186,10 +214,20 @@ def crnn_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, training: bool = 
     if drop_masks is not None and drop_masks[7] is not None:
         h = h * drop_masks[7] / (1.0 - dropout_p)
     strong = torch.sigmoid(F.linear(h, sd["dense.weight"], sd["dense.bias"]))          # CRNN.py:155-156
+    invalid = None
+    if classes_mask is not None:
+        invalid = ~classes_mask[:, None].expand_as(strong)                             # CRNN.py:157-158
     sof = F.linear(h, sd["dense_softmax.weight"], sd["dense_softmax.bias"])
+    if pad_mask is not None:
+        sof = sof.masked_fill(pad_mask.transpose(1, 2), -1e30)                         # CRNN.py:161-162
+    if invalid is not None:
+        sof = sof.masked_fill(invalid, -1e30)                                          # CRNN.py:164-166
     sof = torch.softmax(sof, dim=-1)                                                   # over CLASSES (CRNN.py:125)
     sof = torch.clamp(sof, min=1e-7, max=1)
     weak = (strong * sof).sum(1) / sof.sum(1)
+    if invalid is not None:                                                            # CRNN.py:173-176
+        strong = strong.masked_fill(invalid, 0.0)
+        weak = weak.masked_fill(invalid[:, 0], 0.0)
     return strong.transpose(1, 2), weak
 
 
@@ -422,6 +460,43 @@ class OracleTrainer:
             "train/step": self.step_num, "train/student/tot_self_loss": tot_self.item(), "train/weight": weight,
             "train/student/tot_supervised": strong_self.item(),          # sic, Q11
             "train/student/weak_self_sup_loss": weak_self.item(),
+            "train/student/strong_self_sup_loss": strong_self.item(), "train/lr": self.lr,
+        }
+        self.last = dict(strong_s=strong_s.detach(), weak_s=weak_s.detach(), strong_t=strong_t, weak_t=weak_t)
+        return tot, logs
+
+    def training_step_2024(self, audio, labels, embeddings, valid, mix=None, const_weight=False):
+        """The 2024 recipe's multi-data-set step, recipes/dcase2024_task4_baseline/local/sed_trainer_pretrained.py:318-430.
+        batch_sizes = (maestro, synth, strong, weak, unlabelled).  mix: None (mixup gated off) or the six (c, perm) draws of
+        apply_mixup in call order -- weak group features, weak group embeddings, synth+strong features, embeddings, maestro
+        features, embeddings (:341-351); the labels of a group are mixed by BOTH draws (:283-301).  valid (B, nclass) bool."""
+        i_m, i_sy, i_st, i_w, i_u = np.cumsum(self.batch_sizes)
+        feats = mel_spectrogram(audio)
+        labels, embeddings = labels.clone(), embeddings.clone()
+        if mix is not None:
+            groups = ((i_st, i_w), (i_m, i_st), (0, i_m))
+            for gi, (a, b) in enumerate(groups):
+                (c1, p1), (c2, p2) = mix[2 * gi], mix[2 * gi + 1]
+                feats[a:b], labels[a:b] = mixup_apply(feats[a:b], labels[a:b], c1, p1)
+                embeddings[a:b], labels[a:b] = mixup_apply(embeddings[a:b], labels[a:b], c2, p2)
+        labels_weak = (labels[i_st:i_w].sum(-1) > 0).float()
+        labels = labels.masked_fill(~valid[:, :, None].expand_as(labels), 0.0)
+        labels_weak = labels_weak.masked_fill(~valid[i_st:i_w], 0.0)
+        x = scale_minmax(take_log(feats))
+        strong_s, weak_s = crnn_forward(self.student, x, training=True, embeddings=embeddings, classes_mask=valid)
+        loss_strong = F.binary_cross_entropy(strong_s[:i_st], labels[:i_st])
+        loss_weak = F.binary_cross_entropy(weak_s[i_st:i_w], labels_weak)
+        with torch.no_grad():
+            strong_t, weak_t = crnn_forward(self.teacher, x, training=True, embeddings=embeddings, classes_mask=valid)
+        weight = self.const_max * (1.0 if const_weight else warmup_factor(self.step_num, self.rampup_len))      # :393-396
+        strong_self = self.selfsup_loss(strong_s[i_m:], strong_t[i_m:])
+        weak_self = self.selfsup_loss(weak_s[i_m:], weak_t[i_m:])
+        tot_self = (strong_self + weak_self) * weight
+        tot = loss_strong + loss_weak + tot_self
+        logs = {
+            "train/student/loss_strong": loss_strong.item(), "train/student/loss_weak": loss_weak.item(),
+            "train/step": self.step_num, "train/student/tot_self_loss": tot_self.item(), "train/weight": weight,
+            "train/student/tot_supervised": strong_self.item(), "train/student/weak_self_sup_loss": weak_self.item(),
             "train/student/strong_self_sup_loss": strong_self.item(), "train/lr": self.lr,
         }
         self.last = dict(strong_s=strong_s.detach(), weak_s=weak_s.detach(), strong_t=strong_t, weak_t=weak_t)

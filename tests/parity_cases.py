@@ -1349,3 +1349,226 @@ def case_b48_forward_vs_oracle(dev, bs=(12, 12, 24)):
                 err = (a.cpu() - b).abs().max().item()
                 assert err <= 2e-5 * max(1.0, b.abs().max().item()), "%s bn%d %s: %.3e" % (who, i, nm, err)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# rest of the embedding-fusion surface: classes_mask / pad_mask, dropstep_recurrent, "interpolate"
+# ------------------------------------------------------------------------------------------------
+def net_config_2024():
+    """`net:` of recipes/dcase2024_task4_baseline/confs/pretrained.yaml with n_RNN_cell 192 -> 128 (the HIP GRU's size)."""
+    cfg = dict(recipe_config()["net"])
+    cfg.update(dropout=0.2, rnn_layers=1, nclass=27, n_RNN_cell=128, dropstep_recurrent=0.3, dropstep_recurrent_len=16,
+               use_embeddings=True, embedding_size=768, embedding_type="frame", aggregation_type="pool1d",
+               specaugm_t_p=0.0, specaugm_t_l=5, specaugm_f_p=0.0, specaugm_f_l=10)
+    return cfg
+
+
+def golden_emb2_inputs():
+    xin = O.lcg_fill((3, 128, 64), 41, 0.5, 0.5)
+    emb = O.lcg_fill((3, 768, 51), 42, 1.0)
+    cm = torch.zeros(3, 27, dtype=torch.bool)
+    cm[0, :10] = True; cm[1, 10:] = True; cm[2] = True
+    pad = torch.zeros(3, 1, 16, dtype=torch.bool)
+    pad[0, 0, 12:] = True; pad[1, 0, 15:] = True
+    return xin, emb, cm, pad
+
+
+def case_crnn_masks_vs_reference_golden(dev, golden):
+    """CRNN with the 2024 recipe's options on the HIP kernels against the reference module's recorded outputs
+    (tests/golden/golden_emb2.npz): classes_mask + pad_mask inside the head kernels, dropstep_recurrent on the recorded spans
+    (with embeddings: two spans fused into the embcat kernel; without: the time-mask + dropout kernel), gradients of every
+    parameter; eval-mode posteriors of aggregation_type "interpolate"."""
+    from desed_task_amd.nnet.CRNN import CRNN
+    xin, emb, cm, pad = golden_emb2_inputs()
+    for tag, use_emb in (("a", True), ("b", False)):
+        cfg = dict(net_config_2024(), dropout=0.0, use_embeddings=use_emb)
+        sd = O.make_state_dict(seed=7, nclass=27, embedding_size=768 if use_emb else None)
+        net = CRNN(**cfg)
+        assert [n for n, _ in net.named_parameters()] == list(golden[tag + "_param_names"])
+        net.load_state_dict({k: v.clone() for k, v in sd.items()})
+        net = net.to(dev) if dev != "cpu" else net
+        net.train()
+        spans = [torch.from_numpy(s.astype(np.int32)) for s in golden[tag + "_dropstep"]]
+        order = iter(spans)
+        net._dropstep_bounds = lambda B, n_time, device, _o=order: next(_o).to(device).contiguous()      # the reference's own draws
+        strong, weak = net(to(dev, xin), pad_mask=to(dev, pad), embeddings=to(dev, emb) if use_emb else None, classes_mask=to(dev, cm))
+        assert np.abs(strong.detach().cpu().numpy() - golden[tag + "_strong"]).max() < 2e-5, tag
+        assert np.abs(weak.detach().cpu().numpy() - golden[tag + "_weak"]).max() < 2e-5, tag
+        assert float(strong.detach()[0, 10:].abs().max()) == 0.0 and float(weak.detach()[1, :10].abs().max()) == 0.0
+        tgt_s = to(dev, (O.lcg_fill(tuple(strong.shape), 31, 0.5, 0.5) < 0.2).float())
+        tgt_w = to(dev, (O.lcg_fill(tuple(weak.shape), 32, 0.5, 0.5) < 0.3).float())
+        loss = torch.nn.functional.binary_cross_entropy(strong, tgt_s) + torch.nn.functional.binary_cross_entropy(weak, tgt_w)
+        assert abs(loss.item() - float(golden[tag + "_loss"][0])) < 2e-5 * float(golden[tag + "_loss"][0]), tag
+        loss.backward()
+        params = dict(net.named_parameters())
+        for n, ref in zip(list(golden[tag + "_param_names"]), golden[tag + "_grad_norms"]):
+            if n.startswith("cnn.cnn.conv") and n.endswith(".bias"):
+                continue
+            assert abs(params[n].grad.norm().item() - ref) <= 2e-3 * ref + 1e-7, (tag, n)
+        got = params["dense_softmax.weight"].grad.detach().cpu().numpy()[:, ::8]
+        ref = golden[tag + "_grad__dense_softmax.weight"]
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7, tag
+        got = params["cnn.cnn.conv6.weight"].grad.detach().cpu().numpy().reshape(-1)[:512]
+        ref = golden[tag + "_grad__cnn.cnn.conv6.weight"]
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7, tag
+    cfg = dict(net_config_2024(), dropout=0.0, aggregation_type="interpolate")
+    sd = O.make_state_dict(seed=7, nclass=27, embedding_size=768)
+    net = CRNN(**cfg)
+    net.load_state_dict({k: v.clone() for k, v in sd.items()})
+    net = net.to(dev) if dev != "cpu" else net
+    net.eval()
+    with torch.no_grad():
+        strong, weak = net(to(dev, xin), embeddings=to(dev, emb))
+    assert np.abs(strong.cpu().numpy() - golden["c_strong"]).max() < 2e-5
+    assert np.abs(weak.cpu().numpy() - golden["c_weak"]).max() < 2e-5
+    for agg in ("frame", "global"):
+        try:
+            CRNN(**dict(cfg, aggregation_type=agg))
+            raise AssertionError("aggregation_type %s must be refused" % agg)
+        except NotImplementedError:
+            pass
+
+
+def case_dropstep_draws_and_dropout(dev):
+    """dropstep_recurrent with its own draws and the dropout of the same call site on: the time spans follow torchaudio's mask
+    arithmetic on torch.rand draws (as SpecAugment's), DropStepFn / EmbCatFn equal torch ops on the same spans and keep mask."""
+    from desed_task_amd import ops
+    B, T, C, E, Te, p = 3, 16, 128, 40, 51, 0.5
+    x = O.lcg_fill((B, T, C), 3, 1.0); emb = O.lcg_fill((B, E, Te), 4, 1.0)
+    bx = torch.tensor([[2, 5], [0, 0], [14, 16]], dtype=torch.int32)
+    be = torch.tensor([[0, 4], [7, 9], [3, 3]], dtype=torch.int32)
+    gy = O.lcg_fill((B, T, C), 5, 1.0)
+    # without embeddings
+    xr = x.clone().requires_grad_(True)
+    ref = O.time_mask(xr, (bx[:, 0].long(), bx[:, 1].long())) * np_keep_mask((B, T, C), 77, p) / (1 - p)
+    ref.backward(gy)
+    xd = to(dev, x).clone().requires_grad_(True)
+    y = ops.DropStepFn.apply(xd, to(dev, bx), dict(dropout_p=p, apply_dropout=True, seed=77))
+    y.backward(to(dev, gy))
+    assert torch.equal(y.detach().cpu(), ref.detach()) and torch.equal(xd.grad.cpu(), xr.grad)
+    # with embeddings (both spans, pool1d and interpolate)
+    w = O.lcg_fill((C, C + E), 6, 0.1); bias = O.lcg_fill((C,), 7, 0.1)
+    for mode in (0, 1):
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        if mode == 0:
+            re = torch.nn.functional.adaptive_avg_pool1d(emb, T).transpose(1, 2)
+        else:
+            re = torch.nn.functional.interpolate(emb.unsqueeze(1), size=(E, T), mode="nearest-exact").squeeze(1).transpose(1, 2)
+        z = torch.cat((O.time_mask(xr, (bx[:, 0].long(), bx[:, 1].long())), O.time_mask(re, (be[:, 0].long(), be[:, 1].long()))), -1)
+        z = z * np_keep_mask((B, T, C + E), 99, p) / (1 - p)
+        yr = torch.nn.functional.linear(z, wr, bias)
+        yr.backward(gy)
+        xd, wd = to(dev, x).clone().requires_grad_(True), to(dev, w).clone().requires_grad_(True)
+        cfg = dict(dropout_p=p, apply_dropout=True, seed=99, tmask=to(dev, torch.cat((bx, be), 1).contiguous()), mode=mode)
+        yd = ops.EmbCatFn.apply(xd, to(dev, emb), wd, to(dev, bias).requires_grad_(True), cfg)
+        yd.backward(to(dev, gy))
+        tol = lambda r: 3e-5 * max(1.0, float(r.detach().abs().max()))      # noqa: E731
+        assert float((yd.detach().cpu() - yr.detach()).abs().max()) < tol(yr), mode
+        assert float((xd.grad.cpu() - xr.grad).abs().max()) < tol(xr.grad), mode
+        assert float((wd.grad.cpu() - wr.grad).abs().max()) < tol(wr.grad), mode
+    # the CRNN's own draws: reproducible from torch's seed, within the cap min(len, int(T * p))
+    from desed_task_amd.nnet.CRNN import CRNN
+    net = CRNN(**dict(net_config_2024(), use_embeddings=False))
+    net = net.to(dev) if dev != "cpu" else net
+    device = torch.device(dev)
+    torch.manual_seed(5)
+    if dev != "cpu":
+        torch.cuda.manual_seed(5)
+    b1 = net._dropstep_bounds(48, 156, device).cpu()
+    assert tuple(b1.shape) == (48, 2) and int((b1[:, 1] - b1[:, 0]).max()) <= 16 and int(b1.min()) >= 0 and int(b1[:, 1].max()) <= 156
+    assert int((b1[:, 1] - b1[:, 0]).max()) > 0
+
+
+def inputs_2024(bs=(2, 1, 1, 2, 2), nclass=27):
+    """== tests/golden/make_golden_2024.py::inputs()"""
+    B = sum(bs)
+    n_samp = 16000 * 2 + 1024
+    audio = O.synth_audio(B, n_samp, seed=77)
+    n_out = (1 + n_samp // 256) // 4
+    labels = (O.lcg_fill((B, nclass, n_out), 5, 0.5, 0.5) < 0.1).float()
+    ns = bs[0] + bs[1] + bs[2]
+    labels[ns:ns + bs[3], :, 1:] = 0.0
+    labels[ns + bs[3]:] = 0.0
+    emb = O.lcg_fill((B, 768, 53), 9, 1.0)
+    valid = torch.zeros(B, nclass, dtype=torch.bool)
+    valid[:bs[0], 10:] = True
+    valid[bs[0]:, :10] = True
+    valid[bs[0] + 1] = True
+    return audio, labels, emb, valid
+
+
+def case_training_step_2024(dev, golden):
+    """desed_task_amd.sed_trainer_pretrained_2024.SEDTask4 (the 2024 recipe's 5-data-set step with class masks, mixup of features
+    AND embeddings per data set, consistency losses without MAESTRO) x2 steps through the StepDriver against (i) the scalars the
+    reference's own training_step logged (tests/golden/golden_2024.npz) and (ii) the oracle on the same draws: posteriors,
+    every gradient."""
+    import random
+    from desed_task_amd.arena import FusedAdam
+    from desed_task_amd.launcher import StepDriver
+    from desed_task_amd.nnet.CRNN import CRNN
+    from desed_task_amd.sed_trainer_pretrained_2024 import SEDTask4
+    from desed_task_amd.utils.schedulers import ExponentialWarmup
+    bs, nclass = (2, 1, 1, 2, 2), 27
+    audio, labels, emb, valid = inputs_2024(bs, nclass)
+    config = recipe_config(bs)
+    config["training"].update(mixup_prob=0.5, epoch_decay=100)
+    config["net"] = dict(net_config_2024(), dropout=0.0, dropstep_recurrent=0.0)
+    config["pretrained"] = {"e2e": False, "freezed": True, "model": "beats"}
+    sd = O.make_state_dict(seed=7, nclass=nclass, embedding_size=768)
+    student = CRNN(**config["net"])
+    student.load_state_dict({k: v.clone() for k, v in sd.items()})
+    student = student.to(dev) if dev != "cpu" else student
+    opt = FusedAdam(student.parameters(), lr=1e-3, betas=(0.9, 0.999), arena=student)
+    sched = {"scheduler": ExponentialWarmup(opt, 1e-3, 100), "interval": "step"}
+
+    class Enc:
+        labels = list(range(nclass))
+    task = SEDTask4(config, Enc(), student, None, opt=opt, scheduler=sched)
+    task.train()
+    if dev != "cpu":
+        task.to(dev)
+    driver = StepDriver(task, world_size=1)
+    orc = O.OracleTrainer(sd, batch_sizes=bs, lr=1e-3, rampup_len=100)
+    keys = O.param_keys(sd)
+    gkeys = list(golden["keys"])
+    for step in range(2):
+        random.seed(4 + step); np.random.seed(100 + step); torch.manual_seed(100 + step)
+        gate = 0.5 > random.random()
+        assert gate == (step == 0)
+        mix = None
+        if gate:
+            mix = []
+            for n in (bs[3], bs[1] + bs[2], bs[0]):
+                for _ in range(2):
+                    mix.append((np.random.beta(0.2, 0.2), torch.randperm(n)))
+            np.testing.assert_allclose([c for c, _ in mix], golden["mix_c"], rtol=0, atol=0)         # the reference drew the same
+        random.seed(4 + step); np.random.seed(100 + step); torch.manual_seed(100 + step)
+        loss = driver.run_step((to(dev, audio.clone()), to(dev, labels.clone()), None, to(dev, emb.clone()), to(dev, valid.clone())), step)
+        tot, logs = orc.training_step_2024(audio, labels, emb, valid, mix=mix)
+        ref_grads = orc.optimizer_step(tot)
+        got = {k: (float(v) if not torch.is_tensor(v) else float(v.detach().cpu())) for k, v in task.logged.items()}
+        got["loss"] = float(loss.detach().cpu()); logs["loss"] = tot.item()
+        for k in sorted(logs):
+            assert abs(got[k] - logs[k]) <= 2e-5 + 2e-4 * abs(logs[k]), "step %d %s: hip %.8g oracle %.8g" % (step, k, got[k], logs[k])
+        for k, b in zip(gkeys, golden["values"][step]):
+            assert abs(got[k] - b) <= 2e-5 + 5e-4 * abs(b), "step %d %s: hip %.8g reference %.8g" % (step, k, got[k], b)
+        for a, name in zip([t.detach().cpu() for t in task.last_outputs], ("strong_s", "weak_s", "strong_t", "weak_t")):
+            assert (a - orc.last[name]).abs().max().item() < 1e-3, (step, name)
+        hip_params = dict(task.sed_student.named_parameters())
+        for k in keys:
+            if k.startswith("cnn.cnn.conv") and k.endswith(".bias"):
+                continue
+            emax, emed = grad_error_stats(hip_params[k].grad.detach().cpu(), ref_grads[k])
+            assert (emax <= 1e-4 and emed <= 1e-5) if step == 0 else (emax <= 6e-2 and emed <= 2e-3), "step %d grad %s: %.2e / %.2e" % (step, k, emax, emed)
+    st = dict(task.sed_student.named_parameters())
+    for n in ("cat_tf.weight", "cnn.cnn.conv0.weight"):
+        ref = golden["student_after2__" + n]
+        init = sd[n].numpy().reshape(-1)[:256]
+        mine = st[n].detach().cpu().numpy().reshape(-1)[:256]
+        assert np.linalg.norm(mine - ref) <= 0.15 * np.linalg.norm(ref - init) + 1e-6, n
+    # the recipe's own recurrent width is refused, loudly
+    try:
+        CRNN(**dict(config["net"], n_RNN_cell=192))
+        raise AssertionError("n_RNN_cell = 192 must be refused")
+    except NotImplementedError:
+        pass

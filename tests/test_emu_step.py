@@ -79,3 +79,23 @@ def test_stochastic_step_matches_oracle(emu):
 def test_head_dropout(emu):
     P.case_head_dropout("cpu")
     P.case_head_dropout("cpu", B=2, T=5, p=0.25, seed=7)
+
+
+def test_crnn_masks_dropstep_interpolate_vs_reference_golden(emu):
+    """classes_mask / pad_mask, dropstep_recurrent and aggregation_type "interpolate" against the reference module's outputs."""
+    import os
+    import numpy as np
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_emb2.npz"))
+    P.case_crnn_masks_vs_reference_golden("cpu", G)
+
+
+def test_dropstep_ops(emu):
+    P.case_dropstep_draws_and_dropout("cpu")
+
+
+def test_training_step_2024_vs_reference_golden(emu):
+    """The 2024 recipe's 5-data-set step against the scalars its own reference trainer logged, and against the oracle."""
+    import os
+    import numpy as np
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_2024.npz"))
+    P.case_training_step_2024("cpu", G)

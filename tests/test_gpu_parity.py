@@ -167,3 +167,15 @@ def test_b48_forward_vs_oracle():
     running statistics, per-clip min/max."""
     w = P.case_b48_forward_vs_oracle("cuda")
     print("B=48 posterior errors:", w)
+
+
+def test_crnn_masks_dropstep_interpolate_vs_reference_golden():
+    """SURVEY 8f rank 3, the rest: classes_mask / pad_mask in the head kernels, dropstep_recurrent, "interpolate"."""
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_emb2.npz"))
+    P.case_crnn_masks_vs_reference_golden("cuda", G)
+    P.case_dropstep_draws_and_dropout("cuda")
+
+
+def test_training_step_2024_vs_reference_golden():
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_2024.npz"))
+    P.case_training_step_2024("cuda", G)
