@@ -1,0 +1,356 @@
+// the frozen BEATs feature extractor (recipes/dcase2023_task4_baseline/local/beats/{BEATs.py:109-204,
+// backbone.py:23-160,214-296,446-700}) as an inference path on the MI355X.  fp32 storage everywhere, fp32-level accuracy:
+//   K-B1 kaldi_fbank_kernel   torchaudio.compliance.kaldi.fbank(25 ms / 10 ms, povey window, 512-point FFT, 128 Kaldi-mel bins, log)
+//                             + the (x - mean) / (2 std) of BEATs.preprocess                                  (BEATs.py:109-133)
+//   K-B2 patchify16_kernel    the 16 x 16 / stride 16 patch gather; the patch embedding itself, every Linear of the encoder and
+//                             the FFN (with its GELU in the epilogue) are the split-bf16 MFMA GEMM of sed_gemm_bf16.hip
+//   K-B3 layernorm_kernel     y = LayerNorm(alpha * residual + x): the post-LN / deep-norm residual of every encoder sub-layer
+//   K-B4 posconv_kernel       x + GELU(grouped Conv1d(k = 128, 16 groups)(x)): the convolutional position embedding
+//   K-B5 attention_kernel     multi-head attention with the bucketed relative position bias scaled per (head, query) by the
+//                             GRU-style gate computed from the query (backbone.py:662-682); online softmax, no T x T tensor in HBM
+// First version: the attention and the position convolution run on the f32 vector pipes (their roof equals the exact-f32 MFMA
+// peak); the 86 % of the extractor's FLOPs that sit in Linear layers run on the split-bf16 MFMA.
+#include "sed_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// K-B1: one workgroup (256 threads) per frame.  audio (B, N) in [-1, 1) -> out (B, M, n_mels), M = 1 + (N - 400) / 160.
+// window[400] (povey), tw[256] complex exp(-2 pi i k / 512), sparse Kaldi-mel bank (start, len, weights[n_mels][stride]).
+// ---------------------------------------------------------------------------------------------
+#define FB_LEN 400
+#define FB_SHIFT 160
+#define FB_NFFT 512
+__global__ __launch_bounds__(256) void kaldi_fbank_kernel(const float* __restrict__ audio, float* __restrict__ out, int N, int M,
+                                                          int n_mels, const float* __restrict__ window, const float* __restrict__ tw,
+                                                          const int* __restrict__ fb_start, const int* __restrict__ fb_len,
+                                                          const float* __restrict__ fb_w, int fb_stride, float preemph, float scale,
+                                                          float norm_mean, float norm_inv) {
+    __shared__ float re[FB_NFFT], im[FB_NFFT], pw[FB_NFFT / 2 + 1], red[4];
+    const int tid = threadIdx.x, f = blockIdx.x, b = blockIdx.y;
+    const float* src = audio + (size_t)b * N + (size_t)f * FB_SHIFT;
+    // frame + DC removal
+    float v0 = tid < FB_LEN ? src[tid] * scale : 0.f, v1 = tid + 256 < FB_LEN ? src[tid + 256] * scale : 0.f;
+    float s = wave_sum(v0 + v1);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)FB_LEN;
+    // pre-emphasis needs the left neighbour: park the DC-free frame in `re` first (natural order)
+    re[tid] = tid < FB_LEN ? v0 - mean : 0.f;
+    re[tid + 256] = tid + 256 < FB_LEN ? v1 - mean : 0.f;
+    __syncthreads();
+    float y[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u;
+        y[u] = i < FB_LEN ? (re[i] - preemph * re[i > 0 ? i - 1 : 0]) * window[i] : 0.f;
+    }
+    __syncthreads();
+    // bit-reversed load for the radix-2 decimation-in-time FFT (9 stages of 256 butterflies)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u;
+        const int r = (int)(__brev((unsigned)i) >> 23);
+        re[r] = y[u];
+        im[r] = 0.f;
+    }
+    __syncthreads();
+    for (int st = 0; st < 9; ++st) {
+        const int half = 1 << st, j = tid & (half - 1), i0 = ((tid >> st) << (st + 1)) + j, i1 = i0 + half;
+        const int k = j << (8 - st);                              // twiddle exp(-2 pi i j / (2 half)) = tw[j * 256 / half]
+        const float wr = tw[2 * k], wi = tw[2 * k + 1];
+        const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+        const float tr = br * wr - bi * wi, ti = br * wi + bi * wr;
+        re[i0] = ar + tr; im[i0] = ai + ti;
+        re[i1] = ar - tr; im[i1] = ai - ti;
+        __syncthreads();
+    }
+    pw[tid] = re[tid] * re[tid] + im[tid] * im[tid];
+    if (tid == 0) pw[256] = re[256] * re[256] + im[256] * im[256];
+    __syncthreads();
+    if (tid < n_mels) {
+        const int st = fb_start[tid], ln = fb_len[tid];
+        const float* w = fb_w + (size_t)tid * fb_stride;
+        float acc = 0.f;
+        for (int i = 0; i < ln; ++i) acc = fmaf(w[i], pw[st + i], acc);
+        const float v = logf(fmaxf(acc, 1.1920928955078125e-07f));
+        out[((size_t)b * M + f) * n_mels + tid] = (v - norm_mean) * norm_inv;
+    }
+}
+extern "C" int sed_kaldi_fbank(const float* audio, float* out, int B, int N, int n_mels, const float* window, const float* tw,
+                               const int* fb_start, const int* fb_len, const float* fb_w, int fb_stride, float norm_mean,
+                               float norm_inv, void* stream) {
+    if (n_mels < 1 || n_mels > 256) return SED_ERR_UNSUPPORTED;
+    if (B <= 0 || N < FB_LEN) return SED_OK;
+    const int M = 1 + (N - FB_LEN) / FB_SHIFT;
+    SED_LAUNCH(kaldi_fbank_kernel, dim3(M, B), dim3(256), 0, (hipStream_t)stream, audio, out, N, M, n_mels, window, tw, fb_start,
+               fb_len, fb_w, fb_stride, 0.97f, 32768.0f, norm_mean, norm_inv);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-B2: fbank (B, M, F) -> patches (B * Tp * Fp, P * P), Tp = M / P, Fp = F / P (floor: trailing frames are dropped exactly as
+// Conv2d(stride = kernel = P) does), row = (b * Tp + tp) * Fp + fp (BEATs.py:154-156: tokens run frequency-fastest), column = i * P + j.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ fb, float* __restrict__ out, int M, int F, int P,
+                                                       int Tp, int Fp, size_t n) {
+    const int PP = P * P;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+        const size_t row = idx / PP;
+        const int col = (int)(idx - row * PP), i = col / P, j = col - i * P;
+        const int fp = (int)(row % Fp);
+        const size_t r2 = row / Fp;
+        const int tp = (int)(r2 % Tp), b = (int)(r2 / Tp);
+        out[idx] = fb[((size_t)b * M + (size_t)tp * P + i) * F + fp * P + j];
+    }
+}
+extern "C" int sed_patchify(const float* fbank, float* patches, int B, int M, int F, int P, void* stream) {
+    if (P < 1 || F % P != 0) return SED_ERR_ARG;
+    const int Tp = M / P, Fp = F / P;
+    const size_t n = (size_t)B * Tp * Fp * P * P;
+    if (n == 0) return SED_OK;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    SED_LAUNCH(patchify_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, fbank, patches, M, F, P, Tp, Fp, n);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-B3: y[m] = LayerNorm(alpha * res[m] + x[m]) * gamma + beta over D (one wave per row; D % 64 == 0, D <= 1024), eps 1e-5,
+// biased variance (torch.nn.LayerNorm).  res may be null (plain LayerNorm); y may alias x.
+// ---------------------------------------------------------------------------------------------
+template <int NPL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ res, float alpha,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ y, int Mrows, float eps) {
+    constexpr int D = NPL * 64;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Mrows) return;
+    float v[NPL];
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) {
+        const size_t i = (size_t)row * D + lane + 64 * u;
+        v[u] = res ? fmaf(alpha, res[i], x[i]) : x[i];
+        s += v[u];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) { const float d = v[u] - mean; q = fmaf(d, d, q); }
+    const float inv = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) {
+        const int c = lane + 64 * u;
+        y[(size_t)row * D + c] = (v[u] - mean) * inv * gamma[c] + beta[c];
+    }
+}
+extern "C" int sed_layernorm(const float* x, const float* res, float alpha, const float* gamma, const float* beta, float* y, int M,
+                             int D, float eps, void* stream) {
+    if (M <= 0) return SED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((M + 3) / 4);
+#define LN_CASE(d) \
+    if (D == d) { SED_LAUNCH((layernorm_kernel<d / 64>), grid, dim3(256), 0, s, x, res, alpha, gamma, beta, y, M, eps); return sed_check_launch(); }
+    LN_CASE(128) LN_CASE(256) LN_CASE(512) LN_CASE(768) LN_CASE(1024)
+#undef LN_CASE
+    return SED_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-B4: y = x + GELU(bias + grouped Conv1d(x)), kernel K (even: the reference drops the last output, SamePad), padding K / 2,
+// CG channels per group (backbone.py:30-43,118-120).  x, y (B, T, D); wt (D / CG groups, K, CG co, CG ci): the weight-normalised
+// filter, transposed on the host once (frozen weights) so that a chunk of taps is one contiguous read.
+// Workgroup = 64 tokens x one group: thread (tq = tid % 16, c = tid / 16) owns tokens 4 tq .. 4 tq + 3 x output channels
+// 3 c .. 3 c + 2.  Odd LDS pitches: the 16 token quads of a wave hit 16 distinct banks, the co triples likewise.
+// ---------------------------------------------------------------------------------------------
+#define PC_CG 48
+#define PC_TT 64
+#define PC_KC 4
+#define PC_XP 49
+__global__ __launch_bounds__(256) void posconv_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int T, int D, int K) {
+    SED_DYN_SMEM(smem);
+    float* xs = (float*)smem;                                     // [PC_TT + K - 1][PC_XP]
+    float* ws = xs + (PC_TT + K - 1) * PC_XP;                     // [PC_KC][PC_CG co][PC_XP ci]
+    const int tid = threadIdx.x, tq = tid & 15, c = tid >> 4;
+    const int t0 = blockIdx.x * PC_TT, g = blockIdx.y, b = blockIdx.z;
+    const int nrows = PC_TT + K - 1, half = K / 2;
+    for (int i = tid; i < nrows * PC_CG; i += 256) {
+        const int r = i / PC_CG, ci = i - r * PC_CG, t = t0 - half + r;
+        xs[r * PC_XP + ci] = (t >= 0 && t < T) ? x[((size_t)b * T + t) * D + g * PC_CG + ci] : 0.f;
+    }
+    float acc[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc[j][q] = 0.f;
+    const float* wg = wt + (size_t)g * K * PC_CG * PC_CG;
+    for (int k0 = 0; k0 < K; k0 += PC_KC) {
+        __syncthreads();
+        for (int i = tid; i < PC_KC * PC_CG * PC_CG; i += 256) {
+            const int kk = i / (PC_CG * PC_CG), rem = i - kk * PC_CG * PC_CG, co = rem / PC_CG, ci = rem - co * PC_CG;
+            ws[(kk * PC_CG + co) * PC_XP + ci] = (k0 + kk < K) ? wg[(size_t)(k0 + kk) * PC_CG * PC_CG + rem] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < PC_KC; ++kk) {
+            const float* xr = xs + (4 * tq + k0 + kk) * PC_XP;
+            const float* wr = ws + (kk * PC_CG + 3 * c) * PC_XP;
+#pragma unroll 4
+            for (int ci = 0; ci < PC_CG; ++ci) {
+                const float w0 = wr[ci], w1 = wr[PC_XP + ci], w2 = wr[2 * PC_XP + ci];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xv = xr[j * PC_XP + ci];
+                    acc[j][0] = fmaf(xv, w0, acc[j][0]);
+                    acc[j][1] = fmaf(xv, w1, acc[j][1]);
+                    acc[j][2] = fmaf(xv, w2, acc[j][2]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = t0 + 4 * tq + j;
+        if (t < T) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int ch = g * PC_CG + 3 * c + q;
+                const float v = acc[j][q] + bias[ch];
+                const size_t o = ((size_t)b * T + t) * D + ch;
+                y[o] = x[o] + 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+            }
+        }
+    }
+}
+extern "C" int sed_posconv(const float* x, const float* wt, const float* bias, float* y, int B, int T, int D, int K, int groups,
+                           void* stream) {
+    if (groups < 1 || D % groups != 0 || D / groups != PC_CG || K < 2 || (K & 1) || K % PC_KC != 0) return SED_ERR_UNSUPPORTED;
+    if (B <= 0 || T <= 0) return SED_OK;
+    const int smem = ((PC_TT + K - 1) * PC_XP + PC_KC * PC_CG * PC_XP) * 4;
+    SED_MAX_SMEM(posconv_kernel, smem);
+    SED_LAUNCH(posconv_kernel, dim3((T + PC_TT - 1) / PC_TT, groups, B), dim3(256), smem, (hipStream_t)stream, x, wt, bias, y, T, D, K);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-B5: attention.  qkv (B * T, 3 D): row = b * T + t, [q | k | v], head h at columns h * 64.  out (B * T, D).
+// scores(t, s) = q_t . k_s / 8 + gate(b, h, t) * relb[h][s - t + T - 1]   (the reference's q / 32, (s - max) * 32 is this up to the
+// softmax's shift invariance, backbone.py:529-531,640-643); gate = ga * (gb * grep_a[h] - 1) + 2 with
+// (ga, gb) = sigmoid(sum of 4 | sum of 4 of grep_linear(q_t))  (:662-682).  relb (H, 2 T - 1): the bucket embedding gathered per
+// relative offset on the host (it depends on s - t only, :390-444); null = no position bias; grep_w null = ungated bias.
+// Workgroup = 64 queries of one (b, h); 4 lanes per query, lane p owns keys 16 p .. 16 p + 15 of every 64-key tile for the scores
+// and output dims 16 p .. 16 p + 15 for P V; online softmax; K, V and P tiles in LDS (row pitch 65).
+// ---------------------------------------------------------------------------------------------
+#define AT_HD 64
+#define AT_TQ 64
+#define AT_P 65
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, const float* __restrict__ relb,
+                                                        const float* __restrict__ grep_w, const float* __restrict__ grep_b,
+                                                        const float* __restrict__ grep_a, float* __restrict__ out, int T, int H,
+                                                        float scaling) {
+    SED_DYN_SMEM(smem);
+    float* ks = (float*)smem;                  // [64][65]
+    float* vs = ks + AT_TQ * AT_P;             // [64][65]
+    float* ps = vs + AT_TQ * AT_P;             // [64][65]
+    float* rb = ps + AT_TQ * AT_P;             // [2 T - 1]
+    const int tid = threadIdx.x, r = tid >> 2, p = tid & 3;
+    const int q0 = blockIdx.x * AT_TQ, h = blockIdx.y, b = blockIdx.z, D = H * AT_HD, LD = 3 * D;
+    const int t = q0 + r;
+    const bool live = t < T;
+    if (relb)
+        for (int i = tid; i < 2 * T - 1; i += 256) rb[i] = relb[(size_t)h * (2 * T - 1) + i];
+    float q[AT_HD];
+    {
+        const float* qr = qkv + ((size_t)b * T + (live ? t : 0)) * LD + h * AT_HD;
+#pragma unroll
+        for (int d = 0; d < AT_HD; d += 4) {
+            const float4 v = *(const float4*)(qr + d);
+            q[d] = v.x; q[d + 1] = v.y; q[d + 2] = v.z; q[d + 3] = v.w;
+        }
+    }
+    float gate = relb ? 1.0f : 0.0f;
+    if (relb && grep_w) {
+        float ga = 0.f, gb = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float a = grep_b[o];
+#pragma unroll
+            for (int d = 0; d < AT_HD; ++d) a = fmaf(grep_w[o * AT_HD + d], q[d], a);
+            if (o < 4) ga += a; else gb += a;
+        }
+        ga = sed_sigmoid(ga); gb = sed_sigmoid(gb);
+        gate = ga * (gb * grep_a[h] - 1.0f) + 2.0f;
+    }
+    float m = -INFINITY, l = 0.f, o[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) o[d] = 0.f;
+    for (int s0 = 0; s0 < T; s0 += AT_TQ) {
+        __syncthreads();                                           // previous tile consumed (and rb staged)
+        for (int i = tid; i < AT_TQ * (AT_HD / 4); i += 256) {
+            const int kr = i / (AT_HD / 4), d4 = i - kr * (AT_HD / 4), s = s0 + kr;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (s < T) {
+                const float* base = qkv + ((size_t)b * T + s) * LD + h * AT_HD + 4 * d4;
+                kv = *(const float4*)(base + D);
+                vv = *(const float4*)(base + 2 * D);
+            }
+            float* kd = ks + kr * AT_P + 4 * d4;
+            float* vd = vs + kr * AT_P + 4 * d4;
+            kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+            vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
+        }
+        __syncthreads();
+        float sc[16], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int kk = 16 * p + j, s = s0 + kk;
+            const float* kr = ks + kk * AT_P;
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < AT_HD; ++d) a = fmaf(q[d], kr[d], a);
+            a *= scaling;
+            if (relb && live && s < T) a = fmaf(gate, rb[s - t + T - 1], a);
+            sc[j] = s < T ? a : -INFINITY;
+            mx = fmaxf(mx, sc[j]);
+        }
+        mx = fmaxf(mx, sed_quad_xor1(mx));
+        mx = fmaxf(mx, sed_quad_xor2(mx));
+        const float mn = fmaxf(m, mx);
+        const float corr = expf(m - mn);                           // m = -inf on the first tile: exp(-inf) = 0
+        float ls = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float e = expf(sc[j] - mn);
+            ps[r * AT_P + 16 * p + j] = e;
+            ls += e;
+        }
+        ls = sed_quad_sum(ls);
+        l = l * corr + ls;
+        m = mn;
+        __syncthreads();                                           // the row's four lanes wrote its P values
+#pragma unroll
+        for (int d = 0; d < 16; ++d) o[d] *= corr;
+        for (int kk = 0; kk < AT_TQ; ++kk) {
+            const float pv = ps[r * AT_P + kk];
+            const float* vr = vs + kk * AT_P + 16 * p;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) o[d] = fmaf(pv, vr[d], o[d]);
+        }
+    }
+    if (live) {
+        const float inv = 1.0f / l;
+        float* dst = out + ((size_t)b * T + t) * D + h * AT_HD + 16 * p;
+#pragma unroll
+        for (int d = 0; d < 16; d += 4) *(float4*)(dst + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+    }
+}
+extern "C" int sed_attention_relpos(const float* qkv, const float* relb, const float* grep_w, const float* grep_b,
+                                    const float* grep_a, float* out, int B, int T, int H, int head_dim, void* stream) {
+    if (head_dim != AT_HD || T > 4096) return SED_ERR_UNSUPPORTED;
+    if (B <= 0 || T <= 0) return SED_OK;
+    const int smem = (3 * AT_TQ * AT_P + 2 * T) * 4;
+    SED_MAX_SMEM(attention_kernel, smem);
+    SED_LAUNCH(attention_kernel, dim3((T + AT_TQ - 1) / AT_TQ, H, B), dim3(256), smem, (hipStream_t)stream, qkv, relb, grep_w, grep_b,
+               grep_a, out, T, H, 1.0f / sqrtf((float)head_dim));
+    return sed_check_launch();
+}

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restric
                                                           int lda, int ldb, int ldc, int k_per_slice, int atomic,
                                                           const float* __restrict__ A1, const float* __restrict__ B1,
                                                           const float* __restrict__ bias1, float* __restrict__ C1, int nbatch,
-                                                          const float* __restrict__ Bsw, int ksw) {
+                                                          const float* __restrict__ Bsw, int ksw, int act) {
     // Bsw != null: K-concatenated B -- rows k >= ksw come from Bsw (already offset by -ksw rows); ksw % 32 == 0
     constexpr int BM = GB_BM, BN = 32 * NTN, BK = GB_BK, RS = GB_RS;
     __shared__ __attribute__((aligned(16))) unsigned short As[2 * BM * RS];     // hi plane, lo plane
@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const float* __restric
                 const int gm = m0 + 32 * w + mfma32_row(r, lane);
                 if (gm < M) {
                     float* dst = Cm + (size_t)gm * ldc + gn;
-                    const float v = acc[nt][r] + bv;
+                    float v = acc[nt][r] + bv;
+                    if (act == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));      // exact GELU (sed_linear_bf16x3)
                     if (atomic) atomicAdd(dst, v); else *dst = v;
                 }
             }
@@ -153,12 +154,12 @@ extern "C" int sed_gemm_pair(const float* A0, const float* A1, const float* B0, 
 
 static int gemmb_dispatch(const float* A, const float* Bm, const float* bias, float* Cm, const float* A1, const float* B1,
                           const float* bias1, float* C1, int nbatch, int M, int N, int K, int lda, int ldb, int ldc, int transA,
-                          int transB, int split_k, int accumulate, hipStream_t s, const float* Bsw = nullptr, int ksw = 0) {
+                          int transB, int split_k, int accumulate, hipStream_t s, const float* Bsw = nullptr, int ksw = 0, int act = 0) {
     if (M <= 0 || N <= 0 || K <= 0) return SED_OK;
     bool ok = ((uintptr_t)A % 16 == 0) && ((uintptr_t)Bm % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 &&
               ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0) && !(transA && transB);
     if (nbatch == 2) ok = ok && ((uintptr_t)A1 % 16 == 0) && ((uintptr_t)B1 % 16 == 0);
-    if (!ok && Bsw) return SED_ERR_UNSUPPORTED;
+    if (!ok && (Bsw || act)) return SED_ERR_UNSUPPORTED;
     if (!ok) {
         if (nbatch == 2) return sed_gemm_pair(A, A1, Bm, B1, bias, bias1, Cm, C1, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate, s);
         return sed_gemm(A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate, s);
@@ -171,7 +172,7 @@ static int gemmb_dispatch(const float* A, const float* Bm, const float* bias, fl
     if (ntn == 4 && ((N + 127) / 128) * ((M + 127) / 128) * split_k * nbatch < 200) ntn = 2;     // too few workgroups for 256 CUs
     dim3 grid((N + 32 * ntn - 1) / (32 * ntn), (M + 127) / 128, split_k * nbatch);
 #define GEMMB_CASE(ta, tb, nn) \
-    if (transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_bf16x3_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic, A1, B1, bias1, C1, nbatch, Bsw, ksw); return sed_check_launch(); }
+    if (transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_bf16x3_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic, A1, B1, bias1, C1, nbatch, Bsw, ksw, act); return sed_check_launch(); }
     GEMMB_CASE(0, 0, 2) GEMMB_CASE(0, 0, 4) GEMMB_CASE(0, 1, 2) GEMMB_CASE(0, 1, 4) GEMMB_CASE(1, 0, 2) GEMMB_CASE(1, 0, 4)
 #undef GEMMB_CASE
     return SED_ERR_UNSUPPORTED;
@@ -198,4 +199,13 @@ extern "C" int sed_gemm_kcat_bf16x3(const float* A, const float* B0, const float
     if (ksplit % 32 != 0 || ksplit <= 0 || ksplit >= K) return SED_ERR_ARG;
     return gemmb_dispatch(A, B0, nullptr, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, 0, 0, 1, 0,
                           (hipStream_t)stream, B1 - (size_t)ksplit * ldb, ksplit);
+}
+
+// torch.nn.Linear forward with an optional fused activation: C[M][N] = act(A[M][K] . W[N][K]^T + bias[N]), act 0 = none, 1 = exact
+// GELU (the FFN of the BEATs encoder layers).  16-byte aligned operands, K % 4 == 0.
+extern "C" int sed_linear_bf16x3(const float* A, const float* W, const float* bias, float* Cm, int M, int N, int K, int act,
+                                 void* stream) {
+    if (act < 0 || act > 1) return SED_ERR_ARG;
+    return gemmb_dispatch(A, W, bias, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, K, K, N, 0, 1, 1, 0, (hipStream_t)stream,
+                          nullptr, 0, act);
 }

@@ -282,6 +282,41 @@ int sed_adam_step(float* p, const float* g, float* m, float* v, long long n, flo
 int sed_zero_buffers(float* p0, long long n0, float* p1, long long n1, float* p2, long long n2, float* p3, long long n3,
                      void* stream);
 
+/* ---- frozen BEATs feature extractor (recipes/dcase2023_task4_baseline/local/beats/, inference only) ---------- */
+
+/* torch.nn.Linear forward with an optional fused activation on the split-bf16 MFMA: C (M,N) = act(A (M,K) . W (N,K)^T + bias),
+ * act 0 = none, 1 = exact GELU (backbone.py:279-283: the encoder layers' fc1).  16-byte aligned, K % 4 == 0. */
+int sed_linear_bf16x3(const float* A, const float* W, const float* bias, float* Cm, int M, int N, int K, int act, void* stream);
+
+/* torchaudio.compliance.kaldi.fbank(waveform * 2^15, num_mel_bins, 16 kHz, 25 ms frames, 10 ms shift) with that function's
+ * defaults (povey window, pre-emphasis 0.97, DC removal, snip_edges, 512-point FFT, power spectrum, log) followed by
+ * (x - norm_mean) * norm_inv -- BEATs.preprocess, BEATs.py:109-133.  audio (B,N) -> out (B, 1 + (N - 400) / 160, n_mels).
+ * Host-built tables: window[400], tw[256] complex exp(-2 pi i k / 512), sparse Kaldi-mel bank (start, len, weights). */
+int sed_kaldi_fbank(const float* audio, float* out, int B, int N, int n_mels, const float* window, const float* tw,
+                    const int* fb_start, const int* fb_len, const float* fb_w, int fb_stride, float norm_mean, float norm_inv,
+                    void* stream);
+
+/* The gather of Conv2d(1, E, kernel = stride = P) (BEATs.py:98-104,153-156): fbank (B,M,F) -> patches (B * (M/P) * (F/P), P*P),
+ * token order time-major / frequency-fastest; the patch embedding itself is sed_linear_bf16x3 on these rows. */
+int sed_patchify(const float* fbank, float* patches, int B, int M, int F, int P, void* stream);
+
+/* y = LayerNorm(alpha * res + x) * gamma + beta over the last dimension D (64 | D, D <= 1024); res may be null.  The post-LN /
+ * deep-norm residual of the encoder layers (backbone.py:268-294) and the plain LayerNorms of BEATs.py:157, backbone.py:122. */
+int sed_layernorm(const float* x, const float* res, float alpha, const float* gamma, const float* beta, float* y, int M, int D,
+                  float eps, void* stream);
+
+/* y = x + GELU(bias + grouped Conv1d(x)): the convolutional position embedding (backbone.py:30-43,118-120; even kernel, padding
+ * K/2, last output dropped).  x, y (B,T,D); wt (groups, K, D/groups co, D/groups ci) = the weight-normalised filter transposed
+ * on the host once. */
+int sed_posconv(const float* x, const float* wt, const float* bias, float* y, int B, int T, int D, int K, int groups, void* stream);
+
+/* Multi-head self-attention of MultiheadAttention.forward (backbone.py:446-700, eval mode, no padding mask) on the output of ONE
+ * fused q|k|v projection: qkv (B*T, 3*H*64) -> out (B*T, H*64).  relb (H, 2T-1) = relative position bias per offset s - t (the
+ * bucket embedding of :390-444 gathered on the host), or null; grep_w (8,64), grep_b (8), grep_a (H) = the gate of :662-682, or
+ * null for an ungated bias.  No T x T tensor is written to HBM. */
+int sed_attention_relpos(const float* qkv, const float* relb, const float* grep_w, const float* grep_b, const float* grep_a,
+                         float* out, int B, int T, int H, int head_dim, void* stream);
+
 /* Tuning overrides for tests / sweep tools (no reference counterpart): key 0 = persistent-grid cap of the wide GLU kernels,
  * 1 = split-bf16 variant of the 128-channel GLU backward, 2 = channels per weight chunk of the split-bf16 conv (16|32),
  * 3 = pixels per workgroup of the split-bf16 conv.  value 0 restores the built-in choice.  Not for use while kernels are in

@@ -105,6 +105,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p 
 static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 
+static inline unsigned __brev(unsigned x) { unsigned r = 0; for (int i = 0; i < 32; ++i) { r = (r << 1) | (x & 1u); x >>= 1; } return r; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }

@@ -1572,3 +1572,75 @@ def case_training_step_2024(dev, golden):
         raise AssertionError("n_RNN_cell = 192 must be refused")
     except NotImplementedError:
         pass
+
+
+# ------------------------------------------------------------------------------------------------
+# frozen BEATs extractor
+# ------------------------------------------------------------------------------------------------
+def np_kaldi_fbank64(wave, n_mels=128):
+    """Independent float64 numpy implementation of Kaldi's fbank with the options BEATs uses (cross-check of the unpinned front-end)."""
+    x = wave.astype(np.float64) * 32768.0
+    m = 1 + (len(x) - 400) // 160
+    fr = np.stack([x[i * 160:i * 160 + 400] for i in range(m)])
+    fr = fr - fr.mean(1, keepdims=True)
+    fr = fr - 0.97 * np.concatenate([fr[:, :1], fr[:, :-1]], 1)
+    win = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(400) / 399)) ** 0.85
+    spec = np.abs(np.fft.rfft(fr * win, 512, axis=1)) ** 2
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)      # noqa: E731
+    lo, hi = mel(20.0), mel(8000.0)
+    d = (hi - lo) / (n_mels + 1)
+    melf = mel(31.25 * np.arange(257))
+    bank = np.zeros((n_mels, 257))
+    for b in range(n_mels):
+        l, c, r = lo + b * d, lo + (b + 1) * d, lo + (b + 2) * d
+        bank[b] = np.maximum(0.0, np.minimum((melf - l) / (c - l), (r - melf) / (r - c)))
+    bank[:, 256] = 0.0
+    return np.log(np.maximum(spec @ bank.T, np.finfo(np.float32).eps))
+
+
+def case_beats_fbank(dev):
+    from oracle import beats_oracle as BO
+    from desed_task_amd.beats import KaldiFbank
+    audio = O.synth_audio(2, 400 + 160 * 37 + 55, seed=21)               # ragged tail: the last partial frame is dropped
+    fb = KaldiFbank(128)
+    got = fb(to(dev, audio)).cpu()                                      # mean 0, std 0.5 -> raw log energies
+    ref = torch.stack([BO.kaldi_fbank(w * 2 ** 15) for w in audio])
+    assert tuple(got.shape) == tuple(ref.shape) == (2, 38, 128)
+    assert (got - ref).abs().max().item() < 2e-3                        # log domain; fp32 FFT order differs
+    ref64 = np.stack([np_kaldi_fbank64(w.numpy()) for w in audio])
+    assert np.abs(got.numpy() - ref64).max() < 2e-3 and np.abs(ref.numpy() - ref64).max() < 2e-3
+    norm = fb(to(dev, audio), 15.41663, 6.55582).cpu()
+    assert (norm - (ref - 15.41663) / (2 * 6.55582)).abs().max().item() < 2e-4
+
+
+def case_beats_vs_reference_golden(dev, golden):
+    """desed_task_amd.beats.BEATs (2 encoder layers of the iter3 configuration, closed-form weights) on the HIP kernels against the
+    output of the reference module itself (tests/golden/golden_beats.npz), plus the BEATsModel wrapper's global / frame outputs."""
+    from oracle import beats_oracle as BO
+    from desed_task_amd.beats import BEATs, BEATsConfig, BEATsModel
+    cfg = dict(BO.BEATS_ITER3_CFG, encoder_layers=int(golden["cfg_layers"][0]))
+    sd = BO.make_beats_state_dict(cfg, seed=3)
+    model = BEATs(BEATsConfig(cfg))
+    assert set(model.state_dict().keys()) == set(golden["state_dict_keys"]) == set(sd.keys())
+    model.load_state_dict(sd)
+    model = model.to(dev) if dev != "cpu" else model
+    model.eval()
+    audio = O.synth_audio(2, 400 + 255 * 160, seed=21)
+    feats, pm = model.extract_features(to(dev, audio))
+    assert pm is None and tuple(feats.shape) == (2, 128, 768)
+    ref = golden["features"]
+    err = np.abs(feats.cpu().numpy() - ref).max()
+    assert err < 2e-4 * max(1.0, np.abs(ref).max()), err
+    fb = model.preprocess(to(dev, audio)).cpu().numpy()[:, ::7, ::5]
+    assert np.abs(fb - golden["fbank"]).max() < 2e-4
+    wrapped = BEATsModel(checkpoint={"cfg": cfg, "model": sd})
+    wrapped = wrapped.to(dev) if dev != "cpu" else wrapped
+    out = wrapped(to(dev, audio))
+    assert tuple(out["frame"].shape) == (2, 768, 128) and tuple(out["global"].shape) == (2, 768)
+    assert np.abs(out["frame"].cpu().numpy() - ref.transpose(0, 2, 1)).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    assert np.abs(out["global"].cpu().numpy() - ref.mean(1)).max() < 1e-4
+    try:
+        model.extract_features(to(dev, audio), padding_mask=torch.zeros(2, 41200, dtype=torch.bool))
+        raise AssertionError("padding masks must be refused")
+    except NotImplementedError:
+        pass

@@ -99,3 +99,13 @@ def test_training_step_2024_vs_reference_golden(emu):
     import numpy as np
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_2024.npz"))
     P.case_training_step_2024("cpu", G)
+
+
+def test_beats_fbank_and_extractor_vs_reference_golden(emu):
+    """Kaldi fbank kernel vs the oracle and an independent float64 implementation; the BEATs encoder kernels
+    (patch embedding, position convolution, gated relative-position attention, deep-norm layers) vs the reference module's output."""
+    import os
+    import numpy as np
+    P.case_beats_fbank("cpu")
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_beats.npz"))
+    P.case_beats_vs_reference_golden("cpu", G)

@@ -179,3 +179,10 @@ def test_crnn_masks_dropstep_interpolate_vs_reference_golden():
 def test_training_step_2024_vs_reference_golden():
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_2024.npz"))
     P.case_training_step_2024("cuda", G)
+
+
+def test_beats_extractor_vs_reference_golden():
+    """the frozen BEATs extractor on the GPU against the reference module's recorded output."""
+    P.case_beats_fbank("cuda")
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_beats.npz"))
+    P.case_beats_vs_reference_golden("cuda", G)

@@ -1,0 +1,37 @@
+"""Throughput of the frozen BEATs extractor at the recipe's size: 48 clips of 10 s -> (48, 768, 496) embeddings,
+iter3 configuration (12 layers), random weights.  Secondary workload: not the headline metric of bench.py."""
+import json, sys, time
+sys.path.insert(0, ".")
+import torch
+from desed_task_amd import _lib
+from desed_task_amd.beats import BEATs, BEATsConfig
+CFG = dict(input_patch_size=16, embed_dim=512, conv_bias=False, encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072,
+           encoder_attention_heads=12, activation_fn="gelu", layer_norm_first=False, deep_norm=True, conv_pos=128, conv_pos_groups=16,
+           relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True, dropout=0.0, attention_dropout=0.0,
+           encoder_layerdrop=0.0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+torch.manual_seed(0)
+model = BEATs(BEATsConfig(CFG)).cuda().eval()
+audio = 0.1 * torch.randn(B, 160000, device="cuda")
+for _ in range(2):
+    feats, _ = model.extract_features(audio)
+torch.cuda.synchronize()
+lib = _lib.get(); orig = lib.call; rec = {}
+def timed(name, *a):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); orig(name, *a); e1.record()
+    rec.setdefault(name, []).append((e0, e1))
+t0 = time.perf_counter()
+n = 3
+for _ in range(n):
+    feats, _ = model.extract_features(audio)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+lib.call = timed
+model.extract_features(audio); torch.cuda.synchronize()
+lib.call = orig
+per = {k: round(sum(a.elapsed_time(b) for a, b in v), 3) for k, v in rec.items()}
+flops = B * (496 * (2 * 256 * 512 + 2 * 512 * 768) + 12 * (496 * 2 * 768 * (3 * 768 + 768 + 2 * 3072) + 2 * 2 * 12 * 496 * 496 * 64) + 496 * 768 * 2 * 48 * 128)
+print(json.dumps({"workload": "BEATs iter3 extractor, %d clips of 10 s -> (%d, 768, 496)" % (B, B), "ms_per_batch": round(dt * 1e3, 2),
+                  "clips_per_s": round(B / dt, 1), "tflops_algorithmic": round(flops / dt / 1e12, 1), "ms_by_entry": per,
+                  "finite": bool(torch.isfinite(feats).all())}))
