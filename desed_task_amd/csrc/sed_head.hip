@@ -24,6 +24,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
                                                                 const unsigned char* __restrict__ cvalid,
                                                                 const unsigned char* __restrict__ pad) {
     if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
+    static_assert(NC <= 32, "the class mask of a frame is one 32-bit set");
     constexpr int D = HEAD_D, FPP = HEAD_THREADS / 4;          // frames per pass
     __shared__ __attribute__((aligned(16))) float w1[NC * D];
     __shared__ __attribute__((aligned(16))) float w2[NC * D];
@@ -70,10 +71,16 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
             for (int c = 0; c < NC; ++c) { l1[c] += b1[c]; l2[c] += b2[c]; }
             // CRNN.py:160-166: padded frames and the classes a clip's data set does not annotate cannot be attended to
             // (masked_fill(-1e30) before the class softmax; a fully masked frame therefore attends uniformly)
-            const bool padded = pad && pad[(size_t)b * T + t];
+            // (the masks are gathered into one bit set first and applied with selects: the branchy form -- a conditional store
+            // per class behind `padded || (cvalid && !cvalid[...])` -- lost the fill in hipcc 7.2's code for gfx950)
+            unsigned inval = 0u;                                    // classes outside the clip's data set
+            if (cvalid) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-                if (padded || (cvalid && !cvalid[b * NC + c])) l2[c] = -1e30f;
+                for (int c = 0; c < NC; ++c) inval |= (cvalid[b * NC + c] ? 0u : 1u) << c;
+            }
+            const unsigned gone = (pad && pad[(size_t)b * T + t]) ? 0xFFFFFFFFu : inval;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) l2[c] = ((gone >> c) & 1u) ? -1e30f : l2[c];
             float mx = l2[0];
 #pragma unroll
             for (int c = 1; c < NC; ++c) mx = fmaxf(mx, l2[c]);
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
                 const float s = sed_sigmoid(l1[c]);
                 const float p = l2[c] * inv;
                 const float a = fminf(fmaxf(p, 1e-7f), 1.0f);
-                so[c] = (cvalid && !cvalid[b * NC + c]) ? 0.f : s;        // CRNN.py:173-175 (after the pooling below)
+                so[c] = ((inval >> c) & 1u) ? 0.f : s;                    // CRNN.py:173-175 (after the pooling below)
                 po[c] = p;
                 num[c] += s * a;
                 dn[c] += a;

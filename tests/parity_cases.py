@@ -1034,7 +1034,7 @@ def case_embcat_full_size(dev):
     lib = _lib.get()
     z = torch.empty(B, T, C + E, device=x.device)
     thr24, dscale = ops.dropout_params(p)
-    lib.call("sed_embcat_fwd", x.data_ptr(), emb.data_ptr(), z.data_ptr(), B, T, Te, C, E, 99, thr24, dscale, None, _lib.stream_ptr(x))
+    lib.call("sed_embcat_fwd", x.data_ptr(), emb.data_ptr(), z.data_ptr(), B, T, Te, C, E, 99, thr24, dscale, None, None, 0, _lib.stream_ptr(x))
     kept = z != 0
     rate = float(kept.float().mean())
     assert abs(rate - (1 - p)) < 2e-3, rate
