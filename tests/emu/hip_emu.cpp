@@ -1,14 +1,22 @@
 // TEST INFRASTRUCTURE ONLY -- runtime of the fiber emulator declared in hip_emu.h.
+// A launch runs its workgroups on a small pool of OS threads (SED_EMU_THREADS / emu_set_threads; 1 = the sequential,
+// order-deterministic emulator); the threads of one workgroup are fibers on one OS thread, switched at barriers.
 #include "hip_emu.h"
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
+#include <unistd.h>
 
-EmuFiber* emu_cur = nullptr;
-dim3 emu_blockIdx, emu_blockDim, emu_gridDim;
-char* emu_dyn_smem = nullptr;
-float emu_wave_xchg[16][64][8];
+thread_local EmuFiber* emu_cur = nullptr;
+thread_local dim3 emu_blockIdx;
+dim3 emu_blockDim, emu_gridDim;
+thread_local char* emu_dyn_smem = nullptr;
+thread_local float emu_wave_xchg[16][64][8];
 
-static void* emu_sched_sp = nullptr;
+static thread_local void* emu_sched_sp = nullptr;
 static const std::function<void()>* emu_body = nullptr;
 static const size_t EMU_STACK = 256 * 1024;
 
@@ -47,71 +55,164 @@ static void emu_trampoline() {
 void emu_block_barrier() { emu_cur->state = 1; emu_yield(); }
 void emu_wave_sync() { emu_cur->state = 2; emu_yield(); }
 
-void emu_launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
-    const int nthr = block.x * block.y * block.z;
-    if (nthr > 1024 || nthr <= 0) { fprintf(stderr, "emu: bad block size %d\n", nthr); abort(); }
-    std::vector<EmuFiber> fibers(nthr);
-    std::vector<char> smem_buf(smem + 64);
-    static std::vector<char*> stacks;
-    while ((int)stacks.size() < nthr) stacks.push_back((char*)aligned_alloc(64, EMU_STACK));
-    emu_gridDim = grid; emu_blockDim = block;
-    emu_body = &body;
-    emu_dyn_smem = (char*)(((uintptr_t)smem_buf.data() + 63) & ~(uintptr_t)63);
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-    for (unsigned bx = 0; bx < grid.x; ++bx) {
-        emu_blockIdx = dim3(bx, by, bz);
+// one OS thread's private state: fiber records, their stacks, the dynamic LDS image
+struct EmuWorker {
+    std::vector<EmuFiber> fibers;
+    std::vector<char*> stacks;
+    std::vector<char> smem;
+};
+
+static void emu_run_block(EmuWorker& W, int nthr, dim3 block, unsigned bx, unsigned by, unsigned bz) {
+    std::vector<EmuFiber>& fibers = W.fibers;
+    emu_blockIdx = dim3(bx, by, bz);
+    for (int t = 0; t < nthr; ++t) {
+        EmuFiber& f = fibers[t];
+        f.lin = t;
+        f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+        f.stack = W.stacks[t];
+        f.state = 0;
+        // initial frame: 6 callee-saved slots, then the return address (16-byte aligned slot)
+        uintptr_t top = ((uintptr_t)f.stack + EMU_STACK) & ~(uintptr_t)15;
+        void** sp = (void**)(top - 16);          // slot of the return address: ==0 mod 16
+        sp[0] = (void*)&emu_trampoline;
+        sp -= 6;
+        for (int i = 0; i < 6; ++i) sp[i] = nullptr;
+        f.sp = (void*)sp;
+    }
+    int done = 0;
+    while (done < nthr) {
+        bool progressed = false;
         for (int t = 0; t < nthr; ++t) {
             EmuFiber& f = fibers[t];
-            f.lin = t;
-            f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-            f.stack = stacks[t];
-            f.state = 0;
-            // initial frame: 6 callee-saved slots, then the return address (16-byte aligned slot)
-            uintptr_t top = ((uintptr_t)f.stack + EMU_STACK) & ~(uintptr_t)15;
-            void** sp = (void**)(top - 16);          // slot of the return address: ==0 mod 16
-            sp[0] = (void*)&emu_trampoline;
-            sp -= 6;
-            for (int i = 0; i < 6; ++i) sp[i] = nullptr;
-            f.sp = (void*)sp;
+            if (f.state != 0) continue;
+            emu_cur = &f;
+            emu_switch(&emu_sched_sp, f.sp);
+            progressed = true;
+            if (f.state == 3) ++done;
         }
-        int done = 0;
-        while (done < nthr) {
-            bool progressed = false;
+        // release wave syncs: every not-done lane of the wave must be at state 2
+        const int nw = (nthr + 63) / 64;
+        for (int w = 0; w < nw; ++w) {
+            int lo = w * 64, hi = lo + 64 < nthr ? lo + 64 : nthr;
+            bool all = true, any = false;
+            for (int t = lo; t < hi; ++t) {
+                if (fibers[t].state == 2) any = true;
+                else if (fibers[t].state != 3) all = false;
+            }
+            if (any && all) { for (int t = lo; t < hi; ++t) if (fibers[t].state == 2) fibers[t].state = 0; progressed = true; }
+        }
+        // release the block barrier: every not-done thread must be at state 1
+        {
+            bool all = true, any = false;
             for (int t = 0; t < nthr; ++t) {
-                EmuFiber& f = fibers[t];
-                if (f.state != 0) continue;
-                emu_cur = &f;
-                emu_switch(&emu_sched_sp, f.sp);
-                progressed = true;
-                if (f.state == 3) ++done;
+                if (fibers[t].state == 1) any = true;
+                else if (fibers[t].state != 3) all = false;
             }
-            // release wave syncs: every not-done lane of the wave must be at state 2
-            const int nw = (nthr + 63) / 64;
-            for (int w = 0; w < nw; ++w) {
-                int lo = w * 64, hi = lo + 64 < nthr ? lo + 64 : nthr;
-                bool all = true, any = false;
-                for (int t = lo; t < hi; ++t) {
-                    if (fibers[t].state == 2) any = true;
-                    else if (fibers[t].state != 3) all = false;
-                }
-                if (any && all) { for (int t = lo; t < hi; ++t) if (fibers[t].state == 2) fibers[t].state = 0; progressed = true; }
-            }
-            // release the block barrier: every not-done thread must be at state 1
-            {
-                bool all = true, any = false;
-                for (int t = 0; t < nthr; ++t) {
-                    if (fibers[t].state == 1) any = true;
-                    else if (fibers[t].state != 3) all = false;
-                }
-                if (any && all) { for (int t = 0; t < nthr; ++t) if (fibers[t].state == 1) fibers[t].state = 0; progressed = true; }
-            }
-            if (!progressed) {
-                fprintf(stderr, "emu: DEADLOCK in block (%u,%u,%u): divergent barrier / wave collective\n", bx, by, bz);
-                for (int t = 0; t < nthr; ++t) if (fibers[t].state != 3) { fprintf(stderr, "  thread %d state %d\n", t, fibers[t].state); break; }
-                abort();
-            }
+            if (any && all) { for (int t = 0; t < nthr; ++t) if (fibers[t].state == 1) fibers[t].state = 0; progressed = true; }
+        }
+        if (!progressed) {
+            fprintf(stderr, "emu: DEADLOCK in block (%u,%u,%u): divergent barrier / wave collective\n", bx, by, bz);
+            for (int t = 0; t < nthr; ++t) if (fibers[t].state != 3) { fprintf(stderr, "  thread %d state %d\n", t, fibers[t].state); break; }
+            abort();
         }
     }
     emu_cur = nullptr;
+}
+
+// the launch in flight (one at a time: emu_launch holds launch_mu)
+static struct {
+    dim3 grid, block;
+    size_t smem;
+    int nthr;
+    long total;
+    std::atomic<long> next{0};
+} L;
+
+static void emu_work(EmuWorker& W) {
+    const int nthr = L.nthr;
+    if ((int)W.fibers.size() < nthr) W.fibers.resize(nthr);
+    while ((int)W.stacks.size() < nthr) W.stacks.push_back((char*)aligned_alloc(64, EMU_STACK));
+    if (W.smem.size() < L.smem + 64) W.smem.resize(L.smem + 64);
+    emu_dyn_smem = (char*)(((uintptr_t)W.smem.data() + 63) & ~(uintptr_t)63);
+    for (;;) {
+        const long b = L.next.fetch_add(1, std::memory_order_relaxed);
+        if (b >= L.total) break;
+        const unsigned bx = (unsigned)(b % L.grid.x), by = (unsigned)((b / L.grid.x) % L.grid.y);
+        const unsigned bz = (unsigned)(b / ((long)L.grid.x * L.grid.y));
+        emu_run_block(W, nthr, L.block, bx, by, bz);
+    }
+}
+
+// persistent helper threads; rebuilt after a fork (the child inherits none of them)
+struct EmuPool {
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::vector<std::thread> threads;
+    long epoch = 0;
+    int busy = 0, active = 0;
+    pid_t pid = 0;
+};
+static EmuPool* pool = nullptr;
+static std::mutex launch_mu;
+static int emu_nthreads = -1;
+
+extern "C" void emu_set_threads(int n) { std::lock_guard<std::mutex> g(launch_mu); emu_nthreads = n < 1 ? 1 : (n > 64 ? 64 : n); }
+extern "C" int emu_get_threads() { return emu_nthreads; }
+
+static void emu_helper(EmuPool* P, int idx) {
+    EmuWorker W;
+    long seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(P->mu);
+            P->cv_go.wait(lk, [&] { return P->epoch != seen; });
+            seen = P->epoch;
+            if (idx >= P->active) continue;
+        }
+        emu_work(W);
+        {
+            std::lock_guard<std::mutex> lk(P->mu);
+            if (--P->busy == 0) P->cv_done.notify_one();
+        }
+    }
+}
+
+void emu_launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
+    const int nthr = block.x * block.y * block.z;
+    if (nthr > 1024 || nthr <= 0) { fprintf(stderr, "emu: bad block size %d\n", nthr); abort(); }
+    std::lock_guard<std::mutex> g(launch_mu);
+    if (emu_nthreads < 0) {
+        const char* e = getenv("SED_EMU_THREADS");
+        int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        emu_nthreads = n < 1 ? 1 : (n > 8 && !e ? 8 : (n > 64 ? 64 : n));
+    }
+    emu_gridDim = grid; emu_blockDim = block;
+    emu_body = &body;
+    L.grid = grid; L.block = block; L.smem = smem; L.nthr = nthr;
+    L.total = (long)grid.x * grid.y * grid.z;
+    L.next.store(0);
+    static thread_local EmuWorker mine;
+    int helpers = emu_nthreads - 1;
+    if (L.total < 4) helpers = 0;
+    else if (helpers > L.total - 1) helpers = (int)L.total - 1;
+    if (helpers > 0) {
+        if (!pool || pool->pid != getpid()) { pool = new EmuPool(); pool->pid = getpid(); }   // (a forked child leaks the stale one)
+        while ((int)pool->threads.size() < helpers) {
+            const int idx = (int)pool->threads.size();
+            pool->threads.emplace_back(emu_helper, pool, idx);
+            pool->threads.back().detach();
+        }
+        {
+            std::lock_guard<std::mutex> lk(pool->mu);
+            pool->active = helpers;
+            pool->busy = helpers;
+            ++pool->epoch;
+        }
+        pool->cv_go.notify_all();
+    }
+    emu_work(mine);
+    if (helpers > 0) {
+        std::unique_lock<std::mutex> lk(pool->mu);
+        pool->cv_done.wait(lk, [&] { return pool->busy == 0; });
+    }
 }

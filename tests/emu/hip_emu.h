@@ -51,10 +51,11 @@ struct EmuFiber {
     char* stack;
     int state;        // 0 runnable, 1 at block barrier, 2 at wave sync, 3 done
 };
-extern EmuFiber* emu_cur;
-extern dim3 emu_blockIdx, emu_blockDim, emu_gridDim;
-extern char* emu_dyn_smem;
-extern float emu_wave_xchg[16][64][8];   // [wave][lane][slot] exchange area for collectives
+extern thread_local EmuFiber* emu_cur;            // workgroups run on a pool of OS threads: per-thread block state
+extern thread_local dim3 emu_blockIdx;
+extern dim3 emu_blockDim, emu_gridDim;
+extern thread_local char* emu_dyn_smem;
+extern thread_local float emu_wave_xchg[16][64][8];   // [wave][lane][slot] exchange area for collectives
 
 void emu_launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
 void emu_block_barrier();
@@ -70,7 +71,7 @@ void emu_wave_sync();
 #define __forceinline__ inline
 #define __restrict__
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local
 #define __syncthreads() emu_block_barrier()
 #define SED_DYN_SMEM(name) char* name = emu_dyn_smem
 #define SED_LAUNCH(kern, grid, block, smem, stream, ...) \
@@ -98,12 +99,23 @@ template <typename T> static inline T __shfl_xor(T v, int mask, int = 64) { retu
 template <typename T> static inline T __shfl_down(T v, int d, int = 64) { int l = emu_lane() + d; return emu_xchg(v, l > 63 ? emu_lane() : l); }
 template <typename T> static inline T __shfl(T v, int src, int = 64) { return emu_xchg(v, src); }
 
-static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
-static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
-static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
-static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
-static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
-static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
+template <typename T, typename U>
+static inline T emu_atomic_fadd(T* p, T v) {      // CAS loop on the bit pattern (workgroups of one launch run concurrently)
+    U* u = (U*)p;
+    U o = __atomic_load_n(u, __ATOMIC_RELAXED);
+    for (;;) {
+        T f; memcpy(&f, &o, sizeof(T));
+        f += v;
+        U n; memcpy(&n, &f, sizeof(T));
+        if (__atomic_compare_exchange_n(u, &o, n, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { T r; memcpy(&r, &o, sizeof(T)); return r; }
+    }
+}
+static inline float atomicAdd(float* p, float v) { return emu_atomic_fadd<float, unsigned>(p, v); }
+static inline double atomicAdd(double* p, double v) { return emu_atomic_fadd<double, unsigned long long>(p, v); }
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline int atomicMax(int* p, int v) { int o = __atomic_load_n(p, __ATOMIC_RELAXED); while (v > o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
+static inline int atomicMin(int* p, int v) { int o = __atomic_load_n(p, __ATOMIC_RELAXED); while (v < o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
 
 static inline unsigned __brev(unsigned x) { unsigned r = 0; for (int i = 0; i < 32; ++i) { r = (r << 1) | (x & 1u); x >>= 1; } return r; }
 static inline float __fdividef(float a, float b) { return a / b; }

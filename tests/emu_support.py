@@ -18,6 +18,28 @@ def bind_emulator():
     return _lib.get()
 
 
+def emu_threads(n):
+    """Workgroups of a launch run on n OS threads; 1 = sequential launches and atomics (bit-reproducible runs)."""
+    import ctypes
+    from desed_task_amd import _lib
+    lib = ctypes.CDLL(_lib.get().path)
+    lib.emu_get_threads.restype = ctypes.c_int
+    prev = lib.emu_get_threads()
+    lib.emu_set_threads(int(n))
+    return prev
+
+
 @pytest.fixture(scope="module")
 def emu():
     return bind_emulator()
+
+
+@pytest.fixture
+def emu_sequential(emu):
+    """The emulator with in-order workgroups: two runs of the same launches are arithmetically identical."""
+    prev = emu_threads(1)
+    yield emu
+    if prev > 0:
+        emu_threads(prev)
+    else:
+        emu_threads(int(os.environ.get("SED_EMU_THREADS", min(8, os.cpu_count() or 1))))

@@ -492,7 +492,7 @@ def case_edge_shapes(dev):
     assert tuple(Fh.minmax_scale(empty, apply_log=True).shape) == (0, 128, 17)
 
 
-def case_dyn_args_step(dev, graph=False, steps=4):
+def case_dyn_args_step(dev, graph=False, steps=4, n_samp=16000 + 1024):
     """Step-varying arguments through device memory (desed_task_amd/graph.py) == the by-value eager path.
 
     Two identical tasks, identical host RNG streams: one runs the plain StepDriver, the other runs every step under a
@@ -502,7 +502,7 @@ def case_dyn_args_step(dev, graph=False, steps=4):
     import random
     from desed_task_amd import graph as G
     from desed_task_amd.launcher import StepDriver
-    bs, n_samp = (1, 1, 2), 16000 + 1024
+    bs = (1, 1, 2)
     B = sum(bs)
     sd = O.make_state_dict(seed=7)
     audio = O.synth_audio(B, n_samp, seed=77)
