@@ -104,7 +104,7 @@ class KernelTimer:
         return out
 
 
-GLU_BWD128_SPLIT = False          # flipped when the split-bf16 128-channel GLU backward becomes the default
+GLU_BWD128_SPLIT = True           # the split-bf16 16x16x32 kernel is the default 128-channel GLU backward
 PEAK_HBM_GBS = 8000.0             # same guide: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 
 # entry point -> (kernel that does the work, family, number of leading shape arguments, algorithmic work of ONE call).

@@ -115,6 +115,16 @@ __device__ __forceinline__ void sed_sched_fence() {
 #endif
 }
 
+// Redefines a lane-dependent int opaquely: whatever is derived from it afterwards cannot be hoisted out of the enclosing loop
+// (in fully unrolled tile loops LICM otherwise precomputes dozens of per-element addresses and they end up in scratch).
+__device__ __forceinline__ void sed_opaque(int& x) {
+#ifndef SED_EMU
+    asm volatile("" : "+v"(x));
+#else
+    (void)x;
+#endif
+}
+
 // Rendezvous of the 64 lanes of ONE wave around an exchange through wave-private LDS (a lane reads what another lane of its
 // own wave wrote).  The LDS pipeline executes a wave's DS instructions in issue order, so no hardware barrier is needed: the
 // fence only keeps the compiler from moving the accesses across it.  (A workgroup barrier cannot be used where waves run

@@ -622,11 +622,12 @@ __global__ __launch_bounds__(512, 4) void glu_wide_fwd_b_kernel(const float* __r
     SED_DYN_SMEM(smem);
     unsigned short* xh = (unsigned short*)smem;                        // [ROWS][RS] hi plane of xn
     unsigned short* xl = xh + ROWS * RS;                               // lo plane
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int lo = lane & 31, hi = lane >> 5;
     const int wn = w % WN, wm = w / WN;
     const int R = B * T * F, ntiles = (R + ROWS - 1) / ROWS;
-    const int n = wn * 32 + lo;
-    const int v = tid % (C / 4), r0 = tid / (C / 4);                   // this thread's channel quad / first row when staging
+    int n = wn * 32 + lo;
+    int v = tid % (C / 4), r0 = tid / (C / 4);                         // this thread's channel quad / first row when staging
     constexpr int RSTEP = 512 / (C / 4);
     // ---- B fragments: Wg rows through LDS (coalesced global reads), split into bf16 planes, 64 rows per pass ----
     s16x8 bh[KS], bl[KS];
@@ -686,6 +687,7 @@ __global__ __launch_bounds__(512, 4) void glu_wide_fwd_b_kernel(const float* __r
     if (tile < ntiles) load_tile(tile);
     for (; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
+        sed_opaque(lo); sed_opaque(hi); sed_opaque(n); sed_opaque(v); sed_opaque(r0);   // per-tile addresses: recomputed, not spilled
         __syncthreads();                                               // previous tile fully consumed
         store_tile();
         __syncthreads();
@@ -1220,8 +1222,10 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_b_kernel(const float* __rest
     unsigned short* dl = dh + ROWS * RS;
     unsigned short* dth = dl + ROWS * RS;            // dlin^T [C][RT] hi | lo (swizzled octets)
     unsigned short* dtl = dth + C * RT;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
-    const int wn = w % WN, wm = w / WN, n = wn * 32 + lo;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int lo = lane & 31, hi = lane >> 5;
+    const int wn = w % WN, wm = w / WN;
+    int n = wn * 32 + lo;
     const int R = B * T * F, ntiles = (R + ROWS - 1) / ROWS;
 
     // ---- Wg fragments: b2 = columns of Wg (GEMM2), b1 = rows of gamma (.) Wg (GEMM1); beta folded into the bias ----
@@ -1269,7 +1273,7 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_b_kernel(const float* __rest
         }
     }
     const float gn = gamma[n], bn = beta[n];
-    const int cq = tid % (C / 4), rq = tid / (C / 4);      // this thread's 4x4 staging block: channels 4cq.., rows 4rq..
+    int cq = tid % (C / 4), rq = tid / (C / 4);            // this thread's 4x4 staging block: channels 4cq.., rows 4rq..
     float mu4[4], is4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { mu4[i] = stats[4 * cq + i]; is4[i] = stats[C + 4 * cq + i]; }
@@ -1310,6 +1314,7 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_b_kernel(const float* __rest
     if (tile < ntiles) load_tile(tile);
     for (; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
+        sed_opaque(lo); sed_opaque(hi); sed_opaque(n); sed_opaque(cq); sed_opaque(rq);   // per-tile addresses: recomputed, not spilled
         __syncthreads();
         store_rm(ld0, 4 * rq); store_rm(ld1, 4 * rq + 1); store_rm(ld2, 4 * rq + 2); store_rm(ld3, 4 * rq + 3);
         store_tr(ld0.x, ld1.x, ld2.x, ld3.x, 4 * cq);
@@ -1428,6 +1433,283 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_b_kernel(const float* __rest
         dst[n] = a_dbg; dst[C + n] = a_dgam; dst[2 * C + n] = a_dbet;
     }
 }
+// ---------------------------------------------------------------------------------------------
+// C = 128 on v_mfma_f32_16x16x32_bf16: the same three split-bf16 GEMMs per 64-row tile and the same LDS planes as
+// glu_wide_bwd_b_kernel, but a wave owns 16 output columns x all 64 rows.  Both orientations of Wg are then 4 k-steps x
+// (hi, lo) x 2 GEMMs = 64 VGPRs of fragments per wave instead of 128 (the 32x32 tiling of the kernel above spills 83 dwords
+// per lane at C = 128), four independent accumulator chains (one per 16-row block) keep the MFMA pipe busy, and GEMM3 is
+// 8 blocks of 16x16 per wave (n' block = wave, all 8 channel blocks) = 32 accumulator VGPRs.  ~170 VGPRs, no scratch.
+// The price is LDS read volume: every wave reads the whole A tile (16 KB per plane pair and GEMM), so the planes are laid
+// out for conflict-free ds_read_b128 (see rm_off / tr_off below).
+// One [C][C] slab + one [3][C] vector slab per workgroup partial (KS = 1, WMS = 1 for glu_bwd_reduce_kernel, fix = 1).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void glu128_bwd_c_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                           const float* __restrict__ gout, float* __restrict__ dz,
+                                                           float* __restrict__ part, int B, int T, int F, uint32_t seed,
+                                                           uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;
+    constexpr int C = 128, ROWS = 64, RS = C, RT = ROWS, WS = C + 8, KS = C / 32, RB = ROWS / 16, NB = C / 16, KS3 = ROWS / 32;
+    SED_DYN_SMEM(smem);
+    unsigned short* xh = (unsigned short*)smem;      // xhat  [ROWS][RS] hi | lo
+    unsigned short* xl = xh + ROWS * RS;
+    unsigned short* xth = xl + ROWS * RS;            // xhat^T [C][RT] hi | lo (swizzled octets)
+    unsigned short* xtl = xth + C * RT;
+    unsigned short* dh = xtl + C * RT;               // dlin  [ROWS][RS] hi | lo
+    unsigned short* dl = dh + ROWS * RS;
+    unsigned short* dth = dl + ROWS * RS;            // dlin^T [C][RT] hi | lo (swizzled octets)
+    unsigned short* dtl = dth + C * RT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int i16 = lane & 15, g = lane >> 4;
+    int n = 16 * w + i16;                            // this lane's column: GEMM1 output n, GEMM2 output channel c
+    const int R = B * T * F, ntiles = (R + ROWS - 1) / ROWS;
+    // Unpadded planes, 16-byte octets XOR-swizzled so that every ds_read_b128 lane group ({g even: rows 0-3,12-15} + {g odd:
+    // rows 4-11} and its complement) covers the 16 slots of a 256-byte bank row exactly once:
+    //   row-major  [row][128]: octet o of row m      at slot o ^ (m & 15)
+    //   transposed [ch][64]:   octet o of channel ch at slot o ^ ((ch >> 1) & 7)   (two channels per bank row)
+    auto rm_off = [](int m, int k) { return m * RS + ((((k >> 3) ^ (m & 15))) << 3) + (k & 7); };
+    auto tr_off = [](int ch, int row) { return ch * RT + ((((row >> 3) ^ ((ch >> 1) & 7))) << 3) + (row & 7); };
+    unsigned short* wh = xh;                         // Wg staging (before the tile loop): plain [64][WS] hi | lo over the planes
+    unsigned short* wl = xh + 64 * WS;
+
+    // ---- Wg fragments (16x16x32: lane (i16, g) holds k = 32 ks + 8 g + e of its column) ----
+    s16x8 b1h[KS], b1l[KS], b2h[KS], b2l[KS];
+    float biasp = bg[n];
+#pragma unroll
+    for (int p = 0; p < C / 64; ++p) {               // 64 rows of Wg per pass through the (still unused) xhat planes
+#pragma unroll
+        for (int fold = 0; fold < 2; ++fold) {
+            __syncthreads();
+            for (int i = tid; i < 64 * (C / 4); i += 512) {
+                const int row = i / (C / 4), q = i - row * (C / 4);
+                float4 val = *(const float4*)(Wg + (size_t)(p * 64 + row) * C + 4 * q);
+                if (fold) { val.x *= gamma[4 * q]; val.y *= gamma[4 * q + 1]; val.z *= gamma[4 * q + 2]; val.w *= gamma[4 * q + 3]; }
+                uint2 hv, lv;
+                bf16_split2(val.x, val.y, hv.x, lv.x);
+                bf16_split2(val.z, val.w, hv.y, lv.y);
+                *(uint2*)(wh + row * WS + 4 * q) = hv;
+                *(uint2*)(wl + row * WS + 4 * q) = lv;
+            }
+            __syncthreads();
+            if (!fold) {
+                // column n of rows 64p..64p+63 = k-steps 2p, 2p+1 of the GEMM2 fragment; beta . Wg[n][:] where row n is staged
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    s16x8 fh, fl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        fh[e] = (short)wh[(32 * kk + 8 * g + e) * WS + n];
+                        fl[e] = (short)wl[(32 * kk + 8 * g + e) * WS + n];
+                    }
+                    b2h[2 * p + kk] = fh; b2l[2 * p + kk] = fl;
+                }
+                if (w / 4 == p) {                                       // the four g lanes of column n take 32 k each
+                    const int rown = n - p * 64;
+                    float part_b = 0.f;
+                    for (int k = 32 * g; k < 32 * g + 32; ++k)
+                        part_b = fmaf(beta[k], bf16_pair_sum(wh[rown * WS + k], wl[rown * WS + k]), part_b);
+                    part_b += __shfl_xor(part_b, 16);
+                    part_b += __shfl_xor(part_b, 32);
+                    biasp += part_b;
+                }
+            } else if (w / 4 == p) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    b1h[ks] = *(const s16x8*)(wh + (n - p * 64) * WS + 32 * ks + 8 * g);
+                    b1l[ks] = *(const s16x8*)(wl + (n - p * 64) * WS + 32 * ks + 8 * g);
+                }
+            }
+        }
+    }
+    const float gn = gamma[n], bn = beta[n];
+    int cq = tid % (C / 4), rq = tid / (C / 4);            // this thread's 4x4 staging block: channels 4cq.., rows 4rq..
+
+    f32x4 P[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) P[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float a_dbg = 0.f, a_dgam = 0.f, a_dbet = 0.f;
+
+    float4 ld0, ld1, ld2, ld3;
+    // raw rows of the next tile (prefetched under GEMM3; normalised when they are staged: mean / invstd are re-read from the
+    // cache then instead of living in 8 VGPRs through the GEMMs)
+    // (full tiles take straight-line code: per-row / per-element guards compile to one branch each and fence the scheduler)
+    auto load_row = [&](int row) -> float4 {
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < R && !(GLU_ABL & 4)) val = *(const float4*)(y + (size_t)row * C + 4 * cq);
+        return val;
+    };
+    auto load_tile = [&](int tile) {
+        const int row = tile * ROWS + 4 * rq;
+        if ((tile + 1) * ROWS <= R && !(GLU_ABL & 4)) {
+            const float* src = y + (size_t)row * C + 4 * cq;
+            ld0 = *(const float4*)src; ld1 = *(const float4*)(src + C); ld2 = *(const float4*)(src + 2 * C); ld3 = *(const float4*)(src + 3 * C);
+        } else {
+            ld0 = load_row(row); ld1 = load_row(row + 1); ld2 = load_row(row + 2); ld3 = load_row(row + 3);
+        }
+    };
+    auto normalise = [&](int tile) {
+        const float4 mu = *(const float4*)(stats + 4 * cq), is = *(const float4*)(stats + C + 4 * cq);
+        const int row = tile * ROWS + 4 * rq;
+        auto nrm = [&](float4& v, int r) {
+            const float keep = r < R ? 1.0f : 0.0f;                     // rows past the end: xhat = 0
+            v.x = (v.x - mu.x) * is.x * keep; v.y = (v.y - mu.y) * is.y * keep;
+            v.z = (v.z - mu.z) * is.z * keep; v.w = (v.w - mu.w) * is.w * keep;
+        };
+        nrm(ld0, row); nrm(ld1, row + 1); nrm(ld2, row + 2); nrm(ld3, row + 3);      // rows past the end stay 0
+    };
+    auto store_rm = [&](const float4 val, int m) {                      // one row of the block -> row-major planes
+        uint2 hv, lv;
+        bf16_split2(val.x, val.y, hv.x, lv.x);
+        bf16_split2(val.z, val.w, hv.y, lv.y);
+        *(uint2*)(xh + rm_off(m, 4 * cq)) = hv;
+        *(uint2*)(xl + rm_off(m, 4 * cq)) = lv;
+    };
+    auto store_tr = [&](float a, float b, float c, float d, int ch) {   // one channel of the block -> transposed planes
+        uint2 hv, lv;
+        bf16_split2(a, b, hv.x, lv.x);
+        bf16_split2(c, d, hv.y, lv.y);
+        const int off = tr_off(ch, 4 * rq);
+        *(uint2*)(xth + off) = hv;
+        *(uint2*)(xtl + off) = lv;
+    };
+    // acc[rb] += A[16rb.., :] . B for the four 16-row blocks, A = hi | lo planes (lo plane ROWS * RS further), B = this
+    // wave's fragments.  Per k-step: the eight A reads, then the twelve MFMAs pass by pass across the four blocks, so that
+    // consecutive MFMAs never share an accumulator (left alone the compiler emits read - wait - three dependent MFMAs).
+    // Double-buffering the reads across k-steps was measured and bought nothing (85.8 vs 87.0 us at F = 16).
+    auto gemm_rows = [&](const unsigned short* ph, const s16x8* bh, const s16x8* bl, f32x4* acc) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            s16x8 ah[RB], al[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const unsigned short* ap = ph + rm_off(16 * rb + i16, 32 * ks + 8 * g);
+                ah[rb] = *(const s16x8*)ap;
+                al[rb] = *(const s16x8*)(ap + ROWS * RS);
+            }
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma16_bf16(al[rb], bh[ks], acc[rb]);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma16_bf16(ah[rb], bl[ks], acc[rb]);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma16_bf16(ah[rb], bh[ks], acc[rb]);
+            sed_sched_fence();
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * ROWS;
+        sed_opaque(i16); sed_opaque(g); sed_opaque(n); sed_opaque(cq); sed_opaque(rq);   // addresses are recomputed per tile, not spilled
+        normalise(tile);
+        __syncthreads();
+        store_rm(ld0, 4 * rq); store_rm(ld1, 4 * rq + 1); store_rm(ld2, 4 * rq + 2); store_rm(ld3, 4 * rq + 3);
+        store_tr(ld0.x, ld1.x, ld2.x, ld3.x, 4 * cq);
+        store_tr(ld0.y, ld1.y, ld2.y, ld3.y, 4 * cq + 1);
+        store_tr(ld0.z, ld1.z, ld2.z, ld3.z, 4 * cq + 2);
+        store_tr(ld0.w, ld1.w, ld2.w, ld3.w, 4 * cq + 3);
+        __syncthreads();
+        float g8[2 * RB];                                               // the pooled upstream gradient of this lane's 16 elements
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rr = row0 + 16 * rb + 4 * g + 2 * h;          // R is even: a pooling pair is inside or outside together
+                const int rc = rr < R ? rr : 0;                         // clamped address, value masked: no branch
+                const float gv = (GLU_ABL & 4) ? 1.0f : gout[(size_t)(rc / 2) * C + n];
+                g8[2 * rb + h] = rr < R ? gv * (0.5f * dscale) : 0.f;
+            }
+        // ---- GEMM1: lin = xhat . (gamma Wg)^T, four independent 16-row chains ----
+        f32x4 acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(GLU_ABL & 1)) gemm_rows(xh, b1h, b1l, acc);
+        // ---- epilogue 1: dlin -> both LDS layouts (one split feeds both), e -> acc (seed of GEMM2) ----
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            unsigned short hh[4], ll[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * rb + 4 * g + r;
+                const uint32_t e_idx = (uint32_t)(row0 + m) * (uint32_t)C + (uint32_t)n;
+                // rows past the end: g8 = 0 there, so dlin = e = 0 without a guard (their xhat is 0: everything stays finite)
+                const float xn = fmaf(bf16_pair_sum(xh[rm_off(m, n)], xl[rm_off(m, n)]), gn, bn);
+                const float sg = (GLU_ABL & 2) ? xn : sed_fast_sigmoid(xn);
+                const float lin = acc[rb][r] + biasp;
+                const float gq = ((GLU_ABL & 2) || sed_keep(e_idx, seed, thr24)) ? g8[2 * rb + (r >> 1)] : 0.f;
+                const float dlin = gq * sg;
+                const float e = gq * lin * sg * (1.0f - sg);
+                bf16_split(dlin, hh[r], ll[r]);
+                dh[rm_off(m, n)] = hh[r];
+                dl[rm_off(m, n)] = ll[r];
+                acc[rb][r] = e;
+                a_dbg += dlin;
+            }
+            uint2 hv, lv;
+            hv.x = (unsigned)hh[0] | ((unsigned)hh[1] << 16); hv.y = (unsigned)hh[2] | ((unsigned)hh[3] << 16);
+            lv.x = (unsigned)ll[0] | ((unsigned)ll[1] << 16); lv.y = (unsigned)ll[2] | ((unsigned)ll[3] << 16);
+            const int off = tr_off(n, 16 * rb + 4 * g);                 // rows 16rb + 4g .. +3 of channel n: half an octet
+            *(uint2*)(dth + off) = hv;
+            *(uint2*)(dtl + off) = lv;
+        }
+        __syncthreads();
+        // ---- GEMM2: dxn = dlin . Wg + e ----
+        if (!(GLU_ABL & 1)) gemm_rows(dh, b2h, b2l, acc);
+        // ---- epilogue 2: dz = dxn * gamma, BN reductions (dxn = 0 on rows past the end) ----
+        const bool full = row0 + ROWS <= R;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * rb + 4 * g + r;
+                const float dxn = acc[rb][r];
+                a_dgam = fmaf(dxn, bf16_pair_sum(xh[rm_off(m, n)], xl[rm_off(m, n)]), a_dgam);
+                a_dbet += dxn;
+                if (!(GLU_ABL & 8) && (full || row0 + m < R)) dz[(size_t)(row0 + m) * C + n] = dxn * gn;
+            }
+        // ---- GEMM3: P'[n'][c] += sum_rows dlin[row][n'] * xhat[row][c]   (n' block = wave, every channel block) ----
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+        if (!(GLU_ABL & 1)) {
+            // four steps of (k-step, half of the channel blocks): 8 (+2) reads, then 12 MFMAs pass by pass over 4 accumulators
+            const int rowa = 16 * w + i16;
+            s16x8 ah3, al3;
+#pragma unroll
+            for (int st = 0; st < 2 * KS3; ++st) {
+                const int ks = st >> 1, c0 = 4 * (st & 1);
+                if ((st & 1) == 0) {
+                    const int offa = tr_off(rowa, 32 * ks + 8 * g);
+                    ah3 = *(const s16x8*)(dth + offa);
+                    al3 = *(const s16x8*)(dtl + offa);
+                }
+                s16x8 bh3[4], bl3[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int offb = tr_off(16 * (c0 + q) + i16, 32 * ks + 8 * g);
+                    bh3[q] = *(const s16x8*)(xth + offb);
+                    bl3[q] = *(const s16x8*)(xtl + offb);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) P[c0 + q] = mfma16_bf16(al3, bh3[q], P[c0 + q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) P[c0 + q] = mfma16_bf16(ah3, bl3[q], P[c0 + q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) P[c0 + q] = mfma16_bf16(ah3, bh3[q], P[c0 + q]);
+                sed_sched_fence();
+            }
+        }
+    }
+    float* mine = part + (size_t)blockIdx.x * (C * C + 3 * C);
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[(16 * w + 4 * g + r) * C + 16 * cb + i16] = P[cb][r];
+    a_dbg += __shfl_xor(a_dbg, 16); a_dgam += __shfl_xor(a_dgam, 16); a_dbet += __shfl_xor(a_dbet, 16);
+    a_dbg += __shfl_xor(a_dbg, 32); a_dgam += __shfl_xor(a_dgam, 32); a_dbet += __shfl_xor(a_dbet, 32);
+    if (g == 0) {
+        float* dst = mine + C * C;
+        dst[n] = a_dbg; dst[C + n] = a_dgam; dst[2 * C + n] = a_dbet;
+    }
+}
 // sums the nblk per-workgroup partials of glu_wide_bwd_kernel: [KS][C][C] dWg slabs, then [WMS][3][C] (dbg, dgamma, dbeta).
 // One workgroup per 64 consecutive outputs: 16 float4 columns x 64 groups of partials, fixed summation order.  1024 threads:
 // the launch is a latency chain of dependent loads (256-1024 partials per output), so the walk per thread must be short.
@@ -1503,6 +1785,16 @@ static int launch_glu_wide_bwd(const float* y, const float* stats, const float* 
     const int cap = glu_grid_cap(256);                                  // register-bound: one workgroup per CU
     int grid = ntiles < cap ? ntiles : cap;
     if (grid < 1) { sed_zero4(s, dWg, C * C, dbg, C, dgamma, C, dbeta, C); return SED_OK; }
+    if (SPLIT && C == 128 && sed_tuning[SED_TUNE_GLU_BWD128_SPLIT] != 1) {
+        // 16x16x32 tiling: one [C][C] + one [3][C] slab per partial
+        constexpr int SMEM_C = 8 * 64 * 128 * 2;                          // eight unpadded bf16 planes of one 64 x 128 tile
+        SED_MAX_SMEM(glu128_bwd_c_kernel, SMEM_C);
+        SED_LAUNCH(glu128_bwd_c_kernel, dim3(grid), dim3(512), SMEM_C, s, y, stats, gamma, beta, Wg, bg, gout, dz, scratch, B, T, F,
+                   seed, thr24, dscale, seed_dev);
+        SED_LAUNCH(glu_bwd_reduce_kernel, dim3((C * C + 3 * C + 63) / 64), dim3(GBR_THREADS), 0, s, scratch, dWg, dbg, dgamma, dbeta, grid, C, 1, 1,
+                   gamma, beta, 1);
+        return sed_check_launch();
+    }
     if (SPLIT) {
         SED_MAX_SMEM((glu_wide_bwd_b_kernel<C>), SMEM);
         SED_LAUNCH((glu_wide_bwd_b_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, gamma, beta, Wg, bg, gout, dz, scratch, B, T, F,
@@ -1539,11 +1831,10 @@ extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamm
     hipStream_t s = (hipStream_t)stream;
     if (F % PF != 0) return SED_ERR_UNSUPPORTED;
     if (PT == 1 && PF == 2) {
-        // C = 128 stays on the exact-f32 kernel.  Both bf16 fragment sets of Wg are 128 VGPRs per wave with 32x32 tiles and the
-        // split kernel spills (208 vs 170 us at F = 16; sed_set_tuning(SED_TUNE_GLU_BWD128_SPLIT, 1) selects it for A/B runs); a variant on the
-        // 16x16x32 MFMA (wave = 16 columns x all rows: 64 VGPRs of fragments) was measured too and lost as well (197 us):
-        // the allocator still parked one fragment set in scratch and every wave re-reads the whole A tile from LDS.
-        if (C == 128 && split_bf16 && sed_tuning[SED_TUNE_GLU_BWD128_SPLIT] != 0)
+        // C = 128, split-bf16: the 16x16x32 kernel (glu128_bwd_c_kernel; 87 us at B = 48, F = 16 against 174 us of the exact-f32
+        // kernel and 204 us of the 32x32x16 tiling, whose two fragment sets of 128 VGPRs spill).
+        // sed_set_tuning(SED_TUNE_GLU_BWD128_SPLIT, v) for A/B runs: 1 = the 32x32x16 split kernel, 3 = exact f32.
+        if (C == 128 && split_bf16 && sed_tuning[SED_TUNE_GLU_BWD128_SPLIT] != 3)
             return launch_glu_wide_bwd<128, true>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
         if (C == 64 && split_bf16) return launch_glu_wide_bwd<64, true>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
         if (C == 128) return launch_glu_wide_bwd<128, false>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);

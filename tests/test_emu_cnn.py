@@ -48,3 +48,27 @@ def test_first_block_fused_eval(emu):
     with torch.no_grad():
         pass
     P.case_cnn_block("cpu", 0, 2, 21, 16, training=False, dropout_p=0.0)          # gradients through eval-mode BN: unfused path
+
+
+def test_glu128_bwd_other_variants(emu):
+    from desed_task_amd import _lib
+    for v in (1, 3):
+        _lib.set_tuning("glu_bwd128_split", v)
+        try:
+            P.case_cnn_block("cpu", 4, 2, 9, 8, training=True, dropout_p=0.5, precision="bf16x3", tol=1e-4)
+        finally:
+            _lib.set_tuning("glu_bwd128_split", 0)
+
+
+@pytest.mark.parametrize("layer,B,T,F,cap", [(3, 1, 10, 16, 0), (4, 2, 9, 8, 0), (5, 2, 37, 4, 2), (6, 2, 35, 2, 0), (3, 3, 13, 16, 3)])
+def test_glu128_bwd_16x16x32(emu, layer, B, T, F, cap):
+    """128-channel GLU backward on the 16x16x32 split-bf16 tiling (wave = 16 columns x 64 rows): ragged last tile, several
+    tiles per workgroup (register prefetch of the next tile), partial reduce with one vector slab."""
+    from desed_task_amd import _lib
+    _lib.set_tuning("glu_bwd128_split", 0)          # 0 = the default 16x16x32 kernel (1 = 32x32x16 tiling, 3 = exact f32)
+    _lib.set_tuning("glu_grid_cap", cap)
+    try:
+        P.case_cnn_block("cpu", layer, B, T, F, training=True, dropout_p=0.5, precision="bf16x3", tol=1e-4)
+    finally:
+        _lib.set_tuning("glu_bwd128_split", 0)
+        _lib.set_tuning("glu_grid_cap", 0)

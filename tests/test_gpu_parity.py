@@ -89,6 +89,17 @@ def test_edge_shapes():
     P.case_edge_shapes("cuda")
 
 
+@pytest.mark.parametrize("layer,T,F,variant", [(3, 156, 16, 0), (6, 156, 2, 0), (3, 157, 16, 1), (4, 156, 8, 3)])
+def test_glu128_bwd_variants(layer, T, F, variant):
+    """Every selectable 128-channel GLU backward (sed_set_tuning key 1: 0 = split-bf16 on 16x16x32, 1 = on 32x32x16, 3 = exact f32)."""
+    from desed_task_amd import _lib
+    _lib.set_tuning("glu_bwd128_split", variant)
+    try:
+        P.case_cnn_block("cuda", layer, 3, T, F, training=True, dropout_p=0.5, tol=1e-4, precision="bf16x3")
+    finally:
+        _lib.set_tuning("glu_bwd128_split", 0)
+
+
 @pytest.mark.parametrize("layer,T,F", [c for c in CNN_SHAPES if c[0] > 0])
 def test_cnn_block_train_split_bf16(layer, T, F):
     P.case_cnn_block("cuda", layer, 3, T, F, training=True, dropout_p=0.5, tol=1e-4, precision="bf16x3")

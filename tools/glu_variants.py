@@ -11,12 +11,15 @@ for v in variants:
     so = os.path.join(HERE, "_glu_v%d.so" % v)
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(CSRC, "sed_glu.hip")):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC,
-                               "-I", os.path.join(ROOT, "include"), "-DGLU_ABL=%d" % v, os.path.join(CSRC, "sed_glu.hip"), "-o", so])
+                               "-I", os.path.join(ROOT, "include"), "-DGLU_ABL=%d" % v, os.path.join(CSRC, "sed_glu.hip"), os.path.join(CSRC, "sed_selftest.hip"), "-o", so])
 if not torch.cuda.is_available():
     sys.exit(0)
 P = ctypes.c_void_p
 I = ctypes.c_int
-for (C, T, F, PT, PF) in [(32, 313, 64, 2, 2), (64, 156, 32, 1, 2), (128, 156, 16, 1, 2), (128, 156, 2, 1, 2)]:
+SHAPES = [(32, 313, 64, 2, 2), (64, 156, 32, 1, 2), (128, 156, 16, 1, 2), (128, 156, 8, 1, 2), (128, 156, 4, 1, 2), (128, 156, 2, 1, 2)]
+if os.environ.get("GLU_ONLY128"):
+    SHAPES = [s for s in SHAPES if s[0] == 128]
+for (C, T, F, PT, PF) in SHAPES:
     B = 48
     y = torch.randn(B, T, F, C, device="cuda")
     stats = torch.cat([torch.zeros(C), torch.ones(C), torch.ones(C), torch.zeros(C)]).cuda()
@@ -28,8 +31,9 @@ for (C, T, F, PT, PF) in [(32, 313, 64, 2, 2), (64, 156, 32, 1, 2), (128, 156, 1
     dWg, dbg, dgam, dbet = torch.empty(C, C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
     scr = torch.empty(256 * (2 * C * C + 12 * C), device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    for v in variants:
+    for v, tune in [(v, t) for v in variants for t in ([0, 1, 3] if C == 128 else [0])]:
         lib = ctypes.CDLL(os.path.join(HERE, "_glu_v%d.so" % v))
+        lib.sed_set_tuning(1, tune)            # SED_TUNE_GLU_BWD128_SPLIT: 0 split 16x16x32 (default), 1 split 32x32x16, 3 exact f32
         ff, fb = lib.sed_glu_fwd, lib.sed_glu_bwd
         split = int(os.environ.get("GLU_SPLIT", "1"))
         ff.argtypes = [P] * 5 + [I] * 6 + [ctypes.c_uint, ctypes.c_uint, ctypes.c_float, P, I, P]
@@ -48,4 +52,4 @@ for (C, T, F, PT, PF) in [(32, 313, 64, 2, 2), (64, 156, 32, 1, 2), (128, 156, 1
                 f(*a)
             e1.record(); torch.cuda.synchronize()
             res.append(e0.elapsed_time(e1) / 20 * 1e3)
-        print("split=%d C=%3d F=%2d abl=%2d: fwd %.1f us  bwd %.1f us (incl. zero4)" % (split, C, F, v, res[0], res[1]), flush=True)
+        print("split=%d tune=%d C=%3d F=%2d abl=%2d: fwd %.1f us  bwd %.1f us (incl. zero4)" % (split, tune, C, F, v, res[0], res[1]), flush=True)
