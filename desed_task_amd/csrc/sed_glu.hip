@@ -376,7 +376,8 @@ __global__ __launch_bounds__(256) void glu32_bwd_kernel(const float* __restrict_
     constexpr int C = 32, NP = C * C + 3 * C;
     __shared__ float red[4][NP];                  // per-wave dWg / dbg / dgamma / dbeta, summed into ONE partial per workgroup
     __shared__ float cst[5 * C];                  // mean | invstd | gamma | beta | bg: read per use, 80 VGPRs would not fit
-    const int lane = threadIdx.x & 63, lo = lane & 31, hi = lane >> 5, w = lo >> 2, q = lo & 3;
+    const int lane = threadIdx.x & 63;
+    int lo = lane & 31, hi = lane >> 5, w = lo >> 2, q = lo & 3;
     if (threadIdx.x < C) {
         cst[threadIdx.x] = stats[threadIdx.x]; cst[C + threadIdx.x] = stats[C + threadIdx.x];
         cst[2 * C + threadIdx.x] = gamma[threadIdx.x]; cst[3 * C + threadIdx.x] = beta[threadIdx.x];
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(256) void glu32_bwd_kernel(const float* __restrict_
     const int nwaves = gridDim.x * 4;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += nwaves)
     for (int tr = 0; tr < tpr; ++tr) {
+        sed_opaque(lo); sed_opaque(hi); sed_opaque(w); sed_opaque(q);
         const int b = row / To, to = row - b * To;
         const size_t pix0 = ((size_t)b * T + 2 * to) * F + 16 * tr;              // first pixel of the tile's upper row
         const size_t pix = pix0 + ((q >> 1) ? F : 0) + 2 * w + (q & 1);

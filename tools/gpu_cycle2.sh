@@ -15,7 +15,7 @@ pmc) for pass in "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" 
        set -- $pass; name=$1; shift
        timeout 400 rocprofv3 --kernel-trace --pmc $@ -d gpurun_out/pmc_${tag}_$name -o $name -- python bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > gpurun_out/pmc_${tag}_$name.log 2>&1
      done
-     python tools/pmc_ratio_summary.py gpurun_out/pmc_${tag}_mfma/mfma_results.db SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE > gpurun_out/pmc_${tag}_mfma.md 2>&1
+     python tools/pmc_ratio_summary.py gpurun_out/pmc_${tag}_mfma/mfma_results.db > gpurun_out/pmc_${tag}_mfma.md 2>&1
      python tools/pmc_summary.py gpurun_out/pmc_${tag}_fetch/fetch_results.db > gpurun_out/pmc_${tag}_fetch.md 2>&1
      python tools/pmc_summary.py gpurun_out/pmc_${tag}_write/write_results.db > gpurun_out/pmc_${tag}_write.md 2>&1
      python tools/pmc_traffic_json.py gpurun_out/pmc_${tag}_fetch/fetch_results.db gpurun_out/pmc_${tag}_write/write_results.db > gpurun_out/pmc_${tag}_traffic.json 2>gpurun_out/pmc_${tag}_traffic.err
