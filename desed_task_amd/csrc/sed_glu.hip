@@ -723,6 +723,137 @@ __global__ __launch_bounds__(512, 4) void glu_wide_fwd_b_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// C = 128 forward on v_mfma_f32_16x16x32_bf16 (same tiling as glu128_bwd_c_kernel below): a wave owns 16 output columns x all 64
+// rows of the tile, Wg fragments = 32 VGPRs (64 with the 32x32 tiling, which does not fit the 128-VGPR budget of two resident
+// workgroups without scratch), four independent accumulator chains, unpadded swizzled planes, per-tile address recomputation.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void glu128_fwd_c_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                              const float* __restrict__ Wg, const float* __restrict__ bg,
+                                                              float* __restrict__ out, int B, int T, int F, uint32_t seed,
+                                                              uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev;
+    constexpr int C = 128, ROWS = 64, RS = C, WS = C + 8, KS = C / 32, RB = ROWS / 16;
+    SED_DYN_SMEM(smem);
+    unsigned short* xh = (unsigned short*)smem;      // xn [ROWS][RS] hi | lo, octet o of row m at slot o ^ (m & 15)
+    unsigned short* xl = xh + ROWS * RS;
+    unsigned short* wh = xh;                         // Wg staging (before the tile loop): plain [64][WS] hi | lo
+    unsigned short* wl = xh + 64 * WS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int i16 = lane & 15, g = lane >> 4;
+    int n = 16 * w + i16;
+    const int R = B * T * F, ntiles = (R + ROWS - 1) / ROWS;
+    auto rm_off = [](int m, int k) { return m * RS + ((((k >> 3) ^ (m & 15))) << 3) + (k & 7); };
+    int cq = tid % (C / 4), rq = tid / (C / 4);      // this thread's 4x4 staging block: channels 4cq.., rows 4rq..
+
+    float4 ld0, ld1, ld2, ld3;
+    auto load_tile = [&](int tile) {
+        const int row = tile * ROWS + 4 * rq;
+        if ((tile + 1) * ROWS <= R && !(GLU_ABL & 4)) {
+            const float* src = y + (size_t)row * C + 4 * cq;
+            ld0 = *(const float4*)src; ld1 = *(const float4*)(src + C); ld2 = *(const float4*)(src + 2 * C); ld3 = *(const float4*)(src + 3 * C);
+        } else {
+            auto lr = [&](int r) -> float4 {
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < R && !(GLU_ABL & 4)) val = *(const float4*)(y + (size_t)r * C + 4 * cq);
+                return val;
+            };
+            ld0 = lr(row); ld1 = lr(row + 1); ld2 = lr(row + 2); ld3 = lr(row + 3);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);              // in flight under the fragment set-up
+
+    // ---- Wg fragments: B[k = c][j = n] = Wg[n][c]; lane (i16, g) holds c = 32 ks + 8 g + e of row n ----
+    s16x8 bh[KS], bl[KS];
+#pragma unroll
+    for (int p = 0; p < C / 64; ++p) {
+        __syncthreads();
+        for (int i = tid; i < 64 * (C / 4); i += 512) {
+            const int row = i / (C / 4), q = i - row * (C / 4);
+            const float4 val = *(const float4*)(Wg + (size_t)(p * 64 + row) * C + 4 * q);
+            uint2 hv, lv;
+            bf16_split2(val.x, val.y, hv.x, lv.x);
+            bf16_split2(val.z, val.w, hv.y, lv.y);
+            *(uint2*)(wh + row * WS + 4 * q) = hv;
+            *(uint2*)(wl + row * WS + 4 * q) = lv;
+        }
+        __syncthreads();
+        if (w / 4 == p) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bh[ks] = *(const s16x8*)(wh + (n - p * 64) * WS + 32 * ks + 8 * g);
+                bl[ks] = *(const s16x8*)(wl + (n - p * 64) * WS + 32 * ks + 8 * g);
+            }
+        }
+    }
+    const float bias_n = bg[n];
+    auto store_rm = [&](float4 val, int m, bool live, const float4& sc, const float4& sh) {
+        const float k = live ? 1.0f : 0.0f;                             // rows past the end: xn = 0
+        val.x = fmaf(val.x, sc.x, sh.x) * k; val.y = fmaf(val.y, sc.y, sh.y) * k;
+        val.z = fmaf(val.z, sc.z, sh.z) * k; val.w = fmaf(val.w, sc.w, sh.w) * k;
+        uint2 hv, lv;
+        bf16_split2(val.x, val.y, hv.x, lv.x);
+        bf16_split2(val.z, val.w, hv.y, lv.y);
+        *(uint2*)(xh + rm_off(m, 4 * cq)) = hv;
+        *(uint2*)(xl + rm_off(m, 4 * cq)) = lv;
+    };
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * ROWS;
+        sed_opaque(i16); sed_opaque(g); sed_opaque(n); sed_opaque(cq); sed_opaque(rq);   // addresses recomputed per tile, not spilled
+        __syncthreads();                                                // previous tile fully consumed (first pass: Wg staging)
+        {
+            const float4 sc = *(const float4*)(stats + 2 * C + 4 * cq), sh = *(const float4*)(stats + 3 * C + 4 * cq);
+            const int row = row0 + 4 * rq;
+            store_rm(ld0, 4 * rq, row < R, sc, sh); store_rm(ld1, 4 * rq + 1, row + 1 < R, sc, sh);
+            store_rm(ld2, 4 * rq + 2, row + 2 < R, sc, sh); store_rm(ld3, 4 * rq + 3, row + 3 < R, sc, sh);
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);     // in flight under the MFMAs below
+        f32x4 acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(GLU_ABL & 1)) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s16x8 ah[RB], al[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const unsigned short* ap = xh + rm_off(16 * rb + i16, 32 * ks + 8 * g);
+                    ah[rb] = *(const s16x8*)ap;
+                    al[rb] = *(const s16x8*)(ap + ROWS * RS);
+                }
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma16_bf16(al[rb], bh[ks], acc[rb]);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma16_bf16(ah[rb], bl[ks], acc[rb]);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma16_bf16(ah[rb], bh[ks], acc[rb]);
+                sed_sched_fence();
+            }
+        }
+        // ---- epilogue: gate, dropout, (1,2) pooling over the lane's row pairs ----
+        const bool full = row0 + ROWS <= R;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            float vv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * rb + 4 * g + r;
+                const uint32_t e = (uint32_t)(row0 + m) * (uint32_t)C + (uint32_t)n;
+                const float xn = bf16_pair_sum(xh[rm_off(m, n)], xl[rm_off(m, n)]);
+                const float v = (acc[rb][r] + bias_n) * ((GLU_ABL & 2) ? xn : sed_fast_sigmoid(xn));
+                vv[r] = ((GLU_ABL & 2) || sed_keep(e, seed, thr24)) ? v * dscale : 0.f;
+            }
+            const int o = (row0 + 16 * rb + 4 * g) / 2;                  // R is even: a pooling pair is inside or outside together
+            if (!(GLU_ABL & 8)) {
+                if (full || 2 * o < R) out[(size_t)o * C + n] = 0.5f * (vv[0] + vv[1]);
+                if (full || 2 * o + 2 < R) out[(size_t)(o + 1) * C + n] = 0.5f * (vv[2] + vv[3]);
+            }
+        }
+    }
+}
+
 // persistent-grid cap; sed_set_tuning(SED_TUNE_GLU_GRID_CAP, n) (tests) forces several tiles per workgroup on small problems
 // zero the gradient rows of the frames that floor-mode time pooling drops: dz (B, T, F*C), rows [t0, T) of every clip
 __global__ __launch_bounds__(256) void glu_zero_tail_kernel(float* __restrict__ dz, long long n4, int T, int t0, int tail4,
@@ -745,6 +876,12 @@ static int launch_glu_wide_fwd(const float* y, const float* stats, const float* 
     const int cap = glu_grid_cap(512);                                  // two 8-wave workgroups per CU
     int grid = ntiles < cap ? ntiles : cap;
     if (grid < 1) return SED_OK;
+    if (SPLIT && C == 128 && sed_tuning[SED_TUNE_GLU_FWD128] != 1) {      // 1 = the 32x32x16 tiling (A/B runs)
+        constexpr int SMEM_C = 2 * 64 * (128 + 8) * 2;                    // Wg staging [64][C + 8] hi | lo; the tile planes need 32 KB
+        SED_MAX_SMEM(glu128_fwd_c_kernel, SMEM_C);
+        SED_LAUNCH(glu128_fwd_c_kernel, dim3(grid), dim3(512), SMEM_C, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev);
+        return sed_check_launch();
+    }
     if (SPLIT) {
         SED_MAX_SMEM((glu_wide_fwd_b_kernel<C>), SMEM);
         SED_LAUNCH((glu_wide_fwd_b_kernel<C>), dim3(grid), dim3(512), SMEM, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev);
@@ -1856,7 +1993,7 @@ extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamm
         // LDS-free MFMA kernels: one row of pooling windows per wave iteration, one partial per workgroup + fixed-order reduce
         const int nrows = B * (T / 2);
         int grid = (nrows + 3) / 4;
-        const int cap = C == 32 ? 256 : 1024;      // glu32_bwd needs ~330 registers: one workgroup per CU is all that is resident
+        const int cap = C == 32 ? glu_grid_cap(512) : 1024;   // glu32_bwd: 228 registers -> two 4-wave workgroups per CU are resident
         if (grid > cap) grid = cap;
         if (grid < 1) { sed_zero4(s, dWg, C * C, dbg, C, dgamma, C, dbeta, C); return SED_OK; }
         if (!scratch) return SED_ERR_ARG;

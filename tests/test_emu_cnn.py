@@ -50,14 +50,15 @@ def test_first_block_fused_eval(emu):
     P.case_cnn_block("cpu", 0, 2, 21, 16, training=False, dropout_p=0.0)          # gradients through eval-mode BN: unfused path
 
 
-def test_glu128_bwd_other_variants(emu):
+def test_glu128_other_variants(emu):
+    """The selectable alternatives of the 128-channel GLU kernels: backward on 32x32x16 / exact f32, forward on 32x32x16."""
     from desed_task_amd import _lib
-    for v in (1, 3):
-        _lib.set_tuning("glu_bwd128_split", v)
+    for key, v in (("glu_bwd128_split", 1), ("glu_bwd128_split", 3), ("glu_fwd128", 1)):
+        _lib.set_tuning(key, v)
         try:
             P.case_cnn_block("cpu", 4, 2, 9, 8, training=True, dropout_p=0.5, precision="bf16x3", tol=1e-4)
         finally:
-            _lib.set_tuning("glu_bwd128_split", 0)
+            _lib.set_tuning(key, 0)
 
 
 @pytest.mark.parametrize("layer,B,T,F,cap", [(3, 1, 10, 16, 0), (4, 2, 9, 8, 0), (5, 2, 37, 4, 2), (6, 2, 35, 2, 0), (3, 3, 13, 16, 3)])

@@ -94,10 +94,12 @@ def test_glu128_bwd_variants(layer, T, F, variant):
     """Every selectable 128-channel GLU backward (sed_set_tuning key 1: 0 = split-bf16 on 16x16x32, 1 = on 32x32x16, 3 = exact f32)."""
     from desed_task_amd import _lib
     _lib.set_tuning("glu_bwd128_split", variant)
+    _lib.set_tuning("glu_fwd128", 1 if variant else 0)          # the forward's 32x32x16 tiling rides along with the non-default backwards
     try:
         P.case_cnn_block("cuda", layer, 3, T, F, training=True, dropout_p=0.5, tol=1e-4, precision="bf16x3")
     finally:
         _lib.set_tuning("glu_bwd128_split", 0)
+        _lib.set_tuning("glu_fwd128", 0)
 
 
 @pytest.mark.parametrize("layer,T,F", [c for c in CNN_SHAPES if c[0] > 0])

@@ -33,6 +33,8 @@ for (C, T, F, PT, PF) in SHAPES:
     st = torch.cuda.current_stream().cuda_stream
     for v, tune in [(v, t) for v in variants for t in ([0, 1, 3] if C == 128 else [0])]:
         lib = ctypes.CDLL(os.path.join(HERE, "_glu_v%d.so" % v))
+        lib.sed_set_tuning(0, int(os.environ.get('GLU_CAP', '0')))
+        lib.sed_set_tuning(5, int(os.environ.get('GLU_FWD', '0')))
         lib.sed_set_tuning(1, tune)            # SED_TUNE_GLU_BWD128_SPLIT: 0 split 16x16x32 (default), 1 split 32x32x16, 3 exact f32
         ff, fb = lib.sed_glu_fwd, lib.sed_glu_bwd
         split = int(os.environ.get("GLU_SPLIT", "1"))
