@@ -104,7 +104,8 @@ static inline int wgrad_parts(int CIN, int COUT, int B, int T, int F) {
     if (CIN <= 32) {                                    // all-taps kernel: one partial per workgroup
         const int TF = F >= 32 ? 32 : F, TR = 128 / TF;
         const int ntiles = B * ((T + TR - 1) / TR) * (F / TF);
-        const int cap = CIN <= 16 ? 1024 : 512;       // 4 / 2 resident workgroups per CU: staging of one overlaps MFMAs of another
+        int cap = CIN <= 16 ? 1024 : 512;             // 4 / 2 resident workgroups per CU: staging of one overlaps MFMAs of another
+        if (sed_tuning[SED_TUNE_WGRAD_CAP] > 0) cap = sed_tuning[SED_TUNE_WGRAD_CAP];     // tests: several tiles per workgroup on small inputs
         return ntiles < cap ? ntiles : cap;
     }
     const int ntiles = (B * T * F + 63) / 64;           // per-tap kernel: `splits` partials
@@ -933,12 +934,264 @@ static int launch_wgrad_alltaps(const float* x, const float* dy, float* dWp, int
     return sed_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// weight gradient, narrow layers, split-bf16 MFMA (conv_precision = "bf16x3", F >= 32): all 9 taps in one workgroup as above,
+// but the contraction over the tile's 128 pixels runs on v_mfma_f32_32x32x16_bf16 (CIN = 32) / 16x16x32 (CIN = 16), three per
+// product on hi / lo planes: 5.3x fewer MFMA cycles than the exact-f32 32x32x2 path, fp32-level accuracy.
+// A bf16 MFMA operand is 8 consecutive k (= pixels) of one channel in one 16-byte LDS read, so both operands are staged
+// TRANSPOSED, [channel][pixel], from 4-pixel x 4-channel register blocks (8-byte stores).  A tap shifts the pixel window:
+// the row shift ky is a whole row pitch (aligned), the column shift kx is not, so the x patch is kept in THREE column-shifted
+// copies (a thread loads 6 consecutive patch pixels once and cuts the three 4-pixel windows out of them in registers).
+// Channel pitches: 25 / 17 sixteen-byte slots (32x32x16: the 16 lanes of a ds_read_b128 group are 16 distinct channels
+// mod 16 -> odd pitch) and 26 / 18 slots (16x16x32: a group mixes two k-octets of complementary channel sets -> pitch = 2 mod 4).
+// ---------------------------------------------------------------------------------------------
+// WGN_ABL: timing-ablation mask for tools/wgrad_variants.py (0 in the product build): 1 = no MFMAs, 2 = no operand reads and no
+// MFMAs, 4 = no staging (splits + LDS stores), 8 = no global loads
+#ifndef WGN_ABL
+#define WGN_ABL 0
+#endif
+template <int CIN, int COUT>
+struct WgnCfg {
+    static constexpr int TF = 32, TR = 4, PH = TR + 2;
+    static constexpr bool M16 = CIN == 16;
+    static constexpr int XS = PH * TF + (M16 ? 16 : 8), DS = TR * TF + (M16 ? 16 : 8);     // channel pitch (bf16 elements)
+    static constexpr int XPLANE = CIN * XS, DPLANE = COUT * DS;
+    static constexpr int SMEM_OPS = (6 * XPLANE + 2 * DPLANE) * 2, SMEM_RED = 9 * CIN * COUT * 4;
+    static constexpr int SMEM = SMEM_OPS > SMEM_RED ? SMEM_OPS : SMEM_RED;
+};
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_wgrad_alltaps_bf16_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                      float* __restrict__ dWp, int B, int T, int F) {
+    using Cfg = WgnCfg<CIN, COUT>;
+    constexpr int TF = Cfg::TF, TR = Cfg::TR, PH = Cfg::PH, XS = Cfg::XS, DS = Cfg::DS, XPLANE = Cfg::XPLANE, DPLANE = Cfg::DPLANE;
+    constexpr bool M16 = Cfg::M16;
+    static_assert((CIN == 16 && COUT == 32) || (CIN == 32 && COUT == 64), "the two narrow layers of the recipe");
+    SED_DYN_SMEM(smem);
+    unsigned short* xp = (unsigned short*)smem;          // [column shift 3][hi | lo][CIN][XS]: x[t0 - 1 + i][f0 + c + shift - 1]
+    unsigned short* dp = xp + 6 * XPLANE;                // [hi | lo][COUT][DS]:                dy[t0 + r][f0 + c]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int tid = threadIdx.x, lo = lane & 31, hi = lane >> 5, i16 = lane & 15, g = lane >> 4;
+    const int ftiles = F / TF, ttiles = (T + TR - 1) / TR, ntiles = B * ttiles * ftiles;
+
+    f32x16 acc[M16 ? 1 : 9];
+    f32x4 acc16[M16 ? 9 : 1][2];
+#pragma unroll
+    for (int tp = 0; tp < (M16 ? 1 : 9); ++tp) acc[tp] = f32x16_zero();
+#pragma unroll
+    for (int tp = 0; tp < (M16 ? 9 : 1); ++tp) { acc16[tp][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc16[tp][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    // staging work items: x = (patch row i, column quad cq, channel quad v): 6 pixels x 4 channels in, 3 shifts x 4 channels x
+    // 4 pixels out; dy = (tile row r, column quad cq, channel quad v): 4 pixels x 4 channels in and out.  Lanes run over cq
+    // first: the 16 lanes of a ds_write_b64 group then cover the 64 contiguous bytes of a row segment for two channels 4 apart,
+    // whose pitch is 64 bytes mod 128 (CIN = 32) -- conflict-free; with channel quads first the same stores were 4-way conflicted
+    // and the staging was half of the kernel (timing ablation tools/wgrad_variants.py).  A wave's global load still covers 8 full
+    // 128-byte lines (8 pixels x all channels of a quad group).
+    constexpr int VX = CIN / 4, VD = COUT / 4, NXI = PH * 8 * VX, NDI = TR * 8 * VD;
+    constexpr int NXU = (NXI + 255) / 256, NDU = NDI / 256;
+    float4 lx[NXU][6], ld[NDU][4];
+    auto load_tile = [&](int tile_) {
+        const int ft = tile_ % ftiles, tt = (tile_ / ftiles) % ttiles, b = tile_ / (ftiles * ttiles);
+        const int t0 = tt * TR, f0 = ft * TF;
+#pragma unroll
+        for (int u = 0; u < NXU; ++u) {
+            const int it = tid + 256 * u, cq = it % 8, v = (it / 8) % VX, i = it / (8 * VX);
+            const int t = t0 - 1 + i;
+            const bool rowok = it < NXI && t >= 0 && t < T;
+            const float* src = x + (((size_t)b * T + (rowok ? t : 0)) * F) * CIN + 4 * v;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int f = f0 - 1 + 4 * cq + k;
+                lx[u][k] = (rowok && f >= 0 && f < F && !(WGN_ABL & 8)) ? *(const float4*)(src + (size_t)f * CIN) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NDU; ++u) {
+            const int it = tid + 256 * u, cq = it % 8, v = (it / 8) % VD, r = it / (8 * VD);
+            const int t = t0 + r;
+            const float* src = dy + (((size_t)b * T + (t < T ? t : 0)) * F + f0 + 4 * cq) * COUT + 4 * v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ld[u][k] = (t < T && !(WGN_ABL & 8)) ? *(const float4*)(src + (size_t)k * COUT) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto comp = [](const float4& q, int c) { return c == 0 ? q.x : c == 1 ? q.y : c == 2 ? q.z : q.w; };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NXU; ++u) {
+            const int it = tid + 256 * u, cq = it % 8, v = (it / 8) % VX, i = it / (8 * VX);
+            if (it < NXI) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // the five neighbouring pixel pairs of this channel, split once; shift s uses pairs (s, s + 2)
+                    unsigned ph[5], pl[5];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) bf16_split2(comp(lx[u][k], c), comp(lx[u][k + 1], c), ph[k], pl[k]);
+                    unsigned short* dst = xp + (4 * v + c) * XS + i * TF + 4 * cq;
+#pragma unroll
+                    for (int sft = 0; sft < 3; ++sft) {
+                        uint2 hv, lv;
+                        hv.x = ph[sft]; hv.y = ph[sft + 2];
+                        lv.x = pl[sft]; lv.y = pl[sft + 2];
+                        *(uint2*)(dst + (2 * sft) * XPLANE) = hv;
+                        *(uint2*)(dst + (2 * sft + 1) * XPLANE) = lv;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NDU; ++u) {
+            const int it = tid + 256 * u, cq = it % 8, v = (it / 8) % VD, r = it / (8 * VD);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint2 hv, lv;
+                bf16_split2(comp(ld[u][0], c), comp(ld[u][1], c), hv.x, lv.x);
+                bf16_split2(comp(ld[u][2], c), comp(ld[u][3], c), hv.y, lv.y);
+                unsigned short* dst = dp + (4 * v + c) * DS + r * TF + 4 * cq;
+                *(uint2*)dst = hv;
+                *(uint2*)(dst + DPLANE) = lv;
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        sed_opaque(tid); sed_opaque(lo); sed_opaque(hi); sed_opaque(i16); sed_opaque(g);     // per-tile addresses: recomputed, not spilled
+        __syncthreads();
+        if (!(WGN_ABL & 4)) store_tile();
+        else if (lx[0][0].x + ld[0][0].x == 123.456f) xp[tid] = 1;      // keeps the loads alive
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);      // in flight under the MFMAs
+        if (WGN_ABL & 2) continue;
+        if (M16) {
+            // wave w contracts tile row w (one 32-pixel k-step); both 16-wide COUT tiles.  All 22 operand reads first, then the 54
+            // MFMAs (left alone the compiler emits read - wait - three dependent MFMAs per tap)
+            s16x8 bh[2], bl[2], ah[9], al[9];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const unsigned short* bp = dp + (16 * nt + i16) * DS + w * TF + 8 * g;
+                bh[nt] = *(const s16x8*)bp;
+                bl[nt] = *(const s16x8*)(bp + DPLANE);
+            }
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const unsigned short* ap = xp + (2 * (tp % 3)) * XPLANE + i16 * XS + (w + tp / 3) * TF + 8 * g;
+                ah[tp] = *(const s16x8*)ap;
+                al[tp] = *(const s16x8*)(ap + XPLANE);
+            }
+            sed_sched_fence();
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x4 a = acc16[M16 ? tp : 0][nt];
+                    if (WGN_ABL & 1) { a[0] += (float)(al[tp][0] + bh[nt][1] + ah[tp][2] + bl[nt][3]); }
+                    else {
+                    a = mfma16_bf16(al[tp], bh[nt], a);
+                    a = mfma16_bf16(ah[tp], bl[nt], a);
+                    a = mfma16_bf16(ah[tp], bh[nt], a);
+                    }
+                    acc16[M16 ? tp : 0][nt] = a;
+                }
+        } else {
+            // wave (wn, wk): COUT tile wn, k-steps 4 wk .. 4 wk + 3 (16 pixels each: half a tile row).  One wave per SIMD (312
+            // registers), so nothing else hides the LDS latency: the 20 operand reads of k-step k + 1 are issued before the 27
+            // MFMAs of k-step k (double-buffered operand registers; this kernel may use up to 512 registers anyway).
+            const int wn = w & 1, wk = w >> 1;
+            s16x8 bh[2], bl[2], ah[2][9], al[2][9];
+            auto fetch = [&](int k4, int buf) {
+                const int ks = 4 * wk + k4, r = ks >> 1, c0 = 16 * (ks & 1) + 8 * hi;
+                const unsigned short* bp = dp + (32 * wn + lo) * DS + r * TF + c0;
+                bh[buf] = *(const s16x8*)bp;
+                bl[buf] = *(const s16x8*)(bp + DPLANE);
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const unsigned short* ap = xp + (2 * (tp % 3)) * XPLANE + lo * XS + (r + tp / 3) * TF + c0;
+                    ah[buf][tp] = *(const s16x8*)ap;
+                    al[buf][tp] = *(const s16x8*)(ap + XPLANE);
+                }
+            };
+            fetch(0, 0);
+            sed_sched_fence();
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int cur = k4 & 1;
+                if (k4 + 1 < 4) fetch(k4 + 1, cur ^ 1);
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    f32x16 a = acc[M16 ? 0 : tp];
+                    if (WGN_ABL & 1) { a[0] += (float)(al[cur][tp][0] + bh[cur][1] + ah[cur][tp][2] + bl[cur][3]); }
+                    else {
+                    a = mfma32_bf16(al[cur][tp], bh[cur], a);
+                    a = mfma32_bf16(ah[cur][tp], bl[cur], a);
+                    a = mfma32_bf16(ah[cur][tp], bh[cur], a);
+                    }
+                    acc[M16 ? 0 : tp] = a;
+                }
+                sed_sched_fence();
+            }
+        }
+    }
+    // ---- sum the waves' K slices in LDS (fixed order), store this workgroup's partial [tap][ci][co] ----
+    float* red = (float*)smem;
+    float* part = dWp + (size_t)blockIdx.x * 9 * CIN * COUT;
+    if (M16) {
+        for (int round = 0; round < 4; ++round) {
+            __syncthreads();
+            if (w == round) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* d = red + (tp * CIN + 4 * g + r) * COUT + 16 * nt + i16;
+                            const float v = acc16[M16 ? tp : 0][nt][r];
+                            *d = round == 0 ? v : *d + v;
+                        }
+            }
+        }
+    } else {
+        const int wn = w & 1, wk = w >> 1;
+        for (int round = 0; round < 2; ++round) {
+            __syncthreads();
+            if (wk == round) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* d = red + (tp * CIN + mfma32_row(r, lane)) * COUT + 32 * wn + lo;
+                        const float v = acc[M16 ? 0 : tp][r];
+                        *d = round == 0 ? v : *d + v;
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 9 * CIN * COUT; idx += 256) part[idx] = red[idx];
+}
+template <int CIN, int COUT>
+static int launch_wgrad_alltaps_bf16(const float* x, const float* dy, float* dWp, int B, int T, int F, int grid, hipStream_t s) {
+    using Cfg = WgnCfg<CIN, COUT>;
+    SED_MAX_SMEM((conv_wgrad_alltaps_bf16_kernel<CIN, COUT>), Cfg::SMEM);
+    SED_LAUNCH((conv_wgrad_alltaps_bf16_kernel<CIN, COUT>), dim3(grid), dim3(256), Cfg::SMEM, s, x, dy, dWp, B, T, F);
+    return sed_check_launch();
+}
+
 static int conv_wgrad_impl(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
                            bool split_bf16, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = SED_ERR_UNSUPPORTED;
     const int TF = conv_tf(F);
     if (F % TF != 0 || (F & (F - 1)) != 0) return SED_ERR_UNSUPPORTED;
+    // narrow layers at the production widths: the split-bf16 all-taps kernel (sed_set_tuning(SED_TUNE_WGRAD_NARROW, 1): exact f32)
+    int nparts = wgrad_parts(CIN, COUT, B, T, F);
+    if (split_bf16 && TF == 32 && sed_tuning[SED_TUNE_WGRAD_NARROW] != 1 && ((CIN == 16 && COUT == 32) || (CIN == 32 && COUT == 64))) {
+        // one (CIN = 32: 111 KB of LDS) / two resident workgroups per CU; every workgroup beyond that only adds a partial to write
+        // and reduce (18 / 74 KB each: 1024 / 512 partials were 22 / 29 us of fixed cost per launch)
+        const int capb = sed_tuning[SED_TUNE_WGRAD_CAP] > 0 ? sed_tuning[SED_TUNE_WGRAD_CAP] : (CIN == 16 ? 512 : 256);
+        if (nparts > capb) nparts = capb;
+        if (CIN == 16) rc = launch_wgrad_alltaps_bf16<16, 32>(x, dy, dWp, B, T, F, nparts, s);
+        else rc = launch_wgrad_alltaps_bf16<32, 64>(x, dy, dWp, B, T, F, nparts, s);
+    }
 #define WGA_CASE(ci, co, tf) if (rc != SED_OK && CIN == ci && COUT == co && TF == tf) rc = launch_wgrad_alltaps<ci, co, tf>(x, dy, dWp, B, T, F, s);
     WGA_CASE(16, 32, 32) WGA_CASE(16, 32, 16) WGA_CASE(16, 32, 8) WGA_CASE(32, 64, 32) WGA_CASE(32, 64, 16) WGA_CASE(32, 64, 8)
     WGA_CASE(32, 64, 4)
@@ -950,7 +1203,6 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dWp, float* d
 #undef WG_CASE
     if (rc != SED_OK) return rc;
     const int n = COUT * CIN * 9;
-    const int nparts = wgrad_parts(CIN, COUT, B, T, F);
     SED_LAUNCH(wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(nparts >= 256 ? 1024 : 256), 0, s, (const float*)dWp, dW, nparts, COUT, CIN);
     return sed_check_launch();
 }
@@ -959,8 +1211,8 @@ extern "C" int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float
                               void* stream) {
     return conv_wgrad_impl(x, dy, dWp, dW, B, T, F, CIN, COUT, false, stream);
 }
-// Same contract; the wide layers (CIN >= 64) contract on the split-bf16 MFMA (fp32-level accuracy, ~8e-6 relative), the
-// narrow ones use the exact-f32 all-taps kernel.
+// Same contract; every layer with F >= 32 (narrow ones) or CIN >= 64 contracts on the split-bf16 MFMA (fp32-level accuracy,
+// ~8e-6 relative); narrow layers on tiles narrower than 32 columns use the exact-f32 all-taps kernel.
 extern "C" int sed_conv_wgrad_bf16x3(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN,
                                      int COUT, void* stream) {
     return conv_wgrad_impl(x, dy, dWp, dW, B, T, F, CIN, COUT, true, stream);

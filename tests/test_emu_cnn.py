@@ -73,3 +73,17 @@ def test_glu128_bwd_16x16x32(emu, layer, B, T, F, cap):
     finally:
         _lib.set_tuning("glu_bwd128_split", 0)
         _lib.set_tuning("glu_grid_cap", 0)
+
+
+@pytest.mark.parametrize("layer,B,T,F,cap,narrow", [(1, 2, 9, 64, 3, 0), (2, 3, 7, 32, 2, 0), (1, 1, 4, 32, 0, 0), (2, 2, 6, 32, 0, 1)])
+def test_narrow_wgrad_split_bf16(emu, layer, B, T, F, cap, narrow):
+    """All-taps weight gradient of the 16->32 / 32->64 layers on the split-bf16 MFMA (three column-shifted transposed copies of the
+    halo patch): ragged last frame tile, F edges, several tiles per workgroup (register prefetch); narrow=1 = the exact-f32 kernel."""
+    from desed_task_amd import _lib
+    _lib.set_tuning("wgrad_cap", cap)
+    _lib.set_tuning("wgrad_narrow", narrow)
+    try:
+        P.case_cnn_block("cpu", layer, B, T, F, training=True, dropout_p=0.5, precision="bf16x3", tol=1e-4)
+    finally:
+        _lib.set_tuning("wgrad_cap", 0)
+        _lib.set_tuning("wgrad_narrow", 0)
