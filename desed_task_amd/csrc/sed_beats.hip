@@ -8,8 +8,8 @@
 //   K-B4 posconv_kernel       x + GELU(grouped Conv1d(k = 128, 16 groups)(x)): the convolutional position embedding
 //   K-B5 attention_kernel     multi-head attention with the bucketed relative position bias scaled per (head, query) by the
 //                             GRU-style gate computed from the query (backbone.py:662-682); online softmax, no T x T tensor in HBM
-// First version: the attention and the position convolution run on the f32 vector pipes (their roof equals the exact-f32 MFMA
-// peak); the 86 % of the extractor's FLOPs that sit in Linear layers run on the split-bf16 MFMA.
+// The Linear layers (86 % of the extractor's FLOPs) and the attention run on the split-bf16 MFMA; the position convolution still
+// runs on the f32 vector pipes (first version).
 #include "sed_common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -344,10 +344,226 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         for (int d = 0; d < 16; d += 4) *(float4*)(dst + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
     }
 }
+// ---------------------------------------------------------------------------------------------
+// K-B5 on the matrix cores (default): the same attention, Q K^T and P V on v_mfma_f32_16x16x32_bf16 with split operands (three
+// MFMAs per product: fp32-level accuracy, the extractor's parity bound is 2e-4).  Workgroup = 64 queries of one (b, h), wave w =
+// queries 16 w .. 16 w + 15 (one 16-row MFMA block), key tiles of 64.
+//   scores:  A = Q (the wave's 16 queries x 64 dims, scaled, as bf16 hi / lo fragments in 16 VGPRs for the whole kernel),
+//            B = K^T from [key][dim] hi / lo planes -> four 16 x 16 blocks, D[q = 4 g + r][key = i16]
+//   softmax: a score row lives in the 16 lanes of a lane row: max / sum by quad_perm + row_ror DPP, online rescaling per lane's
+//            four rows; the gated relative-position bias is added in the accumulator layout (gate per row from a 16-float
+//            wave-private exchange, bias row of the head in LDS)
+//   P V:     A = P through wave-private [q][key] hi / lo planes (accumulator layout -> operand layout), B = V from TRANSPOSED
+//            [dim][key] planes (staged from 4 key x 4 dim register blocks), D[q][dim block] = 4 accumulators per wave.
+// All plane pitches are 80 bf16 = 10 sixteen-byte slots (= 2 mod 4: conflict-free ds_read_b128 for the 16x16x32 lane groups).
+// ---------------------------------------------------------------------------------------------
+#define ATM_P 80
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ relb,
+                                                             const float* __restrict__ grep_w, const float* __restrict__ grep_b,
+                                                             const float* __restrict__ grep_a, float* __restrict__ out, int T, int H,
+                                                             float scaling) {
+    SED_DYN_SMEM(smem);
+    unsigned short* kh = (unsigned short*)smem;           // K  [64 keys][ATM_P] hi | lo
+    unsigned short* kl = kh + 64 * ATM_P;
+    unsigned short* vh = kl + 64 * ATM_P;                 // V^T [64 dims][ATM_P] hi | lo
+    unsigned short* vl = vh + 64 * ATM_P;
+    unsigned short* pbase = vl + 64 * ATM_P;              // P  per wave: [16 q][ATM_P] hi | lo
+    float* gsh = (float*)(pbase + 4 * 2 * 16 * ATM_P);    // gate per query: [4 waves][16]
+    float* rb = gsh + 64;                                 // [2 T - 1] bias row of this head
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z, D = H * AT_HD, LD = 3 * D;
+    unsigned short* ph = pbase + w * 2 * 16 * ATM_P;
+    unsigned short* pl = ph + 16 * ATM_P;
+    if (relb)
+        for (int i = tid; i < 2 * T - 1; i += 256) rb[i] = relb[(size_t)h * (2 * T - 1) + i];
+    // ---- Q fragments: lane (i16, g) = query 16 w + i16, dims 32 ks + 8 g + e; the gate from the same 16 values per lane ----
+    s16x8 qh[2], ql[2];
+    {
+        const int tq = q0 + 16 * w + i16;
+        const float* qr = qkv + ((size_t)b * T + (tq < T ? tq : T - 1)) * LD + h * AT_HD;
+        float qv[16];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float4 a = *(const float4*)(qr + 32 * ks + 8 * g), c = *(const float4*)(qr + 32 * ks + 8 * g + 4);
+            qv[8 * ks] = a.x; qv[8 * ks + 1] = a.y; qv[8 * ks + 2] = a.z; qv[8 * ks + 3] = a.w;
+            qv[8 * ks + 4] = c.x; qv[8 * ks + 5] = c.y; qv[8 * ks + 6] = c.z; qv[8 * ks + 7] = c.w;
+        }
+        float gate = relb ? 1.0f : 0.0f;
+        if (relb && grep_w) {
+            float ga = 0.f, gb = 0.f;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                float a = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a = fmaf(grep_w[o * AT_HD + 32 * ks + 8 * g + e], qv[8 * ks + e], a);
+                a += __shfl_xor(a, 16);
+                a += __shfl_xor(a, 32);
+                a += grep_b[o];
+                if (o < 4) ga += a; else gb += a;
+            }
+            ga = sed_sigmoid(ga); gb = sed_sigmoid(gb);
+            gate = ga * (gb * grep_a[h] - 1.0f) + 2.0f;
+        }
+        if (g == 0) gsh[16 * w + i16] = gate;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            unsigned hv[4], lv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bf16_split2(qv[8 * ks + 2 * e] * scaling, qv[8 * ks + 2 * e + 1] * scaling, hv[e], lv[e]);
+            uint4 hq, lq;
+            hq.x = hv[0]; hq.y = hv[1]; hq.z = hv[2]; hq.w = hv[3];
+            lq.x = lv[0]; lq.y = lv[1]; lq.z = lv[2]; lq.w = lv[3];
+            qh[ks] = __builtin_bit_cast(s16x8, hq);
+            ql[ks] = __builtin_bit_cast(s16x8, lq);
+        }
+    }
+    sed_wave_sync();
+    float gate4[4], m4[4], l4[4];
+    int trow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        gate4[r] = gsh[16 * w + 4 * g + r];
+        m4[r] = -INFINITY; l4[r] = 0.f;
+        const int t = q0 + 16 * w + 4 * g + r;
+        trow[r] = t < T ? t : T - 1;                                  // dead query rows compute on a clamped index and are not stored
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kq = tid & 15, dq = tid >> 4;                            // staging block: keys 4 kq .. +3, dims 4 dq .. +3
+    for (int s0 = 0; s0 < T; s0 += 64) {
+        __syncthreads();                                               // previous tile consumed (first pass: rb staged)
+        {
+            float4 kr[4], vr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int s = s0 + 4 * kq + j;
+                kr[j] = make_float4(0.f, 0.f, 0.f, 0.f); vr[j] = kr[j];
+                if (s < T) {
+                    const float* base = qkv + ((size_t)b * T + s) * LD + h * AT_HD + 4 * dq;
+                    kr[j] = *(const float4*)(base + D);
+                    vr[j] = *(const float4*)(base + 2 * D);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                              // K rows: 4 dims of key 4 kq + j
+                uint2 hv, lv;
+                bf16_split2(kr[j].x, kr[j].y, hv.x, lv.x);
+                bf16_split2(kr[j].z, kr[j].w, hv.y, lv.y);
+                *(uint2*)(kh + (4 * kq + j) * ATM_P + 4 * dq) = hv;
+                *(uint2*)(kl + (4 * kq + j) * ATM_P + 4 * dq) = lv;
+            }
+            auto vt = [&](float a, float c, float e, float f, int d) {  // V^T rows: 4 keys of dim d
+                uint2 hv, lv;
+                bf16_split2(a, c, hv.x, lv.x);
+                bf16_split2(e, f, hv.y, lv.y);
+                *(uint2*)(vh + d * ATM_P + 4 * kq) = hv;
+                *(uint2*)(vl + d * ATM_P + 4 * kq) = lv;
+            };
+            vt(vr[0].x, vr[1].x, vr[2].x, vr[3].x, 4 * dq);
+            vt(vr[0].y, vr[1].y, vr[2].y, vr[3].y, 4 * dq + 1);
+            vt(vr[0].z, vr[1].z, vr[2].z, vr[3].z, 4 * dq + 2);
+            vt(vr[0].w, vr[1].w, vr[2].w, vr[3].w, 4 * dq + 3);
+        }
+        __syncthreads();
+        // ---- scores: four 16-key blocks ----
+        f32x4 sc[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned short* bp = kh + (16 * kb + i16) * ATM_P + 32 * ks + 8 * g;
+                const s16x8 bh = *(const s16x8*)bp, bl = *(const s16x8*)(bp + 64 * ATM_P);
+                a = mfma16_bf16(ql[ks], bh, a);
+                a = mfma16_bf16(qh[ks], bl, a);
+                a = mfma16_bf16(qh[ks], bh, a);
+            }
+            sc[kb] = a;
+        }
+        // ---- bias, mask, online softmax (row r of the lane = query 4 g + r; its 64 scores sit in this lane row's 16 lanes x 4 blocks) ----
+        float corr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const int s = s0 + 16 * kb + i16;
+                float v = sc[kb][r];
+                if (relb && s < T) v = fmaf(gate4[r], rb[s - trow[r] + T - 1], v);
+                v = s < T ? v : -INFINITY;
+                sc[kb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = sed_row16_max(mx);
+            const float mn = fmaxf(m4[r], mx);
+            corr[r] = expf(m4[r] - mn);                                // m = -inf on the first tile: exp(-inf) = 0
+            float ls = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const float e = expf(sc[kb][r] - mn);
+                sc[kb][r] = e;
+                ls += e;
+            }
+            ls = sed_row16_sum(ls);
+            l4[r] = l4[r] * corr[r] + ls;
+            m4[r] = mn;
+        }
+        // ---- P: accumulator layout -> [q][key] hi / lo planes of this wave ----
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                unsigned short hh, ll;
+                bf16_split(sc[kb][r], hh, ll);
+                ph[(4 * g + r) * ATM_P + 16 * kb + i16] = hh;
+                pl[(4 * g + r) * ATM_P + 16 * kb + i16] = ll;
+            }
+        sed_wave_sync();
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[db][r] *= corr[r];
+        // ---- O += P V ----
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned short* ap = ph + i16 * ATM_P + 32 * ks + 8 * g;
+            const s16x8 ah = *(const s16x8*)ap, al = *(const s16x8*)(ap + 16 * ATM_P);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const unsigned short* bp = vh + (16 * db + i16) * ATM_P + 32 * ks + 8 * g;
+                const s16x8 bh = *(const s16x8*)bp, bl = *(const s16x8*)(bp + 64 * ATM_P);
+                o[db] = mfma16_bf16(al, bh, o[db]);
+                o[db] = mfma16_bf16(ah, bl, o[db]);
+                o[db] = mfma16_bf16(ah, bh, o[db]);
+            }
+        }
+        sed_wave_sync();                                               // P planes free for the next tile
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = q0 + 16 * w + 4 * g + r;
+        if (t < T) {
+            const float inv = 1.0f / l4[r];
+            float* dst = out + ((size_t)b * T + t) * D + h * AT_HD + i16;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) dst[16 * db] = o[db][r] * inv;
+        }
+    }
+}
 extern "C" int sed_attention_relpos(const float* qkv, const float* relb, const float* grep_w, const float* grep_b,
                                     const float* grep_a, float* out, int B, int T, int H, int head_dim, void* stream) {
     if (head_dim != AT_HD || T > 4096) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
+    if (sed_tuning[SED_TUNE_ATTN_VALU] == 0) {          // default: the matrix-core kernel
+        const int smem_m = (4 * 64 * ATM_P + 4 * 2 * 16 * ATM_P) * 2 + (64 + 2 * T) * 4;
+        SED_MAX_SMEM(attention_mfma_kernel, smem_m);
+        SED_LAUNCH(attention_mfma_kernel, dim3((T + 63) / 64, H, B), dim3(256), smem_m, (hipStream_t)stream, qkv, relb, grep_w, grep_b,
+                   grep_a, out, T, H, 1.0f / sqrtf((float)head_dim));
+        return sed_check_launch();
+    }
     const int smem = (3 * AT_TQ * AT_P + 2 * T) * 4;
     SED_MAX_SMEM(attention_kernel, smem);
     SED_LAUNCH(attention_kernel, dim3((T + AT_TQ - 1) / AT_TQ, H, B), dim3(256), smem, (hipStream_t)stream, qkv, relb, grep_w, grep_b,

@@ -44,7 +44,7 @@ static inline void sed_zero4(hipStream_t s, float* p0, int n0, float* p1, int n1
 // Tuning overrides (tests and sweep tools only; all 0 = built-in choices).  Set explicitly through sed_set_tuning(): the entry
 // points never read the process environment.
 enum { SED_TUNE_GLU_GRID_CAP = 0, SED_TUNE_GLU_BWD128_SPLIT = 1, SED_TUNE_CONVB_CK = 2, SED_TUNE_CONVB_MP = 3, SED_TUNE_B0_NOCENTER = 4, SED_TUNE_GLU_FWD128 = 5, SED_TUNE_WGRAD_NARROW = 6, SED_TUNE_WGRAD_CAP = 7,
-       SED_TUNE_COUNT = 8 };
+       SED_TUNE_ATTN_VALU = 8, SED_TUNE_COUNT = 16 };
 extern int sed_tuning[SED_TUNE_COUNT];
 
 static inline int sed_check_launch() {
@@ -181,6 +181,32 @@ __device__ __forceinline__ float sed_quad_xor2(float v) {
 #else
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
 #endif
+}
+// value of another quad of the same 16-lane row (row_ror:4 / row_ror:8); with sed_quad_xor1/2 first, two of these complete an
+// all-reduce over the 16 lanes of a row (the 16x16 MFMA accumulator keeps one matrix row in the 16 lanes of a lane row)
+__device__ __forceinline__ float sed_row_ror4(float v) {
+#ifdef SED_EMU
+    return __shfl_xor(v, 4);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+#endif
+}
+__device__ __forceinline__ float sed_row_ror8(float v) {
+#ifdef SED_EMU
+    return __shfl_xor(v, 8);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+#endif
+}
+__device__ __forceinline__ float sed_row16_max(float v) {
+    v = fmaxf(v, sed_quad_xor1(v)); v = fmaxf(v, sed_quad_xor2(v));
+    v = fmaxf(v, sed_row_ror4(v)); v = fmaxf(v, sed_row_ror8(v));
+    return v;
+}
+__device__ __forceinline__ float sed_row16_sum(float v) {
+    v += sed_quad_xor1(v); v += sed_quad_xor2(v);
+    v += sed_row_ror4(v); v += sed_row_ror8(v);
+    return v;
 }
 // sum over the four lanes of a quad, result in all four
 __device__ __forceinline__ float sed_quad_sum(float v) {

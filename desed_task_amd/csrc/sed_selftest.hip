@@ -2,7 +2,7 @@
 // C[32][32] = A[32][K] * B[K][32] via v_mfma_f32_32x32x2_f32, and the 16x16x4 analogue.
 #include "sed_common.h"
 
-int sed_tuning[SED_TUNE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+int sed_tuning[SED_TUNE_COUNT] = {0};
 extern "C" int sed_set_tuning(int key, int value) {
     if (key < 0 || key >= SED_TUNE_COUNT) return SED_ERR_ARG;
     sed_tuning[key] = value;

@@ -1644,3 +1644,40 @@ def case_beats_vs_reference_golden(dev, golden):
         raise AssertionError("padding masks must be refused")
     except NotImplementedError:
         pass
+
+
+def case_attention_relpos(dev, B=2, T=100, H=2, gated=True, bias=True, variant=0):
+    """sed_attention_relpos (BEATs K-B5; variant 0 = matrix-core kernel, 1 = vector-pipe kernel) against a float64 restatement of
+    backbone.py:529-531,640-682: scores = q k^T / 8 + gate * bias[s - t], softmax over the keys, times v.  Ragged last tiles."""
+    from desed_task_amd import _lib
+    torch.manual_seed(3)
+    hd, D = 64, 64 * H
+    qkv = torch.randn(B * T, 3 * D) * 0.7
+    relb = torch.randn(H, 2 * T - 1) * 0.5 if bias else None
+    gw, gb, ga = (torch.randn(8, hd) * 0.2, torch.randn(8) * 0.1, torch.randn(H) * 0.5 + 1.0) if gated else (None, None, None)
+    q = qkv[:, :D].view(B, T, H, hd).permute(0, 2, 1, 3).double()
+    k = qkv[:, D:2 * D].view(B, T, H, hd).permute(0, 2, 1, 3).double()
+    v = qkv[:, 2 * D:].view(B, T, H, hd).permute(0, 2, 1, 3).double()
+    sc = q @ k.transpose(-1, -2) / 8.0
+    if bias:
+        idx = torch.arange(T)[None, :] - torch.arange(T)[:, None] + T - 1             # [t][s] -> s - t + T - 1
+        bm = relb.double()[:, idx]                                                      # (H, T, T)
+        gate = torch.ones(B, H, T, dtype=torch.float64)
+        if gated:
+            proj = q @ gw.double().t() + gb.double()                                    # (B,H,T,8)
+            g_a, g_b = torch.sigmoid(proj[..., :4].sum(-1)), torch.sigmoid(proj[..., 4:].sum(-1))
+            gate = g_a * (g_b * ga.double()[None, :, None] - 1.0) + 2.0
+        sc = sc + gate[..., None] * bm[None]
+    ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B * T, D)
+    out = torch.empty(B * T, D, device=dev)
+    qd = to(dev, qkv)
+    dv = [to(dev, t) if t is not None else None for t in (relb, gw, gb, ga)]
+    ptr = lambda t: t.data_ptr() if t is not None else None          # noqa: E731
+    _lib.set_tuning("attn_valu", variant)
+    try:
+        _lib.get().call("sed_attention_relpos", qd.data_ptr(), ptr(dv[0]), ptr(dv[1]), ptr(dv[2]), ptr(dv[3]), out.data_ptr(), B, T, H, hd,
+                        _lib.stream_ptr(out))
+    finally:
+        _lib.set_tuning("attn_valu", 0)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), (variant, err)

@@ -110,3 +110,11 @@ def test_beats_fbank_and_extractor_vs_reference_golden(emu):
     P.case_beats_fbank("cpu")
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_beats.npz"))
     P.case_beats_vs_reference_golden("cpu", G)
+
+
+def test_attention_relpos_kernels(emu):
+    """Both attention kernels (matrix-core default, vector-pipe) vs a float64 restatement: ragged tiles, gate / bias on and off."""
+    for variant in (0, 1):
+        P.case_attention_relpos("cpu", B=1, T=100, H=2, gated=True, bias=True, variant=variant)
+    P.case_attention_relpos("cpu", B=2, T=70, H=1, gated=False, bias=True)
+    P.case_attention_relpos("cpu", B=1, T=33, H=1, gated=False, bias=False)

@@ -199,3 +199,10 @@ def test_beats_extractor_vs_reference_golden():
     P.case_beats_fbank("cuda")
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_beats.npz"))
     P.case_beats_vs_reference_golden("cuda", G)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attention_relpos_kernels(variant):
+    """BEATs attention at the extractor's size (496 tokens: ragged last tile, 12 heads) on both kernels."""
+    P.case_attention_relpos("cuda", B=2, T=496, H=12, gated=True, bias=True, variant=variant)
+    P.case_attention_relpos("cuda", B=1, T=100, H=2, gated=False, bias=False, variant=variant)
