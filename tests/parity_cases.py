@@ -492,7 +492,7 @@ def case_edge_shapes(dev):
     assert tuple(Fh.minmax_scale(empty, apply_log=True).shape) == (0, 128, 17)
 
 
-def case_dyn_args_step(dev, graph=False, steps=4, n_samp=16000 + 1024):
+def case_dyn_args_step(dev, graph=False, steps=4, n_samp=16000 + 1024, seed0=0):
     """Step-varying arguments through device memory (desed_task_amd/graph.py) == the by-value eager path.
 
     Two identical tasks, identical host RNG streams: one runs the plain StepDriver, the other runs every step under a
@@ -526,9 +526,9 @@ def case_dyn_args_step(dev, graph=False, steps=4, n_samp=16000 + 1024):
             dyn = G.DynArgs(dev)
         flips = []
         for step in range(steps):
-            seed_all(step)
+            seed_all(seed0 + step)
             flips.append(random.random() < 0.5)
-            seed_all(step)
+            seed_all(seed0 + step)
             batch = (to(dev, audio.clone()), to(dev, labels.clone()), None, None)
             if mode == "dyn" and not graph:
                 with G.dyn_step(dyn):

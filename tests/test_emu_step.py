@@ -41,7 +41,7 @@ def test_edge_shapes(emu):
 def test_dyn_args_step_equals_eager(emu_sequential):
     """graph.DynArgs: dropout seeds, mixup c/perm, loss weight, EMA factor and Adam factors read from memory.
     In-order workgroups (the strict criterion of the case needs identical atomic orders in both runs)."""
-    P.case_dyn_args_step("cpu", graph=False, steps=3, n_samp=8000 + 1024)
+    P.case_dyn_args_step("cpu", graph=False, steps=2, n_samp=8000 + 1024, seed0=1)       # seeds 41, 42: mixup on, then off
 
 
 def test_validation_step(emu):
