@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--embeddings", action="store_true",
                     help="secondary workload (SURVEY 8f rank 3): the 2023 'pretrained' step, frozen BEATs-shaped embeddings "
                          "(768 x 496 per clip) fused into the CRNN (confs/pretrained.yaml); not the headline metric")
+    ap.add_argument("--gru-dw-atomic", action="store_true", help="A/B: BiGRU weight gradients through zero fill + atomic split-K")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
                     help="A/B runs: override a kernel choice of the library (desed_task_amd._lib.TUNING_KEYS), e.g. glu_bwd128_split=3")
     args = ap.parse_args()
@@ -321,6 +322,9 @@ def main():
     for kv in args.tuning:
         key, val = kv.split("=")
         _lib.set_tuning(key, int(val))
+    if args.gru_dw_atomic:
+        from desed_task_amd import ops as _ops
+        _ops.GRU_DW_ATOMIC = True
     from desed_task_amd.arena import FusedAdam
     from desed_task_amd.launcher import StepDriver, init_distributed
     from desed_task_amd.nnet.CRNN import CRNN

@@ -15,6 +15,9 @@ BN_MOMENTUM = 0.99
 BLOCK0_FUSED = os.environ.get("SED_BLOCK0_FUSED", "1") != "0"     # first block without its pre-BN tensor in HBM (A/B switch)
 
 
+GRU_DW_ATOMIC = False            # A/B switch (bench.py --gru-dw-atomic): the zero-fill + atomic split-K weight-gradient GEMMs
+
+
 def gemm_entry(cfg, pair=True):
     """C-ABI entry of the GRU GEMMs: split-bf16 products by default (fp32-level accuracy, see sed_gemm_bf16.hip),
     exact-f32 MFMA with cfg["gemm_precision"] = "f32" or SED_GEMM_PRECISION=f32."""
@@ -324,12 +327,22 @@ class BiGRULayerFn(torch.autograd.Function):
         # dW_ih[d] = dgi[d]^T . x   and   dW_hh[d] = dgh[d]^T . hprev[d]   (K = B*T, split-K, both directions per launch).
         # (Running these on a side stream beside the next layer's recurrence was measured: 5.159 vs 5.174 ms/step, not kept.)
         ws = st
-        lib.call("sed_zero_buffers", dwi[0].data_ptr(), dwi[0].numel(), dwi[1].data_ptr(), dwi[1].numel(),
-                 dwh[0].data_ptr(), dwh[0].numel(), dwh[1].data_ptr(), dwh[1].numel(), ws)    # split-K GEMMs accumulate
-        lib.call(gemm_entry(cfg), dgi.data_ptr(), dgi.data_ptr() + off, x.data_ptr(), x.data_ptr(), None, None,
-                 dwi[0].data_ptr(), dwi[1].data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, 0, ws)
-        lib.call(gemm_entry(cfg), dgh.data_ptr(), dgh.data_ptr() + off, hprev.data_ptr(), hprev.data_ptr() + H * 4, None, None,
-                 dwh[0].data_ptr(), dwh[1].data_ptr(), 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, 0, ws)
+        if (gemm_entry(cfg).endswith("bf16x3") and I % 4 == 0 and H % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in dwi + dwh)
+                and not (cfg or {}).get("gru_dw_atomic", GRU_DW_ATOMIC)):
+            # deterministic split-K: dense per-slice partials + a fixed-order sum (no zero fill, no fp32 atomics: 5 M atomics on
+            # 98 K addresses were most of these launches)
+            scr = torch.empty(int(lib.value("sed_gemm_splitk_scratch_floats", 3 * H, max(I, H), BT, split)), **f32)
+            lib.call("sed_gemm_pair_splitk_bf16x3", dgi.data_ptr(), dgi.data_ptr() + off, x.data_ptr(), x.data_ptr(),
+                     dwi[0].data_ptr(), dwi[1].data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, scr.data_ptr(), ws)
+            lib.call("sed_gemm_pair_splitk_bf16x3", dgh.data_ptr(), dgh.data_ptr() + off, hprev.data_ptr(), hprev.data_ptr() + H * 4,
+                     dwh[0].data_ptr(), dwh[1].data_ptr(), 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, scr.data_ptr(), ws)
+        else:
+            lib.call("sed_zero_buffers", dwi[0].data_ptr(), dwi[0].numel(), dwi[1].data_ptr(), dwi[1].numel(),
+                     dwh[0].data_ptr(), dwh[0].numel(), dwh[1].data_ptr(), dwh[1].numel(), ws)    # split-K GEMMs accumulate
+            lib.call(gemm_entry(cfg), dgi.data_ptr(), dgi.data_ptr() + off, x.data_ptr(), x.data_ptr(), None, None,
+                     dwi[0].data_ptr(), dwi[1].data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, 0, ws)
+            lib.call(gemm_entry(cfg), dgh.data_ptr(), dgh.data_ptr() + off, hprev.data_ptr(), hprev.data_ptr() + H * 4, None, None,
+                     dwh[0].data_ptr(), dwh[1].data_ptr(), 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, 0, ws)
         d_w_ih, d_w_hh, d_b_ih, d_b_hh = dwi, dwh, dbi, dbh
         return (dx, d_w_ih[0], d_w_hh[0], d_b_ih[0], d_b_hh[0], d_w_ih[1], d_w_hh[1], d_b_ih[1], d_b_hh[1], None)
 

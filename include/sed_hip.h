@@ -190,6 +190,13 @@ int sed_gemm_kcat_bf16x3(const float* A, const float* B0, const float* B1, float
 int sed_gemm_pair_bf16x3(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
                          const float* bias1, float* C0, float* C1, int M, int N, int K, int lda, int ldb, int ldc,
                          int transA, int transB, int split_k, int accumulate, void* stream);
+/* The same pair with a deterministic split-K: slices land as dense partials in `scratch` (sed_gemm_splitk_scratch_floats() floats)
+ * and are summed in slice order; C0 / C1 are overwritten (no zero fill, no atomics).  The weight gradients of a BiGRU layer
+ * (torch.nn.GRU backward, desed_task/nnet/RNN.py:19-30): dW_ih[d] = dgi[d]^T x, dW_hh[d] = dgh[d]^T h_prev[d]. */
+long long sed_gemm_splitk_scratch_floats(int M, int N, int K, int split_k);
+int sed_gemm_pair_splitk_bf16x3(const float* A0, const float* A1, const float* B0, const float* B1, float* C0, float* C1,
+                                int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB, int split_k,
+                                float* scratch, void* stream);
 
 /* Column sums (bias gradients): out[n] = sum_m X[m*ld + n] for n < nsplit, out1[n-nsplit] for nsplit <= n < N. */
 int sed_colsum(const float* X, float* out, float* out1, int nsplit, int M, int N, int ld, void* stream);

@@ -102,9 +102,12 @@ def _worker(rank, world, port, out_dir):
     ck = load_checkpoint(task5, ckpt)
     assert ck["epoch"] == 3 and task5.scheduler["scheduler"].step_num == task2.scheduler["scheduler"].step_num == 2
     driver5 = StepDriver(task5, world_size=world, broadcast_init=False)
+    from tests.emu_support import emu_threads
+    prev_threads = emu_threads(1)        # bit-exact comparison of two runs: in-order workgroups (fp32 atomics in a fixed order)
     for t_, d_ in ((task2, driver), (task5, driver5)):
         random.seed(4); np.random.seed(8); torch.manual_seed(8)
         d_.run_step((audio.clone(), labels.clone(), None, None), 1)
+    emu_threads(prev_threads if prev_threads > 0 else min(8, os.cpu_count() or 1))
     assert torch.equal(task5.sed_student.arena.flat, task2.sed_student.arena.flat)
     assert torch.equal(task5.sed_teacher.arena.flat, task2.sed_teacher.arena.flat)
     assert task5.opt.param_groups[0]["lr"] == task2.opt.param_groups[0]["lr"]
