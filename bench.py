@@ -314,6 +314,7 @@ def main():
                     help="secondary workload (SURVEY 8f rank 3): the 2023 'pretrained' step, frozen BEATs-shaped embeddings "
                          "(768 x 496 per clip) fused into the CRNN (confs/pretrained.yaml); not the headline metric")
     ap.add_argument("--gru-dw-atomic", action="store_true", help="A/B: BiGRU weight gradients through zero fill + atomic split-K")
+    ap.add_argument("--no-gru-dw-side", action="store_true", help="A/B: BiGRU weight-gradient GEMMs on the main stream")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
                     help="A/B runs: override a kernel choice of the library (desed_task_amd._lib.TUNING_KEYS), e.g. glu_bwd128_split=3")
     args = ap.parse_args()
@@ -364,6 +365,9 @@ def main():
         driver = GraphedStepDriver(task, world_size=world, warmup=3)
     else:
         driver = StepDriver(task, world_size=world)
+    if args.no_gru_dw_side:
+        from desed_task_amd import ops as _ops2
+        _ops2.GRU_DW_SIDE_ALLOWED = False
     audio, labels = synthetic_batch(dev, 1234 + rank)
     emb = None
     if args.embeddings:

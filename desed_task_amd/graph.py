@@ -231,7 +231,7 @@ class GraphedStepDriver:
         else:
             task.on_before_zero_grad()
         d.opt.zero_grad(set_to_none=True)
-        loss.backward()
+        d.backward_joined(loss)                          # BiGRU weight-gradient GEMMs on the side stream, joined here
         if d.side is not None:
             torch.cuda.current_stream().wait_stream(d.side)
         if self.world <= 1:

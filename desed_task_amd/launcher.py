@@ -19,6 +19,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import ops as _ops
+
 
 def init_distributed(backend=None):
     """Read RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment (torchrun contract)."""
@@ -54,7 +56,7 @@ class StepDriver:
     `overlap_allreduce=False` gives the single blocking all-reduce over the whole arena (same result, bit for bit: a sum over
     ranks per element either way)."""
 
-    def __init__(self, task, world_size=1, ema_side_stream=True, overlap_allreduce=None, broadcast_init=True):
+    def __init__(self, task, world_size=1, ema_side_stream=True, overlap_allreduce=None, broadcast_init=True, gru_dw_side=True):
         self.task = task
         self.world = world_size
         self.opt = task.opt
@@ -62,6 +64,7 @@ class StepDriver:
         self.arena = getattr(task.sed_student, "arena", None)
         dev = next(task.sed_student.parameters()).device
         self.side = torch.cuda.Stream(device=dev) if (ema_side_stream and dev.type == "cuda") else None
+        self.gru_dw_side = bool(gru_dw_side) and dev.type == "cuda"     # see ops.GRU_DW_SIDE: on only inside this driver's backward()
         if hasattr(self.opt, "grad_scale"):
             self.opt.grad_scale = 1.0 / world_size
         if overlap_allreduce is None:
@@ -114,15 +117,24 @@ class StepDriver:
         asynchronous collective and the CNN backward is enqueued behind it on the compute stream."""
         student = self.task.sed_student
         if not (self.overlap and getattr(student, "_cnn_boundary", None) is not None):
-            loss.backward()
+            self.backward_joined(loss)
             if hasattr(student, "backward_cnn"):
                 student.backward_cnn()
             self.allreduce_grads()
             return
-        loss.backward()
+        self.backward_joined(loss)                       # bucket A holds the BiGRU weight gradients
         self.launch_bucket_a()
         student.backward_cnn()
         self.finish_buckets()
+
+    def backward_joined(self, loss):
+        """loss.backward() with the BiGRU weight-gradient GEMMs on the side stream (ops.GRU_DW_SIDE), joined before returning."""
+        prev, _ops.GRU_DW_SIDE = _ops.GRU_DW_SIDE, self.gru_dw_side and _ops.GRU_DW_SIDE_ALLOWED
+        try:
+            loss.backward()
+        finally:
+            _ops.GRU_DW_SIDE = prev
+        _ops.join_side_stream(loss.device)
 
     def launch_bucket_a(self):
         arena = self.task.sed_student.arena

@@ -17,6 +17,29 @@ BLOCK0_FUSED = os.environ.get("SED_BLOCK0_FUSED", "1") != "0"     # first block 
 
 GRU_DW_ATOMIC = False            # A/B switch (bench.py --gru-dw-atomic): the zero-fill + atomic split-K weight-gradient GEMMs
 
+# Weight-gradient GEMMs of a BiGRU layer on a side HIP stream: they only feed the optimizer, while the next thing on the chain is
+# the other layer's recurrence (96 workgroups: 160 CUs idle).  Only launcher.StepDriver.backward_joined() turns it on, for the
+# duration of its loss.backward(), and joins the side stream before returning (same-box step 4.17 -> 4.13 ms).
+GRU_DW_SIDE = False
+GRU_DW_SIDE_ALLOWED = True       # bench.py --no-gru-dw-side (A/B)
+_side = {}
+
+
+def side_stream(device):
+    if device.type != "cuda":
+        return None
+    key = (device.type, device.index)
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=device)
+    return _side[key]
+
+
+def join_side_stream(device):
+    """The current stream waits for the weight-gradient GEMMs launched on the side stream (no-op if there were none)."""
+    s = _side.get((device.type, device.index))
+    if s is not None:
+        torch.cuda.current_stream(device).wait_stream(s)
+
 
 def gemm_entry(cfg, pair=True):
     """C-ABI entry of the GRU GEMMs: split-bf16 products by default (fp32-level accuracy, see sed_gemm_bf16.hip),
@@ -325,8 +348,22 @@ class BiGRULayerFn(torch.autograd.Function):
             kcat = "sed_gemm_kcat_bf16x3" if gemm_entry(cfg).endswith("bf16x3") else "sed_gemm_kcat"
             lib.call(kcat, dgi.data_ptr(), w_ih_f.data_ptr(), w_ih_r.data_ptr(), dx.data_ptr(), BT, I, 6 * H, 3 * H, 6 * H, I, I, st)
         # dW_ih[d] = dgi[d]^T . x   and   dW_hh[d] = dgh[d]^T . hprev[d]   (K = B*T, split-K, both directions per launch).
-        # (Running these on a side stream beside the next layer's recurrence was measured: 5.159 vs 5.174 ms/step, not kept.)
         ws = st
+        side = side_stream(x.device) if GRU_DW_SIDE else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(x.device))          # after the recurrence and the dX product were enqueued
+            for t in (dgi, dgh, hprev, x):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                BiGRULayerFn._weight_grads(lib, cfg, dgi, dgh, hprev, x, dwi, dwh, B, T, I, H, split, side.cuda_stream, f32)
+        else:
+            BiGRULayerFn._weight_grads(lib, cfg, dgi, dgh, hprev, x, dwi, dwh, B, T, I, H, split, ws, f32)
+        d_w_ih, d_w_hh, d_b_ih, d_b_hh = dwi, dwh, dbi, dbh
+        return (dx, d_w_ih[0], d_w_hh[0], d_b_ih[0], d_b_hh[0], d_w_ih[1], d_w_hh[1], d_b_ih[1], d_b_hh[1], None)
+
+    @staticmethod
+    def _weight_grads(lib, cfg, dgi, dgh, hprev, x, dwi, dwh, B, T, I, H, split, ws, f32):
+        BT, off = B * T, 3 * H * 4
         if (gemm_entry(cfg).endswith("bf16x3") and I % 4 == 0 and H % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in dwi + dwh)
                 and not (cfg or {}).get("gru_dw_atomic", GRU_DW_ATOMIC)):
             # deterministic split-K: dense per-slice partials + a fixed-order sum (no zero fill, no fp32 atomics: 5 M atomics on
@@ -343,8 +380,6 @@ class BiGRULayerFn(torch.autograd.Function):
                      dwi[0].data_ptr(), dwi[1].data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, 0, ws)
             lib.call(gemm_entry(cfg), dgh.data_ptr(), dgh.data_ptr() + off, hprev.data_ptr(), hprev.data_ptr() + H * 4, None, None,
                      dwh[0].data_ptr(), dwh[1].data_ptr(), 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, 0, ws)
-        d_w_ih, d_w_hh, d_b_ih, d_b_hh = dwi, dwh, dbi, dbh
-        return (dx, d_w_ih[0], d_w_hh[0], d_b_ih[0], d_b_hh[0], d_w_ih[1], d_w_hh[1], d_b_ih[1], d_b_hh[1], None)
 
 
 class EmbCatFn(torch.autograd.Function):
