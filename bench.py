@@ -315,11 +315,14 @@ def main():
                          "(768 x 496 per clip) fused into the CRNN (confs/pretrained.yaml); not the headline metric")
     ap.add_argument("--gru-dw-atomic", action="store_true", help="A/B: BiGRU weight gradients through zero fill + atomic split-K")
     ap.add_argument("--no-gru-dw-side", action="store_true", help="A/B: BiGRU weight-gradient GEMMs on the main stream")
+    ap.add_argument("--lib", default=None, help="A/B: bind another build of the C-ABI library (tools/build_variant.py)")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
                     help="A/B runs: override a kernel choice of the library (desed_task_amd._lib.TUNING_KEYS), e.g. glu_bwd128_split=3")
     args = ap.parse_args()
 
     from desed_task_amd import _lib
+    if args.lib:
+        _lib.use_library(os.path.abspath(args.lib), is_emulator=False)
     for kv in args.tuning:
         key, val = kv.split("=")
         _lib.set_tuning(key, int(val))

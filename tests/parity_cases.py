@@ -129,11 +129,14 @@ def np_keep_mask(shape, seed, p):
     n = int(np.prod(shape))
     thr = int(round(p * (1 << 24))) if p > 0 else 0
     M = 0xFFFFFFFF
+    sm = int(seed) & M                                   # the seed goes through the murmur3 finaliser (scalar side of sed_hash)
+    sm ^= sm >> 16; sm = (sm * 0x85EBCA6B) & M
+    sm ^= sm >> 13; sm = (sm * 0xC2B2AE35) & M
+    sm ^= sm >> 16
     x = torch.arange(n, dtype=torch.int64)
-    x = (x * 0x9E3779B1 + int(seed)) & M
-    x ^= x >> 16; x = (x * 0x85EBCA6B) & M
-    x ^= x >> 13; x = (x * 0xC2B2AE35) & M
-    x ^= x >> 16
+    x = (x * 0x9E3779B1 + sm) & M
+    x ^= x >> 15
+    x = (x * 0x2C1B3C6D) & M
     return ((x >> 8) >= thr).to(torch.float32).reshape(shape)
 
 
