@@ -89,12 +89,13 @@ __global__ __launch_bounds__(256) void block0_fwd_kernel(const float* __restrict
                 for (int bb = 0; bb < 3; ++bb) in[a * 3 + bb] = tile[(lr + a) * PW + col + bb];
             float xn[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float acc = 0.f;
+            for (int c = 0; c < 4; c += 2) {                    // two channels per v_pk_fma_f32 (each half is the same fmaf chain)
+                f32x2 acc2 = {0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 9; ++k) acc = fmaf(in[k], wreg[c][k], acc);
-                acc += breg[c];                                 // == conv0_kernel's y, bit for bit (same operation order)
-                xn[c] = fmaf(acc, sc[c], sh[c]);
+                for (int k = 0; k < 9; ++k) acc2 = pk_fma(f32x2{in[k], in[k]}, f32x2{wreg[c][k], wreg[c + 1][k]}, acc2);
+                const float a0 = acc2.x + breg[c], a1 = acc2.y + breg[c + 1];   // == conv0_kernel's y, bit for bit (same operation order)
+                xn[c] = fmaf(a0, sc[c], sh[c]);
+                xn[c + 1] = fmaf(a1, sc[c + 1], sh[c + 1]);
             }
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -235,13 +236,15 @@ __global__ __launch_bounds__(256) void block0_bwd_kernel(const float* __restrict
                     for (int bb = 0; bb < 3; ++bb) in[a * 3 + bb] = tile[(lr + a) * PW + col + bb];
                 float xh[4], xn[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float acc = 0.f;
+                for (int c = 0; c < 4; c += 2) {                // two channels per v_pk_fma_f32
+                    f32x2 acc2 = {0.f, 0.f};
 #pragma unroll
-                    for (int kk = 0; kk < 9; ++kk) acc = fmaf(in[kk], wreg[c][kk], acc);
-                    acc += breg[c];
-                    xh[c] = (acc - mu[c]) * istd[c] * vm;
+                    for (int kk = 0; kk < 9; ++kk) acc2 = pk_fma(f32x2{in[kk], in[kk]}, f32x2{wreg[c][kk], wreg[c + 1][kk]}, acc2);
+                    const float a0 = acc2.x + breg[c], a1 = acc2.y + breg[c + 1];
+                    xh[c] = (a0 - mu[c]) * istd[c] * vm;
+                    xh[c + 1] = (a1 - mu[c + 1]) * istd[c + 1] * vm;
                     xn[c] = fmaf(xh[c], gam4[c], bet4[c]);
+                    xn[c + 1] = fmaf(xh[c + 1], gam4[c + 1], bet4[c + 1]);
                 }
                 float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!tail) go = *(const float4*)(gout + (((size_t)b * To + to) * Fo + 4 * tr + w) * C + 4 * g);
