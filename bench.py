@@ -130,6 +130,10 @@ ENTRIES = {
     "sed_logscale_fwd": ("minmax_partial/apply_kernel", "mel", 2, lambda k: ("hbm", 8.0 * k[1] * k[2])),
     "sed_conv0_fwd": ("conv0_kernel", "block0", 4, lambda k: ("hbm", 4.0 * k[1] * k[2] * k[3] * (1 + k[4]))),
     "sed_conv0_wgrad": ("conv0_wgrad_kernel", "block0", 4, lambda k: ("hbm", 4.0 * k[1] * k[2] * k[3] * (1 + 2 * k[4]))),
+    # fused first block (B,T,F): reads x, writes the pooled 16-channel output / reads x and the pooled gradient (VALU-bound by design:
+    # the conv is recomputed instead of read; the HBM figure is the algorithmic traffic)
+    "sed_block0_fwd": ("block0_fwd_kernel", "block0", 3, lambda k: ("hbm", 4.0 * k[1] * k[2] * k[3] * (1 + 16 / 4))),
+    "sed_block0_bwd": ("block0_bwd_kernel", "block0", 3, lambda k: ("hbm", 4.0 * k[1] * k[2] * k[3] * (1 + 16 / 4))),
     "sed_conv3x3": ("conv3x3_kernel", "conv", 5, lambda k: ("mfma", _conv_fl(k))),
     "sed_conv3x3_bf16x3": ("conv3x3_bf16_kernel", "conv", 5, lambda k: ("mfma", _conv_fl(k))),
     "sed_conv_wgrad": ("conv_wgrad_kernel", "wgrad", 5, lambda k: ("mfma", _conv_fl(k))),
@@ -143,6 +147,7 @@ ENTRIES = {
     "sed_gemm_bf16x3": ("gemm_bf16x3_kernel", "gemm", 3, lambda k: ("mfma", _gemm_fl(k))),
     "sed_gemm_pair": ("gemm_vec_kernel", "gemm", 3, lambda k: ("mfma", 2 * _gemm_fl(k))),
     "sed_gemm_pair_bf16x3": ("gemm_bf16x3_kernel", "gemm", 3, lambda k: ("mfma", 2 * _gemm_fl(k))),
+    "sed_gemm_pair_splitk_bf16x3": ("gemm_bf16x3_kernel", "gemm", 3, lambda k: ("mfma", 2 * _gemm_fl(k))),
     "sed_gemm_kcat": ("gemm_vec_kernel", "gemm", 3, lambda k: ("mfma", _gemm_fl(k))),
     "sed_gemm_kcat_bf16x3": ("gemm_bf16x3_kernel", "gemm", 3, lambda k: ("mfma", _gemm_fl(k))),
     "sed_head_fwd": ("head_fwd_kernel", "head+loss", 4, lambda k: ("hbm", 4.0 * k[1] * k[2] * (k[3] + 2 * k[4]))),   # (B,T,D,NC)
