@@ -21,6 +21,9 @@ import torch.nn as nn
 from . import _lib
 
 
+POSCONV_MFMA = True             # position convolution on the split-bf16 MFMA (False: the f32 vector-pipe kernel, A/B and tests)
+
+
 class BEATsConfig:
     """Same fields and defaults as the reference's BEATsConfig (BEATs.py:24-86); `update(cfg)` takes the checkpoint's dict."""
 
@@ -207,7 +210,11 @@ class BEATs(nn.Module):
                 wqkv=torch.cat((a.q_proj.weight, a.k_proj.weight, a.v_proj.weight), 0).detach().float().contiguous(),
                 bqkv=torch.cat((a.q_proj.bias, a.k_proj.bias, a.v_proj.bias), 0).detach().float().contiguous(),
                 grep_a=a.grep_a.detach().float().reshape(-1).contiguous() if cfg.gru_rel_pos else None))
-        self._packed = dict(wt=wt, layers=layers,
+        # the position convolution's B operand for the split-bf16 MFMA: hi = bf16(w), lo = bf16(w - hi), as bit patterns
+        w_hi = wt.to(torch.bfloat16)
+        w_lo = (wt - w_hi.float()).to(torch.bfloat16)
+        wsplit = torch.stack((w_hi, w_lo)).contiguous().view(torch.int16)
+        self._packed = dict(wt=wt, wsplit=wsplit, layers=layers,
                             wpatch=self.patch_embedding.weight.detach().float().reshape(self.embed, -1).contiguous())
         return self._packed
 
@@ -270,8 +277,12 @@ class BEATs(nn.Module):
             x = linear(x, self.post_extract_proj.weight, self.post_extract_proj.bias, D, E)
         enc = self.encoder
         y = torch.empty_like(x)
-        lib.call("sed_posconv", x.data_ptr(), pk["wt"].data_ptr(), enc.pos_conv[0].bias.data_ptr(), y.data_ptr(), B, T, D, cfg.conv_pos,
-                 cfg.conv_pos_groups, st)
+        if POSCONV_MFMA and D // cfg.conv_pos_groups == 48 and cfg.conv_pos % 4 == 0:
+            lib.call("sed_posconv_bf16x3", x.data_ptr(), pk["wsplit"].data_ptr(), enc.pos_conv[0].bias.data_ptr(), y.data_ptr(), B, T, D,
+                     cfg.conv_pos, cfg.conv_pos_groups, st)
+        else:
+            lib.call("sed_posconv", x.data_ptr(), pk["wt"].data_ptr(), enc.pos_conv[0].bias.data_ptr(), y.data_ptr(), B, T, D, cfg.conv_pos,
+                     cfg.conv_pos_groups, st)
         x = layernorm(y, None, 1.0, enc.layer_norm, D)
         alpha = math.pow(2 * cfg.encoder_layers, 0.25) if cfg.deep_norm else 1.0
         relb = self._rel_bias(T, fb.device)

@@ -8,8 +8,8 @@
 //   K-B4 posconv_kernel       x + GELU(grouped Conv1d(k = 128, 16 groups)(x)): the convolutional position embedding
 //   K-B5 attention_kernel     multi-head attention with the bucketed relative position bias scaled per (head, query) by the
 //                             GRU-style gate computed from the query (backbone.py:662-682); online softmax, no T x T tensor in HBM
-// The Linear layers (86 % of the extractor's FLOPs) and the attention run on the split-bf16 MFMA; the position convolution still
-// runs on the f32 vector pipes (first version).
+// The Linear layers (86 % of the extractor's FLOPs), the attention and the position convolution all run on the split-bf16 MFMA
+// (vector-pipe versions of the last two are kept as sed_posconv and behind sed_set_tuning).
 #include "sed_common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -222,6 +222,89 @@ __global__ __launch_bounds__(256) void posconv_kernel(const float* __restrict__ 
         }
     }
 }
+// ---------------------------------------------------------------------------------------------
+// K-B4 on the matrix cores: the grouped position convolution as a GEMM per (clip, group) -- M = tokens, N = 48 output channels,
+// K = 128 taps x 48 input channels -- on v_mfma_f32_16x16x32_bf16 with split operands (three MFMAs per product).
+// A operand: 8 consecutive input channels of token t + tap - K/2 = one 16-byte read from the [token + halo][48] hi / lo planes of
+// the tile (pitch 48 bf16 = 6 slots = 2 mod 4: conflict-free); B operand: 8 consecutive input channels of (tap, output channel)
+// from the frozen weights, split into bf16 hi / lo planes ONCE on the host side (beats.py::_pack), streamed through LDS four
+// taps at a time by plain 16-byte copies.  Workgroup = 64 tokens x one group, wave = 16 tokens x the 48 output channels.
+// ---------------------------------------------------------------------------------------------
+#define PCM_TT 64
+#define PCM_KC 4
+__global__ __launch_bounds__(256) void posconv_mfma_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wsplit,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int T, int D, int K,
+                                                           int G) {
+    SED_DYN_SMEM(smem);
+    const int nrows = PCM_TT + K - 1, XPL = nrows * PC_CG, WPL = PCM_KC * PC_CG * PC_CG;
+    unsigned short* xh = (unsigned short*)smem;           // [nrows][48] hi | lo
+    unsigned short* wh = xh + 2 * XPL;                    // [PCM_KC][48 co][48 ci] hi | lo
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const int t0 = blockIdx.x * PCM_TT, grp = blockIdx.y, b = blockIdx.z, half = K / 2;
+    for (int i = tid; i < nrows * (PC_CG / 4); i += 256) {
+        const int r = i / (PC_CG / 4), c4 = i - r * (PC_CG / 4), t = t0 - half + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T) v = *(const float4*)(x + ((size_t)b * T + t) * D + grp * PC_CG + 4 * c4);
+        uint2 hv, lv;
+        bf16_split2(v.x, v.y, hv.x, lv.x);
+        bf16_split2(v.z, v.w, hv.y, lv.y);
+        *(uint2*)(xh + r * PC_CG + 4 * c4) = hv;
+        *(uint2*)(xh + XPL + r * PC_CG + 4 * c4) = lv;
+    }
+    f32x4 acc[3];
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const size_t plane = (size_t)G * K * PC_CG * PC_CG;                         // elements per hi / lo plane of the weights
+    for (int k0 = 0; k0 < K; k0 += PCM_KC) {
+        __syncthreads();                                                         // previous chunk consumed (first pass: x staged)
+        const uint4* src = (const uint4*)(wsplit + ((size_t)grp * K + k0) * PC_CG * PC_CG);
+        for (int i = tid; i < 2 * (WPL / 8); i += 256) {
+            const int p = i / (WPL / 8), e = i - p * (WPL / 8);
+            *((uint4*)(wh + p * WPL) + e) = *(const uint4*)((const unsigned short*)src + p * plane + 8 * (size_t)e);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < PCM_KC * PC_CG / 32; ++ks) {                       // 6 k-steps of 32 = 4 octets of (tap, 8 channels)
+            const int o = 4 * ks + g, tapl = o / (PC_CG / 8), c8 = o - tapl * (PC_CG / 8);
+            const unsigned short* ap = xh + (16 * w + i16 + k0 + tapl) * PC_CG + 8 * c8;
+            const s16x8 ah = *(const s16x8*)ap, al = *(const s16x8*)(ap + XPL);
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) {
+                const unsigned short* bp = wh + (tapl * PC_CG + 16 * nb + i16) * PC_CG + 8 * c8;
+                const s16x8 bh = *(const s16x8*)bp, bl = *(const s16x8*)(bp + WPL);
+                acc[nb] = mfma16_bf16(al, bh, acc[nb]);
+                acc[nb] = mfma16_bf16(ah, bl, acc[nb]);
+                acc[nb] = mfma16_bf16(ah, bh, acc[nb]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + 16 * w + 4 * g + r;
+        if (t < T) {
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) {
+                const int ch = grp * PC_CG + 16 * nb + i16;
+                const float v = acc[nb][r] + bias[ch];
+                const size_t oidx = ((size_t)b * T + t) * D + ch;
+                y[oidx] = x[oidx] + 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+            }
+        }
+    }
+}
+// wsplit: (2 planes hi | lo, groups, K, 48 co, 48 ci) bf16 bit patterns of the weight-normalised filter
+extern "C" int sed_posconv_bf16x3(const float* x, const unsigned short* wsplit, const float* bias, float* y, int B, int T, int D, int K,
+                                  int groups, void* stream) {
+    if (groups < 1 || D % groups != 0 || D / groups != PC_CG || K < 2 || (K & 1) || K % PCM_KC != 0 || D % 4 != 0) return SED_ERR_UNSUPPORTED;
+    if (B <= 0 || T <= 0) return SED_OK;
+    const int smem = (2 * (PCM_TT + K - 1) * PC_CG + 2 * PCM_KC * PC_CG * PC_CG) * 2;
+    if (smem > 150 * 1024) return SED_ERR_UNSUPPORTED;
+    SED_MAX_SMEM(posconv_mfma_kernel, smem);
+    SED_LAUNCH(posconv_mfma_kernel, dim3((T + PCM_TT - 1) / PCM_TT, groups, B), dim3(256), smem, (hipStream_t)stream, x, wsplit, bias, y,
+               T, D, K, groups);
+    return sed_check_launch();
+}
+
 extern "C" int sed_posconv(const float* x, const float* wt, const float* bias, float* y, int B, int T, int D, int K, int groups,
                            void* stream) {
     if (groups < 1 || D % groups != 0 || D / groups != PC_CG || K < 2 || (K & 1) || K % PC_KC != 0) return SED_ERR_UNSUPPORTED;

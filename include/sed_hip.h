@@ -316,6 +316,10 @@ int sed_layernorm(const float* x, const float* res, float alpha, const float* ga
  * K/2, last output dropped).  x, y (B,T,D); wt (groups, K, D/groups co, D/groups ci) = the weight-normalised filter transposed
  * on the host once. */
 int sed_posconv(const float* x, const float* wt, const float* bias, float* y, int B, int T, int D, int K, int groups, void* stream);
+/* The same position convolution on the split-bf16 MFMA (default in beats.py).  wsplit: the weight-normalised filter as bf16 hi | lo
+ * planes, (2, groups, K, 48 co, 48 ci), split once on the host (frozen weights). */
+int sed_posconv_bf16x3(const float* x, const unsigned short* wsplit, const float* bias, float* y, int B, int T, int D, int K,
+                       int groups, void* stream);
 
 /* Multi-head self-attention of MultiheadAttention.forward (backbone.py:446-700, eval mode, no padding mask) on the output of ONE
  * fused q|k|v projection: qkv (B*T, 3*H*64) -> out (B*T, H*64).  relb (H, 2T-1) = relative position bias per offset s - t (the

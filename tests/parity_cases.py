@@ -1684,3 +1684,27 @@ def case_attention_relpos(dev, B=2, T=100, H=2, gated=True, bias=True, variant=0
         _lib.set_tuning("attn_valu", 0)
     err = (out.cpu().double() - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), (variant, err)
+
+
+def case_posconv(dev, B=2, T=100, groups=2, K=128):
+    """BEATs position convolution (K-B4): the split-bf16 MFMA entry and the f32 vector-pipe entry against a float64 restatement of
+    x + GELU(SamePad(grouped Conv1d(k, padding k/2))) (backbone.py:30-43,118-120).  Ragged last token tile, halo at both ends."""
+    from desed_task_amd import _lib
+    torch.manual_seed(5)
+    CG = 48
+    D = CG * groups
+    x = torch.randn(B, T, D) * 0.8
+    w = torch.randn(D, CG, K) / np.sqrt(CG * K) * 3.0                   # Conv1d weight (out, in / groups, k)
+    bias = torch.randn(D) * 0.1
+    conv = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), bias.double(), padding=K // 2, groups=groups)[:, :, :T]
+    ref = x.double() + torch.nn.functional.gelu(conv.transpose(1, 2))
+    wt = w.view(groups, CG, CG, K).permute(0, 3, 1, 2).contiguous()        # (groups, K, co, ci)
+    w_hi = wt.to(torch.bfloat16)
+    wsplit = torch.stack((w_hi, (wt - w_hi.float()).to(torch.bfloat16))).contiguous().view(torch.int16)
+    xd, wtd, wsd, bd = to(dev, x), to(dev, wt), to(dev, wsplit), to(dev, bias)
+    lib = _lib.get()
+    for entry, wbuf, tol in (("sed_posconv_bf16x3", wsd, 2e-5), ("sed_posconv", wtd, 5e-6)):
+        y = torch.empty_like(xd)
+        lib.call(entry, xd.data_ptr(), wbuf.data_ptr(), bd.data_ptr(), y.data_ptr(), B, T, D, K, groups, _lib.stream_ptr(xd))
+        err = (y.cpu().double() - ref).abs().max().item()
+        assert err < tol * max(1.0, ref.abs().max().item()), (entry, err)

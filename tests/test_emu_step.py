@@ -118,3 +118,8 @@ def test_attention_relpos_kernels(emu):
         P.case_attention_relpos("cpu", B=1, T=100, H=2, gated=True, bias=True, variant=variant)
     P.case_attention_relpos("cpu", B=2, T=70, H=1, gated=False, bias=True)
     P.case_attention_relpos("cpu", B=1, T=33, H=1, gated=False, bias=False)
+
+
+def test_posconv_kernels(emu):
+    P.case_posconv("cpu", B=1, T=70, groups=1, K=16)
+    P.case_posconv("cpu", B=1, T=33, groups=2, K=8)

@@ -206,3 +206,9 @@ def test_attention_relpos_kernels(variant):
     """BEATs attention at the extractor's size (496 tokens: ragged last tile, 12 heads) on both kernels."""
     P.case_attention_relpos("cuda", B=2, T=496, H=12, gated=True, bias=True, variant=variant)
     P.case_attention_relpos("cuda", B=1, T=100, H=2, gated=False, bias=False, variant=variant)
+
+
+def test_posconv_kernels():
+    """BEATs position convolution at the extractor's size (496 tokens, k = 128, 16 groups of 48) on both kernels."""
+    P.case_posconv("cuda", B=2, T=496, groups=16, K=128)
+    P.case_posconv("cuda", B=1, T=100, groups=2, K=128)
