@@ -328,10 +328,13 @@ int sed_posconv_bf16x3(const float* x, const unsigned short* wsplit, const float
 int sed_attention_relpos(const float* qkv, const float* relb, const float* grep_w, const float* grep_b, const float* grep_a,
                          float* out, int B, int T, int H, int head_dim, void* stream);
 
-/* Tuning overrides for tests / sweep tools (no reference counterpart): key 0 = persistent-grid cap of the wide GLU kernels,
- * 1 = split-bf16 variant of the 128-channel GLU backward, 2 = channels per weight chunk of the split-bf16 conv (16|32),
- * 3 = pixels per workgroup of the split-bf16 conv.  value 0 restores the built-in choice.  Not for use while kernels are in
- * flight on other threads. */
+/* Tuning overrides for tests / sweep tools / A-B runs (no reference counterpart).  value 0 restores the built-in choice.  Keys:
+ *   0  persistent-grid cap of the wide GLU kernels            1  128-channel GLU backward: 1 = 32x32x16 split tiling, 3 = exact f32
+ *   2  channels per weight chunk of the split-bf16 conv       3  pixels per workgroup of the split-bf16 conv
+ *   4  block-0 backward without the local centring constant  5  128-channel GLU forward: 1 = 32x32x16 tiling
+ *   6  narrow weight gradients: 1 = exact-f32 all-taps kernel 7  workgroup cap of the all-taps weight gradients (tests)
+ *   8  BEATs attention: 1 = vector-pipe kernel
+ * Not for use while kernels are in flight on other threads. */
 int sed_set_tuning(int key, int value);
 
 /* Hardware self-test of the MFMA lane maps (no reference counterpart): C = A[M][K] * B[K][M], M = shape (32|16). */
