@@ -322,11 +322,16 @@ extern "C" int sed_colsum(const float* X, float* out, float* out1, int nsplit, i
 #define GRU_NOTRANS ((GRU_VARIANT & 32) != 0)
 #define GRU_NOOBUF ((GRU_VARIANT & 64) != 0)
 #define GRU_NOBAR ((GRU_VARIANT & 128) != 0)
-__global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh0,
+template <int H, int CH>
+__global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh0,
                                                       const float* __restrict__ whh1, const float* __restrict__ bhh0,
                                                       const float* __restrict__ bhh1, float* __restrict__ out,
                                                       float* __restrict__ saved, int B, int T) {
-    constexpr int H = GRU_H, KH = H / 4, CH = GRU_CH, NT_ = GRU_THREADS;   // KH: K quarter per thread
+    constexpr int KH = H / 4, NT_ = 4 * H;                          // KH: K quarter per thread; thread (unit j, quarter)
+    // H = 128 (the 2023 recipe): 512 threads, the thread's whole h slice is read before its FMAs (one LDS latency).  H = 192 (the
+    // 2024 recipe's n_RNN_cell): 768 threads = 3 waves per SIMD = 170 VGPRs, of which the W_hh slice alone is 144: the h slice is
+    // read in blocks of 4 float4 between the FMAs (HB), and the chunk is 4 steps (LDS).
+    constexpr int HB = H <= 128 ? KH / 4 : 4;
     // result planes of a step sit OBP floats apart: with GRU_QSTORE the four lanes of a quad store to four planes at once, so
     // the plane pitch is H + 8 (quad lanes 8 banks apart) instead of H (same bank)
     constexpr int OBP = GRU_QSTORE ? H + 8 : H, OBS = 5 * OBP;
@@ -397,18 +402,23 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __res
         const int nsteps = min(CH, T - c * CH);
         for (int s = 0; s < nsteps; ++s) {
             const float gr = gch[s * 3 * H + j], gz = gch[s * 3 * H + H + j], gn = gch[s * 3 * H + 2 * H + j];
-            // all of this thread's h slice first (one LDS latency, not one per read), then the FMAs
-            float4 hq[KH / 4];
-#pragma unroll
-            for (int k = 0; k < KH / 4; ++k) hq[k] = GRU_NOREAD ? make_float4(gr, gz, gn, gr) : *(const float4*)(hbuf[cur] + half * HP + 4 * k);
+            // a block of this thread's h slice first (H = 128: all of it, one LDS latency, not one per read), then its FMAs
             f32x2 pr = {0.f, 0.f}, pz = {0.f, 0.f}, pn = {0.f, 0.f};
             f32x2 qr = {0.f, 0.f}, qz = {0.f, 0.f}, qn = {0.f, 0.f};      // GRU_ACC6: second accumulator per gate (shorter chains)
 #pragma unroll
-            for (int k = 0; k < (GRU_NOFMA ? 1 : KH / 4); ++k) {
-                const f32x2 lo2 = {hq[k].x, hq[k].y}, hi2 = {hq[k].z, hq[k].w};
-                pr = pk_fma(wr[2 * k], lo2, pr); pz = pk_fma(wz[2 * k], lo2, pz); pn = pk_fma(wn[2 * k], lo2, pn);
-                if (GRU_ACC6) { qr = pk_fma(wr[2 * k + 1], hi2, qr); qz = pk_fma(wz[2 * k + 1], hi2, qz); qn = pk_fma(wn[2 * k + 1], hi2, qn); }
-                else { pr = pk_fma(wr[2 * k + 1], hi2, pr); pz = pk_fma(wz[2 * k + 1], hi2, pz); pn = pk_fma(wn[2 * k + 1], hi2, pn); }
+            for (int kb = 0; kb < KH / 4; kb += HB) {
+                float4 hq[HB];
+#pragma unroll
+                for (int k = 0; k < HB; ++k) hq[k] = GRU_NOREAD ? make_float4(gr, gz, gn, gr) : *(const float4*)(hbuf[cur] + half * HP + 4 * (kb + k));
+#pragma unroll
+                for (int k0 = 0; k0 < (GRU_NOFMA ? 1 : HB); ++k0) {
+                    const int k = kb + k0;
+                    const f32x2 lo2 = {hq[k0].x, hq[k0].y}, hi2 = {hq[k0].z, hq[k0].w};
+                    pr = pk_fma(wr[2 * k], lo2, pr); pz = pk_fma(wz[2 * k], lo2, pz); pn = pk_fma(wn[2 * k], lo2, pn);
+                    if (GRU_ACC6) { qr = pk_fma(wr[2 * k + 1], hi2, qr); qz = pk_fma(wz[2 * k + 1], hi2, qz); qn = pk_fma(wn[2 * k + 1], hi2, qn); }
+                    else { pr = pk_fma(wr[2 * k + 1], hi2, pr); pz = pk_fma(wz[2 * k + 1], hi2, pz); pn = pk_fma(wn[2 * k + 1], hi2, pn); }
+                }
+                if (HB < KH / 4) sed_sched_fence();                       // keeps the later blocks' reads from being hoisted (VGPRs)
             }
             if (GRU_ACC6) { pr += qr; pz += qz; pn += qn; }
             float ar = pr.x + pr.y, az = pz.x + pz.y, an = pn.x + pn.y;
@@ -443,11 +453,16 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_fwd_kernel(const float* __res
 }
 extern "C" int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
                            float* out, float* saved, int B, int T, int H, void* stream) {
-    if (H != GRU_H) return SED_ERR_UNSUPPORTED;
+    if (H != 128 && H != 192) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
-    const int smem = (2 * GRU_CH * 3 * GRU_H + 2 * GRU_CH * 5 * (GRU_QSTORE ? GRU_H + 8 : GRU_H)) * 4;
-    SED_MAX_SMEM(gru_fwd_kernel, smem);
-    SED_LAUNCH(gru_fwd_kernel, dim3(2 * B), dim3(GRU_THREADS), smem, (hipStream_t)stream, gi, whh0, whh1, bhh0, bhh1, out, saved, B, T);
+#define GRU_FWD_CASE(h, ch)                                                                                                       \
+    if (H == h) {                                                                                                                 \
+        const int smem = (2 * ch * 3 * h + 2 * ch * 5 * (GRU_QSTORE ? h + 8 : h)) * 4;                                            \
+        SED_MAX_SMEM((gru_fwd_kernel<h, ch>), smem);                                                                              \
+        SED_LAUNCH((gru_fwd_kernel<h, ch>), dim3(2 * B), dim3(4 * h), smem, (hipStream_t)stream, gi, whh0, whh1, bhh0, bhh1, out, saved, B, T); \
+    }
+    GRU_FWD_CASE(128, GRU_CH) GRU_FWD_CASE(192, 4)
+#undef GRU_FWD_CASE
     return sed_check_launch();
 }
 
@@ -457,13 +472,14 @@ extern "C" int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1
 // hprev (B,T,2,H) = the hidden state each step consumed (for dW_hh = dgh^T hprev).
 // Same chunked LDS staging as the forward: nothing touches global memory inside the step loop.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+template <int H, int CH>
+__global__ __launch_bounds__(4 * H) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                       const float* __restrict__ saved, const float* __restrict__ whh0,
                                                       const float* __restrict__ whh1, float* __restrict__ dgi,
                                                       float* __restrict__ dgh, float* __restrict__ hprev_out,
                                                       float* __restrict__ dbi0, float* __restrict__ dbi1,
                                                       float* __restrict__ dbh0, float* __restrict__ dbh1, int B, int T) {
-    constexpr int H = GRU_H, KH = H / 4, CH = GRU_CH, NT_ = GRU_THREADS;
+    constexpr int KH = H / 4, NT_ = 4 * H, HB = H <= 128 ? KH / 4 : 2;        // HB: gate-vector block (see the forward)
     // gbuf: three planes (da_r, da_z, dhn) of four K-quarters; the quarters start QP floats apart so that the four quarters a
     // wave reads with one ds_read_b128 hit distinct banks (GRU_HPAD), the planes GP apart so that the quad's three stores do.
     // obuf: seven result planes per step in the order dgi(r, z, n) | hprev | dgh(r, z, hn), OBP apart (GRU_QSTORE: the four
@@ -487,7 +503,7 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __res
         wn[jj] = f32x2{W[(size_t)(2 * H + j) * H + k], W[(size_t)(2 * H + j + 1) * H + k]};
     }
     const int nchunks = (T + CH - 1) / CH;
-    constexpr int IV = IB_F / 4 / NT_;         // = 3 float4 per thread per chunk
+    constexpr int IV = (IB_F / 4 + NT_ - 1) / NT_;      // float4 per thread per chunk: 3 (H = 128, 8 steps), 1.5 -> 2 guarded (H = 192, 4 steps)
     float4 ireg[IV];
     // chunk c covers reverse-order positions rs = c*CH .. c*CH+CH-1, forward step index = T-1-rs
     auto load_chunk = [&](int c) {
@@ -496,7 +512,7 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __res
             const int e4 = tid + NT_ * u, s = e4 / (6 * H / 4), q = e4 - s * (6 * H / 4);
             const int rs = c * CH + s;
             ireg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rs < T) {
+            if (e4 < IB_F / 4 && rs < T) {
                 const int step = T - 1 - rs;
                 const int t = dir ? T - 1 - step : step, tp = dir ? t + 1 : t - 1;
                 const size_t bt = (size_t)b * T + t;
@@ -508,7 +524,8 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __res
     };
     auto park_chunk = [&](int c) {
 #pragma unroll
-        for (int u = 0; u < IV; ++u) *(float4*)(ibuf + (c & 1) * IB_F + 4 * (tid + NT_ * u)) = ireg[u];
+        for (int u = 0; u < IV; ++u)
+            if (tid + NT_ * u < IB_F / 4) *(float4*)(ibuf + (c & 1) * IB_F + 4 * (tid + NT_ * u)) = ireg[u];
     };
     auto flush_chunk = [&](int c) {
         constexpr int PER = 7 * H / 4;
@@ -565,21 +582,26 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __res
             }
             __syncthreads();
             const float* gv = gbuf[cur] + half * QP;
-            float4 ga[KH / 4], gc[KH / 4], gd[KH / 4];
-#pragma unroll
-            for (int q4 = 0; q4 < KH / 4; ++q4) {
-                ga[q4] = *(const float4*)(gv + 4 * q4);
-                gc[q4] = *(const float4*)(gv + GP + 4 * q4);
-                gd[q4] = *(const float4*)(gv + 2 * GP + 4 * q4);
-            }
             f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f};     // three independent packed chains
 #pragma unroll
-            for (int q4 = 0; q4 < KH / 4; ++q4) {
-                const f32x2 a0 = {ga[q4].x, ga[q4].y}, a1 = {ga[q4].z, ga[q4].w};
-                const f32x2 c0 = {gc[q4].x, gc[q4].y}, c1 = {gc[q4].z, gc[q4].w};
-                const f32x2 d0 = {gd[q4].x, gd[q4].y}, d1 = {gd[q4].z, gd[q4].w};
-                p0 = pk_fma(wr[2 * q4], a0, p0); p1 = pk_fma(wz[2 * q4], c0, p1); p2 = pk_fma(wn[2 * q4], d0, p2);
-                p0 = pk_fma(wr[2 * q4 + 1], a1, p0); p1 = pk_fma(wz[2 * q4 + 1], c1, p1); p2 = pk_fma(wn[2 * q4 + 1], d1, p2);
+            for (int qb = 0; qb < KH / 4; qb += HB) {
+                float4 ga[HB], gc[HB], gd[HB];
+#pragma unroll
+                for (int q0 = 0; q0 < HB; ++q0) {
+                    ga[q0] = *(const float4*)(gv + 4 * (qb + q0));
+                    gc[q0] = *(const float4*)(gv + GP + 4 * (qb + q0));
+                    gd[q0] = *(const float4*)(gv + 2 * GP + 4 * (qb + q0));
+                }
+#pragma unroll
+                for (int q0 = 0; q0 < HB; ++q0) {
+                    const int q4 = qb + q0;
+                    const f32x2 a0 = {ga[q0].x, ga[q0].y}, a1 = {ga[q0].z, ga[q0].w};
+                    const f32x2 c0 = {gc[q0].x, gc[q0].y}, c1 = {gc[q0].z, gc[q0].w};
+                    const f32x2 d0 = {gd[q0].x, gd[q0].y}, d1 = {gd[q0].z, gd[q0].w};
+                    p0 = pk_fma(wr[2 * q4], a0, p0); p1 = pk_fma(wz[2 * q4], c0, p1); p2 = pk_fma(wn[2 * q4], d0, p2);
+                    p0 = pk_fma(wr[2 * q4 + 1], a1, p0); p1 = pk_fma(wz[2 * q4 + 1], c1, p1); p2 = pk_fma(wn[2 * q4 + 1], d1, p2);
+                }
+                if (HB < KH / 4) sed_sched_fence();
             }
             float acc = ((p0.x + p0.y) + (p1.x + p1.y)) + (p2.x + p2.y);
             acc = sed_quad_sum(acc);
@@ -600,13 +622,18 @@ __global__ __launch_bounds__(GRU_THREADS) void gru_bwd_kernel(const float* __res
 extern "C" int sed_gru_bwd(const float* dout, const float* out, const float* saved, const float* whh0, const float* whh1,
                            float* dgi, float* dgh, float* hprev, float* dbi0, float* dbi1, float* dbh0, float* dbh1, int B, int T,
                            int H, void* stream) {
-    if (H != GRU_H) return SED_ERR_UNSUPPORTED;
+    if (H != 128 && H != 192) return SED_ERR_UNSUPPORTED;
     if ((dbi0 == nullptr) != (dbi1 == nullptr) || (dbh0 == nullptr) != (dbh1 == nullptr)) return SED_ERR_ARG;
     if (dbi0 || dbh0) sed_zero4((hipStream_t)stream, dbi0, dbi0 ? 3 * H : 0, dbi1, dbi1 ? 3 * H : 0, dbh0, dbh0 ? 3 * H : 0, dbh1, dbh1 ? 3 * H : 0);
     if (B <= 0 || T <= 0) return SED_OK;
-    const int smem = (2 * GRU_CH * 6 * GRU_H + 2 * GRU_CH * 7 * (GRU_QSTORE ? GRU_H + 8 : GRU_H)) * 4;
-    SED_MAX_SMEM(gru_bwd_kernel, smem);
-    SED_LAUNCH(gru_bwd_kernel, dim3(2 * B), dim3(GRU_THREADS), smem, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh, hprev,
-               dbi0, dbi1, dbh0, dbh1, B, T);
+#define GRU_BWD_CASE(h, ch)                                                                                                       \
+    if (H == h) {                                                                                                                 \
+        const int smem = (2 * ch * 6 * h + 2 * ch * 7 * (GRU_QSTORE ? h + 8 : h)) * 4;                                            \
+        SED_MAX_SMEM((gru_bwd_kernel<h, ch>), smem);                                                                              \
+        SED_LAUNCH((gru_bwd_kernel<h, ch>), dim3(2 * B), dim3(4 * h), smem, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh, \
+                   hprev, dbi0, dbi1, dbh0, dbh1, B, T);                                                                          \
+    }
+    GRU_BWD_CASE(128, GRU_CH) GRU_BWD_CASE(192, 4)
+#undef GRU_BWD_CASE
     return sed_check_launch();
 }

@@ -4,17 +4,16 @@
 //  loss : recipes/dcase2023_task4_baseline/local/sed_trainer.py:309-342 -- BCE (strong on the first n_strong
 //         clips, weak on the next n_weak), the two teacher BCEs (logging), MSE student-vs-teacher on all clips;
 //         emits the scalars and the gradient seeds d(total)/d(strong_s), d(total)/d(weak_s).
-// Layout: x (B,T,D=256); strong/sof (B,T,NC) (the Python side returns the (B,NC,T) transposed view);
+// Layout: x (B,T,D), D = 2 * n_RNN_cell = 256 (2023 recipe) or 384 (2024 recipe); strong/sof (B,T,NC) (the Python side returns the (B,NC,T) transposed view);
 // labels stay in the reference layout (B,NC,T).
 #include "sed_common.h"
 
-#define HEAD_D 256
 
 // Forward: one workgroup per clip (the attention pooling sums over the clip's frames), FOUR lanes per frame: lane
 // quarter q owns the input features k with (k / 4) % 4 == q, so the four lanes of a frame read 64 contiguous bytes of
 // x and adjacent LDS banks of the weights; the 2*NC partial logits are combined with two xor-shuffles.
 #define HEAD_THREADS 1024
-template <int NC>
+template <int NC, int D>
 __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W1,
                                                                 const float* __restrict__ b1, const float* __restrict__ W2,
                                                                 const float* __restrict__ b2, float* __restrict__ strong,
@@ -25,9 +24,10 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
                                                                 const unsigned char* __restrict__ pad) {
     if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     static_assert(NC <= 32, "the class mask of a frame is one 32-bit set");
-    constexpr int D = HEAD_D, FPP = HEAD_THREADS / 4;          // frames per pass
-    __shared__ __attribute__((aligned(16))) float w1[NC * D];
-    __shared__ __attribute__((aligned(16))) float w2[NC * D];
+    constexpr int FPP = HEAD_THREADS / 4;                      // frames per pass
+    SED_DYN_SMEM(smem_w);                                      // (27 classes x 384 features x 2 matrices = 83 KB: above the static limit)
+    float* w1 = (float*)smem_w;                                // [NC][D]
+    float* w2 = w1 + NC * D;                                   // [NC][D]
     __shared__ float red[HEAD_THREADS / 64][2 * NC];
     const int tid = threadIdx.x, b = blockIdx.x, q = tid & 3;
     for (int i = tid; i < NC * D; i += HEAD_THREADS) { w1[i] = W1[i]; w2[i] = W2[i]; }
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
 // Phase 1: four lanes per frame as in the forward (logit gradients, then this lane's quarter of the dx row);
 // phase 2: thread k owns input feature k over the slice's frames.
 #define HEAD_TS 64
-template <int NC>
+template <int NC, int D>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W1,
                                                        const float* __restrict__ W2, const float* __restrict__ strong,
                                                        const float* __restrict__ psoft, const float* __restrict__ weak,
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ db2, int T, uint32_t seed, uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev,
                                                        const unsigned char* __restrict__ cvalid, const unsigned char* __restrict__ pad) {
     if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
-    constexpr int D = HEAD_D, TS = HEAD_TS;
+    constexpr int TS = HEAD_TS;
     SED_DYN_SMEM(smem);
     float* w1 = (float*)smem;            // NC*D
     float* w2 = w1 + NC * D;             // NC*D
@@ -193,9 +193,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         }
     }
     __syncthreads();
-    // ---- phase 2: weight gradients, thread k owns input feature k (D == 256 threads) ----
-    {
-        const int k = tid;
+    // ---- phase 2: weight gradients, thread k owns input feature k (and k + 256 when D = 384) ----
+    for (int k = tid; k < D; k += 256) {
         float a1[NC], a2[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) { a1[c] = 0.f; a2[c] = 0.f; }
@@ -211,11 +210,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) { atomicAdd(dW1 + c * D + k, a1[c]); atomicAdd(dW2 + c * D + k, a2[c]); }
-        if (tid < 2 * NC) {
-            float s = 0.f;
-            for (int tl = 0; tl < tn; ++tl) s += dl[tl * 2 * NC + tid];
-            atomicAdd(tid < NC ? db1 + tid : db2 + (tid - NC), s);
-        }
+    }
+    if (tid < 2 * NC) {
+        float s = 0.f;
+        for (int tl = 0; tl < tn; ++tl) s += dl[tl * 2 * NC + tid];
+        atomicAdd(tid < NC ? db1 + tid : db2 + (tid - NC), s);
     }
 }
 
@@ -223,12 +222,13 @@ extern "C" int sed_head_fwd(const float* x, const float* W1, const float* b1, co
                             float* psoft, float* weak, float* den, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
                             float dscale, const unsigned* seed_dev, const unsigned char* classes_valid, const unsigned char* pad_mask,
                             void* stream) {
-    if (D != HEAD_D) return SED_ERR_UNSUPPORTED;
+    if (D != 256 && D != 384) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
     hipStream_t s = (hipStream_t)stream;
-#define HEAD_CASE(nc) \
-    if (NC == nc) { SED_LAUNCH((head_fwd_kernel<nc>), dim3(B), dim3(HEAD_THREADS), 0, s, x, W1, b1, W2, b2, strong, psoft, weak, den, T, seed, thr24, dscale, seed_dev, classes_valid, pad_mask); return sed_check_launch(); }
-    HEAD_CASE(10) HEAD_CASE(27)
+    const int smem_f = 2 * NC * D * 4;
+#define HEAD_CASE(nc, d) \
+    if (NC == nc && D == d) { SED_MAX_SMEM((head_fwd_kernel<nc, d>), smem_f); SED_LAUNCH((head_fwd_kernel<nc, d>), dim3(B), dim3(HEAD_THREADS), smem_f, s, x, W1, b1, W2, b2, strong, psoft, weak, den, T, seed, thr24, dscale, seed_dev, classes_valid, pad_mask); return sed_check_launch(); }
+    HEAD_CASE(10, 256) HEAD_CASE(27, 256) HEAD_CASE(10, 384) HEAD_CASE(27, 384)
 #undef HEAD_CASE
     return SED_ERR_UNSUPPORTED;
 }
@@ -238,14 +238,14 @@ extern "C" int sed_head_bwd(const float* x, const float* W1, const float* W2, co
                             float* dW2, float* db1, float* db2, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
                             float dscale, const unsigned* seed_dev, const unsigned char* classes_valid, const unsigned char* pad_mask,
                             void* stream) {
-    if (D != HEAD_D) return SED_ERR_UNSUPPORTED;
+    if (D != 256 && D != 384) return SED_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     sed_zero4(s, dW1, NC * D, dW2, NC * D, db1, NC, db2, NC);
     if (B <= 0 || T <= 0) return SED_OK;
     const int smem = (2 * NC * D + HEAD_TS * 2 * NC) * 4;
-#define HEAD_CASE(nc) \
-    if (NC == nc) { SED_MAX_SMEM((head_bwd_kernel<nc>), smem); SED_LAUNCH((head_bwd_kernel<nc>), dim3((T + HEAD_TS - 1) / HEAD_TS, B), dim3(256), smem, s, x, W1, W2, strong, psoft, weak, den, d_strong, d_weak, dx, dW1, dW2, db1, db2, T, seed, thr24, dscale, seed_dev, classes_valid, pad_mask); return sed_check_launch(); }
-    HEAD_CASE(10) HEAD_CASE(27)
+#define HEAD_CASE(nc, d) \
+    if (NC == nc && D == d) { SED_MAX_SMEM((head_bwd_kernel<nc, d>), smem); SED_LAUNCH((head_bwd_kernel<nc, d>), dim3((T + HEAD_TS - 1) / HEAD_TS, B), dim3(256), smem, s, x, W1, W2, strong, psoft, weak, den, d_strong, d_weak, dx, dW1, dW2, db1, db2, T, seed, thr24, dscale, seed_dev, classes_valid, pad_mask); return sed_check_launch(); }
+    HEAD_CASE(10, 256) HEAD_CASE(27, 256) HEAD_CASE(10, 384) HEAD_CASE(27, 384)
 #undef HEAD_CASE
     return SED_ERR_UNSUPPORTED;
 }

@@ -8,8 +8,8 @@ from ..ops import BiGRULayerFn
 class BidirectionalGRU(nn.Module):
     def __init__(self, n_in, n_hidden, dropout=0, num_layers=1):
         super().__init__()
-        if n_hidden != 128:
-            raise NotImplementedError("HIP GRU kernel is built for n_hidden = 128")
+        if n_hidden not in (128, 192):
+            raise NotImplementedError("HIP GRU kernels are built for n_hidden = 128 and 192 (the 2023 / 2024 recipes' n_RNN_cell)")
         if dropout:
             raise NotImplementedError("inter-layer GRU dropout (dropout_recurrent) is not on the 2023 path")
         self.num_layers = num_layers

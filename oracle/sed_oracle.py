@@ -296,16 +296,16 @@ def lcg_fill(shape, seed: int, scale: float = 1.0, offset: float = 0.0) -> torch
     return torch.from_numpy(((u * 2 - 1) * scale + offset).astype(np.float32)).reshape(shape)
 
 
-def make_state_dict(seed: int = 7, nclass=10, bn_stats: bool = True, embedding_size=None) -> Dict[str, torch.Tensor]:
+def make_state_dict(seed: int = 7, nclass=10, bn_stats: bool = True, embedding_size=None, hidden=128) -> Dict[str, torch.Tensor]:
     """LCG-filled CRNN state dict with magnitudes like torch's default init (U(+-1/sqrt(fan_in)))."""
     sd = {}
     k = seed * 1000
-    for name, shp in crnn_param_shapes(nclass=nclass, embedding_size=embedding_size).items():
+    for name, shp in crnn_param_shapes(nclass=nclass, embedding_size=embedding_size, hidden=hidden).items():
         k += 1
         if "batchnorm" in name:
             sd[name] = lcg_fill(shp, k, 0.25, 1.0) if name.endswith("weight") else lcg_fill(shp, k, 0.1)
         elif name.startswith("rnn."):
-            sd[name] = lcg_fill(shp, k, 1.0 / math.sqrt(128))
+            sd[name] = lcg_fill(shp, k, 1.0 / math.sqrt(hidden))
         else:
             fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else None
             if fan_in is None:   # bias: fan_in of the matching weight

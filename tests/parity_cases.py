@@ -212,9 +212,8 @@ def case_cnn_block(dev, layer, B, T, F, training=True, dropout_p=0.5, seed=1234,
 # ------------------------------------------------------------------------------------------------
 # BiGRU (K7)
 # ------------------------------------------------------------------------------------------------
-def case_bigru(dev, B=2, T=7, I=128, tol=2e-5):
+def case_bigru(dev, B=2, T=7, I=128, tol=2e-5, H=128):
     from desed_task_amd.ops import BiGRULayerFn
-    H = 128
     names = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
     shapes = {"weight_ih": (3 * H, I), "weight_hh": (3 * H, H), "bias_ih": (3 * H,), "bias_hh": (3 * H,)}
     ws = []
@@ -1277,11 +1276,10 @@ def case_stochastic_training_step(dev, bs=(2, 2, 4), n_samp=16000 * 2 + 1024, st
     return worst
 
 
-def case_head_dropout(dev, B=3, T=39, p=0.5, seed=4242):
+def case_head_dropout(dev, B=3, T=39, p=0.5, seed=4242, D=256, NC=10):
     """HeadFn (post-GRU Dropout(0.5) + dense + dense_softmax + class-softmax attention pooling, CRNN.py:152-178,:304) forward
     and backward against torch ops on the same keep mask."""
     from desed_task_amd.ops import HeadFn
-    D, NC = 256, 10
     x = O.lcg_fill((B, T, D), 61, 1.0)
     w1 = O.lcg_fill((NC, D), 62, 1.0 / 16); b1 = O.lcg_fill((NC,), 63, 0.1)
     w2 = O.lcg_fill((NC, D), 64, 1.0 / 16); b2 = O.lcg_fill((NC,), 65, 0.1)
@@ -1358,9 +1356,9 @@ def case_b48_forward_vs_oracle(dev, bs=(12, 12, 24)):
 # rest of the embedding-fusion surface: classes_mask / pad_mask, dropstep_recurrent, "interpolate"
 # ------------------------------------------------------------------------------------------------
 def net_config_2024():
-    """`net:` of recipes/dcase2024_task4_baseline/confs/pretrained.yaml with n_RNN_cell 192 -> 128 (the HIP GRU's size)."""
+    """`net:` of recipes/dcase2024_task4_baseline/confs/pretrained.yaml (n_RNN_cell = 192, 27 classes)."""
     cfg = dict(recipe_config()["net"])
-    cfg.update(dropout=0.2, rnn_layers=1, nclass=27, n_RNN_cell=128, dropstep_recurrent=0.3, dropstep_recurrent_len=16,
+    cfg.update(dropout=0.2, rnn_layers=1, nclass=27, n_RNN_cell=192, dropstep_recurrent=0.3, dropstep_recurrent_len=16,
                use_embeddings=True, embedding_size=768, embedding_type="frame", aggregation_type="pool1d",
                specaugm_t_p=0.0, specaugm_t_l=5, specaugm_f_p=0.0, specaugm_f_l=10)
     return cfg
@@ -1385,7 +1383,7 @@ def case_crnn_masks_vs_reference_golden(dev, golden):
     xin, emb, cm, pad = golden_emb2_inputs()
     for tag, use_emb in (("a", True), ("b", False)):
         cfg = dict(net_config_2024(), dropout=0.0, use_embeddings=use_emb)
-        sd = O.make_state_dict(seed=7, nclass=27, embedding_size=768 if use_emb else None)
+        sd = O.make_state_dict(seed=7, nclass=27, embedding_size=768 if use_emb else None, hidden=192)
         net = CRNN(**cfg)
         assert [n for n, _ in net.named_parameters()] == list(golden[tag + "_param_names"])
         net.load_state_dict({k: v.clone() for k, v in sd.items()})
@@ -1415,7 +1413,7 @@ def case_crnn_masks_vs_reference_golden(dev, golden):
         ref = golden[tag + "_grad__cnn.cnn.conv6.weight"]
         assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7, tag
     cfg = dict(net_config_2024(), dropout=0.0, aggregation_type="interpolate")
-    sd = O.make_state_dict(seed=7, nclass=27, embedding_size=768)
+    sd = O.make_state_dict(seed=7, nclass=27, embedding_size=768, hidden=192)
     net = CRNN(**cfg)
     net.load_state_dict({k: v.clone() for k, v in sd.items()})
     net = net.to(dev) if dev != "cpu" else net
@@ -1517,7 +1515,7 @@ def case_training_step_2024(dev, golden):
     config["training"].update(mixup_prob=0.5, epoch_decay=100)
     config["net"] = dict(net_config_2024(), dropout=0.0, dropstep_recurrent=0.0)
     config["pretrained"] = {"e2e": False, "freezed": True, "model": "beats"}
-    sd = O.make_state_dict(seed=7, nclass=nclass, embedding_size=768)
+    sd = O.make_state_dict(seed=7, nclass=nclass, embedding_size=768, hidden=192)
     student = CRNN(**config["net"])
     student.load_state_dict({k: v.clone() for k, v in sd.items()})
     student = student.to(dev) if dev != "cpu" else student
@@ -1569,10 +1567,10 @@ def case_training_step_2024(dev, golden):
         init = sd[n].numpy().reshape(-1)[:256]
         mine = st[n].detach().cpu().numpy().reshape(-1)[:256]
         assert np.linalg.norm(mine - ref) <= 0.15 * np.linalg.norm(ref - init) + 1e-6, n
-    # the recipe's own recurrent width is refused, loudly
+    # recurrent widths outside the two recipes' are refused, loudly
     try:
-        CRNN(**dict(config["net"], n_RNN_cell=192))
-        raise AssertionError("n_RNN_cell = 192 must be refused")
+        CRNN(**dict(config["net"], n_RNN_cell=256))
+        raise AssertionError("n_RNN_cell = 256 must be refused")
     except NotImplementedError:
         pass
 

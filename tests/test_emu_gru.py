@@ -18,3 +18,10 @@ def test_bigru_layer1(emu):
 
 def test_bigru_multi_chunk(emu):
     P.case_bigru("cpu", B=1, T=19, I=128)        # 2 full chunks of 8 steps + a partial one
+
+
+def test_bigru_192_units(emu):
+    """n_RNN_cell = 192 (recipes/dcase2024_task4_baseline/confs/pretrained.yaml:92): 768-thread recurrences, 4-step chunks; layer 0
+    (I = 128) and layer 1 (I = 384), partial last chunk."""
+    P.case_bigru("cpu", B=2, T=7, I=128, H=192)
+    P.case_bigru("cpu", B=1, T=10, I=384, H=192)

@@ -80,6 +80,7 @@ def test_stochastic_step_matches_oracle(emu):
 def test_head_dropout(emu):
     P.case_head_dropout("cpu")
     P.case_head_dropout("cpu", B=2, T=5, p=0.25, seed=7)
+    P.case_head_dropout("cpu", B=2, T=70, p=0.5, seed=9, D=384, NC=27)        # the 2024 recipe's head: 2 x 192 features, 27 classes
 
 
 def test_crnn_masks_dropstep_interpolate_vs_reference_golden(emu):

@@ -69,6 +69,12 @@ def test_bigru_production_shape():
     P.case_bigru("cuda", B=3, T=156, I=256, tol=5e-5)
 
 
+def test_bigru_192_units():
+    """The 2024 recipe's recurrent stage (n_RNN_cell = 192) at its production length: layer 0 (I = 128) and layer 1 (I = 384)."""
+    P.case_bigru("cuda", B=4, T=156, I=128, tol=5e-5, H=192)
+    P.case_bigru("cuda", B=3, T=156, I=384, tol=5e-5, H=192)
+
+
 def test_training_steps_vs_oracle_and_reference_golden():
     """3 full mean-teacher steps (mel -> mixup -> student/teacher CRNN -> losses -> EMA -> backward -> Adam ->
     warm-up) on the GPU against the oracle trainer AND the scalars recorded from the reference's own
@@ -160,6 +166,7 @@ def test_head_dropout_production_shape():
     """head_fwd/bwd_kernel with the post-GRU Dropout(0.5) on (CRNN.py:304) vs torch ops on the same keep mask."""
     P.case_head_dropout("cuda", B=4, T=156)
     P.case_head_dropout("cuda", B=2, T=5, p=0.25, seed=7)
+    P.case_head_dropout("cuda", B=3, T=156, p=0.5, seed=9, D=384, NC=27)      # the 2024 recipe's head
 
 
 def test_stochastic_steps_vs_oracle():
