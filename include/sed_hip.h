@@ -202,7 +202,8 @@ int sed_gemm_pair_splitk_bf16x3(const float* A0, const float* A1, const float* B
 int sed_colsum(const float* X, float* out, float* out1, int nsplit, int M, int N, int ld, void* stream);
 
 /* GRU recurrence of one layer, both directions: gi (B,T,2,3H) = W_ih x + b_ih per direction; whh0/whh1 (3H,H),
- * bhh0/bhh1 (3H) = forward / reverse direction; out (B,T,2H); saved (B,T,2,4,H) = r,z,n,hn or null. */
+ * bhh0/bhh1 (3H) = forward / reverse direction; out (B,T,2H); saved (B,T,2,4,H) = r,z,n,hn or null.
+ * H = 128 (2023 recipe) or 192 (2024 recipe's n_RNN_cell); other widths return SED_ERR_UNSUPPORTED. */
 int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
                 float* out, float* saved, int B, int T, int H, void* stream);
 
@@ -214,7 +215,7 @@ int sed_gru_bwd(const float* dout, const float* out, const float* saved, const f
 
 /* ---- K8 + K9: attention-pooling head (desed_task/nnet/CRNN.py:152-178, dropout :304) and losses ---------------- */
 
-/* x (B,T,256) -> strong (B,T,NC) = sigmoid(dense), psoft (B,T,NC) = softmax over classes of dense_softmax,
+/* x (B,T,D), D = 256 or 384 (= 2 * n_RNN_cell), NC = 10 or 27 -> strong (B,T,NC) = sigmoid(dense), psoft (B,T,NC) = softmax over classes of dense_softmax,
  * weak (B,NC) = sum_t(strong*clamp(psoft)) / sum_t(clamp(psoft)), den (B,NC) = the denominators.
  * classes_valid (B,NC) bytes or null: the `classes_mask` of the multi-data-set recipes (CRNN.py:157-176; non-zero = the clip's
  * data set annotates the class): other classes cannot be attended to and their strong / weak outputs are 0.  pad_mask (B,T)
