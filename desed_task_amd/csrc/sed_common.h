@@ -44,7 +44,7 @@ static inline void sed_zero4(hipStream_t s, float* p0, int n0, float* p1, int n1
 // Tuning overrides (tests and sweep tools only; all 0 = built-in choices).  Set explicitly through sed_set_tuning(): the entry
 // points never read the process environment.
 enum { SED_TUNE_GLU_GRID_CAP = 0, SED_TUNE_GLU_BWD128_SPLIT = 1, SED_TUNE_CONVB_CK = 2, SED_TUNE_CONVB_MP = 3, SED_TUNE_B0_NOCENTER = 4, SED_TUNE_GLU_FWD128 = 5, SED_TUNE_WGRAD_NARROW = 6, SED_TUNE_WGRAD_CAP = 7,
-       SED_TUNE_ATTN_VALU = 8, SED_TUNE_COUNT = 16 };
+       SED_TUNE_ATTN_VALU = 8, SED_TUNE_WGRAD_WIDE = 9, SED_TUNE_COUNT = 16 };
 extern int sed_tuning[SED_TUNE_COUNT];
 
 static inline int sed_check_launch() {
@@ -112,6 +112,15 @@ __device__ __forceinline__ void bf16_split(float x, unsigned short& hi, unsigned
 __device__ __forceinline__ void sed_sched_fence() {
 #ifndef SED_EMU
     __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// ({hi, lo} >> shift)[31:0], shift in 0..31 (v_alignbit_b32): moves bf16 elements across the dwords of an MFMA operand
+__device__ __forceinline__ unsigned sed_alignbit(unsigned hi, unsigned lo, unsigned shift) {
+#ifdef SED_EMU
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> shift);
+#else
+    return __builtin_amdgcn_alignbit(hi, lo, shift);
 #endif
 }
 

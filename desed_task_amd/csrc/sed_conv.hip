@@ -111,8 +111,19 @@ static inline int wgrad_parts(int CIN, int COUT, int B, int T, int F) {
     const int ntiles = (B * T * F + 63) / 64;           // per-tap kernel: `splits` partials
     return ntiles < 56 ? ntiles : 56;
 }
+// the kernel-row variant of the wide split-bf16 weight gradient runs 3 x (COUT / COH) workgroups per split: 168 / 84 splits for
+// the same ~504 resident workgroups (with 56 it left half of the CUs empty: 131 vs 75 us at 64 -> 128, F = 16)
+static inline bool wgrad_row_ok(int CIN, int COUT, int F) {
+    return F >= 8 && 64 % F == 0 && COUT == 128 && (CIN == 64 || CIN == 128);
+}
+static inline int wgrad_row_parts(int CIN, int B, int T, int F) {
+    const int ntiles = (B * T * F + 63) / 64, cap = CIN == 64 ? 168 : 84;
+    return ntiles < cap ? ntiles : cap;
+}
 extern "C" long long sed_conv_wgrad_scratch_floats(int B, int T, int F, int CIN, int COUT) {
-    return (long long)wgrad_parts(CIN, COUT, B, T, F) * 9 * CIN * COUT;
+    int parts = wgrad_parts(CIN, COUT, B, T, F);
+    if (wgrad_row_ok(CIN, COUT, F) && wgrad_row_parts(CIN, B, T, F) > parts) parts = wgrad_row_parts(CIN, B, T, F);
+    return (long long)parts * 9 * CIN * COUT;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -756,6 +767,165 @@ static int launch_wgrad_bf16(const float* x, const float* dy, float* dWp, int B,
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same weight gradient with ONE KERNEL ROW (three taps: column shifts -1, 0, +1) per workgroup (F >= 8, F | 64).
+// conv_wgrad_bf16_kernel fetches, splits and transposes x and dy once per tap -- nine times per launch: 553 MB through L2 / MALL
+// at 128 -> 128, F = 8, VALU issue 0.41 - 0.48 for the splitting and index arithmetic.  Here the tile of x (row-shifted by the
+// kernel row, as before) and of dy is staged ONCE for three taps; the column shift is applied to the A operand in registers:
+// a k-octet = 8 consecutive pixels of a channel = four dwords of bf16 pairs, and the octet shifted by one pixel is four
+// v_alignbit_b32 of neighbouring dwords plus ONE extra dword from the previous / next octet (zero at a row end: F >= 8 and
+// F | 64 make rows and 64-pixel tiles start on octet boundaries).  Three times the MFMA work per staged tile; the accumulators
+// stay at 96 VGPRs because a workgroup owns COH = 64 of the 128 output channels when CIN = 128 (grid z = 2).  Traffic: x is read
+// 3 x (COUT / COH) times, dy 3 times, instead of 9 + 9.
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int COH>
+struct WgrCfg {
+    static constexpr int KT = 64, RS = 64;
+    static constexpr int MT = CIN / 32, NT = COH / 32;
+    static constexpr int WM = MT >= 4 ? 2 : 1, WN = 4 / WM;
+    static constexpr int MTW = MT / WM, NTW = NT / WN;
+    static constexpr int NBX = (KT / 4) * (CIN / 4) / 256, NBD = (KT / 4) * (COH / 4) / 256;
+    static constexpr int SMEM = 2 * (CIN + COH) * RS * 2;
+    static_assert(NBX >= 1 && NBD >= 1 && MTW * WM == MT && NTW * WN == NT && MTW * NTW == 2, "tile split");
+};
+template <int CIN, int COUT, int COH>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_row_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ dWp, int B, int T, int F) {
+    using Cfg = WgrCfg<CIN, COUT, COH>;
+    constexpr int KT = Cfg::KT, RS = Cfg::RS, WN = Cfg::WN, MTW = Cfg::MTW, NTW = Cfg::NTW, NBX = Cfg::NBX, NBD = Cfg::NBD;
+    SED_DYN_SMEM(smem);
+    unsigned short* xh = (unsigned short*)smem;      // [CIN][RS] hi, then lo
+    unsigned short* xl = xh + CIN * RS;
+    unsigned short* dh = xl + CIN * RS;              // [COH][RS] hi, then lo
+    unsigned short* dl = dh + COH * RS;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int tid = threadIdx.x, lo = lane & 31, hi = lane >> 5;
+    const int wn = w % WN, wm = w / WN;
+    const int da = (int)blockIdx.y - 1, co0 = blockIdx.z * COH;
+    const int npix = B * T * F;
+    const int ntiles = (npix + KT - 1) / KT;
+    const int fsh = 31 - __builtin_clz(F);           // F is a power of two (checked by the launcher)
+
+    f32x16 acc[3][MTW][NTW];
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[t3][m][n] = f32x16_zero();
+
+    float4 rx[NBX * 4], rd[NBD * 4];
+    auto load_tile = [&](int tile) {
+        const int p0 = tile * KT;
+#pragma unroll
+        for (int u = 0; u < NBX; ++u) {
+            const int blk = tid + 256 * u, cq = (blk >> 1) % (CIN / 4), pq = (blk & 1) + 2 * ((blk >> 1) / (CIN / 4));
+            // the 4 pixels of a block share one (clip, frame) row (F >= 8): one pair of divisions by the run-time T per block
+            const int pb = p0 + 4 * pq, tt = pb >> fsh, t = tt % T, bb = tt / T, t2 = t + da, f = pb & (F - 1);
+            const bool ok = pb < npix && t2 >= 0 && t2 < T;
+            const float* src = x + (((size_t)bb * T + (ok ? t2 : 0)) * F + f) * CIN + 4 * cq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rx[4 * u + j] = ok ? *(const float4*)(src + (size_t)j * CIN) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < NBD; ++u) {
+            const int blk = tid + 256 * u, cq = (blk >> 1) % (COH / 4), pq = (blk & 1) + 2 * ((blk >> 1) / (COH / 4));
+            const int pb = p0 + 4 * pq;
+            const float* src = dy + (size_t)pb * COUT + co0 + 4 * cq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rd[4 * u + j] = pb < npix ? *(const float4*)(src + (size_t)j * COUT) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NBX; ++u) {
+            const int blk = tid + 256 * u;
+            wgb_store_block(rx[4 * u], rx[4 * u + 1], rx[4 * u + 2], rx[4 * u + 3], xh, xl, (blk >> 1) % (CIN / 4),
+                            (blk & 1) + 2 * ((blk >> 1) / (CIN / 4)), RS);
+        }
+#pragma unroll
+        for (int u = 0; u < NBD; ++u) {
+            const int blk = tid + 256 * u;
+            wgb_store_block(rd[4 * u], rd[4 * u + 1], rd[4 * u + 2], rd[4 * u + 3], dh, dl, (blk >> 1) % (COH / 4),
+                            (blk & 1) + 2 * ((blk >> 1) / (COH / 4)), RS);
+        }
+    };
+    // the operand octet shifted by one pixel: to the left neighbour (x[p - 1]) or to the right one (x[p + 1])
+    auto shift_m1 = [](const uint4 c, unsigned prev3) {
+        uint4 r;
+        r.x = sed_alignbit(c.x, prev3, 16); r.y = sed_alignbit(c.y, c.x, 16); r.z = sed_alignbit(c.z, c.y, 16); r.w = sed_alignbit(c.w, c.z, 16);
+        return r;
+    };
+    auto shift_p1 = [](const uint4 c, unsigned next0) {
+        uint4 r;
+        r.x = sed_alignbit(c.y, c.x, 16); r.y = sed_alignbit(c.z, c.y, 16); r.z = sed_alignbit(c.w, c.z, 16); r.w = sed_alignbit(next0, c.w, 16);
+        return r;
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        sed_opaque(tid); sed_opaque(lo); sed_opaque(hi);
+        __syncthreads();                                  // previous tile's fragments are consumed
+        store_tile();
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+#pragma unroll
+        for (int ks = 0; ks < KT / 16; ++ks) {
+            const int oct = 2 * ks + hi;                  // this lane's pixel octet of the K tile
+            const bool first = ((8 * oct) & (F - 1)) == 0, last = ((8 * oct + 8) & (F - 1)) == 0;     // row ends (uniform per half wave)
+            s16x8 a_hi[3][MTW], a_lo[3][MTW];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int row = (wm * MTW + m) * 32 + lo, sw = (row ^ (row >> 2)) & 7;
+                const int off = row * RS + 8 * (oct ^ sw);
+                const int offp = row * RS + 8 * (((oct + 7) & 7) ^ sw) + 6, offn = row * RS + 8 * (((oct + 1) & 7) ^ sw);
+                const uint4 ch = *(const uint4*)(xh + off), cl = *(const uint4*)(xl + off);
+                const unsigned ph = first ? 0u : *(const unsigned*)(xh + offp), pl = first ? 0u : *(const unsigned*)(xl + offp);
+                const unsigned nh = last ? 0u : *(const unsigned*)(xh + offn), nl = last ? 0u : *(const unsigned*)(xl + offn);
+                a_hi[0][m] = __builtin_bit_cast(s16x8, shift_m1(ch, ph)); a_lo[0][m] = __builtin_bit_cast(s16x8, shift_m1(cl, pl));
+                a_hi[1][m] = __builtin_bit_cast(s16x8, ch);               a_lo[1][m] = __builtin_bit_cast(s16x8, cl);
+                a_hi[2][m] = __builtin_bit_cast(s16x8, shift_p1(ch, nh)); a_lo[2][m] = __builtin_bit_cast(s16x8, shift_p1(cl, nl));
+            }
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int row = (wn * NTW + n) * 32 + lo;
+                const int off = row * RS + 8 * (oct ^ ((row ^ (row >> 2)) & 7));
+                const s16x8 b_hi = *(const s16x8*)(dh + off);
+                const s16x8 b_lo = *(const s16x8*)(dl + off);
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) {
+                        acc[t3][m][n] = mfma32_bf16(a_lo[t3][m], b_hi, acc[t3][m][n]);
+                        acc[t3][m][n] = mfma32_bf16(a_hi[t3][m], b_lo, acc[t3][m][n]);
+                        acc[t3][m][n] = mfma32_bf16(a_hi[t3][m], b_hi, acc[t3][m][n]);
+                    }
+            }
+        }
+    }
+    // ---- this workgroup's partials: dWp[split][tap][ci][co], taps 3 (da + 1) .. + 2, channels co0 .. co0 + COH ----
+#pragma unroll
+    for (int t3 = 0; t3 < 3; ++t3) {
+        float* part = dWp + ((size_t)blockIdx.x * 9 + 3 * (da + 1) + t3) * CIN * COUT;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int co = co0 + (wn * NTW + n) * 32 + lo;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[(size_t)((wm * MTW + m) * 32 + mfma32_row(r, lane)) * COUT + co] = acc[t3][m][n][r];
+            }
+    }
+}
+template <int CIN, int COUT, int COH>
+static int launch_wgrad_bf16_row(const float* x, const float* dy, float* dWp, int B, int T, int F, int splits, hipStream_t s) {
+    using Cfg = WgrCfg<CIN, COUT, COH>;
+    SED_MAX_SMEM((conv_wgrad_bf16_row_kernel<CIN, COUT, COH>), Cfg::SMEM);
+    SED_LAUNCH((conv_wgrad_bf16_row_kernel<CIN, COUT, COH>), dim3(splits, 3, COUT / COH), dim3(256), Cfg::SMEM, s, x, dy, dWp, B, T, F);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient, narrow layers (CIN <= 32): ALL 9 taps in one workgroup, so x and dy are read from HBM once
 // instead of once per tap.  Tile = the forward's 128-pixel TR x TF patch: halo patch of x [PP][CIN] and the dy
 // tile [128][COUT] in LDS; K = pixels of the tile, split across waves (WK) with the COUT tiles (WN); each wave
@@ -1196,6 +1366,12 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dWp, float* d
     WGA_CASE(16, 32, 32) WGA_CASE(16, 32, 16) WGA_CASE(16, 32, 8) WGA_CASE(32, 64, 32) WGA_CASE(32, 64, 16) WGA_CASE(32, 64, 8)
     WGA_CASE(32, 64, 4)
 #undef WGA_CASE
+    // wide layers, split-bf16: one kernel row (three taps) per workgroup when a row is whole octets (sed_set_tuning key 9 = 1: one tap)
+    if (rc != SED_OK && split_bf16 && wgrad_row_ok(CIN, COUT, F) && sed_tuning[SED_TUNE_WGRAD_WIDE] != 1) {
+        nparts = wgrad_row_parts(CIN, B, T, F);
+        if (CIN == 64) rc = launch_wgrad_bf16_row<64, 128, 128>(x, dy, dWp, B, T, F, nparts, s);
+        else rc = launch_wgrad_bf16_row<128, 128, 64>(x, dy, dWp, B, T, F, nparts, s);
+    }
 #define WG_CASE(ci, co)                                                                                        \
     if (rc != SED_OK && CIN == ci && COUT == co)                                                               \
         rc = split_bf16 ? launch_wgrad_bf16<ci, co>(x, dy, dWp, B, T, F, s) : launch_wgrad<ci, co>(x, dy, dWp, B, T, F, s);

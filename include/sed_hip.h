@@ -334,7 +334,7 @@ int sed_attention_relpos(const float* qkv, const float* relb, const float* grep_
  *   2  channels per weight chunk of the split-bf16 conv       3  pixels per workgroup of the split-bf16 conv
  *   4  block-0 backward without the local centring constant  5  128-channel GLU forward: 1 = 32x32x16 tiling
  *   6  narrow weight gradients: 1 = exact-f32 all-taps kernel 7  workgroup cap of the all-taps weight gradients (tests)
- *   8  BEATs attention: 1 = vector-pipe kernel
+ *   8  BEATs attention: 1 = vector-pipe kernel                9  wide weight gradients: 1 = one tap per workgroup
  * Not for use while kernels are in flight on other threads. */
 int sed_set_tuning(int key, int value);
 

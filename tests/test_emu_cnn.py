@@ -87,3 +87,15 @@ def test_narrow_wgrad_split_bf16(emu, layer, B, T, F, cap, narrow):
     finally:
         _lib.set_tuning("wgrad_cap", 0)
         _lib.set_tuning("wgrad_narrow", 0)
+
+
+@pytest.mark.parametrize("layer,B,T,F,onetap", [(3, 2, 121, 16, 0), (4, 3, 85, 8, 0), (3, 1, 10, 16, 1), (4, 1, 9, 8, 1)])
+def test_wide_wgrad_kernel_row(emu, layer, B, T, F, onetap):
+    """Wide weight gradients: one kernel row (three taps, column shifts by v_alignbit on the operand octets) per workgroup, several
+    tiles per workgroup (B T F > 64 x the split count), ragged last tile; onetap = 1: the one-tap kernel."""
+    from desed_task_amd import _lib
+    _lib.set_tuning("wgrad_wide", onetap)
+    try:
+        P.case_cnn_block("cpu", layer, B, T, F, training=True, dropout_p=0.5, precision="bf16x3", tol=1e-4)
+    finally:
+        _lib.set_tuning("wgrad_wide", 0)
