@@ -588,7 +588,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 template <int CIN, int COUT>
 static int launch_wgrad(const float* x, const float* dy, float* dWp, int B, int T, int F, hipStream_t s) {
     using Cfg = WgCfg<CIN, COUT>;
-    const int ntiles = (B * T * F + Cfg::KT - 1) / Cfg::KT;
     const int splits = wgrad_parts(CIN, COUT, B, T, F);   // 56 x 9 taps = 504 workgroups ~ 2 per CU
     SED_MAX_SMEM((conv_wgrad_kernel<CIN, COUT>), Cfg::SMEM);
     SED_LAUNCH((conv_wgrad_kernel<CIN, COUT>), dim3(splits, 9), dim3(256), Cfg::SMEM, s, x, dy, dWp, B, T, F);
