@@ -64,7 +64,10 @@ class StepDriver:
         self.arena = getattr(task.sed_student, "arena", None)
         dev = next(task.sed_student.parameters()).device
         self.side = torch.cuda.Stream(device=dev) if (ema_side_stream and dev.type == "cuda") else None
-        self.gru_dw_side = bool(gru_dw_side) and dev.type == "cuda"     # see ops.GRU_DW_SIDE: on only inside this driver's backward()
+        # see ops.GRU_DW_SIDE: on only inside this driver's backward(), and only without a process group: with two gloo ranks on one
+        # GPU (the only multi-rank configuration that can be run here) the side-stream launches made a step 20 x slower (206 vs
+        # 10 ms), unexplained -- under data parallelism the GEMMs stay on the compute stream until that is understood on RCCL
+        self.gru_dw_side = bool(gru_dw_side) and dev.type == "cuda" and world_size == 1
         if hasattr(self.opt, "grad_scale"):
             self.opt.grad_scale = 1.0 / world_size
         if overlap_allreduce is None:
