@@ -332,6 +332,9 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
     // 2024 recipe's n_RNN_cell): 768 threads = 3 waves per SIMD = 170 VGPRs, of which the W_hh slice alone is 144: the h slice is
     // read in blocks of 4 float4 between the FMAs (HB), and the chunk is 4 steps (LDS).
     constexpr int HB = H <= 128 ? KH / 4 : 4;
+    // H = 192: the last WL float4 blocks of the n gate's weight slice live in LDS ([block][thread] float4: lane-contiguous reads)
+    // instead of registers -- 32 of the 144 weights per thread: the rest then (nearly) fits the 170-VGPR budget
+    constexpr int WL = H <= 128 ? 0 : 8, WR = KH / 4 - WL;
     // result planes of a step sit OBP floats apart: with GRU_QSTORE the four lanes of a quad store to four planes at once, so
     // the plane pitch is H + 8 (quad lanes 8 banks apart) instead of H (same bank)
     constexpr int OBP = GRU_QSTORE ? H + 8 : H, OBS = 5 * OBP;
@@ -343,17 +346,20 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
     SED_DYN_SMEM(smem);
     float* gis = (float*)smem;                 // [2][CH][3H]
     float* obuf = gis + 2 * GI_F;              // [2][CH][5H] = h | r | z | n | hn
+    float4* wls = (float4*)(obuf + 2 * OB_F);  // [WL][NT_] float4 (H = 192 only)
     const int tid = threadIdx.x, j = tid >> 2, half = tid & 3;    // `half` = which K quarter
     const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const float* W = dir ? whh1 : whh0;
     const float* bhh = dir ? bhh1 : bhh0;
-    f32x2 wr[KH / 2], wz[KH / 2], wn[KH / 2];
+    f32x2 wr[KH / 2], wz[KH / 2], wn[2 * WR];
 #pragma unroll
     for (int k = 0; k < KH / 2; ++k) {
         wr[k] = *(const f32x2*)(W + (size_t)(0 * H + j) * H + half * KH + 2 * k);
         wz[k] = *(const f32x2*)(W + (size_t)(1 * H + j) * H + half * KH + 2 * k);
-        wn[k] = *(const f32x2*)(W + (size_t)(2 * H + j) * H + half * KH + 2 * k);
+        if (k < 2 * WR) wn[k] = *(const f32x2*)(W + (size_t)(2 * H + j) * H + half * KH + 2 * k);
     }
+#pragma unroll
+    for (int q = 0; q < WL; ++q) wls[q * NT_ + tid] = *(const float4*)(W + (size_t)(2 * H + j) * H + half * KH + 4 * (WR + q));
     const float br = bhh[j], bz = bhh[H + j], bn = bhh[2 * H + j];
     if (tid < H) hbuf[0][(tid / KH) * HP + tid % KH] = 0.f;
     float hprev = 0.f;
@@ -414,9 +420,12 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
                 for (int k0 = 0; k0 < (GRU_NOFMA ? 1 : HB); ++k0) {
                     const int k = kb + k0;
                     const f32x2 lo2 = {hq[k0].x, hq[k0].y}, hi2 = {hq[k0].z, hq[k0].w};
-                    pr = pk_fma(wr[2 * k], lo2, pr); pz = pk_fma(wz[2 * k], lo2, pz); pn = pk_fma(wn[2 * k], lo2, pn);
-                    if (GRU_ACC6) { qr = pk_fma(wr[2 * k + 1], hi2, qr); qz = pk_fma(wz[2 * k + 1], hi2, qz); qn = pk_fma(wn[2 * k + 1], hi2, qn); }
-                    else { pr = pk_fma(wr[2 * k + 1], hi2, pr); pz = pk_fma(wz[2 * k + 1], hi2, pz); pn = pk_fma(wn[2 * k + 1], hi2, pn); }
+                    f32x2 wn0, wn1;
+                    if (k < WR) { wn0 = wn[2 * (k < WR ? k : 0)]; wn1 = wn[2 * (k < WR ? k : 0) + 1]; }
+                    else { const float4 w4 = wls[(k - WR) * NT_ + tid]; wn0 = f32x2{w4.x, w4.y}; wn1 = f32x2{w4.z, w4.w}; }
+                    pr = pk_fma(wr[2 * k], lo2, pr); pz = pk_fma(wz[2 * k], lo2, pz); pn = pk_fma(wn0, lo2, pn);
+                    if (GRU_ACC6) { qr = pk_fma(wr[2 * k + 1], hi2, qr); qz = pk_fma(wz[2 * k + 1], hi2, qz); qn = pk_fma(wn1, hi2, qn); }
+                    else { pr = pk_fma(wr[2 * k + 1], hi2, pr); pz = pk_fma(wz[2 * k + 1], hi2, pz); pn = pk_fma(wn1, hi2, pn); }
                 }
                 if (HB < KH / 4) sed_sched_fence();                       // keeps the later blocks' reads from being hoisted (VGPRs)
             }
@@ -457,7 +466,7 @@ extern "C" int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1
     if (B <= 0 || T <= 0) return SED_OK;
 #define GRU_FWD_CASE(h, ch)                                                                                                       \
     if (H == h) {                                                                                                                 \
-        const int smem = (2 * ch * 3 * h + 2 * ch * 5 * (GRU_QSTORE ? h + 8 : h)) * 4;                                            \
+        const int smem = (2 * ch * 3 * h + 2 * ch * 5 * (GRU_QSTORE ? h + 8 : h)) * 4 + (h <= 128 ? 0 : 8 * 4 * h * 16);         \
         SED_MAX_SMEM((gru_fwd_kernel<h, ch>), smem);                                                                              \
         SED_LAUNCH((gru_fwd_kernel<h, ch>), dim3(2 * B), dim3(4 * h), smem, (hipStream_t)stream, gi, whh0, whh1, bhh0, bhh1, out, saved, B, T); \
     }
@@ -480,6 +489,7 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_kernel(const float* __restrict_
                                                       float* __restrict__ dbi0, float* __restrict__ dbi1,
                                                       float* __restrict__ dbh0, float* __restrict__ dbh1, int B, int T) {
     constexpr int KH = H / 4, NT_ = 4 * H, HB = H <= 128 ? KH / 4 : 2;        // HB: gate-vector block (see the forward)
+    constexpr int WL = H <= 128 ? 0 : 8, WR = KH / 4 - WL;                    // float4 blocks of the n-gate slice in LDS / in registers
     // gbuf: three planes (da_r, da_z, dhn) of four K-quarters; the quarters start QP floats apart so that the four quarters a
     // wave reads with one ds_read_b128 hit distinct banks (GRU_HPAD), the planes GP apart so that the quad's three stores do.
     // obuf: seven result planes per step in the order dgi(r, z, n) | hprev | dgh(r, z, hn), OBP apart (GRU_QSTORE: the four
@@ -491,16 +501,23 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_kernel(const float* __restrict_
     SED_DYN_SMEM(smem);
     float* ibuf = (float*)smem;                // [2][CH][6H] = r | z | n | hn | hprev | dout
     float* obuf = ibuf + 2 * IB_F;             // [2][CH][7H] = dgi(3H) | dgh(3H) | hprev(H)
+    float4* wls = (float4*)(obuf + 2 * OB_F);  // [WL][NT_] float4 (H = 192 only)
     const int tid = threadIdx.x, k = tid >> 2, half = tid & 3;    // `half` = which quarter of the gate rows
     const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const float* W = dir ? whh1 : whh0;
-    f32x2 wr[KH / 2], wz[KH / 2], wn[KH / 2];  // W^T slices: contributions of gate rows j in this thread's quarter to unit k
+    f32x2 wr[KH / 2], wz[KH / 2], wn[2 * WR];  // W^T slices: contributions of gate rows j in this thread's quarter to unit k
 #pragma unroll
     for (int jj = 0; jj < KH / 2; ++jj) {
         const int j = half * KH + 2 * jj;
         wr[jj] = f32x2{W[(size_t)(0 * H + j) * H + k], W[(size_t)(0 * H + j + 1) * H + k]};
         wz[jj] = f32x2{W[(size_t)(1 * H + j) * H + k], W[(size_t)(1 * H + j + 1) * H + k]};
-        wn[jj] = f32x2{W[(size_t)(2 * H + j) * H + k], W[(size_t)(2 * H + j + 1) * H + k]};
+        if (jj < 2 * WR) wn[jj] = f32x2{W[(size_t)(2 * H + j) * H + k], W[(size_t)(2 * H + j + 1) * H + k]};
+    }
+#pragma unroll
+    for (int q = 0; q < WL; ++q) {
+        const int j = half * KH + 4 * (WR + q);
+        wls[q * NT_ + tid] = make_float4(W[(size_t)(2 * H + j) * H + k], W[(size_t)(2 * H + j + 1) * H + k],
+                                         W[(size_t)(2 * H + j + 2) * H + k], W[(size_t)(2 * H + j + 3) * H + k]);
     }
     const int nchunks = (T + CH - 1) / CH;
     constexpr int IV = (IB_F / 4 + NT_ - 1) / NT_;      // float4 per thread per chunk: 3 (H = 128, 8 steps), 1.5 -> 2 guarded (H = 192, 4 steps)
@@ -598,8 +615,11 @@ __global__ __launch_bounds__(4 * H) void gru_bwd_kernel(const float* __restrict_
                     const f32x2 a0 = {ga[q0].x, ga[q0].y}, a1 = {ga[q0].z, ga[q0].w};
                     const f32x2 c0 = {gc[q0].x, gc[q0].y}, c1 = {gc[q0].z, gc[q0].w};
                     const f32x2 d0 = {gd[q0].x, gd[q0].y}, d1 = {gd[q0].z, gd[q0].w};
-                    p0 = pk_fma(wr[2 * q4], a0, p0); p1 = pk_fma(wz[2 * q4], c0, p1); p2 = pk_fma(wn[2 * q4], d0, p2);
-                    p0 = pk_fma(wr[2 * q4 + 1], a1, p0); p1 = pk_fma(wz[2 * q4 + 1], c1, p1); p2 = pk_fma(wn[2 * q4 + 1], d1, p2);
+                    f32x2 wn0, wn1;
+                    if (q4 < WR) { wn0 = wn[2 * (q4 < WR ? q4 : 0)]; wn1 = wn[2 * (q4 < WR ? q4 : 0) + 1]; }
+                    else { const float4 w4 = wls[(q4 - WR) * NT_ + tid]; wn0 = f32x2{w4.x, w4.y}; wn1 = f32x2{w4.z, w4.w}; }
+                    p0 = pk_fma(wr[2 * q4], a0, p0); p1 = pk_fma(wz[2 * q4], c0, p1); p2 = pk_fma(wn0, d0, p2);
+                    p0 = pk_fma(wr[2 * q4 + 1], a1, p0); p1 = pk_fma(wz[2 * q4 + 1], c1, p1); p2 = pk_fma(wn1, d1, p2);
                 }
                 if (HB < KH / 4) sed_sched_fence();
             }
@@ -628,12 +648,12 @@ extern "C" int sed_gru_bwd(const float* dout, const float* out, const float* sav
     if (B <= 0 || T <= 0) return SED_OK;
 #define GRU_BWD_CASE(h, ch)                                                                                                       \
     if (H == h) {                                                                                                                 \
-        const int smem = (2 * ch * 6 * h + 2 * ch * 7 * (GRU_QSTORE ? h + 8 : h)) * 4;                                            \
+        const int smem = (2 * ch * 6 * h + 2 * ch * 7 * (GRU_QSTORE ? h + 8 : h)) * 4 + (h <= 128 ? 0 : 8 * 4 * h * 16);         \
         SED_MAX_SMEM((gru_bwd_kernel<h, ch>), smem);                                                                              \
         SED_LAUNCH((gru_bwd_kernel<h, ch>), dim3(2 * B), dim3(4 * h), smem, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh, \
                    hprev, dbi0, dbi1, dbh0, dbh1, B, T);                                                                          \
     }
-    GRU_BWD_CASE(128, GRU_CH) GRU_BWD_CASE(192, 4)
+    GRU_BWD_CASE(128, GRU_CH) GRU_BWD_CASE(192, 2)
 #undef GRU_BWD_CASE
     return sed_check_launch();
 }
