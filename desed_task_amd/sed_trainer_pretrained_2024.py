@@ -13,8 +13,7 @@ the features' (c, perm), once more with the embeddings' own draw (:283-301); the
 `training.epoch_decay` (:393-396).
 
 Not built from this file: validation / test of the 2024 recipe (MAESTRO segment metrics, class-wise median filters, mpAUC) and
-`pretrained.e2e`; the recipe's `net.n_RNN_cell: 192` is outside what the HIP GRU kernel is built for (128 units) -- the CRNN
-constructor refuses it.
+`pretrained.e2e`.  The recipe's own `net:` section (n_RNN_cell 192, 27 classes, dropstep_recurrent) is what the parity fixtures use.
 """
 import random
 
