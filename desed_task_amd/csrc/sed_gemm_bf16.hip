@@ -172,7 +172,7 @@ static int gemmb_dispatch(const float* A, const float* Bm, const float* bias, fl
     split_k = (K + kps - 1) / kps;
     const int atomic = (!part && (split_k > 1 || accumulate)) ? 1 : 0;
     int ntn = N > 64 ? 4 : 2;
-    if (ntn == 4 && ((N + 127) / 128) * ((M + 127) / 128) * split_k * nbatch < 200) ntn = 2;     // too few workgroups for 256 CUs
+    if (ntn == 4 && ((N + 127) / 128) * ((M + 127) / 128) * split_k * nbatch < 400) ntn = 2;     // too few workgroups for 512 resident slots
     dim3 grid((N + 32 * ntn - 1) / (32 * ntn), (M + 127) / 128, split_k * nbatch);
 #define GEMMB_CASE(ta, tb, nn) \
     if (transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_bf16x3_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic, A1, B1, bias1, C1, nbatch, Bsw, ksw, act, part); return sed_check_launch(); }
