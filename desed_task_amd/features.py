@@ -208,15 +208,24 @@ def mixup_multi_(jobs):
         for data, perm, c, mode, c_dev, perm_dev in jobs:
             mixup_(data, perm, c, mode=mode, c_dev=c_dev, perm_dev=perm_dev)
         return
-    rec, keep = [], []
+    # host permutations (eager path): every DISTINCT permutation of the call goes up in ONE blocking copy (a group's features and
+    # labels share theirs; the 2023 step used to pay four synchronous uploads here, the 2024 step six)
+    perms, slot = [], {}
+    for _, perm, _, _, _, perm_dev in jobs:
+        if perm_dev is None and id(perm) not in slot:
+            slot[id(perm)] = sum(p.numel() for p in perms)
+            perms.append(perm.reshape(-1).to(torch.int32))
+    perm_all = None
+    if perms:
+        # blocking on purpose (see mixup_): the concatenation is a temporary pageable host tensor
+        perm_all = torch.cat(perms).to(_clip_major(jobs[0][0]).device)
+    rec = []
     for data, perm, c, mode, c_dev, perm_dev in jobs:
         base = _clip_major(data)
         _lib.check_tensor(base, "mixup data")
         n = base.shape[0]
         if perm_dev is None:
-            perm_d = perm.to(torch.int32).to(base.device)       # blocking on purpose (see mixup_)
-            keep.append(perm_d)
-            perm_dev = perm_d.data_ptr()
+            perm_dev = perm_all.data_ptr() + 4 * slot[id(perm)]
         cf, of = np.float32(c), np.float32(1.0 - c)
         bits = lambda v: struct.unpack("<I", struct.pack("<f", float(v)))[0]      # noqa: E731
         rec += [base.data_ptr(), perm_dev, c_dev or 0, bits(cf), bits(of), n, base.numel() // n, int(mode)]

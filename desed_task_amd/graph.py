@@ -191,6 +191,31 @@ class dyn_step:
         return False
 
 
+def quiesce_collectives(dev):
+    """Called right before a stream capture: drain the device AND the collective backend's watchdog.
+
+    ProcessGroupNCCL keeps every collective it issued in a work list that its watchdog thread polls with hipEventQuery every 100 ms
+    until the work has completed.  On this ROCm stack an event query from ANOTHER thread while this thread captures is refused
+    (`capture_error_mode="thread_local"` notwithstanding): the watchdog's query fails -- its exception aborts the process -- and the
+    capture is invalidated (the next launch returns hipErrorStreamCaptureInvalidated).  That, not a numeric race, was round 3's
+    "one run in 43" of the one-rank RCCL rehearsal: tools/rehearsal_loop.py reproduced it as 6 dead processes in 87 repetitions,
+    every survivor bit-identical.  With the device idle, `_wait_for_pending_works()` returns as soon as the watchdog has retired
+    the last work item; after that it has no event left to query until the next collective -- and none is ever issued during a
+    capture (launcher.StepDriver keeps all collectives outside the graphs)."""
+    torch.cuda.synchronize(dev)
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    groups = list(getattr(dist.distributed_c10d._world, "pg_map", {}).keys()) or [dist.distributed_c10d._get_default_group()]
+    for pg in groups:
+        try:
+            nccl = dist.get_backend(pg) == "nccl"
+        except Exception:  # noqa: BLE001 -- a group this rank is not part of
+            continue
+        if nccl:
+            pg._wait_for_pending_works()
+
+
 class GraphedStepDriver:
     """launcher.StepDriver with the step captured in a hipGraph (see the module docstring).
 
@@ -223,6 +248,32 @@ class GraphedStepDriver:
         self.static = None
         self.loss = None
         self.stream = None
+        self.eager_fallbacks = 0    # pipelined graph: steps run eagerly because no next batch was announced (epoch ends)
+        self.reprimes = 0           # ... and front halves run inline because the previous step had prefetched nothing
+
+    def _primed(self):
+        """Pipelined front end: has the previous step left this step's front half in the task's hand-over buffers?  (A replay runs no
+        Python: after the capture the task's flags stay set until an eager step consumes them or reset_pipeline() clears them.)"""
+        t = self.task
+        return bool(getattr(t, "_feat_ready", False) or (getattr(t, "_pro", None) or {}).get("ready"))
+
+    def _reprime(self, batch, teacher_level):
+        """Run the front half of `batch` now (eagerly, on the prefetch stream, joined): the captured step that follows consumes it
+        exactly as if the previous step had prefetched it.  The host draws it makes (mixup coin / c / permutations, the teacher
+        CNN's seeds) are the ones the unpipelined order makes at the head of this step."""
+        task = self.task
+        if teacher_level and (len(batch) < 2 or batch[1] is None):
+            raise ValueError('prefetch "teacher": the batch must carry its labels')
+        for src, dst in ((batch[0], self.static_next), (batch[1] if teacher_level else None, self.static_next_labels)):
+            if src is not None and src.data_ptr() != dst.data_ptr():
+                if src.shape != dst.shape:
+                    raise ValueError("batch tensor shapes changed after the step was captured")
+                dst.copy_(src, non_blocking=True)
+        task.set_next_batch(self.static_next, self.static_next_labels if teacher_level else None)
+        task.launch_prefetch(task.prefetch_point)
+        task.join_prefetch()
+        self.eager._announced = None            # (whatever was announced before the pipeline was reset is void)
+        self.reprimes += 1
 
     def _device(self):
         return next(self.task.sed_student.parameters()).device
@@ -316,6 +367,19 @@ class GraphedStepDriver:
         task = self.task
         pipelined = getattr(task, "prefetch_point", None) is not None
         teacher_level = pipelined and getattr(task, "prefetch_level", "features") == "teacher"
+        if pipelined and self.graph is not None:
+            # The captured step has both halves of the pipeline baked in: it CONSUMES the front half prefetched by the previous step
+            # and PRODUCES the next one from the static next-batch buffers.  Two situations break that chain:
+            #  * nothing is announced (last batch of an epoch): a replay would run its side branch on the stale contents of the
+            #    static buffers -- consuming host draws and moving the teacher's BatchNorm statistics for a batch nobody trains on.
+            #    That step runs EAGERLY instead (same kernels, by-value arguments, no side branch), like launcher.StepDriver does;
+            #  * nothing was prefetched for this batch (the step after such an eager step, or after reset_pipeline(): weights were
+            #    loaded in between): the front half of THIS batch is run inline first (`_reprime`), then the replay proceeds.
+            if next_batch is None:
+                self.eager_fallbacks += 1
+                return self.eager.run_step(batch, batch_idx, None, staged=self.static_next)
+            if not self._primed():
+                self._reprime(batch, teacher_level)
         if pipelined:
             self.eager.announce(batch, next_batch, staged=self.static_next)
             nxt, nxt_lab = task._next_audio, task._next_labels
@@ -346,10 +410,15 @@ class GraphedStepDriver:
             for st, t in zip(self.static, batch):
                 if st is not None:
                     st.copy_(t)
-            torch.cuda.synchronize(dev)
+            B = batch[0].shape[0] if torch.is_tensor(batch[0]) else 0
+            if B:
+                from . import ops as _ops
+                _ops.loss_work(dev, B)              # (scratch the loss kernel caches per device: allocated OUTSIDE the capture pool)
+            quiesce_collectives(dev)
             self.graph = torch.cuda.CUDAGraph()
             with dyn_step(self.dyn, record=True):
-                # thread_local: the RCCL watchdog thread of an initialised process group polls events while we capture
+                # thread_local: calls other threads make (allocator, a collective backend's housekeeping) must not fail this capture;
+                # the one that does fail on this stack -- the RCCL watchdog's event query -- has been drained by quiesce_collectives()
                 with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                     self.loss = self._step_body(tuple(st if st is not None else t for st, t in zip(self.static, batch)))
                 student = self.task.sed_student

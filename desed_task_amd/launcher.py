@@ -79,6 +79,7 @@ class StepDriver:
         min-max) AND the teacher's CNN forward run under this step's backward (SEDTask4.launch_prefetch).  The next run_step must
         be given exactly the announced batch."""
         self.task = task
+        _ops.reset_loss_work()
         if prefetch is not None:
             task.prefetch_point = None if prefetch in ("off", False) else ("backward" if prefetch == "teacher" else prefetch)
             task.prefetch_level = "teacher" if prefetch == "teacher" else "features"
@@ -275,9 +276,9 @@ class StepDriver:
         else:
             task.set_next_batch(nxt, None)
 
-    def run_step(self, batch, batch_idx=0, next_batch=None):
+    def run_step(self, batch, batch_idx=0, next_batch=None, staged=None):
         task = self.task
-        self.announce(batch, next_batch)
+        self.announce(batch, next_batch, staged=staged)
         self.arm_overlap()
         loss = task.training_step(batch, batch_idx)
         if self.side is not None:

@@ -623,7 +623,7 @@ class MeanTeacherLossFn(torch.autograd.Function):
         lib.call("sed_mt_loss", strong_s.data_ptr(), weak_s.data_ptr(), strong_t.data_ptr(), weak_t.data_ptr(), labels.data_ptr(),
                  labels_weak.data_ptr(), buf.data_ptr(), g_strong.data_ptr(), g_weak.data_ptr(), B, T, NC, int(n_strong),
                  int(n_weak), float(weight), getattr(weight, "dev", None), int(bool(selfsup_bce)), int(selfsup_from), _p(valid),
-                 _loss_work(strong_s.device, B).data_ptr(), _lib.stream_ptr(strong_s))
+                 loss_work(strong_s.device, B).data_ptr(), _lib.stream_ptr(strong_s))
         ctx.save_for_backward(g_strong, g_weak)
         ctx.mark_non_differentiable(scalars)
         ctx.set_materialize_grads(False)
@@ -658,10 +658,21 @@ def is_unit_grad(g):
     return u is not None and g.data_ptr() == u.data_ptr() and g.dim() == 0
 
 
-def _loss_work(device, B):
-    """Scratch of sed_mt_loss (per-clip partial sums + the ticket word, zero once: the kernel leaves the ticket at 0)."""
+def loss_work(device, B):
+    """Scratch of sed_mt_loss: per-clip partial sums + the ticket word (zeroed once: the kernel leaves the ticket at 0).  One buffer
+    per (device, batch size, STREAM): launches on one stream are serialised, so everything that shares a buffer is ordered; two steps
+    in flight on different streams (two tasks driven from two drivers) get their own tickets.  GraphedStepDriver creates the buffer
+    before its capture begins, so it never lives in a graph's private pool."""
     device = torch.device(device)
-    key = (device.type, device.index, int(B))
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (device.type, device.index, int(B), stream)
     if key not in _LOSS_WORK:
         _LOSS_WORK[key] = torch.zeros(8 * B + 1, device=device, dtype=torch.float32)
     return _LOSS_WORK[key]
+
+
+def reset_loss_work():
+    """Zero every cached loss scratch (its ticket word in particular): a launch that faulted mid-way would otherwise leave a stale
+    ticket behind for every later step.  Called when a step driver is constructed."""
+    for t in _LOSS_WORK.values():
+        t.zero_()

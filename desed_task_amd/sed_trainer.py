@@ -5,7 +5,8 @@ Kept from the reference: constructor signature, `mel_spec`, `scaler`, `take_log`
 (batch tuple in, 0-d loss tensor with grad out, the same 11 logged keys, in-place mutation of features/labels
 by mixup, python/numpy/torch-CPU RNG consumption order), `on_before_zero_grad` -> `update_ema`,
 `lr_scheduler_step`, `configure_optimizers`, `on_save_checkpoint`, `train_dataloader`.
-Validation/test/metric code (sed_trainer.py:367-975) is outside this path: those hooks raise.
+Validation / test forward + decoding (sed_trainer.py:367-487, 602-720) and the epoch-end metrics (:489-600, 722-975) are the
+SURVEY 8f rank 1-2 rows: `validation_step`, `validation_epoch_end`, `test_step`, `on_test_epoch_end` below.
 
 It subclasses pytorch_lightning.LightningModule when Lightning is importable, else a minimal stand-in with
 `hparams`/`log` so the step can be driven by desed_task_amd.launcher (one process per GPU).
@@ -201,7 +202,8 @@ class SEDTask4(_Base):
         self._next_audio = audio
 
     def set_next_batch(self, audio, labels=None):
-        """Announce the NEXT batch: waveforms and -- for prefetch_level "teacher" -- its labels (mixed in place one step early)."""
+        """Announce the NEXT batch: waveforms and -- for prefetch_level "teacher" -- its labels (copied into the hand-over buffer and
+        mixed THERE one step early; the caller's tensor is only read)."""
         self._next_audio, self._next_labels = audio, labels
 
     def _feature_buffer(self, audio):
@@ -233,17 +235,18 @@ class SEDTask4(_Base):
                 self.mel_spec.frames_major(audio, out=self._feature_buffer(audio))
                 self._feat_ready = True
                 return
-            x, lab, lab_w = self._front(audio, labels, fresh=True)
+            # The labels are mixed in the hand-over buffer, NOT in the caller's tensor: an inline front half that has to re-run on
+            # the same announced batch (after reset_pipeline(): weights loaded in between) then starts from unmixed labels.
+            lab = self._pro_buffer("labels", labels)
+            lab.copy_(labels)
+            x, lab, lab_w = self._front(audio, lab, fresh=True)
             with torch.no_grad(), _ops.seed_stream("teacher_cnn"):
                 ht = self.sed_teacher.forward_cnn(x)
-            # into PERSISTENT buffers: a captured step reads fixed addresses, and the driver may restage the announced labels'
-            # buffer before the next step
-            pro = self._pro_buffers(lab, lab_w, x, ht)
-            pro["labels"].copy_(lab)
-            pro["labels_weak"].copy_(lab_w)
-            pro["x"].copy_(x)
-            pro["ht"].copy_(ht)
-            pro["ready"] = True
+            # into PERSISTENT buffers: a captured step reads fixed addresses
+            self._pro_buffer("labels_weak", lab_w).copy_(lab_w)
+            self._pro_buffer("x", x).copy_(x)
+            self._pro_buffer("ht", ht).copy_(ht)
+            self._pro["ready"] = True
             _ops.probe("prefetch_end")
 
         if audio.device.type != "cuda":
@@ -267,15 +270,17 @@ class SEDTask4(_Base):
         with torch.cuda.stream(self._pf_stream):
             body()
 
-    def _pro_buffers(self, labels, labels_weak, x, ht):
+    def _pro_buffer(self, key, like):
+        """Persistent hand-over buffer `key` of the pipelined front half, shaped like `like` (created on first use)."""
         p = self._pro
-        if (p is None or p["labels"].shape != labels.shape or p["x"].shape != x.shape or p["ht"].shape != ht.shape
-                or p["x"].device != x.device):
-            if p is not None and p["ready"]:
+        if p is None:
+            p = self._pro = {"ready": False}
+        t = p.get(key)
+        if t is None or t.shape != like.shape or t.device != like.device or t.dtype != like.dtype:
+            if p["ready"]:
                 raise RuntimeError("the batch shape changed between a prefetch and the step that consumes it")
-            self._pro = {"labels": torch.empty_like(labels), "labels_weak": torch.empty_like(labels_weak), "x": torch.empty_like(x),
-                         "ht": torch.empty_like(ht), "ready": False}
-        return self._pro
+            t = p[key] = torch.empty_like(like, memory_format=torch.contiguous_format)
+        return t
 
     def reset_pipeline(self):
         """Forget a front half that was prefetched for the next step (after weights were loaded in between: the teacher's CNN output

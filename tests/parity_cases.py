@@ -692,6 +692,75 @@ def case_prefetch_equals_unpipelined(dev, point="tails", graph=False, steps=5, n
         pass
 
 
+def case_pipelined_epoch_boundary(dev, point="teacher", graph=True, epochs=3, per_epoch=3, n_samp=16000 + 1024, reset_after=None):
+    """The pipelined front end across EPOCH BOUNDARIES: the last batch of an epoch announces no successor, the first
+    batch of the next epoch was announced by nobody.  A captured step has both halves of the pipeline baked in, so the graphed
+    driver must run the unannounced-successor step eagerly and re-prime the front half inline afterwards -- the whole sequence
+    must equal the UNPIPELINED StepDriver bit for bit (weights of student and teacher, BatchNorm statistics of both, every loss).
+    reset_after = k: `task.reset_pipeline()` after step k (weights were loaded in between: launcher.load_checkpoint) although step
+    k + 1 had been announced -- its front half must then be recomputed inline from UNMIXED labels; that sequence is compared with
+    the eager pipelined StepDriver doing the same (the recomputed front half draws again, so the plain order is no reference)."""
+    import random
+    from desed_task_amd import graph as G
+    from desed_task_amd import ops as _ops
+    from desed_task_amd.launcher import StepDriver
+    bs = (1, 1, 2)
+    B = sum(bs)
+    sd = O.make_state_dict(seed=7)
+    n_out = (1 + n_samp // 256) // 4
+    steps = epochs * per_epoch
+    batches = [(to(dev, O.synth_audio(B, n_samp, seed=500 + 7 * i)), to(dev, O.synth_labels(bs, 10, n_out, seed=60 + i))) for i in range(steps)]
+    originals = [b[1].clone() for b in batches]
+
+    def bn_state(task):
+        out = []
+        for model in (task.sed_student, task.sed_teacher):
+            for i in range(7):
+                bn = getattr(model.cnn.cnn, "batchnorm%d" % i)
+                out += [bn.running_mean.detach().cpu().clone(), bn.running_var.detach().cpu().clone()]
+        return torch.cat(out)
+
+    results = []
+    for mode in ("reference", "pipelined"):
+        task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=5)
+        if mode == "reference":
+            driver = StepDriver(task, world_size=1, prefetch=None if reset_after is None else point)
+        else:
+            driver = G.GraphedStepDriver(task, world_size=1, warmup=1, prefetch=point) if graph else StepDriver(task, world_size=1, prefetch=point)
+        pipelined = mode == "pipelined" or reset_after is not None
+        random.seed(41); np.random.seed(101); torch.manual_seed(101)
+        if dev != "cpu":
+            torch.cuda.manual_seed(101)
+        _ops.reseed_dropout()
+        losses = []
+        for step in range(steps):
+            a, l = batches[step]
+            last_of_epoch = (step + 1) % per_epoch == 0
+            nxt = None
+            if pipelined and not last_of_epoch:
+                nxt = (batches[step + 1][0], batches[step + 1][1], None, None)
+            loss = driver.run_step((a, l.clone(), None, None), step, next_batch=nxt) if pipelined else driver.run_step((a, l.clone(), None, None), step)
+            losses.append(float(loss.detach()))
+            if reset_after is not None and step == reset_after:
+                assert nxt is not None, "reset_after must not be the last step of an epoch"
+                task.reset_pipeline()
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        if mode == "pipelined" and graph:
+            want_fallbacks = epochs - (1 if per_epoch <= 2 else 0)          # (an epoch end inside the warm-up / capture steps is eager anyway)
+            assert driver.eager_fallbacks >= epochs - 1 and driver.eager_fallbacks <= epochs, driver.eager_fallbacks
+            assert driver.reprimes == (epochs - 1) + (1 if reset_after is not None else 0), driver.reprimes
+            del want_fallbacks
+        # the announced label tensors are only READ by the pipelined front half (mixed in the hand-over buffer)
+        for b, o in zip(batches, originals):
+            assert torch.equal(b[1], o), "an announced label tensor was modified in place"
+        results.append((losses, task.sed_student.arena.flat.detach().cpu().clone(), task.sed_teacher.arena.flat.detach().cpu().clone(), bn_state(task)))
+    (l0, s0, t0, b0), (l1, s1, t1, b1) = results
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(s0, s1) and torch.equal(t0, t1) and torch.equal(b0, b1)
+    return l0
+
+
 def case_step_bit_reproducible(dev, steps=3, n_samp=16000 + 1024):
     """Since round 3 no kernel of the default training step adds floats with atomics (loss sums, head and BiGRU bias gradients
     moved to per-workgroup records summed in a fixed order): the same seeded steps give the SAME BITS -- run twice eagerly, and once
@@ -1371,7 +1440,8 @@ class StochasticRecorder:
         import importlib
         cnn_mod = importlib.import_module("desed_task_amd.nnet.CNN")
         crnn_mod = importlib.import_module("desed_task_amd.nnet.CRNN")      # (the package re-exports the class under that name)
-        self.rec = {"student": {"seeds": [], "objs": [], "bounds": None}, "teacher": {"seeds": [], "objs": [], "bounds": None}}
+        self.rec = {"student": {"seeds": [], "objs": [], "bounds": None, "bounds_all": []},
+                    "teacher": {"seeds": [], "objs": [], "bounds": None, "bounds_all": []}}
         self._cur = [None]
         self._mods = (cnn_mod, crnn_mod)
         self._orig_seed = cnn_mod.new_seed
@@ -1387,6 +1457,7 @@ class StochasticRecorder:
         def specaug_bounds(*a, _o=self._orig_bounds, **k):
             b = _o(*a, **k)
             rec[cur[0]]["bounds"] = b
+            rec[cur[0]]["bounds_all"].append(b)
             return b
 
         cnn_mod.new_seed = new_seed
@@ -1408,7 +1479,7 @@ class StochasticRecorder:
 
     def reset(self):
         for v in self.rec.values():
-            v["seeds"], v["objs"], v["bounds"] = [], [], None
+            v["seeds"], v["objs"], v["bounds"], v["bounds_all"] = [], [], None, []
 
     def close(self):
         for m in self._mods:
@@ -1416,6 +1487,27 @@ class StochasticRecorder:
         Fh.specaug_bounds = self._orig_bounds
         for model, meth in self._models:
             object.__delattr__(model, meth)
+
+    def seed_values(self, who, dyn=None):
+        """The seeds `who` drew, in call order: recorded ints (eager) or, under a captured step, the CURRENT contents of the DynArgs
+        host mirror for the recorded call sites (= the draws of the last step run)."""
+        r = self.rec[who]
+        return list(r["seeds"]) if dyn is None else [dyn.seed_value(o) for o in r["objs"]]
+
+    @staticmethod
+    def draws_from(seeds8, bounds, B, n_frames, p=0.5):
+        """(aug, drop_masks) in the oracle's conventions from explicit values: the 7 CNN seeds + the head's, and a (B, 4) bounds
+        tensor -- for steps whose draws were made at different times (pipelined front half: the teacher's CNN one step early)."""
+        b = bounds.cpu().long()
+        aug = dict(f=(b[:, 0], b[:, 1]), t=(b[:, 2], b[:, 3]))
+        assert len(seeds8) == 8
+        masks = []
+        T, Fq = n_frames, 128
+        for i, co in enumerate(O.NB_FILTERS):
+            masks.append(np_keep_mask((B, T, Fq, co), seeds8[i], p).permute(0, 3, 1, 2))
+            T, Fq = T // O.POOLING[i][0], Fq // O.POOLING[i][1]
+        masks.append(np_keep_mask((B, T, 256), seeds8[7], p))
+        return aug, masks
 
     def oracle_draws(self, who, B, n_frames, p=0.5, embedding_size=None, dyn=None):
         """-> (aug, drop_masks) in the oracle's conventions (masks NCHW for the CNN blocks, (B,T',256) for the head).
@@ -1449,6 +1541,21 @@ def _mixup_draws(bs, seeds):
         mix = dict(c_weak=cw, perm_weak=pw, c_strong=cs, perm_strong=ps)
     random.seed(seeds[0]); np.random.seed(seeds[1]); torch.manual_seed(seeds[2])
     return mix
+
+
+def _mixup_draws_n(bs, seeds, n):
+    """The draws of the next n front halves after seeding ONCE (pipelined front end: step k + 1's draws are made during step k)."""
+    import random
+    random.seed(seeds[0]); np.random.seed(seeds[1]); torch.manual_seed(seeds[2])
+    out = []
+    for _ in range(n):
+        mix = None
+        if 0.5 > random.random():
+            cw = np.random.beta(0.2, 0.2); pw = torch.randperm(bs[1]); cs = np.random.beta(0.2, 0.2); ps = torch.randperm(bs[0])
+            mix = dict(c_weak=cw, perm_weak=pw, c_strong=cs, perm_strong=ps)
+        out.append(mix)
+    random.seed(seeds[0]); np.random.seed(seeds[1]); torch.manual_seed(seeds[2])
+    return out
 
 
 DIAG = None      # a list here collects the error statistics of case_training_step (diagnostics)
@@ -1599,7 +1706,7 @@ def case_b48_forward_vs_oracle(dev, bs=(12, 12, 24)):
     return out
 
 
-def case_b48_graph_step_vs_oracle(dev, bs=(12, 12, 24), n_samp=160000, warmup=1, replays=1, tol_scale=1.0):
+def case_b48_graph_step_vs_oracle(dev, bs=(12, 12, 24), n_samp=160000, warmup=1, replays=1, tol_scale=1.0, prefetch=None):
     """The benchmarked configuration THROUGH THE BENCHMARKED LAUNCH PATH, with the backward pass: B = 48 (12/12/24) clips of 10 s,
     dropout + SpecAugment + mixup on, student != teacher, run by graph.GraphedStepDriver -- `warmup` eager steps, the capture step,
     `replays` replayed steps -- and EVERY step compared with OracleTrainer on the draws the HIP path made: logged scalars <= 2e-4
@@ -1607,34 +1714,72 @@ def case_b48_graph_step_vs_oracle(dev, bs=(12, 12, 24), n_samp=160000, warmup=1,
     (local/sed_trainer.py:269-365).  The launch geometry of the weight-gradient / split-K / partial-sum kernels depends on the
     batch, so only this size exercises what bench.py times.  The student is put back on its initial weights after every step (on
     both sides): Adam's +-lr sign flips of near-zero gradient elements would otherwise widen the later steps' tolerances; Adam's
-    moments, the schedule and the EMA teacher keep evolving, so step-varying arguments still change from replay to replay."""
+    moments, the schedule and the EMA teacher keep evolving, so step-varying arguments still change from replay to replay.
+
+    prefetch="teacher" (bench.py's default front end): a DIFFERENT batch every step; step k's front half (mel, mixup, log / min-max)
+    and the teacher's CNN forward ran under step k - 1's backward, so the draws that belong to step k's oracle step were made at
+    three different times -- mixup and the teacher's CNN seeds / SpecAugment bounds during step k - 1, the student's and the
+    teacher head's during step k -- and are carried over accordingly.  Runs unchanged under SED_DDP_REHEARSE=1 with a one-rank
+    process group (graph up to the end of backward + RCCL all-reduce + eager Adam: the N > 1 structure)."""
     from desed_task_amd.graph import GraphedStepDriver
     torch.set_num_threads(min(64, torch.get_num_threads()))
     B = sum(bs)
     n_frames = 1 + n_samp // 256
+    n_steps = warmup + 1 + replays
+    pipelined = prefetch is not None
+    assert prefetch in (None, "teacher")
     sd, sd_t = O.make_state_dict(seed=13), O.make_state_dict(seed=14)
-    audio = O.synth_audio(B, n_samp, seed=5)
-    labels = O.synth_labels(bs, 10, n_frames // 4, seed=6)
+    n_batches = n_steps + 1 if pipelined else 1                 # (the last step announces one more batch so that it is a replay too)
+    audios = [O.synth_audio(B, n_samp, seed=5 + 31 * i) for i in range(n_batches)]
+    labelss = [O.synth_labels(bs, 10, n_frames // 4, seed=6 + i) for i in range(n_batches)]
     task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=100)
     task.sed_teacher.load_state_dict({k: v.clone() for k, v in sd_t.items()})
-    driver = GraphedStepDriver(task, world_size=1, warmup=warmup)
+    driver = GraphedStepDriver(task, world_size=1, warmup=warmup, prefetch=prefetch)
     orc = O.OracleTrainer(sd, batch_sizes=bs, lr=1e-3, rampup_len=100, teacher_sd=sd_t)
     flat0 = task.sed_student.arena.flat.detach().clone()
     rec = StochasticRecorder(task)
-    audio_d = to(dev, audio)
-    worst = {"post": 0.0, "scalar": 0.0, "grad_max": 0.0, "grad_med": 0.0, "modes": []}
+    audio_d = [to(dev, a) for a in audios]
+    worst = {"post": 0.0, "scalar": 0.0, "grad_max": 0.0, "grad_med": 0.0, "modes": [], "exchange": bool(driver.eager.exchange)}
+    mixes, t_cnn = {}, {}           # pipelined: per step, the mixup draws / (teacher CNN seeds, bounds) made one step early
     try:
-        for step in range(warmup + 1 + replays):
+        for step in range(n_steps):
             mode = "eager" if step < warmup else ("capture" if step == warmup else "replay")
-            mix = _mixup_draws(bs, (4 + step, 100 + step, 100 + step))       # seeds 4 -> mixup on, 5 -> off, 6 -> on
+            bi = step if pipelined else 0
+            audio, labels = audios[bi], labelss[bi]
+            seeds = (4 + step, 100 + step, 100 + step)                       # seeds 4 -> mixup on, 5 -> off, 6 -> on
+            if not pipelined:
+                mix = _mixup_draws(bs, seeds)
+            elif step == 0:
+                mixes[0], mixes[1] = _mixup_draws_n(bs, seeds, 2)            # inline front half of step 0, then step 1's prefetch
+            else:
+                mixes[step + 1] = _mixup_draws_n(bs, seeds, 1)[0]
             if mode != "replay":
                 rec.reset()                         # a replay re-runs no Python: the capture's call sites stay valid
-            loss = driver.run_step((audio_d.clone(), to(dev, labels.clone()), None, None), step)
+            batch = (audio_d[bi].clone(), to(dev, labels.clone()), None, None)
+            if pipelined:
+                nxt = (audio_d[bi + 1], to(dev, labelss[bi + 1].clone()), None, None)
+                loss = driver.run_step(batch, step, next_batch=nxt)
+            else:
+                loss = driver.run_step(batch, step)
             torch.cuda.synchronize()
             assert (driver.graph is not None) == (mode != "eager")
             dyn = driver.dyn if mode != "eager" else None
             aug_s, drop_s = rec.oracle_draws("student", B, n_frames, dyn=dyn)
-            aug_t, drop_t = rec.oracle_draws("teacher", B, n_frames, dyn=dyn)
+            if not pipelined:
+                aug_t, drop_t = rec.oracle_draws("teacher", B, n_frames, dyn=dyn)
+            else:
+                mix = mixes[step]
+                tv = rec.seed_values("teacher", dyn=dyn)
+                tb = rec.rec["teacher"]["bounds_all"]
+                if step == 0:                       # inline: [7 CNN seeds (step 0), head (0)] then the prefetch's [7 CNN seeds (step 1)]
+                    assert len(tv) == 15 and len(tb) == 2, (len(tv), len(tb))
+                    t_cnn[0] = (tv[0:7], tb[0].cpu().clone())
+                    head, t_cnn[1] = tv[7], (tv[8:15], tb[1].cpu().clone())
+                else:                               # [head (k)] then the prefetch's [7 CNN seeds (k + 1)]; bounds: the graph's static tensor
+                    assert len(tv) == 8 and len(tb) == 1, (len(tv), len(tb))
+                    head, t_cnn[step + 1] = tv[0], (tv[1:8], tb[0].cpu().clone())
+                aug_t, drop_t = StochasticRecorder.draws_from(list(t_cnn[step][0]) + [head], t_cnn[step][1], B, n_frames)
+                assert driver.eager_fallbacks == 0 and driver.reprimes == 0
             tot, logs = orc.training_step(audio, labels, mix=mix, aug_s=aug_s, aug_t=aug_t, drop_s=drop_s, drop_t=drop_t)
             ref_grads = orc.optimizer_step(tot)
             got = {k: (float(v) if not torch.is_tensor(v) else float(v.detach().cpu())) for k, v in task.logged.items()}
@@ -1673,6 +1818,8 @@ def case_b48_graph_step_vs_oracle(dev, bs=(12, 12, 24), n_samp=160000, warmup=1,
                     orc.student[k].copy_(sd[k])
             worst["modes"].append(mode)
         assert worst["modes"].count("replay") == replays and "capture" in worst["modes"]
+        if pipelined:
+            assert any(m is not None for m in mixes.values()) and any(m is None for m in list(mixes.values())[:n_steps])
     finally:
         rec.close()
     return worst

@@ -161,3 +161,10 @@ def test_attention_relpos_kernels(emu):
 def test_posconv_kernels(emu):
     P.case_posconv("cpu", B=1, T=70, groups=1, K=16)
     P.case_posconv("cpu", B=1, T=33, groups=2, K=8)
+
+
+def test_pipelined_epoch_boundaries_and_reset(emu):
+    """Eager pipelined driver across epoch boundaries (no successor announced at an epoch's end) == the unpipelined order, and
+    reset_pipeline() between two steps recomputes the front half from UNMIXED labels (the hipGraph forms run on the GPU)."""
+    P.case_pipelined_epoch_boundary("cpu", point="teacher", graph=False, epochs=2, per_epoch=2, n_samp=2048 + 1024)
+    P.case_pipelined_epoch_boundary("cpu", point="teacher", graph=False, epochs=2, per_epoch=3, n_samp=2048 + 1024, reset_after=0)
