@@ -338,6 +338,27 @@ def cpu_baseline_bounded():
     return {"value": round(best["clips_per_s"], 3), "unit": "clips/s", "cores": best["threads"], "kind": "port", "sample": head + desc}
 
 
+def rccl_debug_lines(limit=12):
+    """With NCCL_DEBUG=INFO: what RCCL itself says it runs -- the lines of this rank's debug file that name an algorithm / protocol
+    / ring or tree (main() points NCCL_DEBUG_FILE at /tmp/sed_bench_rccl_<pid>.log).  None when RCCL debugging is off."""
+    path = os.environ.get("NCCL_DEBUG_FILE")
+    if not path or os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):
+        return None
+    path = path.replace("%p", str(os.getpid())).replace("%h", os.uname().nodename)
+    try:
+        with open(path, errors="replace") as fh:
+            lines = [ln.strip() for ln in fh if any(k in ln for k in ("Algo", "proto", "Protocol", "Ring", "Tree", "Channel", "AllReduce"))]
+    except OSError:
+        return ["(no RCCL debug file at %s)" % path]
+    seen, out = set(), []
+    for ln in lines:
+        key = ln.split("NCCL INFO", 1)[-1].strip()
+        if key not in seen:
+            seen.add(key)
+            out.append(key[:200])
+    return out[-limit:]
+
+
 def free_port():
     import socket
     sock = socket.socket()
@@ -387,6 +408,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="A/B at N > 1: ONE blocking all-reduce over the whole gradient arena after backward (one graph) instead of "
                          "bucket A under the CNN backward (two graphs); same as SED_DDP_OVERLAP=0")
+    ap.add_argument("--overlap", action="store_true",
+                    help="A/B at N > 1: force the bucketed exchange (bucket A's asynchronous all-reduce under the CNN backward; with "
+                         "--prefetch teacher that costs the one-graph structure); same as SED_DDP_OVERLAP=1")
     ap.add_argument("--gru-dw-side", action="store_true",
                     help="A/B at N > 1: BiGRU weight-gradient GEMMs on the side stream as at N = 1 (default off at N > 1, see "
                          "launcher.StepDriver); same as SED_GRU_DW_SIDE=1")
@@ -411,8 +435,17 @@ def main():
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
                     help="A/B runs: override a kernel choice of the library (desed_task_amd._lib.TUNING_KEYS), e.g. glu_bwd128_split=3")
     args = ap.parse_args()
+    if args.no_overlap and args.overlap:
+        raise SystemExit("--overlap and --no-overlap exclude each other")
     if args.no_overlap:
         os.environ["SED_DDP_OVERLAP"] = "0"
+    if args.overlap:
+        os.environ["SED_DDP_OVERLAP"] = "1"
+    if os.environ.get("NCCL_DEBUG", "").upper() in ("INFO", "TRACE") and (args.gpus > 1 or args.rehearse_exchange):
+        # RCCL's own account of what it runs (algorithm / protocol per collective size) goes to a file per rank that rank 0 quotes
+        # in `dist.rccl_debug` -- it must be set before the communicator exists, i.e. here, before self_launch / init_distributed
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING,COLL")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/sed_bench_rccl_%p.log")
     if args.gru_dw_side:
         os.environ["SED_GRU_DW_SIDE"] = "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -509,15 +542,13 @@ def main():
     inputs = {"audio": audio, "emb": emb, "next_audio": audio}
 
     def next_labels():
-        """prefetch 'teacher': the announced batch's labels (mixed in place one step early): the loader writes them into the graph's
-        static buffer once it exists, a fresh copy before."""
+        """prefetch 'teacher': the announced batch's labels.  The step only READS them (they are copied into its hand-over buffer and
+        mixed there), so once the graph's static next-label buffer exists the loader's copy of the synthetic labels simply lives in
+        it -- like the waveforms, resident in HBM before the timed region; before the capture: a fresh copy."""
         if args.prefetch != "teacher":
             return None
         buf = inputs.get("next_labels")
-        if buf is None:
-            return labels.clone()
-        buf.copy_(labels)
-        return buf
+        return labels.clone() if buf is None else buf
 
     def one_step(i):
         # graph mode: the driver copies every batch tensor into its static input buffers, so `labels` (mixed in place by the
@@ -545,8 +576,8 @@ def main():
             one_step(i)
     if use_graph and driver.input_buffers() is not None:
         # the synthetic clips already live in HBM: hand the graph's own input buffers back as the batch, like a loader that
-        # writes its batches straight into them, so that no per-step staging copy of the 30 MB of audio is timed.  The labels are
-        # mixed in place by the step and are therefore re-staged every step.
+        # writes its batches straight into them, so that no per-step staging copy of the 30 MB of audio is timed.  Round 4: the step
+        # no longer mixes the announced labels in place, so they are staged once as well (round 3 re-staged 300 KB every step).
         bufs = driver.input_buffers()
         inputs["audio"] = bufs[0]
         if emb is not None:
@@ -554,6 +585,8 @@ def main():
         if pipelined:       # the loader's target for the NEXT batch's waveforms; one step later the same buffer IS the batch
             inputs["audio"] = inputs["next_audio"] = driver.next_audio_buffer()
             inputs["next_labels"] = driver.next_label_buffer()
+            if inputs["next_labels"] is not None:
+                inputs["next_labels"].copy_(labels)
     def sync():
         if not dry:
             torch.cuda.synchronize()
@@ -576,6 +609,19 @@ def main():
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    # Data-parallel runs: PROBE_STEPS more steps of the SAME launch path (graph replays + eager exchange tail, or eager steps) with
+    # marks around the exchange tail -- after the timed region, so the K timed steps carry no extra events.
+    exchange_probe = None
+    if grouped:
+        from desed_task_amd.launcher import ExchangeProbe
+        PROBE_STEPS = 2 if dry else 7
+        d0 = driver.eager if use_graph else driver
+        d0.probe = exchange_probe = ExchangeProbe(dev)
+        for i in range(PROBE_STEPS):
+            one_step(args.warmup + args.steps + i)
+        sync()
+        d0.probe = None
+        exchange_probe.steps = exchange_probe.steps[1:]         # (the first one absorbs the barrier's wake-up)
     # Per-launch HIP events cannot be placed inside a graph replay, and bracketing all ~330 launches of a step with events
     # would perturb the timed region: the kernels are timed over EAGER_STEPS eager steps of the same workload right after the
     # timed region (same process, same tensors, every launch bracketed by events on the stream it is launched on; the first of
@@ -618,7 +664,17 @@ def main():
                      "overlap_allreduce": bool(d0.overlap), "gru_dw_side_stream": bool(d0.gru_dw_side), "graph_scheme": scheme,
                      "bucket_log": [[tag, lo, round(4 * n / 1e6, 3)] for tag, lo, n in d0.bucket_log],
                      "bucket_log_fields": "[bucket, first float of the gradient arena, MB] of the last step's collectives, in issue order",
-                     "ms_per_step_per_rank": per_rank, "ms_per_step_rank_min": min(per_rank), "ms_per_step_rank_max": max(per_rank)}
+                     "ms_per_step_per_rank": per_rank, "ms_per_step_rank_min": min(per_rank), "ms_per_step_rank_max": max(per_rank),
+                     # measured on rank 0 over the probe steps that follow the timed region (launcher.ExchangeProbe): medians, us
+                     "exchange_tail_us": exchange_probe.summary() if exchange_probe is not None else None,
+                     "exchange_tail_fields": "segment -> {device_us: HIP-event time on the compute stream (null on the CPU emulator), "
+                                             "host_us: host clock between the same two points}.  'exposed_exchange' = end of backward "
+                                             "(of the replayed graph) -> gradients reduced = what the collective(s) add to a step; "
+                                             "host_us > device_us there means the host, not the link, sets the gap before Adam",
+                     "expected": "N ranks ~ N x (1-GPU clips/s) x t1 / (t1 + exposed_exchange): the step has no other cross-rank work; "
+                                 "falsified by exposed_exchange.device_us >> 100 (a 4.45 MB all-reduce should be latency-bound) or by "
+                                 "ms_per_step_rank_max - ms_per_step_rank_min > 5 % (a straggling rank, not the exchange)",
+                     "rccl_debug": rccl_debug_lines()}
     loss_val = float(task.logged["train/student/loss_strong"])
     backend_name = dist.get_backend() if grouped else None
     if grouped:

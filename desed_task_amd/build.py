@@ -3,8 +3,10 @@
     python -m desed_task_amd.build          # -> desed_task_amd/libsed_hip.so
 
 hipcc cross-compiles for gfx950 without a GPU.  One object per .hip source, compiled in parallel and
-cached by mtime, then linked into ONE shared library whose exported symbols are exactly the
-`extern "C"` entry points declared in include/sed_hip.h.
+cached by mtime, then linked into ONE shared library.  Everything is compiled with -fvisibility=hidden; the
+`SED_API` (extern "C", default visibility) entry points declared in include/sed_hip.h are the only exported
+symbols: a linker version script (`global: sed_*; local: *`) also hides the kernel host stubs hipcc insists on
+exporting (tests/test_abi.py checks the dynamic symbol table against the header).
 """
 import os
 import subprocess
@@ -16,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsed_hip.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I", CSRC]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-I", CSRC]
 
 
 def sources():
@@ -57,7 +59,12 @@ def build(verbose=True, force=False):
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(cc, jobs))
     if jobs or force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        # hipcc keeps the host stubs of __global__ kernels at default visibility whatever -fvisibility says: the version script
+        # makes the dynamic symbol table exactly the C ABI (every entry point is named sed_*)
+        vs = os.path.join(OBJ, "exports.map")
+        with open(vs, "w") as fh:
+            fh.write("{ global: sed_*; local: *; };\n")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void kaldi_fbank_kernel(const float* __restric
         out[((size_t)b * M + f) * n_mels + tid] = (v - norm_mean) * norm_inv;
     }
 }
-extern "C" int sed_kaldi_fbank(const float* audio, float* out, int B, int N, int n_mels, const float* window, const float* tw,
+SED_API int sed_kaldi_fbank(const float* audio, float* out, int B, int N, int n_mels, const float* window, const float* tw,
                                const int* fb_start, const int* fb_len, const float* fb_w, int fb_stride, float norm_mean,
                                float norm_inv, void* stream) {
     if (n_mels < 1 || n_mels > 256) return SED_ERR_UNSUPPORTED;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         out[idx] = fb[((size_t)b * M + (size_t)tp * P + i) * F + fp * P + j];
     }
 }
-extern "C" int sed_patchify(const float* fbank, float* patches, int B, int M, int F, int P, void* stream) {
+SED_API int sed_patchify(const float* fbank, float* patches, int B, int M, int F, int P, void* stream) {
     if (P < 1 || F % P != 0) return SED_ERR_ARG;
     const int Tp = M / P, Fp = F / P;
     const size_t n = (size_t)B * Tp * Fp * P * P;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         y[(size_t)row * D + c] = (v[u] - mean) * inv * gamma[c] + beta[c];
     }
 }
-extern "C" int sed_layernorm(const float* x, const float* res, float alpha, const float* gamma, const float* beta, float* y, int M,
+SED_API int sed_layernorm(const float* x, const float* res, float alpha, const float* gamma, const float* beta, float* y, int M,
                              int D, float eps, void* stream) {
     if (M <= 0) return SED_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void posconv_mfma_kernel(const float* __restri
     }
 }
 // wsplit: (2 planes hi | lo, groups, K, 48 co, 48 ci) bf16 bit patterns of the weight-normalised filter
-extern "C" int sed_posconv_bf16x3(const float* x, const unsigned short* wsplit, const float* bias, float* y, int B, int T, int D, int K,
+SED_API int sed_posconv_bf16x3(const float* x, const unsigned short* wsplit, const float* bias, float* y, int B, int T, int D, int K,
                                   int groups, void* stream) {
     if (groups < 1 || D % groups != 0 || D / groups != PC_CG || K < 2 || (K & 1) || K % PCM_KC != 0 || D % 4 != 0) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
@@ -313,7 +313,7 @@ extern "C" int sed_posconv_bf16x3(const float* x, const unsigned short* wsplit, 
     return sed_check_launch();
 }
 
-extern "C" int sed_posconv(const float* x, const float* wt, const float* bias, float* y, int B, int T, int D, int K, int groups,
+SED_API int sed_posconv(const float* x, const float* wt, const float* bias, float* y, int B, int T, int D, int K, int groups,
                            void* stream) {
     if (groups < 1 || D % groups != 0 || D / groups != PC_CG || K < 2 || (K & 1) || K % PC_KC != 0) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         }
     }
 }
-extern "C" int sed_attention_relpos(const float* qkv, const float* relb, const float* grep_w, const float* grep_b,
+SED_API int sed_attention_relpos(const float* qkv, const float* relb, const float* grep_w, const float* grep_b,
                                     const float* grep_a, float* out, int B, int T, int H, int head_dim, void* stream) {
     if (head_dim != AT_HD || T > 4096) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;

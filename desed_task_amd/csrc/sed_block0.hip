@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void block0_fwd_kernel(const float* __restrict
     }
 }
 
-extern "C" int sed_block0_fwd(const float* x, const float* W, const float* bias, const int* bounds, const float* stats,
+SED_API int sed_block0_fwd(const float* x, const float* W, const float* bias, const int* bounds, const float* stats,
                               const float* Wg, const float* bg, float* out, int B, int T, int F, unsigned seed, unsigned thr24,
                               float dscale, const unsigned* seed_dev, void* stream) {
     if (F > B0_MAXF || F < 8 || F % 8 != 0) return SED_ERR_UNSUPPORTED;
@@ -437,12 +437,12 @@ static inline int block0_bwd_grid(int B, int T) {
     return ntiles < cap ? ntiles : cap;
 }
 // floats of scratch: one partial record per workgroup + the reduced sums (doubles)
-extern "C" long long sed_block0_bwd_scratch_floats(int B, int T, int F) {
+SED_API long long sed_block0_bwd_scratch_floats(int B, int T, int F) {
     (void)F;
     return (long long)block0_bwd_grid(B, T) * B0_NP + 2 * B0_NP + 2;
 }
 
-extern "C" int sed_block0_bwd(const float* x, const float* W, const float* bias, const int* bounds, const float* stats,
+SED_API int sed_block0_bwd(const float* x, const float* W, const float* bias, const int* bounds, const float* stats,
                               const float* gamma, const float* beta, const float* Wg, const float* bg, const float* gout,
                               float* dW, float* dbias, float* dgamma, float* dbeta, float* dWg, float* dbg, float* scratch, int B,
                               int T, int F, unsigned seed, unsigned thr24, float dscale, const unsigned* seed_dev, void* stream) {

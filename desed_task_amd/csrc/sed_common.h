@@ -17,6 +17,10 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));      // 8 bf16 bit patt
 
 #include <stdint.h>
 
+// The C-ABI entry points (include/sed_hip.h) are the ONLY symbols libsed_hip.so exports: the library is compiled with
+// -fvisibility=hidden (kernel host stubs, template instantiations and helpers stay internal), the entry points opt back in.
+#define SED_API extern "C" __attribute__((visibility("default")))
+
 #define SED_MAX_SMEM(kern, bytes) \
     (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
 

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     Wf[((a * 3 + b) * CIN + ci) * COUT + co] = w;
     if (Wd) Wd[(((2 - a) * 3 + (2 - b)) * COUT + co) * CIN + ci] = w;
 }
-extern "C" int sed_conv_pack_weights(const float* W, float* Wf, float* Wd, int COUT, int CIN, void* stream) {
+SED_API int sed_conv_pack_weights(const float* W, float* Wf, float* Wd, int COUT, int CIN, void* stream) {
     const int n = COUT * CIN * 9;
     SED_LAUNCH(pack_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, Wf, Wd, COUT, CIN);
     return sed_check_launch();
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackJobs jobs) 
     if (jobs.Wd[j]) jobs.Wd[j][(((2 - a) * 3 + (2 - b)) * COUT + co) * CIN + ci] = w;
 }
 // n <= 8 layers; W/Wf/Wd: host arrays of n device pointers (Wd entries may be null); cout/cin: host int arrays.
-extern "C" int sed_conv_pack_multi(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout, const int* cin,
+SED_API int sed_conv_pack_multi(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout, const int* cin,
                                    void* stream) {
     if (n < 1 || n > 8) return SED_ERR_ARG;
     PackJobs jobs;
@@ -120,7 +120,7 @@ static inline int wgrad_row_parts(int CIN, int B, int T, int F) {
     const int ntiles = (B * T * F + 63) / 64, cap = CIN == 64 ? 168 : 84;
     return ntiles < cap ? ntiles : cap;
 }
-extern "C" long long sed_conv_wgrad_scratch_floats(int B, int T, int F, int CIN, int COUT) {
+SED_API long long sed_conv_wgrad_scratch_floats(int B, int T, int F, int CIN, int COUT) {
     int parts = wgrad_parts(CIN, COUT, B, T, F);
     if (wgrad_row_ok(CIN, COUT, F) && wgrad_row_parts(CIN, B, T, F) > parts) parts = wgrad_row_parts(CIN, B, T, F);
     return (long long)parts * 9 * CIN * COUT;
@@ -305,7 +305,7 @@ static inline int conv_tf(int F) { return F >= 32 ? 32 : F; }
 static inline int conv_mp(int F, int CIN, int COUT) { return (CIN == 128 && COUT == 128 && F <= 4) ? 64 : 128; }
 
 // number of workgroups (= rows of `partial`, each 2*COUT floats) the forward launch uses
-extern "C" int sed_conv_fwd_blocks(int B, int T, int F, int CIN, int COUT) {
+SED_API int sed_conv_fwd_blocks(int B, int T, int F, int CIN, int COUT) {
     if (CIN == 1) return B * ((T + 15) / 16);
     const int TF = conv_tf(F);
     const int TR = conv_mp(F, CIN, COUT) / TF;
@@ -314,7 +314,7 @@ extern "C" int sed_conv_fwd_blocks(int B, int T, int F, int CIN, int COUT) {
 
 // x (B,T,F,CIN), Wp packed [9][CIN][COUT], bias [COUT] or null, y (B,T,F,COUT), partial: null or
 // [sed_conv_fwd_blocks][2*COUT] floats.
-extern "C" int sed_conv3x3(const float* x, const float* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
+SED_API int sed_conv3x3(const float* x, const float* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
                            int CIN, int COUT, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (B <= 0 || T <= 0) return SED_OK;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
 }
 // x (B,T,F) scaled log-mel; W (16,1,3,3) PyTorch layout; bounds (B,4) int32 or null.  y null = statistics pass only (the
 // conv output stays in registers: first half of the fused first block, sed_block0.hip).
-extern "C" int sed_conv0_fwd(const float* x, const float* W, const float* bias, const int* bounds, float* y, float* partial,
+SED_API int sed_conv0_fwd(const float* x, const float* W, const float* bias, const int* bounds, float* y, float* partial,
                              int B, int T, int F, int COUT, void* stream) {
     if (COUT != 16 || F > 128 || F < 1) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(BNF_THREADS) void bn_finalize_kernel(const float* _
     stats[2 * C + c] = sc;
     stats[3 * C + c] = beta[c] - mean * sc;
 }
-extern "C" int sed_bn_finalize(const float* partial, int nblocks, int C, float count, const float* gamma, const float* beta,
+SED_API int sed_bn_finalize(const float* partial, int nblocks, int C, float count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* stats, int training,
                                int update_running, void* stream) {
     if (C <= 0) return SED_ERR_ARG;
@@ -1439,13 +1439,13 @@ static int conv_wgrad_impl(const float* x, const float* dy, float* dWp, float* d
     return sed_check_launch();
 }
 // x (B,T,F,CIN), dy (B,T,F,COUT) -> dW (COUT,CIN,3,3).  dWp: scratch of sed_conv_wgrad_scratch_floats() floats.
-extern "C" int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
+SED_API int sed_conv_wgrad(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN, int COUT,
                               void* stream) {
     return conv_wgrad_impl(x, dy, dWp, dW, B, T, F, CIN, COUT, false, stream);
 }
 // Same contract; every layer with F >= 32 (narrow ones) or CIN >= 64 contracts on the split-bf16 MFMA (fp32-level accuracy,
 // ~8e-6 relative); narrow layers on tiles narrower than 32 columns use the exact-f32 all-taps kernel.
-extern "C" int sed_conv_wgrad_bf16x3(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN,
+SED_API int sed_conv_wgrad_bf16x3(const float* x, const float* dy, float* dWp, float* dW, int B, int T, int F, int CIN,
                                      int COUT, void* stream) {
     return conv_wgrad_impl(x, dy, dWp, dW, B, T, F, CIN, COUT, true, stream);
 }
@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
 // dW (16,1,3,3) PyTorch layout, accumulated with atomics (zeroed here).
 // fuse_bn = 0: `dyz` is dy.  fuse_bn = 1: `dyz` is dz = dL/d(xhat) and the BatchNorm backward is applied on the fly
 // (y, stats, gamma, dgamma, dbeta as for sed_bn_bwd_apply); dbias (16) then receives the conv-bias gradient.
-extern "C" int sed_conv0_wgrad(const float* x, const int* bounds, const float* dyz, const float* y, const float* stats,
+SED_API int sed_conv0_wgrad(const float* x, const int* bounds, const float* dyz, const float* y, const float* stats,
                                const float* gamma, const float* dgamma, const float* dbeta, float* dW, float* dbias, int B, int T,
                                int F, int COUT, int fuse_bn, int training, void* stream) {
     if (COUT != 16 || F > 128 || F < 1) return SED_ERR_UNSUPPORTED;

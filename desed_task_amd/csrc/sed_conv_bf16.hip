@@ -80,7 +80,7 @@ static inline int convb_ck(int CIN, int COUT) {
     return CIN < ck ? CIN : ck;
 }
 // n <= 8 layers; Wf / Wd buffers of 9*CIN*COUT*4 BYTES each (same size as the fp32 packs).
-extern "C" int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout,
+SED_API int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout,
                                         const int* cin, void* stream) {
     if (n < 1 || n > 8) return SED_ERR_ARG;
     PackBJobs jobs;
@@ -437,7 +437,7 @@ static inline int convb_mp(int F, int CIN, int COUT) {
     if (CIN == 128 && COUT == 128 && F <= 4) return 128;
     return 256;
 }
-extern "C" int sed_conv_fwd_blocks_bf16(int B, int T, int F, int CIN, int COUT) {
+SED_API int sed_conv_fwd_blocks_bf16(int B, int T, int F, int CIN, int COUT) {
     if (CIN == 1) return B * ((T + 15) / 16);
     const int TF = F >= 32 ? 32 : F;
     const int TR = convb_mp(F, CIN, COUT) / TF;
@@ -486,7 +486,7 @@ static int convb_dispatch(const float* x, const void* Wp, const float* bias, flo
 }
 
 // Same contract as sed_conv3x3 with Wp from sed_conv_pack_multi_bf16; the partial layout is sed_conv_fwd_blocks_bf16's.
-extern "C" int sed_conv3x3_bf16x3(const float* x, const void* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
+SED_API int sed_conv3x3_bf16x3(const float* x, const void* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
                                   int CIN, int COUT, void* stream) {
     return convb_dispatch<false>(x, Wp, bias, y, partial, B, T, F, CIN, COUT, (hipStream_t)stream, ConvBnb());
 }
@@ -494,7 +494,7 @@ extern "C" int sed_conv3x3_bf16x3(const float* x, const void* Wp, const float* b
 // Data gradient of a training-mode block with the BatchNorm backward folded into its operand staging (see ConvBnb above):
 // dz (B,T,F,CIN) = dL/d(xhat), ybn = the block's saved pre-BN conv output, stats = mean | invstd, Wd = the data-gradient pack.
 // Writes dx (B,T,F,COUT), dy_out (B,T,F,CIN) = dL/d(conv output) for the weight gradient, and dbias[CIN] = 0.  dy_out must not alias dz.
-extern "C" int sed_conv3x3_bf16x3_bnbwd(const float* dz, const float* ybn, const float* stats, const float* gamma, const float* dgamma,
+SED_API int sed_conv3x3_bf16x3_bnbwd(const float* dz, const float* ybn, const float* stats, const float* gamma, const float* dgamma,
                                         const float* dbeta, const void* Wd, float* dx, float* dy_out, float* dbias, int B, int T, int F,
                                         int CIN, int COUT, void* stream) {
     if (!dz || !ybn || !stats || !gamma || !dgamma || !dbeta || !dy_out || dy_out == dz) return SED_ERR_ARG;

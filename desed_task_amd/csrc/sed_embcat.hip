@@ -85,7 +85,7 @@ __global__ __launch_bounds__(EMB_THREADS) void embcat_fwd_kernel(const float* __
 }
 
 // x (B,T,C), emb (B,E,Te) -> z (B,T,C+E).  thr24 = 0 disables the dropout (dscale is then 1).
-extern "C" int sed_embcat_fwd(const float* x, const float* emb, float* z, int B, int T, int Te, int C, int E, unsigned seed,
+SED_API int sed_embcat_fwd(const float* x, const float* emb, float* z, int B, int T, int Te, int C, int E, unsigned seed,
                               unsigned thr24, float dscale, const unsigned* seed_dev, const int* tmask, int mode, void* stream) {
     if (B <= 0 || T <= 0) return SED_OK;
     if (Te < 1 || C < 1 || E < 1 || mode < 0 || mode > 1) return SED_ERR_ARG;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void embcat_bwd_kernel(const float* __restrict
 }
 
 // dzx (M, C) = the first C columns of dz = dy . W_cat_tf -> dx (M, C) = dzx masked with the forward's dropout mask.
-extern "C" int sed_embcat_bwd(const float* dzx, float* dx, int M, int C, int E, unsigned seed, unsigned thr24, float dscale,
+SED_API int sed_embcat_bwd(const float* dzx, float* dx, int M, int C, int E, unsigned seed, unsigned thr24, float dscale,
                               const unsigned* seed_dev, const int* tmask, int T, void* stream) {
     if (M <= 0) return SED_OK;
     if (C < 1 || E < 1 || (tmask && (T < 1 || M % T != 0))) return SED_ERR_ARG;

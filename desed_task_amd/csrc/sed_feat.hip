@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void minmax_apply_kernel(const float* __restri
 
 // x: (B, L) linear mel (apply_log=1) or any tensor (apply_log=0).  logbuf: (B, L) scratch for the log values
 // (may alias out).  partial: B*32*2 floats.  minmax: optional (B,2) output.  out may alias x when apply_log=0.
-extern "C" int sed_logscale_fwd(const float* x, float* logbuf, float* out, float* partial, float* minmax, int B, int L,
+SED_API int sed_logscale_fwd(const float* x, float* logbuf, float* out, float* partial, float* minmax, int B, int L,
                                 int apply_log, float eps, void* stream) {
     if (B <= 0 || L <= 0) return B < 0 || L < 0 ? SED_ERR_ARG : SED_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -88,7 +88,7 @@ extern "C" int sed_logscale_fwd(const float* x, float* logbuf, float* out, float
 __global__ __launch_bounds__(256) void logdb_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = logdb(x[i]);
 }
-extern "C" int sed_take_log(const float* x, float* y, long long n, void* stream) {
+SED_API int sed_take_log(const float* x, float* y, long long n, void* stream) {
     if (n <= 0) return SED_OK;
     int grid = (int)min((long long)4096, (n + 255) / 256);
     SED_LAUNCH(logdb_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void mixup_kernel(float* __restrict__ data, co
     }
 }
 // data: (n, L) in place; tmp: (n, L) scratch; perm: n int32 on device.  mode 0 = features, 1 = soft labels, 2 = hard labels.
-extern "C" int sed_mixup(float* data, float* tmp, const int* perm, float c, float one_minus_c, int n, int L, int mode,
+SED_API int sed_mixup(float* data, float* tmp, const int* perm, float c, float one_minus_c, int n, int L, int mode,
                          const float* c_dev, void* stream) {
     if (n <= 0 || L <= 0) return SED_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void mixup_multi_kernel(MixJobs J) {
             }
     }
 }
-extern "C" int sed_mixup_multi(const long long* jobs, int njobs, void* stream) {
+SED_API int sed_mixup_multi(const long long* jobs, int njobs, void* stream) {
     if (njobs <= 0) return SED_OK;
     if (njobs > MIX_JOBS || jobs == nullptr) return SED_ERR_ARG;
     MixJobs J;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void specaug_kernel(const float* __restrict__ 
         yo[e] = masked ? 0.0f : xi[e];
     }
 }
-extern "C" int sed_specaug(const float* x, float* y, const int* bounds, int B, int T, int Fq, void* stream) {
+SED_API int sed_specaug(const float* x, float* y, const int* bounds, int B, int T, int Fq, void* stream) {
     if (B <= 0) return SED_OK;
     int gx = min(64, (T * Fq + 255) / 256);
     SED_LAUNCH(specaug_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, y, bounds, T, Fq);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void specaug_bounds_seeded_kernel(int* __restr
     }
     bounds[4 * b] = f0; bounds[4 * b + 1] = f1; bounds[4 * b + 2] = t0; bounds[4 * b + 3] = t1;
 }
-extern "C" int sed_specaug_bounds_seeded(int* bounds, int B, int n, int f_param, int n_freq, int t_param, int n_time, unsigned seed,
+SED_API int sed_specaug_bounds_seeded(int* bounds, int B, int n, int f_param, int n_freq, int t_param, int n_time, unsigned seed,
                                          const unsigned* seed_dev, void* stream) {
     if (B <= 0) return SED_OK;
     if (n != 1 && n != B) return SED_ERR_ARG;
@@ -280,7 +280,7 @@ extern "C" int sed_specaug_bounds_seeded(int* bounds, int B, int n, int f_param,
     return sed_check_launch();
 }
 
-extern "C" int sed_specaug_bounds(const float* u_f, const float* u_t, int* bounds, int B, int n, int f_param, int n_freq,
+SED_API int sed_specaug_bounds(const float* u_f, const float* u_t, int* bounds, int B, int n, int f_param, int n_freq,
                                   int t_param, int n_time, void* stream) {
     if (B <= 0) return SED_OK;
     if (n != 1 && n != B) return SED_ERR_ARG;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void weak_labels_kernel(const float* __restric
     acc = wave_sum(acc);
     if (lane == 0) out[r] = acc > 0.f ? 1.0f : 0.0f;
 }
-extern "C" int sed_weak_labels(const float* labels, float* out, int n, int NC, int T, void* stream) {
+SED_API int sed_weak_labels(const float* labels, float* out, int n, int NC, int T, void* stream) {
     if (n <= 0 || NC <= 0) return SED_OK;
     if (T <= 0) return SED_ERR_ARG;
     SED_LAUNCH(weak_labels_kernel, dim3((n * NC + 3) / 4), dim3(256), 0, (hipStream_t)stream, labels, out, n * NC, T);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void dropstep_kernel(const float* __restrict__
         y[i] = (!gone && sed_keep((uint32_t)i, seed, thr24)) ? x[i] * dscale : 0.f;
     }
 }
-extern "C" int sed_dropstep(const float* x, float* y, const int* bounds, int B, int T, int C, unsigned seed, unsigned thr24,
+SED_API int sed_dropstep(const float* x, float* y, const int* bounds, int B, int T, int C, unsigned seed, unsigned thr24,
                             float dscale, const unsigned* seed_dev, void* stream) {
     if (B <= 0 || T <= 0 || C <= 0) return SED_OK;
     const size_t n = (size_t)B * T * C;

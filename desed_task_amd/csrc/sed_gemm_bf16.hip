@@ -150,9 +150,9 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_kernel(const float* __rest
 }  // namespace
 
 // defined in sed_gru.hip: the exact-f32 path, used when the operands do not meet the 16-byte requirements below
-extern "C" int sed_gemm(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
+SED_API int sed_gemm(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
                         int ldc, int transA, int transB, int split_k, int accumulate, void* stream);
-extern "C" int sed_gemm_pair(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
+SED_API int sed_gemm_pair(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
                              const float* bias1, float* C0, float* C1, int M, int N, int K, int lda, int ldb, int ldc, int transA,
                              int transB, int split_k, int accumulate, void* stream);
 
@@ -184,13 +184,13 @@ static int gemmb_dispatch(const float* A, const float* Bm, const float* bias, fl
 }
 
 // Same contract as sed_gemm, split-bf16 products (fp32-level accuracy, ~8e-6 relative).
-extern "C" int sed_gemm_bf16x3(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
+SED_API int sed_gemm_bf16x3(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
                                int ldc, int transA, int transB, int split_k, int accumulate, void* stream) {
     return gemmb_dispatch(A, Bm, bias, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, transA, transB, split_k,
                           accumulate, (hipStream_t)stream);
 }
 // Same contract as sed_gemm_pair, split-bf16 products.
-extern "C" int sed_gemm_pair_bf16x3(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
+SED_API int sed_gemm_pair_bf16x3(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
                                     const float* bias1, float* C0, float* C1, int M, int N, int K, int lda, int ldb, int ldc,
                                     int transA, int transB, int split_k, int accumulate, void* stream) {
     return gemmb_dispatch(A0, B0, bias0, C0, A1, B1, bias1, C1, 2, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate,
@@ -219,10 +219,10 @@ static inline int splitk_slices(int K, int split_k) {
     const int kps = ((K + split_k - 1) / split_k + 31) / 32 * 32;
     return (K + kps - 1) / kps;
 }
-extern "C" long long sed_gemm_splitk_scratch_floats(int M, int N, int K, int split_k) {
+SED_API long long sed_gemm_splitk_scratch_floats(int M, int N, int K, int split_k) {
     return 2LL * splitk_slices(K, split_k) * M * N;
 }
-extern "C" int sed_gemm_pair_splitk_bf16x3(const float* A0, const float* A1, const float* B0, const float* B1, float* C0, float* C1,
+SED_API int sed_gemm_pair_splitk_bf16x3(const float* A0, const float* A1, const float* B0, const float* B1, float* C0, float* C1,
                                            int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB, int split_k,
                                            float* scratch, void* stream) {
     if (M <= 0 || N <= 0) return SED_OK;
@@ -239,7 +239,7 @@ extern "C" int sed_gemm_pair_splitk_bf16x3(const float* A0, const float* A1, con
 
 // C[M][N] = A[M][K] . [B0 ; B1]: the B operand is two row-major tensors stacked along K (rows [0, ksplit) from B0, the rest
 // from B1; ksplit % 32 == 0) -- dX of a bidirectional GRU layer, whose dgi rows hold both directions side by side.
-extern "C" int sed_gemm_kcat_bf16x3(const float* A, const float* B0, const float* B1, float* Cm, int M, int N, int K, int ksplit,
+SED_API int sed_gemm_kcat_bf16x3(const float* A, const float* B0, const float* B1, float* Cm, int M, int N, int K, int ksplit,
                                     int lda, int ldb, int ldc, void* stream) {
     if (ksplit % 32 != 0 || ksplit <= 0 || ksplit >= K) return SED_ERR_ARG;
     return gemmb_dispatch(A, B0, nullptr, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, 0, 0, 1, 0,
@@ -248,7 +248,7 @@ extern "C" int sed_gemm_kcat_bf16x3(const float* A, const float* B0, const float
 
 // torch.nn.Linear forward with an optional fused activation: C[M][N] = act(A[M][K] . W[N][K]^T + bias[N]), act 0 = none, 1 = exact
 // GELU (the FFN of the BEATs encoder layers).  16-byte aligned operands, K % 4 == 0.
-extern "C" int sed_linear_bf16x3(const float* A, const float* W, const float* bias, float* Cm, int M, int N, int K, int act,
+SED_API int sed_linear_bf16x3(const float* A, const float* W, const float* bias, float* Cm, int M, int N, int K, int act,
                                  void* stream) {
     if (act < 0 || act > 1) return SED_ERR_ARG;
     return gemmb_dispatch(A, W, bias, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, K, K, N, 0, 1, 1, 0, (hipStream_t)stream,

@@ -952,7 +952,7 @@ static int launch_glu_wide_fwd(const float* y, const float* stats, const float* 
 
 // y (B,T,F,C); stats 4*C (mean, invstd, scale, shift); Wg (C,C) [out][in]; out (B,T/PT,F/PF,C).
 // dropout: keep element e when hash(e, seed) >> 8 >= thr24 (thr24 = round(p * 2^24)); dscale = 1/(1-p).
-extern "C" int sed_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
+SED_API int sed_glu_fwd(const float* y, const float* stats, const float* Wg, const float* bg, float* out, int B, int T, int F,
                            int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale,
                            const unsigned* seed_dev, int split_bf16, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -2035,7 +2035,7 @@ static int launch_glu_wide_bwd(const float* y, const float* stats, const float* 
 
 // Floats of scratch sed_glu_bwd needs: the 64/128-channel (1,2)-pooled blocks keep one partial (dWg, dbg, dgamma,
 // dbeta) per workgroup (at most 256) and reduce them in a fixed order; the narrow blocks accumulate with atomics (0).
-extern "C" long long sed_glu_bwd_scratch_floats(int B, int T, int F, int C, int PT, int PF) {
+SED_API long long sed_glu_bwd_scratch_floats(int B, int T, int F, int C, int PT, int PF) {
     (void)B; (void)T; (void)F;
     if (PT == 1 && PF == 2 && (C == 64 || C == 128)) {
         const int nt3 = (C / 32) * (C / 32), ks = nt3 >= 8 ? 1 : 8 / nt3, wms = 8 / (C / 32);
@@ -2048,7 +2048,7 @@ extern "C" long long sed_glu_bwd_scratch_floats(int B, int T, int F, int C, int 
 // gout (B,T/PT,F/PF,C) -> dz (B,T,F,C) = dL/d xhat; dWg (C,C), dbg, dgamma, dbeta (C) are overwritten (zeroed here and
 // accumulated with fp32 atomics on the narrow blocks; reduced from `scratch`, see above, on the wide ones).
 // When T % PT != 0 the dropped frames of dz are zeroed too.
-extern "C" int sed_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
+SED_API int sed_glu_bwd(const float* y, const float* stats, const float* gamma, const float* beta, const float* Wg,
                            const float* bg, const float* gout, float* dz, float* dWg, float* dbg, float* dgamma, float* dbeta,
                            float* scratch, int B, int T, int F, int C, int PT, int PF, unsigned seed, unsigned thr24, float dscale,
                            const unsigned* seed_dev, int split_bf16, void* stream) {
@@ -2134,7 +2134,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         *(float4*)(dz + p * C + 4 * v) = g;
     }
 }
-extern "C" int sed_bn_bwd_apply(const float* y, float* dz, const float* stats, const float* gamma, const float* dgamma,
+SED_API int sed_bn_bwd_apply(const float* y, float* dz, const float* stats, const float* gamma, const float* dgamma,
                                 const float* dbeta, float* dbias, long long npix, int C, int training, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (npix <= 0) return SED_OK;

@@ -248,13 +248,13 @@ static int gemm_dispatch(const float* A, const float* Bm, const float* bias, flo
 
 // C[M][N] = opA(A)[M][K] * opB(B)[K][N] + bias.  accumulate != 0 adds into C (atomics); split_k > 1 requires
 // the caller to have zeroed C (or accumulate).  Leading dimensions are in floats.
-extern "C" int sed_gemm(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
+SED_API int sed_gemm(const float* A, const float* Bm, const float* bias, float* Cm, int M, int N, int K, int lda, int ldb,
                         int ldc, int transA, int transB, int split_k, int accumulate, void* stream) {
     return gemm_dispatch(A, Bm, bias, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, transA, transB, split_k,
                          accumulate, (hipStream_t)stream);
 }
 // Two same-shape problems (the two GRU directions) in ONE launch: (A0,B0,bias0 -> C0) and (A1,B1,bias1 -> C1).
-extern "C" int sed_gemm_pair(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
+SED_API int sed_gemm_pair(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
                              const float* bias1, float* C0, float* C1, int M, int N, int K, int lda, int ldb, int ldc, int transA,
                              int transB, int split_k, int accumulate, void* stream) {
     return gemm_dispatch(A0, B0, bias0, C0, A1, B1, bias1, C1, 2, M, N, K, lda, ldb, ldc, transA, transB, split_k, accumulate,
@@ -263,7 +263,7 @@ extern "C" int sed_gemm_pair(const float* A0, const float* A1, const float* B0, 
 
 // C[M][N] = A[M][K] . [B0 ; B1]: B is two row-major tensors stacked along K (rows [0, ksplit) from B0, the rest from B1;
 // ksplit % 32 == 0).  Exact-f32 MFMA; 16-byte aligned operands required.
-extern "C" int sed_gemm_kcat(const float* A, const float* B0, const float* B1, float* Cm, int M, int N, int K, int ksplit, int lda,
+SED_API int sed_gemm_kcat(const float* A, const float* B0, const float* B1, float* Cm, int M, int N, int K, int ksplit, int lda,
                              int ldb, int ldc, void* stream) {
     if (ksplit % 32 != 0 || ksplit <= 0 || ksplit >= K) return SED_ERR_ARG;
     return gemm_dispatch(A, B0, nullptr, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, 0, 0, 1, 0,
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     }
 }
 // out[n] = sum_m X[m*ld + n] for n < nsplit, out1[n - nsplit] for nsplit <= n < N (out1 may be null when nsplit == N).
-extern "C" int sed_colsum(const float* X, float* out, float* out1, int nsplit, int M, int N, int ld, void* stream) {
+SED_API int sed_colsum(const float* X, float* out, float* out1, int nsplit, int M, int N, int ld, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (nsplit > N || (nsplit < N && out1 == nullptr)) return SED_ERR_ARG;
     sed_zero4(s, out, nsplit, out1, N - nsplit, nullptr, 0, nullptr, 0);
@@ -481,7 +481,7 @@ static inline int gru_lds_claim(int smem) {
     return kb * 1024 > smem ? kb * 1024 : smem;
 }
 
-extern "C" int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
+SED_API int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
                            float* out, float* saved, int B, int T, int H, void* stream) {
     if (H != 128 && H != 192) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void gru_bias_reduce_kernel(const float* __res
     if (j < 3 * H) { if (dbi) dbi[j] = v; }
     else if (dbh) dbh[j - 3 * H] = v;
 }
-extern "C" int sed_gru_bwd(const float* dout, const float* out, const float* saved, const float* whh0, const float* whh1,
+SED_API int sed_gru_bwd(const float* dout, const float* out, const float* saved, const float* whh0, const float* whh1,
                            float* dgi, float* dgh, float* hprev, float* dbi0, float* dbi1, float* dbh0, float* dbh1, int B, int T,
                            int H, float* scratch, void* stream) {
     if (H != 128 && H != 192) return SED_ERR_UNSUPPORTED;

@@ -257,11 +257,11 @@ __global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const float* __res
         else db2[j - 2 * ncd - NC] = v;
     }
 }
-extern "C" long long sed_head_bwd_scratch_floats(int B, int T, int D, int NC) {
+SED_API long long sed_head_bwd_scratch_floats(int B, int T, int D, int NC) {
     return (long long)B * ((T + HEAD_TS - 1) / HEAD_TS) * (2 * NC * D + 2 * NC);
 }
 
-extern "C" int sed_head_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, float* strong,
+SED_API int sed_head_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, float* strong,
                             float* psoft, float* weak, float* den, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
                             float dscale, const unsigned* seed_dev, const unsigned char* classes_valid, const unsigned char* pad_mask,
                             void* stream) {
@@ -276,7 +276,7 @@ extern "C" int sed_head_fwd(const float* x, const float* W1, const float* b1, co
     return SED_ERR_UNSUPPORTED;
 }
 
-extern "C" int sed_head_bwd(const float* x, const float* W1, const float* W2, const float* strong, const float* psoft,
+SED_API int sed_head_bwd(const float* x, const float* W1, const float* W2, const float* strong, const float* psoft,
                             const float* weak, const float* den, const float* d_strong, const float* d_weak, float* dx, float* dW1,
                             float* dW2, float* db1, float* db2, int B, int T, int D, int NC, unsigned seed, unsigned thr24,
                             float dscale, const unsigned* seed_dev, const unsigned char* classes_valid, const unsigned char* pad_mask,
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
         if (tid == 0) *(unsigned*)(work + 8 * (size_t)B) = 0u;
     }
 }
-extern "C" int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
+SED_API int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
                            const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
                            int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, int selfsup_bce,
                            int selfsup_from, const unsigned char* valid, float* work, void* stream) {

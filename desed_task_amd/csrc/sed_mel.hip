@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
     }
 }
 
-extern "C" int sed_mel_fwd(const float* audio, float* out, int B, int N, int T, int n_fft, int hop, int n_mels,
+SED_API int sed_mel_fwd(const float* audio, float* out, int B, int N, int T, int n_fft, int hop, int n_mels,
                            const float* window, const float* tw1024, const float* tw2048, const int* fb_start,
                            const int* fb_len, const float* fb_w, int fb_stride, int apply_log, void* stream) {
     if (n_fft != MEL_NFFT || n_mels > 128 || n_mels < 1 || N < n_fft / 2 + 1 || T != 1 + N / hop) return SED_ERR_UNSUPPORTED;

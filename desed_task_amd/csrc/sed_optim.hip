@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ teacher, c
     if (i == 0) for (size_t j = n4 * 4; j < n; ++j) teacher[j] = teacher[j] * alpha + one_minus_alpha * student[j];
 }
 // teacher <- alpha * teacher + (1 - alpha) * student over n floats (16-byte aligned buffers)
-extern "C" int sed_ema_update(float* teacher, const float* student, long long n, float alpha, float one_minus_alpha,
+SED_API int sed_ema_update(float* teacher, const float* student, long long n, float alpha, float one_minus_alpha,
                               const float* alpha_dev, void* stream) {
     if (n <= 0) return SED_OK;
     const size_t n4 = (size_t)n / 4;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 // torch.optim.Adam (no weight decay, no amsgrad): step_size = lr / (1 - b1^t), inv_bc2_sqrt = 1 / sqrt(1 - b2^t).
 // grad_scale folds the data-parallel 1/world_size averaging into the update.
-extern "C" int sed_adam_step(float* p, const float* g, float* m, float* v, long long n, float b1, float b2, float eps,
+SED_API int sed_adam_step(float* p, const float* g, float* m, float* v, long long n, float b1, float b2, float eps,
                              float step_size, float inv_bc2_sqrt, float grad_scale, const float* hyper_dev, void* stream) {
     if (n <= 0) return SED_OK;
     int grid = (int)(((size_t)n + 255) / 256);
@@ -57,7 +57,7 @@ extern "C" int sed_adam_step(float* p, const float* g, float* m, float* v, long 
 }
 
 // Zero up to four (small) accumulator buffers in one launch; null / 0 entries are skipped.
-extern "C" int sed_zero_buffers(float* p0, long long n0, float* p1, long long n1, float* p2, long long n2, float* p3, long long n3,
+SED_API int sed_zero_buffers(float* p0, long long n0, float* p1, long long n1, float* p2, long long n2, float* p3, long long n3,
                                 void* stream) {
     sed_zero4((hipStream_t)stream, p0, (int)n0, p1, (int)n1, p2, (int)n2, p3, (int)n3);
     return sed_check_launch();

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void median_filter_kernel(const float* __restr
 }
 
 // scores (B,T,NC) -> out (B,T,NC); win odd or even, 1 <= win <= 15 (scipy picks element win/2 of the sorted window).
-extern "C" int sed_median_filter(const float* scores, float* out, int B, int T, int NC, int win, void* stream) {
+SED_API int sed_median_filter(const float* scores, float* out, int B, int T, int NC, int win, void* stream) {
     if (win < 1 || win > POST_MAX_WIN) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0 || NC <= 0) return SED_OK;
     const size_t n = (size_t)B * T * NC;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void threshold_events_kernel(const float* __re
     counts[idx] = n;
 }
 
-extern "C" int sed_threshold_events(const float* scores, const float* thresholds, const int* true_len, int* counts, int* events,
+SED_API int sed_threshold_events(const float* scores, const float* thresholds, const int* true_len, int* counts, int* events,
                                     int B, int T, int NC, int n_thr, int max_events, void* stream) {
     if (n_thr <= 0 || max_events < (T + 1) / 2) return SED_ERR_ARG;
     if (B <= 0 || T <= 0 || NC <= 0) return SED_OK;

@@ -3,7 +3,7 @@
 #include "sed_common.h"
 
 int sed_tuning[SED_TUNE_COUNT] = {0};
-extern "C" int sed_set_tuning(int key, int value) {
+SED_API int sed_set_tuning(int key, int value) {
     if (key < 0 || key >= SED_TUNE_COUNT) return SED_ERR_ARG;
     sed_tuning[key] = value;
     return SED_OK;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64) void selftest_mfma16_bf16_kernel(const float* A
 #pragma unroll
     for (int r = 0; r < 4; ++r) C[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[r];
 }
-extern "C" int sed_selftest_mfma(const float* A, const float* Bm, float* C, int K, int shape, void* stream) {
+SED_API int sed_selftest_mfma(const float* A, const float* Bm, float* C, int K, int shape, void* stream) {
     if (shape == 32) SED_LAUNCH(selftest_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, C, K);
     else if (shape == 3216) SED_LAUNCH(selftest_mfma32_bf16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, C, K);
     else if (shape == 1632) SED_LAUNCH(selftest_mfma16_bf16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, C, K);

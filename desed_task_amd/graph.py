@@ -338,13 +338,16 @@ class GraphedStepDriver:
         bucket B all-reduce -> Adam + scheduler (eager, by-value arguments).  No collective is ever captured."""
         d = self.eager
         d.bucket_log = []               # (arm_overlap() runs at the capture only: the log is the LAST step's collectives)
+        d._mark("backward_done")        # (two graphs: of the heads + BiGRU -- bucket A is complete)
         if self.graph_cnn is not None:
             d.launch_bucket_a()
             self.graph_cnn.replay()
             d.finish_buckets()
         else:
             d.allreduce_grads()
+        d._mark("exchange_done")
         d.opt.step()
+        d._mark("adam_done")
         self.task.lr_scheduler_step(d.sched, 0, None)
 
     def run_step(self, batch, batch_idx=0, next_batch=None):
@@ -443,7 +446,12 @@ class GraphedStepDriver:
                         st.copy_(t, non_blocking=True)
             self.dyn.run_host_ops()
         self.dyn.upload()
+        probe = self.eager.probe
+        if probe is not None:
+            probe.begin()
         self.graph.replay()
         if self.eager.exchange:
             self._finish_multi()
+        if probe is not None:
+            probe.end()
         return self.loss

@@ -29,6 +29,65 @@ from . import ops as _ops
 PREFETCH_ENQUEUE_LATE = os.environ.get("SED_PF_LATE", "1") != "0"
 
 
+class ExchangeProbe:
+    """Where the time of a data-parallel step's TAIL goes (bench.py's `dist` object): marks on the compute stream
+    (HIP events, so device time) and on the host clock at
+        step_start -> backward_done -> [A_issued -> A_done ->] exchange_done -> adam_done
+    `backward_done -> exchange_done` on the DEVICE clock is the exposed cost of the gradient exchange (the collective(s) plus
+    whatever the host added by enqueueing late); the same interval on the HOST clock is what the host spent issuing it -- if that
+    exceeds the device interval the step is host-bound there (the GPU idles between the graph and Adam).  Collectives are issued
+    through torch.distributed on the backend's own stream; Work.wait() makes the compute stream wait for them, so a mark recorded
+    right after the wait lies behind the collective on the device timeline.  On a CPU device only the host clock exists."""
+
+    def __init__(self, device):
+        self.cuda = torch.device(device).type == "cuda"
+        self.steps, self.cur = [], None
+
+    def begin(self):
+        self.cur = []
+        self.mark("step_start")
+
+    def mark(self, tag):
+        if self.cur is None:
+            return
+        import time
+        ev = None
+        if self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+        self.cur.append((tag, ev, time.perf_counter()))
+
+    def end(self):
+        if self.cur is not None:
+            self.steps.append(self.cur)
+        self.cur = None
+
+    def summary(self):
+        """{"<tag a> -> <tag b>": {"device_us": median, "host_us": median}, ...} over the recorded steps + the exposed totals."""
+        import statistics
+        if self.cuda:
+            torch.cuda.synchronize()
+        seg = {}
+        for marks in self.steps:
+            for (ta, ea, ha), (tb, eb, hb) in zip(marks, marks[1:]):
+                d = seg.setdefault("%s -> %s" % (ta, tb), {"device_us": [], "host_us": []})
+                d["host_us"].append((hb - ha) * 1e6)
+                if ea is not None:
+                    d["device_us"].append(ea.elapsed_time(eb) * 1e3)
+            tags = [m[0] for m in marks]
+            if "backward_done" in tags and "exchange_done" in tags:
+                a, b = marks[tags.index("backward_done")], marks[tags.index("exchange_done")]
+                d = seg.setdefault("exposed_exchange (backward_done -> exchange_done)", {"device_us": [], "host_us": []})
+                d["host_us"].append((b[2] - a[2]) * 1e6)
+                if a[1] is not None:
+                    d["device_us"].append(a[1].elapsed_time(b[1]) * 1e3)
+        out = {}
+        for k, d in seg.items():
+            out[k] = {"device_us": round(statistics.median(d["device_us"]), 1) if d["device_us"] else None,
+                      "host_us": round(statistics.median(d["host_us"]), 1), "samples": len(d["host_us"])}
+        return out
+
+
 def rehearsing():
     """SED_DDP_REHEARSE=1: run the data-parallel step structure (graph split, bucketed all-reduces, eager Adam, start-up broadcast)
     on a process group of ONE rank.  The sums over one rank change no bit, so the step must equal the plain single-GPU step exactly
@@ -110,6 +169,7 @@ class StepDriver:
         self.overlap = bool(overlap_allreduce) and self.exchange and self.arena is not None
         self.bucket_log = []            # [(tag, first float, number of floats)] of the collectives of the last step (tests)
         self._work_a = None
+        self.probe = None               # an ExchangeProbe while bench.py times the tail of the step
         if self.exchange and broadcast_init and dist.is_initialized():
             self.broadcast_state()
 
@@ -167,9 +227,11 @@ class StepDriver:
             self.backward_joined(loss)
             if hasattr(student, "backward_cnn"):
                 student.backward_cnn()
+            self._mark("backward_done")
             self.allreduce_grads()
             return
         self.backward_joined(loss)                       # bucket A holds the BiGRU weight gradients
+        self._mark("backward_done")                      # (of the heads + BiGRU: bucket A is complete)
         self.launch_bucket_a()
         student.backward_cnn()
         self.finish_buckets()
@@ -190,6 +252,7 @@ class StepDriver:
         flat_a = all(p.grad is None or p.grad.data_ptr() == base + 4 * o
                      for p, o in zip(arena.params, arena.offsets) if o >= split)
         self._work_a = (self._reduce_bucket("A", split, n, async_op=True) or True) if flat_a else None
+        self._mark("A_issued")
 
     def finish_buckets(self):
         arena = self.task.sed_student.arena
@@ -208,10 +271,13 @@ class StepDriver:
             _gloo_fence(flat)
             self._finish_scale(arena)
             return
+        self._mark("cnn_backward_enqueued")
+        if self._work_a is not None and self._work_a is not True:
+            self._work_a.wait()
+        self._mark("A_done")
         wb = self._reduce_bucket("B", 0, split, async_op=True)
-        for w in (self._work_a, wb):
-            if w is not None and w is not True:
-                w.wait()
+        if wb is not None:
+            wb.wait()
         self._work_a = None
         # gloo only: its copy-back of the reduced buckets runs on streams of its own, and Work.wait() did not reliably order it in
         # front of a non-default compute stream on this stack -- the one two-rank run in nine that differed (2e-5) used this path
@@ -247,6 +313,10 @@ class StepDriver:
                     if not hasattr(self.opt, "grad_scale"):
                         p.grad.div_(self.world)
 
+    def _mark(self, tag):
+        if self.probe is not None:
+            self.probe.mark(tag)
+
     def arm_overlap(self):
         """Cut the student's autograd graph at the CNN output for this step when the overlapped exchange is on."""
         self.bucket_log = []
@@ -278,6 +348,16 @@ class StepDriver:
 
     def run_step(self, batch, batch_idx=0, next_batch=None, staged=None):
         task = self.task
+        if self.probe is not None:
+            self.probe.begin()
+        try:
+            return self._run_step(batch, batch_idx, next_batch, staged)
+        finally:
+            if self.probe is not None:
+                self.probe.end()
+
+    def _run_step(self, batch, batch_idx, next_batch, staged):
+        task = self.task
         self.announce(batch, next_batch, staged=staged)
         self.arm_overlap()
         loss = task.training_step(batch, batch_idx)
@@ -303,7 +383,9 @@ class StepDriver:
             task.join_prefetch()
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)   # Adam overwrites theta_s that the EMA reads
+        self._mark("exchange_done")
         self.opt.step()
+        self._mark("adam_done")
         task.lr_scheduler_step(self.sched, 0, None)
         return loss
 

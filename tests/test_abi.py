@@ -19,6 +19,11 @@ def test_library_exports_every_declared_symbol():
     dll = ctypes.CDLL(path)                                 # loads on a GPU-less host (no compute calls made)
     for name in protos:
         assert hasattr(dll, name), "libsed_hip.so does not export %s" % name
+    # ... and NOTHING else: the dynamic symbol table is exactly the header (no kernel stubs, no template instantiations)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in nm.splitlines() if ln.strip())
+    assert exported == sorted(protos), sorted(set(exported) ^ set(protos))[:10]
     # every prototype cites the reference call site it replaces or says it has none
     text = open(os.path.join(ROOT, "include", "sed_hip.h")).read()
     assert "sed_trainer.py" in text and "CRNN.py" in text and "CNN.py" in text and "RNN.py" in text

@@ -268,6 +268,12 @@ def test_bench_self_launch_dry_run():
     assert [b[0] for b in d["bucket_log"]] == ["AB"] and abs(d["bucket_log"][0][2] - 4.45) < 0.01
     assert "pipelined" in out["config"]["front_end"]
     assert len(d["ms_per_step_per_rank"]) == 2
+    # what makes a future N > 1 line self-explaining: the measured exchange tail, on the host clock here
+    tail = d["exchange_tail_us"]
+    exposed = [k for k in tail if k.startswith("exposed_exchange")]
+    assert exposed and tail[exposed[0]]["host_us"] > 0 and tail[exposed[0]]["device_us"] is None
+    assert "backward_done -> exchange_done" in tail and "exchange_done -> adam_done" in tail
+    assert "falsified by" in d["expected"] and "rccl_debug" in d
     # without a GPU and without --dry-run the bench refuses loudly instead of producing a number
     if not torch.cuda.is_available():
         r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, capture_output=True,

@@ -244,6 +244,17 @@ def test_b48_pipelined_graph_step_vs_oracle():
     assert w["modes"] == ["eager", "capture", "replay"] and w["exchange"] is False
 
 
+@pytest.mark.timeout(1500)
+def test_long_horizon_training_vs_oracle():
+    """300 consecutive optimiser steps (fresh batch each step, dropout + SpecAugment + mixup, warm-up, ramp-up, EMA, Adam), HIP vs
+    the oracle on the recorded draws, each side carrying its own weights forward: per-step loss (first 50), loss-curve window means
+    (1 %), final weight distances.  SED_LONG_STEPS overrides the length."""
+    steps = int(os.environ.get("SED_LONG_STEPS", "300"))
+    w = P.case_long_horizon_training("cuda", steps=steps)
+    print("long-horizon training vs oracle:", w)
+    assert w["student_rel_l2"] < 0.05 and w["teacher_rel_l2"] < 0.05
+
+
 def test_crnn_masks_dropstep_interpolate_vs_reference_golden():
     """SURVEY 8f rank 3, the rest: classes_mask / pad_mask in the head kernels, dropstep_recurrent, "interpolate"."""
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_emb2.npz"))
