@@ -27,13 +27,18 @@
 
 #define B0_TR 16            // input rows per workgroup tile (8 pooled rows, two per wave)
 #define B0_MAXF 128
+// LDS row pitch of the halo tile.  A wave's tap read covers 8 consecutive columns of TWO consecutive tile rows (16 pixels = 4 pooling
+// windows), and ds_read_b32 banks are (address / 4) mod 32 per group of 32 lanes: with the natural pitch F + 2 (== 2 mod 32 for every
+// F the recipes use) six of the eight columns of the two rows shared a bank -- every tap read was a 2-way conflict
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.49 on block0_fwd_kernel, profiles/r03f_pmc_wait.md).  F + 8 is == 8 mod 32: disjoint.
+#define B0_PITCH(F) ((F) + 8)
 
 // stage the (B0_TR + 2) x (F + 2) halo tile of clip b, rows t0 - 1 .. t0 + B0_TR, minus `center` (zero padding and
 // SpecAugment-masked bins hold 0 - center)
 template <int BATCH>
 __device__ __forceinline__ void b0_stage(float* tile, const float* __restrict__ x, const int* __restrict__ bounds, int b, int t0, int T,
                                          int F, float center) {
-    const int PW = F + 2, n = (B0_TR + 2) * PW;
+    const int PW = F + 2, PT = B0_PITCH(F), n = (B0_TR + 2) * PW;
     int mf0 = 0, mf1 = 0, mt0 = 0, mt1 = 0;
     if (bounds) { mf0 = bounds[4 * b]; mf1 = bounds[4 * b + 1]; mt0 = bounds[4 * b + 2]; mt1 = bounds[4 * b + 3]; }
     // every load is unconditional (clamped address, the predicate is applied to the value) and all of a thread's loads are issued
@@ -43,6 +48,7 @@ __device__ __forceinline__ void b0_stage(float* tile, const float* __restrict__ 
     for (int base = threadIdx.x; base < n; base += 256 * BATCH) {
         float v[BATCH];
         bool ok[BATCH];
+        int pad[BATCH];                                         // row * (pitch - width): where the element lands in the padded tile
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
             const int idx = base + 256 * u, ic = idx < n ? idx : n - 1;
@@ -50,6 +56,7 @@ __device__ __forceinline__ void b0_stage(float* tile, const float* __restrict__ 
             const int t = t0 - 1 + i, f = j - 1;
             const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t), fc = f < 0 ? 0 : (f >= F ? F - 1 : f);
             v[u] = x[((size_t)b * T + tc) * F + fc];
+            pad[u] = i * (PT - PW);
             ok[u] = t >= 0 && t < T && f >= 0 && f < F && !((f >= mf0 && f < mf1) || (t >= mt0 && t < mt1));
         }
         // all BATCH loads are issued before the first value is touched: without the fence the scheduler pairs every load with its
@@ -60,7 +67,7 @@ __device__ __forceinline__ void b0_stage(float* tile, const float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
             const int idx = base + 256 * u;
-            if (idx < n) tile[idx] = (ok[u] ? v[u] : 0.f) - center;
+            if (idx < n) tile[idx + pad[u]] = (ok[u] ? v[u] : 0.f) - center;
         }
     }
 }
@@ -76,9 +83,9 @@ __global__ __launch_bounds__(256) void block0_fwd_kernel(const float* __restrict
                                                          const unsigned* __restrict__ seed_dev) {
     if (seed_dev) seed += *seed_dev;            // per-step entropy in device memory (hipGraph replays)
     constexpr int C = 16;
-    __shared__ float tile[(B0_TR + 2) * (B0_MAXF + 2)];
+    __shared__ float tile[(B0_TR + 2) * B0_PITCH(B0_MAXF)];
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-    const int b = blockIdx.y, t0 = blockIdx.x * B0_TR, PW = F + 2;
+    const int b = blockIdx.y, t0 = blockIdx.x * B0_TR, PW = B0_PITCH(F);
     float wreg[4][9], breg[4], wa[4], sc[4], sh[4], bgr[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -179,12 +186,12 @@ __global__ __launch_bounds__(256, 2) void block0_bwd_kernel(const float* __restr
                                                          int center) {
     if (seed_dev) seed += *seed_dev;
     constexpr int C = 16;
-    __shared__ float tile[(B0_TR + 2) * (B0_MAXF + 2)];
+    __shared__ float tile[(B0_TR + 2) * B0_PITCH(B0_MAXF)];
     __shared__ float red[4][B0_NP];
     __shared__ __attribute__((aligned(16))) float tbuf[4][2][16 * B0_TS];
     __shared__ float kred[4];
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-    const int PW = F + 2, ntiles = B * tiles_t;
+    const int PW = B0_PITCH(F), ntiles = B * tiles_t;
     const int To = T / 2, Fo = F / 2, tpr = Fo / 4;
     // ---- centring constant: mean of a sample of this workgroup's first tile (any value is exact; a good one keeps S1 small) ----
     float k;

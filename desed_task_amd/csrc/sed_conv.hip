@@ -382,29 +382,36 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
         }
     }
     __syncthreads();
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    // Round 4: two channels per v_pk_fma_f32 (each half is the same fmaf chain as before: y keeps its bits), the statistics on the
+    // packed pipe as well, and the pixel -> (row, column) split carried incrementally (a runtime-F integer division per pixel cost
+    // about as many issue slots as the 36 FMAs it addressed).
+    f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+    int pr = (tid >> 2) / F, pc = (tid >> 2) - pr * F;
     for (int p = tid >> 2; p < C0_TR * F; p += 64) {
-        const int pr = p / F, pc = p - pr * F, t = t0 + pr;
+        const int t = t0 + pr;
         if (t < T) {
             float in[9];
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int bb = 0; bb < 3; ++bb) in[a * 3 + bb] = tile[(pr + a) * PW + pc + bb];
-            float o[4];
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) acc = fmaf(in[k], wreg[c][k], acc);
-                acc += breg[c];
-                o[c] = acc;
-                s[c] += acc;
-                s2[c] += acc * acc;
+            for (int k = 0; k < 9; ++k) {
+                const f32x2 xv = {in[k], in[k]};
+                a01 = pk_fma(xv, f32x2{wreg[0][k], wreg[1][k]}, a01);
+                a23 = pk_fma(xv, f32x2{wreg[2][k], wreg[3][k]}, a23);
             }
-            if (y) *(float4*)(y + (((size_t)b * T + t) * F + pc) * COUT + 4 * cq) = make_float4(o[0], o[1], o[2], o[3]);
+            a01 += f32x2{breg[0], breg[1]};
+            a23 += f32x2{breg[2], breg[3]};
+            s01 += a01; s23 += a23;
+            q01 = pk_fma(a01, a01, q01); q23 = pk_fma(a23, a23, q23);
+            if (y) *(float4*)(y + (((size_t)b * T + t) * F + pc) * COUT + 4 * cq) = make_float4(a01.x, a01.y, a23.x, a23.y);
         }
+        pc += 64;
+        while (pc >= F) { pc -= F; ++pr; }
     }
+    const float s[4] = {s01.x, s01.y, s23.x, s23.y}, s2[4] = {q01.x, q01.y, q23.x, q23.y};
     if (partial) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {

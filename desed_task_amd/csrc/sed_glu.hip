@@ -785,18 +785,26 @@ __global__ __launch_bounds__(512, 4) void glu_wide_fwd_b_kernel(const float* __r
 // C = 128 forward on v_mfma_f32_16x16x32_bf16 (same tiling as glu128_bwd_c_kernel below): a wave owns 16 output columns x all 64
 // rows of the tile, Wg fragments = 32 VGPRs (64 with the 32x32 tiling, which does not fit the 128-VGPR budget of two resident
 // workgroups without scratch), four independent accumulator chains, unpadded swizzled planes, per-tile address recomputation.
+//
+// DB (round 4, default): the activation planes are DOUBLE-BUFFERED in LDS (2 x 32 KB).  The single-buffered kernel serialised every
+// tile into [park the tile | barrier | MFMAs + gate / dropout / pooling epilogue | barrier]: its own timing ablation said loads 7 us,
+// parking 7, epilogue 9, MFMAs + stores 12 of the 35 us at F = 16, none of them overlapping inside a workgroup (r03: 2.0 - 2.6 TB/s,
+// SQ_WAIT_ANY 0.45 - 0.52).  Here tile t + 1 is parked into the other buffer BEFORE the MFMAs of tile t -- its ds_writes drain while the
+// matrix pipe works -- and one barrier per tile is left (everybody done with buffer t, buffer t + 1 complete).  Same arithmetic, same
+// operation order per element: bit-identical output.
 // ---------------------------------------------------------------------------------------------
+template <bool DB>
 __global__ __launch_bounds__(512, 4) void glu128_fwd_c_kernel(const float* __restrict__ y, const float* __restrict__ stats,
                                                               const float* __restrict__ Wg, const float* __restrict__ bg,
                                                               float* __restrict__ out, int B, int T, int F, uint32_t seed,
                                                               uint32_t thr24, float dscale, const unsigned* __restrict__ seed_dev) {
     if (seed_dev) seed += *seed_dev;
     constexpr int C = 128, ROWS = 64, RS = C, WS = C + 8, KS = C / 32, RB = ROWS / 16;
+    constexpr int BUF = 2 * ROWS * RS;               // one buffer = hi plane + lo plane (ushorts)
     SED_DYN_SMEM(smem);
-    unsigned short* xh = (unsigned short*)smem;      // xn [ROWS][RS] hi | lo, octet o of row m at slot o ^ (m & 15)
-    unsigned short* xl = xh + ROWS * RS;
-    unsigned short* wh = xh;                         // Wg staging (before the tile loop): plain [64][WS] hi | lo
-    unsigned short* wl = xh + 64 * WS;
+    unsigned short* xbase = (unsigned short*)smem;   // xn [ROWS][RS] hi | lo, octet o of row m at slot o ^ (m & 15); DB: two such buffers
+    unsigned short* wh = xbase;                      // Wg staging (before the tile loop): plain [64][WS] hi | lo
+    unsigned short* wl = xbase + 64 * WS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int i16 = lane & 15, g = lane >> 4;
     int n = 16 * w + i16;
@@ -846,7 +854,7 @@ __global__ __launch_bounds__(512, 4) void glu128_fwd_c_kernel(const float* __res
         }
     }
     const float bias_n = bg[n];
-    auto store_rm = [&](float4 val, int m, bool live, const float4& sc, const float4& sh) {
+    auto store_rm = [&](unsigned short* xh, float4 val, int m, bool live, const float4& sc, const float4& sh) {
         const float k = live ? 1.0f : 0.0f;                             // rows past the end: xn = 0
         val.x = fmaf(val.x, sc.x, sh.x) * k; val.y = fmaf(val.y, sc.y, sh.y) * k;
         val.z = fmaf(val.z, sc.z, sh.z) * k; val.w = fmaf(val.w, sc.w, sh.w) * k;
@@ -854,20 +862,42 @@ __global__ __launch_bounds__(512, 4) void glu128_fwd_c_kernel(const float* __res
         bf16_split2(val.x, val.y, hv.x, lv.x);
         bf16_split2(val.z, val.w, hv.y, lv.y);
         *(uint2*)(xh + rm_off(m, 4 * cq)) = hv;
-        *(uint2*)(xl + rm_off(m, 4 * cq)) = lv;
+        *(uint2*)(xh + ROWS * RS + rm_off(m, 4 * cq)) = lv;
     };
+    auto park = [&](unsigned short* xh, int row0) {     // BatchNorm + bf16 split of the tile held in ld0..3 -> planes of buffer xh
+        const float4 sc = *(const float4*)(stats + 2 * C + 4 * cq), sh = *(const float4*)(stats + 3 * C + 4 * cq);
+        const int row = row0 + 4 * rq;
+        store_rm(xh, ld0, 4 * rq, row < R, sc, sh); store_rm(xh, ld1, 4 * rq + 1, row + 1 < R, sc, sh);
+        store_rm(xh, ld2, 4 * rq + 2, row + 2 < R, sc, sh); store_rm(xh, ld3, 4 * rq + 3, row + 3 < R, sc, sh);
+    };
+    int buf = 0;
+    if (DB) {
+        __syncthreads();                                                // Wg staging consumed: the planes may be written
+        if (tile < ntiles) {
+            park(xbase, tile * ROWS);
+            if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+        }
+        __syncthreads();
+    }
     for (; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS;
         sed_opaque(i16); sed_opaque(g); sed_opaque(n); sed_opaque(cq); sed_opaque(rq);   // addresses recomputed per tile, not spilled
-        __syncthreads();                                                // previous tile fully consumed (first pass: Wg staging)
-        {
-            const float4 sc = *(const float4*)(stats + 2 * C + 4 * cq), sh = *(const float4*)(stats + 3 * C + 4 * cq);
-            const int row = row0 + 4 * rq;
-            store_rm(ld0, 4 * rq, row < R, sc, sh); store_rm(ld1, 4 * rq + 1, row + 1 < R, sc, sh);
-            store_rm(ld2, 4 * rq + 2, row + 2 < R, sc, sh); store_rm(ld3, 4 * rq + 3, row + 3 < R, sc, sh);
+        unsigned short* xh = xbase + (DB ? buf * BUF : 0);
+        unsigned short* xl = xh + ROWS * RS;
+        if (DB) {
+            // tile t + 1 (raw values loaded one iteration ago) goes into the OTHER buffer now; nobody reads that buffer before the
+            // barrier at the end of this iteration, and its last readers passed the barrier at the end of the previous one
+            const int tn = tile + (int)gridDim.x;
+            if (tn < ntiles) {
+                park(xbase + (buf ^ 1) * BUF, tn * ROWS);
+                if (tn + (int)gridDim.x < ntiles) load_tile(tn + gridDim.x);   // in flight under the MFMAs and the epilogue below
+            }
+        } else {
+            __syncthreads();                                            // previous tile fully consumed (first pass: Wg staging)
+            park(xh, row0);
+            __syncthreads();
+            if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);     // in flight under the MFMAs below
         }
-        __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);     // in flight under the MFMAs below
         f32x4 acc[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -909,6 +939,10 @@ __global__ __launch_bounds__(512, 4) void glu128_fwd_c_kernel(const float* __res
                 if (full || 2 * o + 2 < R) out[(size_t)(o + 1) * C + n] = 0.5f * (vv[2] + vv[3]);
             }
         }
+        if (DB) {
+            __syncthreads();                                            // buffer `buf` is free again, buffer `buf ^ 1` is complete
+            buf ^= 1;
+        }
     }
 }
 
@@ -934,10 +968,16 @@ static int launch_glu_wide_fwd(const float* y, const float* stats, const float* 
     const int cap = glu_grid_cap(512);                                  // two 8-wave workgroups per CU
     int grid = ntiles < cap ? ntiles : cap;
     if (grid < 1) return SED_OK;
-    if (SPLIT && C == 128 && sed_tuning[SED_TUNE_GLU_FWD128] != 1) {      // 1 = the 32x32x16 tiling (A/B runs)
-        constexpr int SMEM_C = 2 * 64 * (128 + 8) * 2;                    // Wg staging [64][C + 8] hi | lo; the tile planes need 32 KB
-        SED_MAX_SMEM(glu128_fwd_c_kernel, SMEM_C);
-        SED_LAUNCH(glu128_fwd_c_kernel, dim3(grid), dim3(512), SMEM_C, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev);
+    if (SPLIT && C == 128 && sed_tuning[SED_TUNE_GLU_FWD128] != 1) {      // 1 = the 32x32x16 tiling, 2 = single-buffered planes (A/B runs)
+        if (sed_tuning[SED_TUNE_GLU_FWD128] == 2) {
+            constexpr int SMEM_C = 2 * 64 * (128 + 8) * 2;                // Wg staging [64][C + 8] hi | lo; the tile planes need 32 KB
+            SED_MAX_SMEM(glu128_fwd_c_kernel<false>, SMEM_C);
+            SED_LAUNCH(glu128_fwd_c_kernel<false>, dim3(grid), dim3(512), SMEM_C, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev);
+        } else {
+            constexpr int SMEM_D = 2 * 2 * 64 * 128 * 2;                  // two buffers of hi | lo planes (the Wg staging fits inside)
+            SED_MAX_SMEM(glu128_fwd_c_kernel<true>, SMEM_D);
+            SED_LAUNCH(glu128_fwd_c_kernel<true>, dim3(grid), dim3(512), SMEM_D, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev);
+        }
         return sed_check_launch();
     }
     if (SPLIT) {
