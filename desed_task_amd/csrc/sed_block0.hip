@@ -38,6 +38,10 @@
 template <int BATCH>
 __device__ __forceinline__ void b0_stage(float* tile, const float* __restrict__ x, const int* __restrict__ bounds, int b, int t0, int T,
                                          int F, float center) {
+    // (forward only: the persistent backward kernel sits at 254 registers and spills 17 of them with the float4 path)
+    if constexpr (BATCH >= 8) {
+        if (sed_stage_halo_f4<B0_TR, 256, B0_MAXF>(tile, x, bounds, b, t0, T, F, B0_PITCH(F), center)) return;
+    }
     const int PW = F + 2, PT = B0_PITCH(F), n = (B0_TR + 2) * PW;
     int mf0 = 0, mf1 = 0, mt0 = 0, mt1 = 0;
     if (bounds) { mf0 = bounds[4 * b]; mf1 = bounds[4 * b + 1]; mt0 = bounds[4 * b + 2]; mt1 = bounds[4 * b + 3]; }

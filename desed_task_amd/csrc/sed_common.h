@@ -322,6 +322,56 @@ __device__ __forceinline__ void sed_wave_prio_high() {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Halo tile of the single-channel first layer (conv0 / block 0): rows t0 - 1 .. t0 + ROWS of clip b, bins -1 .. F, staged into LDS at
+// row pitch `pitch` (tile[i * pitch + j] <-> frame t0 - 1 + i, bin j - 1), minus `center`; zero padding and SpecAugment-masked
+// bins / frames hold 0 - center.  Round 4: float4 row loads on a (row, bin quad) thread map -- the two halo COLUMNS are always zero
+// padding and are written, never loaded; a row of F bins is F / 4 aligned 16-byte loads.  The scalar version it replaces walked
+// the flattened (ROWS + 2) x (F + 2) tile one float at a time and paid an integer division by the runtime width, two clamps and
+// five compares per element: ~ 60 instructions per load, ten loads per thread -- a quarter of conv0_kernel's instructions.
+// All loads are unconditional (clamped row) and in flight before the first LDS store (tools/isa_exposed_loads.py).
+// Needs F % 4 == 0 and F / 4 a power of two (every n_mels of the recipes); returns false otherwise (caller takes the scalar path).
+// ---------------------------------------------------------------------------------------------
+template <int ROWS, int NTHREADS, int MAXF, int NB = 8>       // NB: float4 loads in flight per thread (register budget of the caller)
+__device__ __forceinline__ bool sed_stage_halo_f4(float* tile, const float* __restrict__ x, const int* __restrict__ bounds, int b, int t0,
+                                                  int T, int F, int pitch, float center) {
+    const int nq = F >> 2;
+    if ((F & 3) || (nq & (nq - 1)) || nq < 1) return false;
+    const int sh = 31 - __builtin_clz(nq), total = (ROWS + 2) << sh, tid = threadIdx.x;
+    int mf0 = 0, mf1 = 0, mt0 = 0, mt1 = 0;
+    if (bounds) { mf0 = bounds[4 * b]; mf1 = bounds[4 * b + 1]; mt0 = bounds[4 * b + 2]; mt1 = bounds[4 * b + 3]; }
+    constexpr int NIT = ((ROWS + 2) * (MAXF / 4) + NTHREADS - 1) / NTHREADS, NBB = NIT < NB ? NIT : NB;
+#pragma unroll
+    for (int u0 = 0; u0 < NIT; u0 += NBB) {
+        float4 v[NBB];
+#pragma unroll
+        for (int k = 0; k < NBB; ++k) {
+            const int idx = tid + NTHREADS * (u0 + k), ic = idx < total ? idx : total - 1;
+            const int i = ic >> sh, q = ic - (i << sh);
+            const int t = t0 - 1 + i, tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+            v[k] = *(const float4*)(x + ((size_t)b * T + tc) * F + 4 * q);
+        }
+        sed_sched_fence();
+#pragma unroll
+        for (int k = 0; k < NBB; ++k) { sed_pin(v[k].x); sed_pin(v[k].y); sed_pin(v[k].z); sed_pin(v[k].w); }
+#pragma unroll
+        for (int k = 0; k < NBB; ++k) {
+            const int idx = tid + NTHREADS * (u0 + k);
+            if (idx < total) {
+                const int i = idx >> sh, q = idx - (i << sh), t = t0 - 1 + i, f = 4 * q;
+                const bool rowok = t >= 0 && t < T && !(t >= mt0 && t < mt1);
+                float* d = tile + i * pitch + 1 + f;
+                d[0] = ((rowok && !(f >= mf0 && f < mf1)) ? v[k].x : 0.f) - center;
+                d[1] = ((rowok && !(f + 1 >= mf0 && f + 1 < mf1)) ? v[k].y : 0.f) - center;
+                d[2] = ((rowok && !(f + 2 >= mf0 && f + 2 < mf1)) ? v[k].z : 0.f) - center;
+                d[3] = ((rowok && !(f + 3 >= mf0 && f + 3 < mf1)) ? v[k].w : 0.f) - center;
+            }
+        }
+    }
+    if (tid < 2 * (ROWS + 2)) tile[(tid >> 1) * pitch + ((tid & 1) ? F + 1 : 0)] = 0.f - center;
+    return true;
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // packed fp32 FMA (v_pk_fma_f32): two lanes-worth of FMAs per VALU issue slot
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }

@@ -360,7 +360,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
     }
     int mf0 = 0, mf1 = 0, mt0 = 0, mt1 = 0;
     if (bounds) { mf0 = bounds[4 * b]; mf1 = bounds[4 * b + 1]; mt0 = bounds[4 * b + 2]; mt1 = bounds[4 * b + 3]; }
-    {   // halo tile: unconditional loads (clamped address, predicate applied to the value), all in flight before the first store --
+    if (!sed_stage_halo_f4<C0_TR, 256, 128>(tile, x, bounds, b, t0, T, F, PW, 0.f)) {
+        // (scalar fallback for widths that are not 4 x a power of two) halo tile: unconditional loads (clamped address, predicate applied to the value), all in flight before the first store --
         // with the load inside the bounds branch every one of the ten was followed by s_waitcnt vmcnt(0) (tools/isa_exposed_loads.py)
         const int n = (C0_TR + 2) * PW;
         constexpr int NIT = ((C0_TR + 2) * (128 + 2) + 255) / 256;
@@ -382,34 +383,45 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ x,
         }
     }
     __syncthreads();
-    // Round 4: two channels per v_pk_fma_f32 (each half is the same fmaf chain as before: y keeps its bits), the statistics on the
-    // packed pipe as well, and the pixel -> (row, column) split carried incrementally (a runtime-F integer division per pixel cost
-    // about as many issue slots as the 36 FMAs it addressed).
+    // Round 4: a lane owns a VERTICAL PAIR of pixels (rows 2 rp, 2 rp + 1 of one bin) for its four channels: twelve LDS values feed
+    // 36 packed FMAs (the six taps of the two middle rows serve both pixels) where one pixel per lane read nine values for 18 -- the
+    // ISA of the one-pixel loop was 55 instructions of which 18 were FMAs.  Every output is still its own fmaf chain over the taps
+    // 0..8 in the same order (two channels per v_pk_fma_f32), so y keeps its bits; the statistics are summed on the packed pipe
+    // too, and the item -> (row pair, bin) split is carried incrementally (no runtime-F division per item).
     f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
-    int pr = (tid >> 2) / F, pc = (tid >> 2) - pr * F;
-    for (int p = tid >> 2; p < C0_TR * F; p += 64) {
-        const int t = t0 + pr;
-        if (t < T) {
-            float in[9];
+    int rp = (tid >> 2) / F, pc = (tid >> 2) - rp * F;
+    for (int p = tid >> 2; p < (C0_TR / 2) * F; p += 64) {
+        const int ta = t0 + 2 * rp;
+        if (ta < T) {
+            float in[4][3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int bb = 0; bb < 3; ++bb) in[a * 3 + bb] = tile[(pr + a) * PW + pc + bb];
-            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+                for (int bb = 0; bb < 3; ++bb) in[a][bb] = tile[(2 * rp + a) * PW + pc + bb];
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f}, b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const f32x2 xv = {in[k], in[k]};
-                a01 = pk_fma(xv, f32x2{wreg[0][k], wreg[1][k]}, a01);
-                a23 = pk_fma(xv, f32x2{wreg[2][k], wreg[3][k]}, a23);
+                const f32x2 w01 = {wreg[0][k], wreg[1][k]}, w23 = {wreg[2][k], wreg[3][k]};
+                const float xa = in[k / 3][k % 3], xb = in[k / 3 + 1][k % 3];
+                a01 = pk_fma(f32x2{xa, xa}, w01, a01);
+                a23 = pk_fma(f32x2{xa, xa}, w23, a23);
+                b01 = pk_fma(f32x2{xb, xb}, w01, b01);
+                b23 = pk_fma(f32x2{xb, xb}, w23, b23);
             }
-            a01 += f32x2{breg[0], breg[1]};
-            a23 += f32x2{breg[2], breg[3]};
+            const f32x2 bias01 = {breg[0], breg[1]}, bias23 = {breg[2], breg[3]};
+            a01 += bias01; a23 += bias23;
             s01 += a01; s23 += a23;
             q01 = pk_fma(a01, a01, q01); q23 = pk_fma(a23, a23, q23);
-            if (y) *(float4*)(y + (((size_t)b * T + t) * F + pc) * COUT + 4 * cq) = make_float4(a01.x, a01.y, a23.x, a23.y);
+            if (y) *(float4*)(y + (((size_t)b * T + ta) * F + pc) * COUT + 4 * cq) = make_float4(a01.x, a01.y, a23.x, a23.y);
+            if (ta + 1 < T) {
+                b01 += bias01; b23 += bias23;
+                s01 += b01; s23 += b23;
+                q01 = pk_fma(b01, b01, q01); q23 = pk_fma(b23, b23, q23);
+                if (y) *(float4*)(y + (((size_t)b * T + ta + 1) * F + pc) * COUT + 4 * cq) = make_float4(b01.x, b01.y, b23.x, b23.y);
+            }
         }
         pc += 64;
-        while (pc >= F) { pc -= F; ++pr; }
+        while (pc >= F) { pc -= F; ++rp; }
     }
     const float s[4] = {s01.x, s01.y, s23.x, s23.y}, s2[4] = {q01.x, q01.y, q23.x, q23.y};
     if (partial) {

@@ -786,12 +786,17 @@ __global__ __launch_bounds__(512, 4) void glu_wide_fwd_b_kernel(const float* __r
 // rows of the tile, Wg fragments = 32 VGPRs (64 with the 32x32 tiling, which does not fit the 128-VGPR budget of two resident
 // workgroups without scratch), four independent accumulator chains, unpadded swizzled planes, per-tile address recomputation.
 //
-// DB (round 4, default): the activation planes are DOUBLE-BUFFERED in LDS (2 x 32 KB).  The single-buffered kernel serialised every
+// DB (round 4; sed_set_tuning glu_fwd128 = 3, NOT the default -- measured neutral, see the end of this comment): the activation
+// planes are DOUBLE-BUFFERED in LDS (2 x 32 KB).  The single-buffered kernel serialised every
 // tile into [park the tile | barrier | MFMAs + gate / dropout / pooling epilogue | barrier]: its own timing ablation said loads 7 us,
 // parking 7, epilogue 9, MFMAs + stores 12 of the 35 us at F = 16, none of them overlapping inside a workgroup (r03: 2.0 - 2.6 TB/s,
 // SQ_WAIT_ANY 0.45 - 0.52).  Here tile t + 1 is parked into the other buffer BEFORE the MFMAs of tile t -- its ds_writes drain while the
 // matrix pipe works -- and one barrier per tile is left (everybody done with buffer t, buffer t + 1 complete).  Same arithmetic, same
-// operation order per element: bit-identical output.
+// operation order per element: bit-identical output.  Measured (same box, alternating, tools/ab_tuning.sh): step 3.232 / 3.212 ms with it,
+// 3.223 / 3.225 without; per launch inside the replayed step (rocprofv3) 22.99 vs 22.29 us on average over the four shapes: the barrier
+// and the parking were NOT what the kernel waits for -- with two resident workgroups per CU one's parking already overlaps the other's
+// MFMAs, and the 25 issue slots per element of the gate (exp, rcp, dropout hash) put the kernel's VALU floor at ~ 6 TB/s-equivalent
+// (DESIGN.md section 11).  Kept selectable so that the number can be reproduced.
 // ---------------------------------------------------------------------------------------------
 template <bool DB>
 __global__ __launch_bounds__(512, 4) void glu128_fwd_c_kernel(const float* __restrict__ y, const float* __restrict__ stats,
@@ -968,8 +973,8 @@ static int launch_glu_wide_fwd(const float* y, const float* stats, const float* 
     const int cap = glu_grid_cap(512);                                  // two 8-wave workgroups per CU
     int grid = ntiles < cap ? ntiles : cap;
     if (grid < 1) return SED_OK;
-    if (SPLIT && C == 128 && sed_tuning[SED_TUNE_GLU_FWD128] != 1) {      // 1 = the 32x32x16 tiling, 2 = single-buffered planes (A/B runs)
-        if (sed_tuning[SED_TUNE_GLU_FWD128] == 2) {
+    if (SPLIT && C == 128 && sed_tuning[SED_TUNE_GLU_FWD128] != 1) {      // 1 = the 32x32x16 tiling, 3 = double-buffered planes (A/B runs)
+        if (sed_tuning[SED_TUNE_GLU_FWD128] != 3) {
             constexpr int SMEM_C = 2 * 64 * (128 + 8) * 2;                // Wg staging [64][C + 8] hi | lo; the tile planes need 32 KB
             SED_MAX_SMEM(glu128_fwd_c_kernel<false>, SMEM_C);
             SED_LAUNCH(glu128_fwd_c_kernel<false>, dim3(grid), dim3(512), SMEM_C, s, y, stats, Wg, bg, out, B, T, F, seed, thr24, dscale, seed_dev);
