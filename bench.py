@@ -428,8 +428,6 @@ def main():
                     help="diagnostics: GPU wall-clock stamps inside the replayed step (tools/ts_probe.py); adds ~10 one-thread kernels")
     ap.add_argument("--dump-launches", default=None, metavar="PATH",
                     help="diagnostics: write every launch shape's median time (the rows behind roofline_families) as JSON to PATH")
-    ap.add_argument("--upload-memcpy", action="store_true",
-                    help="A/B: upload the step-varying arguments with hipMemcpyAsync (round 3) instead of the sed_copy_words kernel")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: run the same program on the CPU emulator of the kernels over gloo at toy sizes (launch-path check "
                          "only, the numbers are meaningless)")
@@ -487,9 +485,6 @@ def main():
     if args.no_bn_fold:
         from desed_task_amd import ops as _ops3
         _ops3.BN_BWD_FOLD = False
-    if args.upload_memcpy:
-        from desed_task_amd import graph as _graph_mod
-        _graph_mod.UPLOAD_KERNEL = False
     if args.rehearse_exchange:
         if args.gpus != 1:
             raise SystemExit("--rehearse-exchange is the one-rank rehearsal of the N > 1 step: use it with --gpus 1")

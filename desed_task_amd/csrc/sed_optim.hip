@@ -62,18 +62,3 @@ SED_API int sed_zero_buffers(float* p0, long long n0, float* p1, long long n1, f
     sed_zero4((hipStream_t)stream, p0, (int)n0, p1, (int)n1, p2, (int)n2, p3, (int)n3);
     return sed_check_launch();
 }
-
-// Upload of the step-varying launch arguments (desed_task_amd/graph.py, DynArgs): n 32-bit words from HOST-PINNED memory (device-
-// mapped: the kernel reads it over the fabric) into the device buffer the replayed graph's kernels read.  A kernel on the step's own
-// stream instead of hipMemcpyAsync: the runtime's copy went out as a blit on ANOTHER hardware queue, and the two cross-queue
-// hand-overs (previous Adam -> copy -> first kernel of the graph) were most of the ~ 50 us a replayed step spent outside its graph.
-__global__ __launch_bounds__(256) void copy_words_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, int n) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
-}
-SED_API int sed_copy_words(unsigned* dst, const unsigned* src, int n, void* stream) {
-    if (n <= 0) return SED_OK;
-    int grid = (n + 255) / 256;
-    if (grid > 64) grid = 64;
-    SED_LAUNCH(copy_words_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, src, n);
-    return sed_check_launch();
-}

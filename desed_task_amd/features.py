@@ -135,9 +135,10 @@ def take_log(mels):
     return y
 
 
-def minmax_scale(x, eps=1e-8, apply_log=False, return_minmax=False):
+def minmax_scale(x, eps=1e-8, apply_log=False, return_minmax=False, out=None):
     """Instance min-max scaling over all non-batch dims to [-1, 1]; optionally fused with take_log.
-    Works on any layout whose clips are contiguous blocks (our (B,F,T) views included)."""
+    Works on any layout whose clips are contiguous blocks (our (B,F,T) views included).
+    out: a tensor of x's shape AND strides to write into (the pipelined front half's hand-over buffer) instead of a fresh one."""
     if x.dim() == 3 and not x.is_contiguous():
         xt = as_btf(x)
         view_back = True
@@ -147,7 +148,14 @@ def minmax_scale(x, eps=1e-8, apply_log=False, return_minmax=False):
     _lib.check_tensor(xt, "features")
     B = xt.shape[0]
     L = xt.numel() // max(B, 1)
-    out = torch.empty_like(xt)
+    if out is None:
+        out = torch.empty_like(xt)
+    else:
+        if out.shape != x.shape or out.stride() != x.stride() or out.dtype != xt.dtype or out.device != xt.device:
+            raise ValueError("minmax_scale: `out` must have the input's shape, strides, dtype and device")
+        out = out.transpose(1, 2) if view_back else out
+        if not out.is_contiguous():
+            raise ValueError("minmax_scale: `out` must be dense in the input's layout")
     partial = torch.empty(B * 64, device=xt.device, dtype=torch.float32)
     mm = torch.empty(B, 2, device=xt.device, dtype=torch.float32) if return_minmax else None
     _lib.get().call("sed_logscale_fwd", xt.data_ptr(), out.data_ptr(), out.data_ptr(), partial.data_ptr(),

@@ -21,8 +21,6 @@ plain eager path.
 import torch
 
 _active = None
-UPLOAD_KERNEL = True        # DynArgs.upload(): kernel reading the pinned slot (default) vs hipMemcpyAsync (bench.py --upload-memcpy, A/B)
-
 
 def active():
     """The DynArgs the current step runs under (None = plain eager launches with by-value arguments)."""
@@ -99,13 +97,9 @@ class DynArgs:
         if self._ring_ev[i] is not None:
             self._ring_ev[i].synchronize()           # the copy that last read this slot (RING steps ago) has executed
         self._ring[i].copy_(self.hbuf)               # host -> host, synchronous, 2.3 KB
-        if UPLOAD_KERNEL:
-            # a kernel on the step's own stream reads the pinned (device-mapped) slot: no blit on another hardware queue between the
-            # previous step's Adam and this step's first kernel (sed_copy_words)
-            from . import _lib
-            _lib.get().call("sed_copy_words", self.dev.data_ptr(), self._ring[i].data_ptr(), self.dev.numel(), _lib.stream_ptr(self.dev))
-        else:
-            self.dev.copy_(self._ring[i], non_blocking=True)
+        # (round 4: a kernel on the step's own stream reading the pinned slot instead of this runtime copy -- which goes out as a blit
+        #  on another hardware queue -- was built and measured: 3.153 / 3.146 vs 3.161 / 3.144 ms per step, same box: neutral, removed)
+        self.dev.copy_(self._ring[i], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._ring_ev[i] = ev

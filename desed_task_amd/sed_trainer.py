@@ -105,10 +105,11 @@ class SEDTask4(_Base):
         s = self.scaler
         return isinstance(s, TorchScaler) and s.statistic == "instance" and s.normtype == "minmax" and tuple(s.dims) == (1, 2)
 
-    def scaled_logmel(self, mel_feats):
-        """scaler(take_log(mels)) -- one fused log + per-clip min/max + affine pass when the scaler is instance/minmax."""
+    def scaled_logmel(self, mel_feats, out=None):
+        """scaler(take_log(mels)) -- one fused log + per-clip min/max + affine pass when the scaler is instance/minmax.
+        out: write into this tensor (mel_feats' shape and strides) when the fused pass runs; ignored otherwise."""
         if self._fused_scaler():
-            return features.minmax_scale(mel_feats, eps=self.scaler.eps, apply_log=True)
+            return features.minmax_scale(mel_feats, eps=self.scaler.eps, apply_log=True, out=out)
         return self.scaler(self.take_log(mel_feats))
 
     def detect(self, mel_feats, model, embeddings=None):
@@ -239,12 +240,14 @@ class SEDTask4(_Base):
             # the same announced batch (after reset_pipeline(): weights loaded in between) then starts from unmixed labels.
             lab = self._pro_buffer("labels", labels)
             lab.copy_(labels)
-            x, lab, lab_w = self._front(audio, lab, fresh=True)
+            x, lab, lab_w = self._front(audio, lab, fresh=True, x_into_pro=True)
             with torch.no_grad(), _ops.seed_stream("teacher_cnn"):
                 ht = self.sed_teacher.forward_cnn(x)
-            # into PERSISTENT buffers: a captured step reads fixed addresses
+            # into PERSISTENT buffers: a captured step reads fixed addresses (x was written there directly when the scaler is fused)
             self._pro_buffer("labels_weak", lab_w).copy_(lab_w)
-            self._pro_buffer("x", x).copy_(x)
+            px = self._pro_buffer("x", x)
+            if px.data_ptr() != x.data_ptr():
+                px.copy_(x)
             self._pro_buffer("ht", ht).copy_(ht)
             self._pro["ready"] = True
             _ops.probe("prefetch_end")
@@ -276,10 +279,10 @@ class SEDTask4(_Base):
         if p is None:
             p = self._pro = {"ready": False}
         t = p.get(key)
-        if t is None or t.shape != like.shape or t.device != like.device or t.dtype != like.dtype:
+        if t is None or t.shape != like.shape or t.stride() != like.stride() or t.device != like.device or t.dtype != like.dtype:
             if p["ready"]:
                 raise RuntimeError("the batch shape changed between a prefetch and the step that consumes it")
-            t = p[key] = torch.empty_like(like, memory_format=torch.contiguous_format)
+            t = p[key] = torch.empty_like(like)      # (preserve_format: x is a (B, n_mels, T) VIEW of frame-major storage and must stay one)
         return t
 
     def reset_pipeline(self):
@@ -309,7 +312,7 @@ class SEDTask4(_Base):
             return self.mel_spec.frames_major(audio, out=self._feature_buffer(audio)).transpose(1, 2)
         return self.mel_spec(audio)
 
-    def _front(self, audio, labels, fresh=False):
+    def _front(self, audio, labels, fresh=False, x_into_pro=False):
         """Front half of the step (sed_trainer.py:280-301 + the log / scaler part of detect): mel -> weak labels -> mixup of the
         weak and the strong group (features and labels in place; coin flip, c, permutations drawn on the host in the reference's
         order) -> log + per-clip min-max.  -> (x, labels, labels_weak)"""
@@ -340,7 +343,9 @@ class SEDTask4(_Base):
             mixup_inplace_(features_[weak_sl], labels_weak, mixup_label_type=mixup_type, batch=mb)
             mixup_inplace_(features_[strong_sl], labels[strong_sl], mixup_label_type=mixup_type, batch=mb)
             mb.launch()
-        return self.scaled_logmel(features_), labels, labels_weak         # x is shared by student and teacher
+        # x is shared by student and teacher; the pipelined front half writes it straight into its hand-over buffer
+        x_out = self._pro_buffer("x", features_) if x_into_pro else None
+        return self.scaled_logmel(features_, out=x_out), labels, labels_weak
 
     def training_step(self, batch, batch_indx):
         from .nnet.CRNN import CRNN

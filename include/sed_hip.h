@@ -315,11 +315,6 @@ int sed_ema_update(float* teacher, const float* student, long long n, float alph
 int sed_adam_step(float* p, const float* g, float* m, float* v, long long n, float b1, float b2, float eps,
                   float step_size, float inv_bc2_sqrt, float grad_scale, const float* hyper_dev, void* stream);
 
-/* graph.DynArgs upload (no reference counterpart: the reference passes these as Python scalars per launch): copy n 32-bit words
- * from host-pinned, device-mapped memory `src` to device memory `dst` with a kernel on `stream` (not a runtime memcpy: that goes out
- * on another hardware queue and costs two cross-queue hand-overs between two replayed steps). */
-int sed_copy_words(unsigned* dst, const unsigned* src, int n, void* stream);
-
 /* Zero up to four small accumulator buffers in one launch (null / 0 entries are skipped). */
 int sed_zero_buffers(float* p0, long long n0, float* p1, long long n1, float* p2, long long n2, float* p3, long long n3,
                      void* stream);
