@@ -238,7 +238,8 @@ class GraphedStepDriver:
         from .launcher import StepDriver
         self.eager = StepDriver(task, world_size, ema_side_stream=ema_side_stream, prefetch=prefetch)
         self.static_next = None     # pipelined front-end: static buffer of the NEXT batch's waveforms (the graph's mel branch reads it)
-        self.static_next_labels = None      # ... and, prefetch "teacher", of its labels (mixed in place by the graph's prologue)
+        self.static_next_labels = None      # ... and, prefetch "teacher", of its labels (read by the graph's side branch)
+        self.static_next_extras = {}        # ... and of whatever else of the next batch the front half reads (2024: the embeddings)
         self.task = task
         self.world = world_size
         self.warmup = warmup
@@ -265,12 +266,15 @@ class GraphedStepDriver:
         task = self.task
         if teacher_level and (len(batch) < 2 or batch[1] is None):
             raise ValueError('prefetch "teacher": the batch must carry its labels')
-        for src, dst in ((batch[0], self.static_next), (batch[1] if teacher_level else None, self.static_next_labels)):
+        extras = task.next_batch_extras(batch) if (teacher_level and hasattr(task, "next_batch_extras")) else {}
+        pairs = [(batch[0], self.static_next), (batch[1] if teacher_level else None, self.static_next_labels)]
+        pairs += [(extras[k], self.static_next_extras[k]) for k in self.static_next_extras]
+        for src, dst in pairs:
             if src is not None and src.data_ptr() != dst.data_ptr():
                 if src.shape != dst.shape:
                     raise ValueError("batch tensor shapes changed after the step was captured")
                 dst.copy_(src, non_blocking=True)
-        task.set_next_batch(self.static_next, self.static_next_labels if teacher_level else None)
+        task.set_next_batch(self.static_next, self.static_next_labels if teacher_level else None, dict(self.static_next_extras))
         task.launch_prefetch(task.prefetch_point)
         task.join_prefetch()
         self.eager._announced = None            # (whatever was announced before the pipeline was reset is void)
@@ -289,6 +293,10 @@ class GraphedStepDriver:
     def next_label_buffer(self):
         """prefetch "teacher": the static buffer of the NEXT batch's labels (mixed in place by the graph's prologue)."""
         return self.static_next_labels
+
+    def next_extra_buffers(self):
+        """prefetch "teacher": {name: static buffer} of the other next-batch tensors the front half reads (2024: "embeddings")."""
+        return self.static_next_extras
 
     def next_audio_buffer(self):
         """Pipelined front-end: the static buffer the graph's prefetch branch reads the NEXT batch's waveforms from (None when off
@@ -386,7 +394,7 @@ class GraphedStepDriver:
                 self._reprime(batch, teacher_level)
         if pipelined:
             self.eager.announce(batch, next_batch, staged=self.static_next)
-            nxt, nxt_lab = task._next_audio, task._next_labels
+            nxt, nxt_lab, nxt_ext = task._next_audio, task._next_labels, (task._next_extras or {})
             if self.graph is None:
                 ready = task._feat_ready or (task._pro is not None and task._pro["ready"])
                 if nxt is None or not ready or (teacher_level and nxt_lab is None):
@@ -395,13 +403,19 @@ class GraphedStepDriver:
                 self.static_next = torch.empty_like(nxt)
                 if teacher_level:
                     self.static_next_labels = torch.empty_like(nxt_lab)
-            for src, dst in ((nxt, self.static_next), (nxt_lab if teacher_level else None, self.static_next_labels)):
+                    self.static_next_extras = {k: torch.empty_like(v) for k, v in nxt_ext.items()}
+            pairs = [(nxt, self.static_next), (nxt_lab if teacher_level else None, self.static_next_labels)]
+            if teacher_level:
+                if set(nxt_ext) != set(self.static_next_extras):
+                    raise ValueError("the announced batch's extra tensors changed after the step was captured")
+                pairs += [(nxt_ext[k], self.static_next_extras[k]) for k in self.static_next_extras]
+            for src, dst in pairs:
                 if src is not None and src.data_ptr() != dst.data_ptr():
                     if src.shape != dst.shape:
                         raise ValueError("next_batch tensor shapes changed after the step was captured")
                     dst.copy_(src, non_blocking=True)
             if self.graph is None:
-                task.set_next_batch(self.static_next, self.static_next_labels)
+                task.set_next_batch(self.static_next, self.static_next_labels, dict(self.static_next_extras))
             else:
                 task.set_next_batch(None, None)
         if self.graph is None:
@@ -435,14 +449,16 @@ class GraphedStepDriver:
         else:
             if len(batch) != len(self.static):
                 raise ValueError("batch arity changed after the step was captured")
+            skip = getattr(task, "prefetched_batch_fields", (1,)) if teacher_level else ()
             for st, t in zip(self.static, batch):
                 if st is not None:
                     if not torch.is_tensor(t) or t.shape != st.shape:
                         raise ValueError("batch tensor shapes changed after the step was captured")
                     if pipelined and st is self.static[0]:
                         continue                            # the graph reads this batch's FEATURES (prefetched), not its waveforms
-                    if teacher_level and st is self.static[1]:
-                        continue                            # ... and its labels as the previous replay's prologue mixed them
+                    if teacher_level and any(st is self.static[i] for i in skip if i < len(self.static)):
+                        continue                            # ... and its labels (+ the 2024 step's embeddings) as the previous
+                                                            # replay's side branch left them in the hand-over buffers
                     if t.data_ptr() != st.data_ptr():       # a loader may fill the static buffers directly (input_buffers())
                         st.copy_(t, non_blocking=True)
             self.dyn.run_host_ops()

@@ -342,7 +342,8 @@ class StepDriver:
         if getattr(task, "prefetch_level", "features") == "teacher" and nxt is not None:
             if len(next_batch) < 2 or next_batch[1] is None:
                 raise ValueError('prefetch "teacher": next_batch must carry the labels too (they are mixed one step early)')
-            task.set_next_batch(nxt, next_batch[1])
+            extras = task.next_batch_extras(next_batch) if hasattr(task, "next_batch_extras") else {}
+            task.set_next_batch(nxt, next_batch[1], extras)
         else:
             task.set_next_batch(nxt, None)
 

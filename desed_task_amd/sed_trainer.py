@@ -195,6 +195,7 @@ class SEDTask4(_Base):
     _feat_ready = False
     _next_audio = None
     _next_labels = None
+    _next_extras = None                 # other tensors of the announced batch the front half needs (2024: the embeddings)
     _pro = None
     _pf_stream = None
 
@@ -202,10 +203,21 @@ class SEDTask4(_Base):
         """Announce the waveforms of the NEXT batch (None: there is none); consumed by launch_prefetch() in this step."""
         self._next_audio = audio
 
-    def set_next_batch(self, audio, labels=None):
+    def set_next_batch(self, audio, labels=None, extras=None):
         """Announce the NEXT batch: waveforms and -- for prefetch_level "teacher" -- its labels (copied into the hand-over buffer and
-        mixed THERE one step early; the caller's tensor is only read)."""
-        self._next_audio, self._next_labels = audio, labels
+        mixed THERE one step early; the caller's tensor is only read) and whatever else of it the front half needs (`extras`, see
+        next_batch_extras)."""
+        self._next_audio, self._next_labels, self._next_extras = audio, labels, (extras or None)
+
+    prefetch_teacher_ok = True          # this class's training_step consumes a "teacher"-level prefetch (subclasses that override
+                                        # training_step without that support must set it to False)
+
+    prefetched_batch_fields = (1,)      # batch-tuple positions (besides the waveforms) a primed "teacher"-level step does not read
+
+    def next_batch_extras(self, next_batch):
+        """{name: tensor} of the announced batch tuple that the pipelined front half reads besides waveforms and labels.  The plain
+        and the 2023 `pretrained` steps need nothing (their embeddings enter behind the CNN and are not mixed)."""
+        return {}
 
     def _feature_buffer(self, audio):
         T = 1 + audio.shape[1] // self.mel_spec.hop_length
@@ -220,13 +232,13 @@ class SEDTask4(_Base):
         """Fork point `point` of the step: if it is the configured one and a next batch was announced, enqueue its front half on
         the prefetch stream (ordered after everything the current stream -- and the streams in `after`: the EMA's -- has enqueued
         so far)."""
-        audio, labels = self._next_audio, self._next_labels
+        audio, labels, extras = self._next_audio, self._next_labels, self._next_extras
         if point != self.prefetch_point or audio is None:
             return
-        self._next_audio = self._next_labels = None
+        self._next_audio = self._next_labels = self._next_extras = None
         teacher = self.prefetch_level == "teacher" and labels is not None
-        if teacher and type(self).training_step is not SEDTask4.training_step:
-            raise NotImplementedError('prefetch_level "teacher" is built for the 2023 training step only')
+        if teacher and not self.prefetch_teacher_ok:
+            raise NotImplementedError('prefetch_level "teacher" is not built for %s.training_step' % type(self).__name__)
         if teacher and point != "backward":
             raise RuntimeError('prefetch_level "teacher" needs the fork point "backward" (the teacher weights after this step\'s EMA)')
 
@@ -236,11 +248,7 @@ class SEDTask4(_Base):
                 self.mel_spec.frames_major(audio, out=self._feature_buffer(audio))
                 self._feat_ready = True
                 return
-            # The labels are mixed in the hand-over buffer, NOT in the caller's tensor: an inline front half that has to re-run on
-            # the same announced batch (after reset_pipeline(): weights loaded in between) then starts from unmixed labels.
-            lab = self._pro_buffer("labels", labels)
-            lab.copy_(labels)
-            x, lab, lab_w = self._front(audio, lab, fresh=True, x_into_pro=True)
+            x, lab_w = self._prefetch_front(audio, labels, extras or {})
             with torch.no_grad(), _ops.seed_stream("teacher_cnn"):
                 ht = self.sed_teacher.forward_cnn(x)
             # into PERSISTENT buffers: a captured step reads fixed addresses (x was written there directly when the scaler is fused)
@@ -267,11 +275,20 @@ class SEDTask4(_Base):
                 self._pf_stream.wait_stream(s)
         # the announced tensors were allocated on the caller's stream and may be released by the caller as soon as run_step returns:
         # tell the allocator that this stream still reads (and mixes) them
-        for t in (audio, labels):
+        for t in (audio, labels) + tuple((extras or {}).values()):
             if t is not None:
                 t.record_stream(self._pf_stream)
         with torch.cuda.stream(self._pf_stream):
             body()
+
+    def _prefetch_front(self, audio, labels, extras):
+        """Front half of the ANNOUNCED batch for the pipelined step -> (x, labels_weak); the mixed labels are left in the hand-over
+        buffer `_pro["labels"]`.  They are mixed THERE, not in the caller's tensor: an inline front half that has to re-run on the
+        same announced batch (after reset_pipeline(): weights loaded in between) then starts from unmixed labels."""
+        lab = self._pro_buffer("labels", labels)
+        lab.copy_(labels)
+        x, _, lab_w = self._front(audio, lab, fresh=True, x_into_pro=True)
+        return x, lab_w
 
     def _pro_buffer(self, key, like):
         """Persistent hand-over buffer `key` of the pipelined front half, shaped like `like` (created on first use)."""
@@ -289,7 +306,7 @@ class SEDTask4(_Base):
         """Forget a front half that was prefetched for the next step (after weights were loaded in between: the teacher's CNN output
         in the hand-over buffers belongs to the old weights).  The next step then runs its front half inline."""
         self._feat_ready = False
-        self._next_audio = self._next_labels = None
+        self._next_audio = self._next_labels = self._next_extras = None
         if self._pro is not None:
             self._pro["ready"] = False
 
@@ -347,8 +364,49 @@ class SEDTask4(_Base):
         x_out = self._pro_buffer("x", features_) if x_into_pro else None
         return self.scaled_logmel(features_, out=x_out), labels, labels_weak
 
-    def training_step(self, batch, batch_indx):
+    def _forward_pair(self, x, ht=None, embeddings=None, **tail_kw):
+        """Student (with grad) and teacher (no grad) forward on the same scaled features x -> (strong_s, weak_s, strong_t, weak_t).
+        ht: the teacher's CNN output when the previous step already computed it (pipelined front half), else None.
+        tail_kw: forward_tail keywords of the multi-data-set recipes (classes_mask, pad_mask).
+        Both CNN encoders first (they fill the GPU), then the two latency-bound tails -- BiGRU recurrence (96 workgroups each) + head --
+        side by side on two HIP streams: they are independent and together still leave CUs idle.  (Running the WHOLE teacher forward
+        concurrently was measured to be a net loss.)  The teacher's CNN draws its dropout / SpecAugment seeds from its own private
+        stream, so that when it runs -- here, or one step ahead -- changes no mask."""
         from .nnet.CRNN import CRNN
+        split = isinstance(self.sed_student, CRNN) and isinstance(self.sed_teacher, CRNN)
+        tstream = self._tail_stream(x.device)
+        if tstream is None:
+            self.launch_prefetch("tails")       # (single-stream / CPU path: the position of the fork is immaterial)
+            if split:
+                strong_s, weak_s = self.sed_student.forward_tail(self.sed_student.forward_cnn(x), embeddings, **tail_kw)
+            else:
+                strong_s, weak_s = self.sed_student(x, embeddings=embeddings, **tail_kw)
+            with torch.no_grad():
+                if split:
+                    if ht is None:
+                        with _ops.seed_stream("teacher_cnn"):
+                            ht = self.sed_teacher.forward_cnn(x)
+                    strong_t, weak_t = self.sed_teacher.forward_tail(ht, embeddings, **tail_kw)
+                else:
+                    strong_t, weak_t = self.sed_teacher(x, embeddings=embeddings, **tail_kw)
+            return strong_s, weak_s, strong_t, weak_t
+        hs = self.sed_student.forward_cnn(x)
+        if ht is None:
+            with torch.no_grad(), _ops.seed_stream("teacher_cnn"):
+                ht = self.sed_teacher.forward_cnn(x)
+        main = torch.cuda.current_stream(x.device)
+        self.launch_prefetch("tails")
+        tstream.wait_stream(main)
+        with torch.cuda.stream(tstream), torch.no_grad():
+            strong_t, weak_t = self.sed_teacher.forward_tail(ht, embeddings, **tail_kw)
+        strong_s, weak_s = self.sed_student.forward_tail(hs, embeddings, **tail_kw)
+        main.wait_stream(tstream)
+        ht.record_stream(tstream)
+        strong_t.record_stream(main)
+        weak_t.record_stream(main)
+        return strong_s, weak_s, strong_t, weak_t
+
+    def training_step(self, batch, batch_indx):
         audio, labels = batch[0], batch[1]
         embeddings = self._batch_embeddings(batch)        # NOT mixed up with the features (sed_trainer_pretrained.py:320-330)
         indx_synth, indx_weak, indx_unlabelled = self.hparams["training"]["batch_size"]
@@ -364,37 +422,7 @@ class SEDTask4(_Base):
         else:
             x, labels, labels_weak = self._front(audio, labels)
             ht = None
-        split = isinstance(self.sed_student, CRNN) and isinstance(self.sed_teacher, CRNN)
-        tstream = self._tail_stream(x.device)
-        if tstream is None:
-            self.launch_prefetch("tails")       # (single-stream / CPU path: the position of the fork is immaterial)
-            strong_s, weak_s = self.sed_student(x, embeddings=embeddings)
-            with torch.no_grad():
-                if split:
-                    if ht is None:
-                        with _ops.seed_stream("teacher_cnn"):
-                            ht = self.sed_teacher.forward_cnn(x)
-                    strong_t, weak_t = self.sed_teacher.forward_tail(ht, embeddings)
-                else:
-                    strong_t, weak_t = self.sed_teacher(x, embeddings=embeddings)
-        else:
-            # Both CNN encoders first (they fill the GPU), then the two latency-bound tails -- BiGRU recurrence (96
-            # workgroups each) + head -- side by side on two HIP streams: they are independent and together still leave
-            # CUs idle.  (Running the WHOLE teacher forward concurrently was measured to be a net loss.)
-            hs = self.sed_student.forward_cnn(x)
-            if ht is None:
-                with torch.no_grad(), _ops.seed_stream("teacher_cnn"):
-                    ht = self.sed_teacher.forward_cnn(x)
-            main = torch.cuda.current_stream(x.device)
-            self.launch_prefetch("tails")
-            tstream.wait_stream(main)
-            with torch.cuda.stream(tstream), torch.no_grad():
-                strong_t, weak_t = self.sed_teacher.forward_tail(ht, embeddings)
-            strong_s, weak_s = self.sed_student.forward_tail(hs, embeddings)
-            main.wait_stream(tstream)
-            ht.record_stream(tstream)
-            strong_t.record_stream(main)
-            weak_t.record_stream(main)
+        strong_s, weak_s, strong_t, weak_t = self._forward_pair(x, ht, embeddings)
         sched = self.scheduler["scheduler"]
         const_max = self.hparams["training"]["const_max"]
         if dyn is not None:

@@ -57,17 +57,27 @@ class SEDTask4(_SEDTask4):
             mixup_inplace_(embeddings[sl], labels[sl], mixup_label_type=mixup_type, dyn=dyn, gate=gate, batch=batches[1])
         return features_, embeddings, labels
 
-    def training_step(self, batch, batch_indx):
-        audio, labels, padded_indxs, embeddings, valid_class_mask = self._unpack_batch(batch)
-        features_ = self._features(audio)
-        indx_maestro, indx_synth, indx_strong, indx_weak, indx_unlabelled = (int(v) for v in np.cumsum(self.hparams["training"]["batch_size"]))
+    # ---- pipelined front half (SEDTask4.launch_prefetch, round 4) ---------------------------------------------------------------
+    # The 2024 front half is mel -> mixup inside each data set (features + labels, then embeddings + labels again) -> weak labels
+    # -> log / min-max.  Announced one step early it works on COPIES of the announced labels and embeddings (the hand-over buffers
+    # `_pro["labels"]`, `_pro["embeddings"]`), so the caller's tensors are only read.
+    prefetched_batch_fields = (1, 3)    # labels and embeddings come out of the hand-over buffers
+
+    def next_batch_extras(self, next_batch):
+        if len(next_batch) < 4 or next_batch[3] is None:
+            raise ValueError("the 2024 step expects batches (audio, labels, padded_indxs, embeddings, valid_class_mask)")
+        return {"embeddings": next_batch[3]}
+
+    def _group_bounds(self):
+        return tuple(int(v) for v in np.cumsum(self.hparams["training"]["batch_size"]))
+
+    def _front_2024(self, audio, labels, embeddings, fresh=False, x_into_pro=False):
+        """mel -> per-data-set mixup of (features, labels) and (embeddings, labels), in place on the tensors given -> weak labels
+        (after mixup, :354) -> log / min-max (:318-356).  Host draws in the reference's order.  -> (x, labels_weak)"""
+        features_ = self._features(audio, fresh)
+        indx_maestro, indx_synth, indx_strong, indx_weak, indx_unlabelled = self._group_bounds()
         if indx_weak > features_.shape[0]:
             raise ValueError("batch smaller than the configured data-set sizes")
-        embeddings = embeddings.float()
-        if not embeddings.is_contiguous():
-            embeddings = embeddings.contiguous()
-        valid = (valid_class_mask != 0).to(torch.uint8).contiguous()
-
         mixup_type = self.hparams["training"].get("mixup")
         groups = ((indx_strong, indx_weak), (indx_maestro, indx_strong), (0, indx_maestro))          # :341-351, in this order
         dyn = _graph.active()
@@ -87,13 +97,41 @@ class SEDTask4(_SEDTask4):
                 self.apply_mixup(features_, embeddings, labels, a, b, batches=mbs)
             mbs[0].launch()
             mbs[1].launch()
-
         labels_weak = features.weak_labels(labels[indx_strong:indx_weak])       # after mixup (:354); class masking: loss kernel
-        x = self.scaled_logmel(features_)
-        self.launch_prefetch("tails")
-        strong_s, weak_s = self.sed_student(x, embeddings=embeddings, classes_mask=valid)
-        with torch.no_grad():
-            strong_t, weak_t = self.sed_teacher(x, embeddings=embeddings, classes_mask=valid)
+        x_out = self._pro_buffer("x", features_) if x_into_pro else None
+        return self.scaled_logmel(features_, out=x_out), labels_weak
+
+    @staticmethod
+    def _dense_embeddings(embeddings):
+        embeddings = embeddings.float()
+        return embeddings if embeddings.is_contiguous() else embeddings.contiguous()
+
+    def _prefetch_front(self, audio, labels, extras):
+        lab = self._pro_buffer("labels", labels)
+        lab.copy_(labels)
+        src = self._dense_embeddings(extras["embeddings"])
+        emb = self._pro_buffer("embeddings", src)
+        emb.copy_(src)
+        return self._front_2024(audio, lab, emb, fresh=True, x_into_pro=True)
+
+    def training_step(self, batch, batch_indx):
+        audio, labels, padded_indxs, embeddings, valid_class_mask = self._unpack_batch(batch)
+        indx_maestro, indx_synth, indx_strong, indx_weak, indx_unlabelled = self._group_bounds()
+        valid = (valid_class_mask != 0).to(torch.uint8).contiguous()
+        dyn = _graph.active()
+        pro = self._pro if (self._pro is not None and self._pro["ready"]) else None
+        if pro is not None:
+            # the previous step ran this step's front half and the teacher's CNN forward under its backward
+            pro["ready"] = False
+            if pro["labels"].shape != labels.shape or pro["embeddings"].shape != embeddings.shape:
+                raise RuntimeError("the prefetched front half does not match this batch's shape")
+            x, ht = pro["x"].clone(), pro["ht"]       # (clone: this step's backward still reads x while the next prefetch rewrites it)
+            labels, labels_weak, embeddings = pro["labels"], pro["labels_weak"], pro["embeddings"]
+        else:
+            embeddings = self._dense_embeddings(embeddings)
+            x, labels_weak = self._front_2024(audio, labels, embeddings)
+            ht = None
+        strong_s, weak_s, strong_t, weak_t = self._forward_pair(x, ht, embeddings, classes_mask=valid)
 
         sched = self.scheduler["scheduler"]
         const_max = self.hparams["training"]["const_max"]

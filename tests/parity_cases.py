@@ -2124,6 +2124,94 @@ def case_training_step_2024(dev, golden):
 # ------------------------------------------------------------------------------------------------
 # frozen BEATs extractor
 # ------------------------------------------------------------------------------------------------
+def build_task_2024(dev, bs=(2, 1, 1, 2, 2), nclass=27, dropout=0.5, dropstep=0.3, seed=7):
+    """The 2024 recipe's task (27 classes, n_RNN_cell 192, frozen 768-d embeddings, dropstep_recurrent) on closed-form weights."""
+    from desed_task_amd.arena import FusedAdam
+    from desed_task_amd.nnet.CRNN import CRNN
+    from desed_task_amd.sed_trainer_pretrained_2024 import SEDTask4
+    from desed_task_amd.utils.schedulers import ExponentialWarmup
+    config = recipe_config(bs)
+    config["training"].update(mixup_prob=0.5, epoch_decay=100)
+    config["net"] = dict(net_config_2024(), dropout=dropout, dropstep_recurrent=dropstep)
+    if dropout > 0:
+        config["net"].update(specaugm_t_p=0.2, specaugm_f_p=0.2)
+    config["pretrained"] = {"e2e": False, "freezed": True, "model": "beats"}
+    sd = O.make_state_dict(seed=seed, nclass=nclass, embedding_size=768, hidden=192)
+    student = CRNN(**config["net"])
+    student.load_state_dict({k: v.clone() for k, v in sd.items()})
+    student = student.to(dev) if dev != "cpu" else student
+    opt = FusedAdam(student.parameters(), lr=1e-3, betas=(0.9, 0.999), arena=student)
+    sched = {"scheduler": ExponentialWarmup(opt, 1e-3, 5), "interval": "step"}
+
+    class Enc:
+        labels = list(range(nclass))
+    task = SEDTask4(config, Enc(), student, None, opt=opt, scheduler=sched)
+    task.train()
+    if dev != "cpu":
+        task.to(dev)
+    return task
+
+
+def case_prefetch_2024_equals_unpipelined(dev, graph=False, steps=5, n_samp=16000 + 1024, te=31):
+    """The 2024 five-data-set step with its front half (mel, per-data-set mixup of features AND embeddings, weak labels, log /
+    min-max) and the teacher's CNN forward pipelined under the previous step's backward == the unpipelined order, bit for bit, over
+    different batches, with dropout + SpecAugment + dropstep + mixup on; the last step announces no successor.  The announced labels
+    and embeddings are only read (mixed in the hand-over buffers).  graph=True: GraphedStepDriver (eager, capture, replays, eager
+    fallback at the end)."""
+    import random
+    from desed_task_amd import graph as G
+    from desed_task_amd import ops as _ops
+    from desed_task_amd.launcher import StepDriver
+    bs, nclass = (2, 1, 1, 2, 2), 27
+    B = sum(bs)
+    n_out = (1 + n_samp // 256) // 4
+    ns = bs[0] + bs[1] + bs[2]
+    batches = []
+    for i in range(steps):
+        audio = O.synth_audio(B, n_samp, seed=700 + 13 * i)
+        labels = (O.lcg_fill((B, nclass, n_out), 50 + i, 0.5, 0.5) < 0.1).float()
+        labels[ns:ns + bs[3], :, 1:] = 0.0
+        labels[ns + bs[3]:] = 0.0
+        emb = O.lcg_fill((B, 768, te), 90 + i, 1.0)
+        valid = torch.zeros(B, nclass, dtype=torch.bool)
+        valid[:bs[0], 10:] = True
+        valid[bs[0]:, :10] = True
+        batches.append(tuple(to(dev, t) for t in (audio, labels, emb, valid)))
+    originals = [(b[1].clone(), b[2].clone()) for b in batches]
+    results = []
+    for mode in ("plain", "pipelined"):
+        task = build_task_2024(dev, bs, nclass)
+        pf = "teacher" if mode == "pipelined" else None
+        driver = G.GraphedStepDriver(task, world_size=1, warmup=1, prefetch=pf) if graph else StepDriver(task, world_size=1, prefetch=pf)
+        random.seed(41); np.random.seed(101); torch.manual_seed(101)
+        if dev != "cpu":
+            torch.cuda.manual_seed(101)
+        _ops.reseed_dropout()
+        losses = []
+        for step in range(steps):
+            a, l, e, v = batches[step]
+            if mode == "pipelined":
+                batch = (a, l, None, e, v)                                   # announced tensors are only read: no private copies
+                nxt = (batches[step + 1][0], batches[step + 1][1], None, batches[step + 1][2], batches[step + 1][3]) if step + 1 < steps else None
+                loss = driver.run_step(batch, step, next_batch=nxt)
+            else:
+                loss = driver.run_step((a, l.clone(), None, e.clone(), v), step)      # (the plain step mixes its batch in place)
+            losses.append(float(loss.detach()))
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        if mode == "pipelined":
+            for b, (lo, eo) in zip(batches[1:], originals[1:]):
+                assert torch.equal(b[1], lo) and torch.equal(b[2], eo), "an announced tensor was modified in place"
+            assert task._pro is not None and "embeddings" in task._pro
+            if graph:
+                assert driver.next_extra_buffers().keys() == {"embeddings"} and driver.eager_fallbacks == 1
+        results.append((losses, task.sed_student.arena.flat.detach().cpu().clone(), task.sed_teacher.arena.flat.detach().cpu().clone()))
+    (l0, s0, t0), (l1, s1, t1) = results
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(s0, s1) and torch.equal(t0, t1)
+    return l0
+
+
 def np_kaldi_fbank64(wave, n_mels=128):
     """Independent float64 numpy implementation of Kaldi's fbank with the options BEATs uses (cross-check of the unpinned front-end)."""
     x = wave.astype(np.float64) * 32768.0

@@ -168,3 +168,8 @@ def test_pipelined_epoch_boundaries_and_reset(emu):
     reset_pipeline() between two steps recomputes the front half from UNMIXED labels (the hipGraph forms run on the GPU)."""
     P.case_pipelined_epoch_boundary("cpu", point="teacher", graph=False, epochs=2, per_epoch=2, n_samp=2048 + 1024)
     P.case_pipelined_epoch_boundary("cpu", point="teacher", graph=False, epochs=2, per_epoch=3, n_samp=2048 + 1024, reset_after=0)
+
+
+def test_prefetched_2024_step_equals_unpipelined(emu):
+    """The 2024 five-data-set step, front half + teacher CNN forward one step early == the unpipelined order, bit for bit."""
+    P.case_prefetch_2024_equals_unpipelined("cpu", graph=False, steps=3, n_samp=2048 + 1024, te=9)

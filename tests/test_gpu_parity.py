@@ -262,6 +262,13 @@ def test_crnn_masks_dropstep_interpolate_vs_reference_golden():
     P.case_dropstep_draws_and_dropout("cuda")
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_prefetched_2024_step_equals_unpipelined(graph):
+    """the 2024 step's front half (mixup of features AND embeddings per data set) and the teacher's CNN forward
+    under the previous step's backward, eager and hipGraph == the unpipelined order, bit for bit."""
+    P.case_prefetch_2024_equals_unpipelined("cuda", graph=graph)
+
+
 def test_training_step_2024_vs_reference_golden():
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_2024.npz"))
     P.case_training_step_2024("cuda", G)
