@@ -202,13 +202,13 @@ SED_API int sed_gemm_pair_bf16x3(const float* A0, const float* A1, const float* 
 // (M = 384, N = 128 / 256, K = 7488, 26 slices) faster than 5 M fp32 atomics on 98 K addresses (31 / 43 us per pair).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ C0, float* __restrict__ C1,
                                                             int nslices, int M, int N, int ldc) {
-    const int MN4 = M * N / 4, i = blockIdx.x * 256 + threadIdx.x, zb = blockIdx.y;
+    const int MN4 = M * N / 4, i = blockIdx.x * 256 + threadIdx.x, zb = blockIdx.y, nb = gridDim.y;      // nb: 2 = pair, 1 = single
     if (i >= MN4) return;
     const float4* src = (const float4*)part + (size_t)zb * MN4 + i;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
     for (int z = 0; z < nslices; ++z) {
-        const float4 v = src[(size_t)2 * z * MN4];
+        const float4 v = src[(size_t)nb * z * MN4];
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     const int e = 4 * i, m = e / N, n = e - m * N;
@@ -233,6 +233,22 @@ SED_API int sed_gemm_pair_splitk_bf16x3(const float* A0, const float* A1, const 
                                   nullptr, 0, 0, scratch);
     if (rc != SED_OK) return rc;
     SED_LAUNCH(splitk_reduce_kernel, dim3((M * N / 4 + 255) / 256, 2), dim3(256), 0, s, (const float*)scratch, C0, C1,
+               splitk_slices(K, split_k), M, N, ldc);
+    return sed_check_launch();
+}
+
+// One product with the same deterministic split-K (the `cat_tf` weight gradient of the embedding recipes: dW = dy^T . z over K = B T
+// rows; until round 4 it accumulated its slices with float atomics into a zero-filled dW).  scratch: sed_gemm_splitk_scratch_floats.
+SED_API int sed_gemm_splitk_bf16x3(const float* A, const float* Bm, float* Cm, int M, int N, int K, int lda, int ldb, int ldc,
+                                   int transA, int transB, int split_k, float* scratch, void* stream) {
+    if (M <= 0 || N <= 0) return SED_OK;
+    if (!scratch || N % 4 != 0 || ldc % 4 != 0 || K <= 0) return SED_ERR_ARG;
+    if (((uintptr_t)Cm & 15) != 0) return SED_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = gemmb_dispatch(A, Bm, nullptr, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, transA, transB,
+                                  split_k, 0, s, nullptr, 0, 0, scratch);
+    if (rc != SED_OK) return rc;
+    SED_LAUNCH(splitk_reduce_kernel, dim3((M * N / 4 + 255) / 256, 1), dim3(256), 0, s, (const float*)scratch, Cm, Cm,
                splitk_slices(K, split_k), M, N, ldc);
     return sed_check_launch();
 }

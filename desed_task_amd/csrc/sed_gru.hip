@@ -270,33 +270,33 @@ SED_API int sed_gemm_kcat(const float* A, const float* B0, const float* B1, floa
                          (hipStream_t)stream, B1 - (size_t)ksplit * ldb, ksplit);
 }
 
-// column sums: out[n] = sum_m X[m*ld + n], n < N  (bias gradients); out is zeroed here, atomics across row chunks.
-// A workgroup covers 64 columns x rows_per_block rows: four row lanes per column (256-byte row reads per wave), combined in
-// LDS, one atomic per column.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ out, float* __restrict__ out1,
-                                                     int nsplit, int M, int N, int ld, int rows_per_block) {
-    __shared__ float part[4][64];
-    const int col = threadIdx.x & 63, lane = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + col;
-    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+// column sums: out[n] = sum_m X[m*ld + n], n < N  (bias gradients).  Deterministic since round 4 (it was zero fill + one float
+// atomic per (column, row chunk): the last float atomics on a recipe path -- the `cat_tf` bias gradient of the embedding recipes):
+// one workgroup owns 16 columns for ALL rows -- 64 row lanes per column (a wave reads 4 rows x 64 B), each summing its rows in
+// order, combined by a fixed-order tree in LDS.  M ~ 10^4 rows x 64 B per workgroup: a few us, no scratch, no zero fill.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ X, float* __restrict__ out, float* __restrict__ out1,
+                                                      int nsplit, int M, int N, int ld) {
+    __shared__ float part[64][16];
+    const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + col;
     float acc = 0.f;
     if (n < N)
-        for (int r = r0 + lane; r < r1; r += 4) acc += X[(size_t)r * ld + n];
+        for (int r = lane; r < M; r += 64) acc += X[(size_t)r * ld + n];
     part[lane][col] = acc;
     __syncthreads();
-    if (lane == 0 && n < N) {
-        acc = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
-        atomicAdd(n < nsplit ? out + n : out1 + (n - nsplit), acc);
+#pragma unroll
+    for (int h = 32; h > 0; h >>= 1) {
+        if (lane < h) part[lane][col] += part[lane + h][col];
+        __syncthreads();
     }
+    if (lane == 0 && n < N) *(n < nsplit ? out + n : out1 + (n - nsplit)) = part[0][col];
 }
 // out[n] = sum_m X[m*ld + n] for n < nsplit, out1[n - nsplit] for nsplit <= n < N (out1 may be null when nsplit == N).
 SED_API int sed_colsum(const float* X, float* out, float* out1, int nsplit, int M, int N, int ld, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (nsplit > N || (nsplit < N && out1 == nullptr)) return SED_ERR_ARG;
-    sed_zero4(s, out, nsplit, out1, N - nsplit, nullptr, 0, nullptr, 0);
-    if (M <= 0 || N <= 0) return SED_OK;
-    const int rpb = 32;
-    SED_LAUNCH(colsum_kernel, dim3((N + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, s, X, out, out1, nsplit, M, N, ld, rpb);
+    if (N <= 0) return SED_OK;
+    SED_LAUNCH(colsum_kernel, dim3((N + 15) / 16), dim3(1024), 0, s, X, out, out1, nsplit, M > 0 ? M : 0, N, ld);
     return sed_check_launch();
 }
 

@@ -511,8 +511,13 @@ class EmbCatFn(torch.autograd.Function):
                      _p(ctx.tmask), T, st)
         dw, db = _grad_buf(cfg, w), _grad_buf(cfg, b)
         split = max(1, min(32, M // 256))
-        lib.call("sed_zero_buffers", dw.data_ptr(), dw.numel(), None, 0, None, 0, None, 0, st)             # split-K accumulates
-        lib.call(entry, dy.data_ptr(), z.data_ptr(), None, dw.data_ptr(), C, W, M, C, W, W, 1, 0, split, 0, st)  # dy^T . z
+        if entry.endswith("bf16x3") and W % 4 == 0 and dw.data_ptr() % 16 == 0:
+            # deterministic split-K (dense per-slice partials + a fixed-order sum): no zero fill, no float atomics
+            scr = torch.empty(int(lib.value("sed_gemm_splitk_scratch_floats", C, W, M, split)), device=dy.device, dtype=torch.float32)
+            lib.call("sed_gemm_splitk_bf16x3", dy.data_ptr(), z.data_ptr(), dw.data_ptr(), C, W, M, C, W, W, 1, 0, split, scr.data_ptr(), st)
+        else:
+            lib.call("sed_zero_buffers", dw.data_ptr(), dw.numel(), None, 0, None, 0, None, 0, st)             # split-K accumulates
+            lib.call(entry, dy.data_ptr(), z.data_ptr(), None, dw.data_ptr(), C, W, M, C, W, W, 1, 0, split, 0, st)  # dy^T . z
         lib.call("sed_colsum", dy.data_ptr(), db.data_ptr(), None, C, M, C, C, st)
         return dx, None, dw, db, None
 

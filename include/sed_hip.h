@@ -219,6 +219,10 @@ long long sed_gemm_splitk_scratch_floats(int M, int N, int K, int split_k);
 int sed_gemm_pair_splitk_bf16x3(const float* A0, const float* A1, const float* B0, const float* B1, float* C0, float* C1,
                                 int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB, int split_k,
                                 float* scratch, void* stream);
+/* One product with the same deterministic split-K (`cat_tf` weight gradient of the embedding recipes, CRNN.py:283-296 backward:
+ * dW = dy^T . [x | emb] over K = B T rows).  scratch: sed_gemm_splitk_scratch_floats(M, N, K, split_k) floats. */
+int sed_gemm_splitk_bf16x3(const float* A, const float* Bm, float* Cm, int M, int N, int K, int lda, int ldb, int ldc,
+                           int transA, int transB, int split_k, float* scratch, void* stream);
 
 /* Column sums (bias gradients): out[n] = sum_m X[m*ld + n] for n < nsplit, out1[n-nsplit] for nsplit <= n < N. */
 int sed_colsum(const float* X, float* out, float* out1, int nsplit, int M, int N, int ld, void* stream);

@@ -150,6 +150,73 @@ def test_two_rank_gradient_average(tmp_path):
     assert ck["lr_schedulers"][0]["step_num"] == 2 and ck["global_step"] == 1
 
 
+def _multi_step_worker(rank, world, port, out_dir):
+    """Three consecutive data-parallel steps (dropout + SpecAugment + mixup on, different clips per rank): at EVERY step the reduced
+    gradient arena must be the sum of the ranks' local arenas as they were handed to the collective, and the students must stay
+    bit-identical across ranks -- by induction the N-rank run is the single-GPU reference step per rank (rank-local BatchNorm
+    statistics, mixup and loss means) with the gradient mean in Adam."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from tests.emu_support import bind_emulator
+    bind_emulator()
+    import random
+    from oracle import sed_oracle as O
+    from tests import parity_cases as P
+    from desed_task_amd import ops as _ops
+    from desed_task_amd.launcher import StepDriver, init_distributed
+    init_distributed(backend="gloo")
+    bs, n_samp, steps = (1, 1, 1), 4096 + 1024, 3
+    sd = O.make_state_dict(seed=7)
+    task = P.build_task("cpu", bs, sd, dropout=0.5, specaug=True, rampup=5)
+    driver = StepDriver(task, world_size=world, overlap_allreduce=False)       # one all-reduce over the whole arena: one pre / post pair
+    n_out = (1 + n_samp // 256) // 4
+    random.seed(4); np.random.seed(7 + rank); torch.manual_seed(7 + rank)
+    _ops.reseed_dropout()
+    real_all_reduce = dist.all_reduce
+    record = []
+
+    def spy(tensor, *a, **k):
+        pre = tensor.detach().clone()
+        out = real_all_reduce(tensor, *a, **k)
+        record.append((pre, tensor.detach().clone()))
+        return out
+
+    dist.all_reduce = spy
+    ok = True
+    try:
+        for step in range(steps):
+            audio = O.synth_audio(3, n_samp, seed=300 + 10 * step + rank)
+            labels = O.synth_labels(bs, 10, n_out, seed=40 + 10 * step + rank)
+            del record[:]
+            driver.run_step((audio, labels, None, None), step)
+            assert len(record) == 1 and record[0][0].numel() == task.sed_student.arena.numel
+            pre, post = record[0]
+            dist.all_reduce = real_all_reduce
+            pres = [torch.zeros_like(pre) for _ in range(world)]
+            dist.all_gather(pres, pre)
+            flats = [torch.zeros_like(pre) for _ in range(world)]
+            dist.all_gather(flats, task.sed_student.arena.flat.detach().clone())
+            dist.all_reduce = spy
+            want = pres[0] + pres[1]
+            ok &= bool((pres[0] - pres[1]).abs().max() > 1e-7)                                       # ranks saw different data / masks
+            ok &= bool((post - want).abs().max() <= 1e-6 * want.abs().max() + 1e-12)                 # sum of the local gradients
+            ok &= bool(torch.equal(flats[0], flats[1]))                                              # same Adam on every rank
+    finally:
+        dist.all_reduce = real_all_reduce
+    if rank == 0:
+        torch.save(dict(ok=ok, steps=steps), os.path.join(out_dir, "multi.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_multi_step_semantics(tmp_path):
+    mp.spawn(_multi_step_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    d = torch.load(os.path.join(str(tmp_path), "multi.pt"))
+    assert d["ok"] and d["steps"] == 3
+
+
 def _rehearsal_worker(rank, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", SED_DDP_REHEARSE="1")
