@@ -76,7 +76,6 @@ static inline int convb_ck(int CIN, int COUT) {
     // 64 <-> 128 channels: 16-channel chunks halve the LDS stage (68 KB at 256 pixels) and fit 128 VGPRs, so two workgroups
     // share a CU: 72.8 -> 63.0 us (forward) and 63.3 -> 56.8 us (data gradient).  128 -> 128 gains nothing (59.6 vs 60.9 us).
     int ck = ((CIN == 64 && COUT == 128) || (CIN == 128 && COUT == 64)) ? 16 : 32;
-    if (sed_tuning[SED_TUNE_CONVB_CS] == 2 && CIN == 128 && COUT == 128) ck = 16;     // the cout-split kernels stage 16-channel chunks
     if (e && CIN >= 32) ck = e == 16 ? 16 : 32;
     return CIN < ck ? CIN : ck;
 }
@@ -124,25 +123,15 @@ struct ConvBnb {
     float inv_count;
 };
 
-// CS (round 4): the output channels of a layer split across CS workgroups per pixel tile (COUT / CS channels each, same patch).  The
-// 128-channel layers at F <= 8 are ONE round of ~ 234 tiles on 256 CUs: every workgroup's prologue, barriers and 128 KB epilogue
-// burst coincide and nothing overlaps them (MFMA-busy 0.35).  With CS = 2 and 16-channel chunks a workgroup needs 51 KB of LDS and
-// <= 128 registers, so the two halves of a tile are co-resident on one CU and out of phase; the weight traffic per pixel is unchanged
-// (each half streams its own rows of the slabs), only the 54 KB patch is staged twice.
-template <int CIN, int COUTT, int TF, bool STATS, int MP = 128, int CKT = 32, bool BNB = false, int CS = 1>
-__global__ __launch_bounds__(CONVB_THREADS(COUTT / CS)) void conv3x3_bf16_kernel(const float* __restrict__ x,
+template <int CIN, int COUT, int TF, bool STATS, int MP = 128, int CKT = 32, bool BNB = false>
+__global__ __launch_bounds__(CONVB_THREADS(COUT)) void conv3x3_bf16_kernel(const float* __restrict__ x,
                                                                             const unsigned short* __restrict__ Wp,
                                                                             const float* __restrict__ bias, float* __restrict__ y,
                                                                             float* __restrict__ partial, int B, int T, int F,
                                                                             ConvBnb bnb) {
-    constexpr int COUT = COUTT / CS;                                    // channels of THIS workgroup (rows co0 .. co0 + COUT of the layer)
-    static_assert(CS == 1 || (COUT % 32 == 0 && CIN > 32), "cout split: whole MFMA tiles per half, non-persistent layers only");
     using Cfg = ConvBCfg<CIN, COUT, TF, MP, CKT>;
     constexpr int TR = Cfg::TR, PW = Cfg::PW, PP = Cfg::PP, CK = Cfg::CK, RSS = Cfg::RSS, NCH = Cfg::NCH, NT = Cfg::NT,
-                  NTW = Cfg::NTW, THREADS = Cfg::THREADS, WM = Cfg::WM, NCOL = Cfg::NCOL, WBUF_S = Cfg::WBUF_S;
-    constexpr int SLAB = 2 * COUTT * CK;                                // shorts per (tap, chunk) slab of the WHOLE layer in global memory
-    const int co0 = CS == 1 ? 0 : (int)(blockIdx.x % CS) * COUT;        // (the halves of a tile are neighbours in the grid: its patch
-                                                                        //  is fetched from L2 by the second one)
+                  NTW = Cfg::NTW, THREADS = Cfg::THREADS, WM = Cfg::WM, NCOL = Cfg::NCOL, SLAB = Cfg::SLAB, WBUF_S = Cfg::WBUF_S;
     SED_DYN_SMEM(smem_raw);
     // (no integer round-trip on the LDS pointer: that would demote every LDS access to a flat_* instruction)
     unsigned short* patch = (unsigned short*)smem_raw;                  // 16-byte aligned; hi plane, then lo plane
@@ -169,7 +158,7 @@ __global__ __launch_bounds__(CONVB_THREADS(COUTT / CS)) void conv3x3_bf16_kernel
     // fetched into registers at the start of an iteration and parked in LDS at its end, so their L2 latency hides behind
     // three taps of MFMAs (timing ablation, tools/convb_variants.py: with one tap per iteration the slab wait was 30-60 %
     // of the kernel).  The halo patch of the next cin chunk is prefetched the same way during the last row of a chunk.
-    constexpr int WPIECES = 2 * COUT * CK / 8;                          // 16-byte pieces of this workgroup's share of a slab
+    constexpr int WPIECES = SLAB / 8;                                   // 16-byte pieces per slab
     constexpr int WV = (WPIECES + THREADS - 1) / THREADS;
     constexpr int V = CK / 4;
     constexpr int NLD = (PP * V + THREADS - 1) / THREADS;
@@ -202,13 +191,7 @@ __global__ __launch_bounds__(CONVB_THREADS(COUTT / CS)) void conv3x3_bf16_kernel
             for (int i = 0; i < WV; ++i) {
                 const int piece = tid + THREADS * i;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (piece < WPIECES && !(CONVB_ABL & 1)) {
-                    if (CS == 1) v = src[piece];
-                    else {          // this half's rows of each plane: [plane][co0 .. co0 + COUT)[CK]
-                        const int plane = piece / (COUT * CK / 8), rem = piece - plane * (COUT * CK / 8);
-                        v = src[plane * (COUTT * CK / 8) + co0 * (CK / 8) + rem];
-                    }
-                }
+                if (piece < WPIECES && !(CONVB_ABL & 1)) v = src[piece];
                 wreg[t3 * WV + i] = v;
             }
         }
@@ -244,7 +227,7 @@ __global__ __launch_bounds__(CONVB_THREADS(COUTT / CS)) void conv3x3_bf16_kernel
     bool primed = false;
     int tile_it = blockIdx.x;
     do {
-    const int tile = PERS ? tile_it : (int)blockIdx.x / CS;
+    const int tile = PERS ? tile_it : (int)blockIdx.x;
     const int ft = tile % ftiles, tt = (tile / ftiles) % ttiles, b = tile / (ftiles * ttiles);
     const int t0 = tt * TR, f0 = ft * TF;
     const int tile_n = PERS ? tile + (int)gridDim.x : ntiles;
@@ -275,7 +258,7 @@ __global__ __launch_bounds__(CONVB_THREADS(COUTT / CS)) void conv3x3_bf16_kernel
                         g.z = bistd.z * (g.z - bm1.z - (yv.z - bmean.z) * bistd.z * bm2.z);
                         g.w = bistd.w * (g.w - bm1.w - (yv.w - bmean.w) * bistd.w * bm2.w);
                         ld[u] = g;
-                        if (i >= 1 && i <= TR && j >= 1 && j <= TF && co0 == 0)   // this tile's own pixels: dy for the weight gradient
+                        if (i >= 1 && i <= TR && j >= 1 && j <= TF)        // this workgroup's own pixels: dy for the weight gradient
                             *(float4*)(bnb.dy_out + (((size_t)b * T + t) * F + f) * CIN + cc * CK + 4 * v) = g;
                     }
                 }
@@ -343,7 +326,7 @@ __global__ __launch_bounds__(CONVB_THREADS(COUTT / CS)) void conv3x3_bf16_kernel
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int co = (wn * NTW + nt) * 32 + lo;
-        const float bv = (bias != nullptr && co < COUT) ? bias[co0 + co] : 0.f;
+        const float bv = (bias != nullptr && co < COUT) ? bias[co] : 0.f;
         float s = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -351,7 +334,7 @@ __global__ __launch_bounds__(CONVB_THREADS(COUTT / CS)) void conv3x3_bf16_kernel
             const int t = t0 + pp / TF, f = f0 + pp % TF;
             if (t < T && co < COUT) {
                 const float v = acc[nt][r] + bv;
-                if (!(CONVB_ABL & 32)) y[(((size_t)b * T + t) * F + f) * COUTT + co0 + co] = v;
+                if (!(CONVB_ABL & 32)) y[(((size_t)b * T + t) * F + f) * COUT + co] = v;
                 s += v;
                 s2 += v * v;
             }
@@ -372,7 +355,7 @@ __global__ __launch_bounds__(CONVB_THREADS(COUTT / CS)) void conv3x3_bf16_kernel
             float v = 0.f;
 #pragma unroll
             for (int ww = 0; ww < WM; ++ww) v += red[(ww * 2 + which) * (NT * 32) + co];
-            partial[(size_t)(which * COUTT + co0 + co) * ntiles + tile] = v;      // [2*COUT][ntiles], see bn_finalize_kernel
+            partial[(size_t)tid * ntiles + tile] = v;         // [2*COUT][ntiles], see bn_finalize_kernel
         }
     }
     if (PERS && STATS && NCOL > COUT) {     // (the statistics epilogue wrote `red` over the zero rows of a narrow output: restore them)
@@ -416,28 +399,28 @@ static inline int convb_persistent_grid(K kern, int threads, int smem, int ntile
 #endif
 }
 
-template <int CIN, int COUT, int TF, int MP = 128, int CKT = 32, bool BNB = false, int CS = 1>
+template <int CIN, int COUT, int TF, int MP = 128, int CKT = 32, bool BNB = false>
 static int launch_convb(const float* x, const unsigned short* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
                         hipStream_t s, ConvBnb bnb = ConvBnb()) {
-    using Cfg = ConvBCfg<CIN, COUT / CS, TF, MP, CKT>;      // per-workgroup configuration (COUT / CS output channels each)
+    using Cfg = ConvBCfg<CIN, COUT, TF, MP, CKT>;
     const int ntiles = B * ((T + Cfg::TR - 1) / Cfg::TR) * (F / TF);
     if constexpr (BNB) {
         if constexpr (CIN >= COUT) {         // data gradients only (a block's convolution never narrows in the forward direction)
-            SED_MAX_SMEM((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT, true, CS>), Cfg::SMEM_BNB);
-            const int nblk = CS > 1 ? ntiles * CS : convb_persistent_grid(conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT, true, CS>, Cfg::THREADS, Cfg::SMEM_BNB, ntiles, CIN);
-            SED_LAUNCH((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT, true, CS>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM_BNB, s, x, Wp, bias, y, partial, B, T, F, bnb);
+            SED_MAX_SMEM((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT, true>), Cfg::SMEM_BNB);
+            const int nblk = convb_persistent_grid(conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT, true>, Cfg::THREADS, Cfg::SMEM_BNB, ntiles, CIN);
+            SED_LAUNCH((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT, true>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM_BNB, s, x, Wp, bias, y, partial, B, T, F, bnb);
             return sed_check_launch();
         } else {
             return SED_ERR_UNSUPPORTED;
         }
     } else if (partial) {
-        SED_MAX_SMEM((conv3x3_bf16_kernel<CIN, COUT, TF, true, MP, CKT, false, CS>), Cfg::SMEM);
-        const int nblk = CS > 1 ? ntiles * CS : convb_persistent_grid(conv3x3_bf16_kernel<CIN, COUT, TF, true, MP, CKT, false, CS>, Cfg::THREADS, Cfg::SMEM, ntiles, CIN);
-        SED_LAUNCH((conv3x3_bf16_kernel<CIN, COUT, TF, true, MP, CKT, false, CS>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F, bnb);
+        SED_MAX_SMEM((conv3x3_bf16_kernel<CIN, COUT, TF, true, MP, CKT>), Cfg::SMEM);
+        const int nblk = convb_persistent_grid(conv3x3_bf16_kernel<CIN, COUT, TF, true, MP, CKT>, Cfg::THREADS, Cfg::SMEM, ntiles, CIN);
+        SED_LAUNCH((conv3x3_bf16_kernel<CIN, COUT, TF, true, MP, CKT>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F, bnb);
     } else {
-        SED_MAX_SMEM((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT, false, CS>), Cfg::SMEM);
-        const int nblk = CS > 1 ? ntiles * CS : convb_persistent_grid(conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT, false, CS>, Cfg::THREADS, Cfg::SMEM, ntiles, CIN);
-        SED_LAUNCH((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT, false, CS>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F, bnb);
+        SED_MAX_SMEM((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT>), Cfg::SMEM);
+        const int nblk = convb_persistent_grid(conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT>, Cfg::THREADS, Cfg::SMEM, ntiles, CIN);
+        SED_LAUNCH((conv3x3_bf16_kernel<CIN, COUT, TF, false, MP, CKT>), dim3(nblk), dim3(Cfg::THREADS), Cfg::SMEM, s, x, Wp, bias, y, partial, B, T, F, bnb);
     }
     return sed_check_launch();
 }
@@ -470,14 +453,6 @@ static int convb_dispatch(const float* x, const void* Wp, const float* bias, flo
     const unsigned short* W = (const unsigned short*)Wp;
     const int MP = convb_mp(F, CIN, COUT);
     const int CK = CIN >= 32 ? convb_ck(CIN, COUT) : 32;      // narrower inputs are a single chunk either way
-    // cout split across two co-resident workgroups per tile (16-channel chunks; sed_set_tuning key 13 = 2): the 128-channel layers
-    const int CSP = sed_tuning[SED_TUNE_CONVB_CS];
-#define CONVB_CASE16S(ci, co, tf, mp) \
-    if (CSP == 2 && CIN == ci && COUT == co && TF == tf && MP == mp && CK == 16) return launch_convb<ci, co, tf, mp, 16, BNB, 2>(x, W, bias, y, partial, B, T, F, s, bnb);
-    // (tile / split combinations whose 8 waves tile the half: MP / 32 pixel waves x (COUT / 2) / 32 channel tiles)
-    CONVB_CASE16S(128, 128, 8, 256) CONVB_CASE16S(128, 128, 8, 128) CONVB_CASE16S(128, 128, 4, 128) CONVB_CASE16S(128, 128, 2, 128)
-    CONVB_CASE16S(64, 128, 16, 256)
-#undef CONVB_CASE16S
 #define CONVB_CASE16(ci, co, tf, mp) \
     if (CIN == ci && COUT == co && TF == tf && MP == mp && CK == 16) return launch_convb<ci, co, tf, mp, 16, BNB>(x, W, bias, y, partial, B, T, F, s, bnb);
     // 16-channel weight chunks (half the LDS per workgroup): the wide production shapes

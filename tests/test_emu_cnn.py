@@ -67,19 +67,6 @@ def test_conv_persistent_workgroups(emu, layer, B, T, F):
             _lib.set_tuning("convb_tpw", 0)
 
 
-@pytest.mark.parametrize("layer,B,T,F", [(4, 2, 35, 8), (5, 2, 37, 4), (3, 1, 20, 16), (6, 2, 33, 2)])
-def test_conv_cout_split_workgroups(emu, layer, B, T, F):
-    """Split-bf16 convolutions with the output channels of a tile shared by two workgroups (sed_set_tuning convb_cs = 2, 16-channel
-    chunks): forward with statistics, BN-folded data gradient (dy written by the first half only), ragged last tile.  Layer 6 (F = 2)
-    has no split instantiation at its 64-pixel tiles and must fall back to the unsplit 16-channel-chunk kernel."""
-    from desed_task_amd import _lib
-    _lib.set_tuning("convb_cs", 2)
-    try:
-        P.case_cnn_block("cpu", layer, B, T, F, training=True, dropout_p=0.5, precision="bf16x3", tol=1e-4)
-    finally:
-        _lib.set_tuning("convb_cs", 0)
-
-
 def test_first_block_fused_eval(emu):
     import torch
     with torch.no_grad():

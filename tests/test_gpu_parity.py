@@ -113,17 +113,6 @@ def test_cnn_block_train_split_bf16(layer, T, F):
     P.case_cnn_block("cuda", layer, 3, T, F, training=True, dropout_p=0.5, tol=1e-4, precision="bf16x3")
 
 
-@pytest.mark.parametrize("layer,T,F", [(3, 156, 16), (4, 156, 8), (5, 156, 4)])
-def test_cnn_block_cout_split_workgroups(layer, T, F):
-    """The 128-channel split-bf16 convolutions with a tile's output channels shared by two co-resident workgroups
-    (sed_set_tuning convb_cs = 2): forward + statistics and the BN-folded data gradient at the production shapes."""
-    _lib.set_tuning("convb_cs", 2)
-    try:
-        P.case_cnn_block("cuda", layer, 3, T, F, training=True, dropout_p=0.5, tol=1e-4, precision="bf16x3")
-    finally:
-        _lib.set_tuning("convb_cs", 0)
-
-
 def test_graph_replay_step_equals_eager():
     """GraphedStepDriver (1 eager step, 1 capture, 3 replays; dropout + SpecAugment + mixup on) against the eager
     StepDriver on identical host RNG streams: the hipGraph path reads every step-varying argument from device memory."""
