@@ -399,9 +399,19 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
     __syncthreads();
     if (is_last) {
         __threadfence();
+        // Round 4: the 8 B per-clip records come in with ALL 256 threads at once and are then added in clip order out of LDS.  Eight
+        // threads walking them in global memory was a chain of B dependent L2 round trips -- most of this kernel's 20 us, on the
+        // critical path between the forward and the backward pass.  Same order of additions: same bits.
+        __shared__ float fin[8 * 256];
+        const bool staged = B <= 256;
+        if (staged) {
+            for (int idx = tid; idx < 8 * B; idx += 256) fin[idx] = ((volatile float*)work)[idx];
+            __syncthreads();
+        }
         if (tid < 8) {
             float sum = 0.f;
-            for (int i = 0; i < B; ++i) sum += ((volatile float*)work)[8 * i + tid];
+            if (staged) for (int i = 0; i < B; ++i) sum += fin[8 * i + tid];
+            else for (int i = 0; i < B; ++i) sum += ((volatile float*)work)[8 * i + tid];
             scalars[tid] = sum;
             if (tid == 7) scalars[8] = sum;     // the total once more: the differentiable 0-d output is a view of this slot
         }
