@@ -23,6 +23,11 @@ pmc) for pass in "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" 
      python tools/pmc_summary.py gpurun_out/pmc_${tag}_write/write_results.db > gpurun_out/pmc_${tag}_write.md 2>&1
      python tools/pmc_traffic_json.py gpurun_out/pmc_${tag}_fetch/fetch_results.db gpurun_out/pmc_${tag}_write/write_results.db 9 > gpurun_out/pmc_${tag}_traffic.json 2>gpurun_out/pmc_${tag}_traffic.err
      head -30 gpurun_out/pmc_${tag}_mfma.md | cut -c1-200 ;;
+pmcw) bash tools/pmc_wait.sh $tag > /dev/null 2>&1; grep -E "block0|conv0_kernel|glu128|kernel \|" gpurun_out/pmcw_$tag.md | cut -c1-110 ;;
+smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+second) timeout 300 python tools/bench_2024.py --graph --prefetch 2>/dev/null | tail -1 > gpurun_out/bench2024_$tag.json; cut -c1-80,330- gpurun_out/bench2024_$tag.json
+        timeout 300 python tools/bench_2024.py --graph 2>/dev/null | tail -1 > gpurun_out/bench2024_inline_$tag.json
+        timeout 300 python bench.py --embeddings --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_emb_$tag.json; cut -c1-300 gpurun_out/bench_emb_$tag.json ;;
 ab:*) # same-box A/B of two builds of the library (tools/build_variant.py / a saved copy): ab:<libA>:<libB>, alternated twice
      IFS=: read -r _ la lb <<< "$w"
      for rep in 1 2; do for lib in $la $lb; do
