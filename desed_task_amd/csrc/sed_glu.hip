@@ -1555,6 +1555,16 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_b_kernel(const float* __rest
         *(uint2*)(xth + off) = hv;
         *(uint2*)(xtl + off) = lv;
     };
+    // xhat of this lane's row quad 8 wm + 2 j + hi (rows 32 wm + 8 j + 4 hi .. + 3) of its column n, out of the TRANSPOSED planes:
+    // one 8-byte read per plane instead of four 2-byte reads from the row-major planes (round 4; same bf16 pairs, same sums)
+    auto xhat4 = [&](int j, float* out4) {
+        const int rqd = 8 * wm + 2 * j + hi, off = n * RT + 4 * (rqd ^ (2 * ((n >> 4) & 7)));
+        const uint2 hv = *(const uint2*)(xth + off), lv = *(const uint2*)(xtl + off);
+        out4[0] = bf16_pair_sum((unsigned short)(hv.x & 0xFFFFu), (unsigned short)(lv.x & 0xFFFFu));
+        out4[1] = bf16_pair_sum((unsigned short)(hv.x >> 16), (unsigned short)(lv.x >> 16));
+        out4[2] = bf16_pair_sum((unsigned short)(hv.y & 0xFFFFu), (unsigned short)(lv.y & 0xFFFFu));
+        out4[3] = bf16_pair_sum((unsigned short)(hv.y >> 16), (unsigned short)(lv.y >> 16));
+    };
     const float gsc = 0.5f * dscale;
     float g8n[8];
     auto load_g8 = [&](int tile_) {
@@ -1604,14 +1614,15 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_b_kernel(const float* __rest
         // ---- epilogue 1: dlin -> both LDS layouts, e -> acc (seed of GEMM2) ----
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float dv[4];
+            float dv[4], xq[4];
+            xhat4(j, xq);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = 4 * j + q, m = 32 * wm + 8 * j + 4 * hi + q;
                 const uint32_t e_idx = (uint32_t)(row0 + m) * (uint32_t)C + (uint32_t)n;
                 float dlin = 0.f, e = 0.f;
                 if (row0 + m < R) {
-                    const float xn = fmaf(bf16_pair_sum(xh[m * RS + n], xl[m * RS + n]), gn, bn);
+                    const float xn = fmaf(xq[q], gn, bn);
                     const float sg = sed_fast_sigmoid(xn);
                     const float lin = acc[r] + biasp;
                     const float g = sed_keep(e_idx, seed, thr24) ? g8[2 * j + (q >> 1)] * gsc : 0.f;
@@ -1649,13 +1660,18 @@ __global__ __launch_bounds__(512) void glu_wide_bwd_b_kernel(const float* __rest
         }
         // ---- epilogue 2: dz = dxn * gamma, BN reductions ----
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = 32 * wm + mfma32_row(r, lane);
-            if (row0 + m < R) {
-                const float dxn = acc[r];
-                a_dgam = fmaf(dxn, bf16_pair_sum(xh[m * RS + n], xl[m * RS + n]), a_dgam);
-                a_dbet += dxn;
-                dz[(size_t)(row0 + m) * C + n] = dxn * gn;
+        for (int j = 0; j < 4; ++j) {
+            float xq[4];
+            xhat4(j, xq);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * j + q, m = 32 * wm + 8 * j + 4 * hi + q;      // == 32 wm + mfma32_row(r, lane)
+                if (row0 + m < R) {
+                    const float dxn = acc[r];
+                    a_dgam = fmaf(dxn, xq[q], a_dgam);
+                    a_dbet += dxn;
+                    dz[(size_t)(row0 + m) * C + n] = dxn * gn;
+                }
             }
         }
         // ---- GEMM3: P'[n'][c] += sum_rows dlin[row][n'] * xhat[row][c] ----
@@ -1830,6 +1846,17 @@ __global__ __launch_bounds__(512) void glu128_bwd_c_kernel(const float* __restri
         *(uint2*)(xth + off) = hv;
         *(uint2*)(xtl + off) = lv;
     };
+    // xhat of this lane's four rows 16 rb + 4 g .. + 3 of its column n, out of the TRANSPOSED planes: the four rows are one 8-byte
+    // half-octet of channel n there (round 4: 2 ds_read_b64 instead of 8 ds_read_u16 from the row-major planes per block and
+    // epilogue -- 48 of the ~ 220 LDS instructions a lane issues per tile; same bf16 pairs, same sums)
+    auto xhat4 = [&](int rb, float* out4) {
+        const int off = tr_off(n, 16 * rb + 4 * g);
+        const uint2 hv = *(const uint2*)(xth + off), lv = *(const uint2*)(xtl + off);
+        out4[0] = bf16_pair_sum((unsigned short)(hv.x & 0xFFFFu), (unsigned short)(lv.x & 0xFFFFu));
+        out4[1] = bf16_pair_sum((unsigned short)(hv.x >> 16), (unsigned short)(lv.x >> 16));
+        out4[2] = bf16_pair_sum((unsigned short)(hv.y & 0xFFFFu), (unsigned short)(lv.y & 0xFFFFu));
+        out4[3] = bf16_pair_sum((unsigned short)(hv.y >> 16), (unsigned short)(lv.y >> 16));
+    };
     // acc[rb] += A[16rb.., :] . B for the four 16-row blocks, A = hi | lo planes (lo plane ROWS * RS further), B = this
     // wave's fragments.  Per k-step: the eight A reads, then the twelve MFMAs pass by pass across the four blocks, so that
     // consecutive MFMAs never share an accumulator (left alone the compiler emits read - wait - three dependent MFMAs).
@@ -1897,12 +1924,14 @@ __global__ __launch_bounds__(512) void glu128_bwd_c_kernel(const float* __restri
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             unsigned short hh[4], ll[4];
+            float xq[4];
+            xhat4(rb, xq);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = 16 * rb + 4 * g + r;
                 const uint32_t e_idx = (uint32_t)(row0 + m) * (uint32_t)C + (uint32_t)n;
                 // rows past the end: g8 = 0 there, so dlin = e = 0 without a guard (their xhat is 0: everything stays finite)
-                const float xn = fmaf(bf16_pair_sum(xh[rm_off(m, n)], xl[rm_off(m, n)]), gn, bn);
+                const float xn = fmaf(xq[r], gn, bn);
                 const float sg = (GLU_ABL & 2) ? xn : sed_fast_sigmoid(xn);
                 const float lin = acc[rb][r] + biasp;
                 const float gq = ((GLU_ABL & 2) || sed_keep(e_idx, seed, thr24)) ? g8[2 * rb + (r >> 1)] : 0.f;
@@ -1927,15 +1956,18 @@ __global__ __launch_bounds__(512) void glu128_bwd_c_kernel(const float* __restri
         // ---- epilogue 2: dz = dxn * gamma, BN reductions (dxn = 0 on rows past the end) ----
         const bool full = row0 + ROWS <= R;
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RB; ++rb) {
+            float xq[4];
+            xhat4(rb, xq);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = 16 * rb + 4 * g + r;
                 const float dxn = acc[rb][r];
-                a_dgam = fmaf(dxn, bf16_pair_sum(xh[rm_off(m, n)], xl[rm_off(m, n)]), a_dgam);
+                a_dgam = fmaf(dxn, xq[r], a_dgam);
                 a_dbet += dxn;
                 if (!(GLU_ABL & 8) && (full || row0 + m < R)) dz[(size_t)(row0 + m) * C + n] = dxn * gn;
             }
+        }
         // ---- GEMM3: P'[n'][c] += sum_rows dlin[row][n'] * xhat[row][c]   (n' block = wave, every channel block) ----
         if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
         if (!(GLU_ABL & 1)) {

@@ -4,8 +4,14 @@ import torch
 sys.path.insert(0, ".")
 from desed_task_amd.ops import ConvBlockFn
 from desed_task_amd import _lib
+import os
+for kv in sys.argv[1:]:                 # lib=<path>: time another build of the library (same-box A/B)
+    if kv.startswith("lib="):
+        _lib.use_library(os.path.abspath(kv[4:]), is_emulator=False)
 lib = _lib.get(); orig = lib.call; rec = {}
 for kv in sys.argv[1:]:                 # e.g. block0_bwd_v1=1 glu_grid_cap=640
+    if kv.startswith("lib="):
+        continue
     key, v = kv.split("="); _lib.set_tuning(key, int(v))
 B, T, F = 48, 626, 128
 x = torch.randn(B, T, F, device="cuda", requires_grad=False)
