@@ -42,44 +42,40 @@ __device__ __forceinline__ void b0_stage(float* tile, const float* __restrict__ 
     if constexpr (BATCH >= 8) {
         if (sed_stage_halo_f4<B0_TR, 256, B0_MAXF>(tile, x, bounds, b, t0, T, F, B0_PITCH(F), center)) return;
     }
-    const int PT = B0_PITCH(F);
+    const int PW = F + 2, PT = B0_PITCH(F), n = (B0_TR + 2) * PW;
     int mf0 = 0, mf1 = 0, mt0 = 0, mt1 = 0;
     if (bounds) { mf0 = bounds[4 * b]; mf1 = bounds[4 * b + 1]; mt0 = bounds[4 * b + 2]; mt1 = bounds[4 * b + 3]; }
-    // Scalar path (the backward's; the forward's fallback).  Round 4: a (row, bin) thread map -- thread = bin f = tid & 127 of row
-    // 2 u + (tid >> 7), u = 0 .. 8 -- instead of a walk over the flattened (B0_TR + 2) x (F + 2) tile, which paid an integer division
-    // by the runtime width, two clamps and five compares per element (274 instructions per batch of four loads, 12 % of the backward's
-    // instruction stream).  The two halo columns are zero padding: written, never loaded.
-    // Every load is unconditional (clamped address, the predicate is applied to the value) and all loads of a batch are issued before
-    // the first store: with the load inside the bounds branch the compiler waited for each one right behind it (tools/isa_exposed_loads.py)
+    // every load is unconditional (clamped address, the predicate is applied to the value) and all of a thread's loads are issued
+    // before the first store: with the load inside the bounds branch the compiler waited for each one right behind it -- ten
+    // exposed memory latencies per tile (tools/isa_exposed_loads.py)
     // (BATCH loads in flight per thread: the persistent backward kernels have few registers to spare)
-    static_assert(B0_MAXF == 128 && (B0_TR + 2) % 2 == 0, "thread map: 128 bins x 2 rows per pass");
-    constexpr int NPASS = (B0_TR + 2) / 2;
-    const int f = threadIdx.x & 127, rsel = threadIdx.x >> 7, fc = f < F ? f : F - 1;
-    const bool fok = f < F && !(f >= mf0 && f < mf1);
-#pragma unroll 1
-    for (int u0 = 0; u0 < NPASS; u0 += BATCH) {
+    // (round 4: a division-free (row, bin) thread map for this scalar path was built for the backward -- 274 -> ~ 35 instructions per
+    //  batch -- and measured 191.8 vs 188.4 us per launch: at 254 registers the kernel spilled 4 - 7 of them for it; kept as it was)
+    for (int base = threadIdx.x; base < n; base += 256 * BATCH) {
         float v[BATCH];
+        bool ok[BATCH];
+        int pad[BATCH];                                         // row * (pitch - width): where the element lands in the padded tile
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int i = 2 * (u0 + k < NPASS ? u0 + k : NPASS - 1) + rsel, t = t0 - 1 + i;
-            const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
-            v[k] = x[((size_t)b * T + tc) * F + fc];
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = base + 256 * u, ic = idx < n ? idx : n - 1;
+            const int i = ic / PW, j = ic - i * PW;
+            const int t = t0 - 1 + i, f = j - 1;
+            const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t), fc = f < 0 ? 0 : (f >= F ? F - 1 : f);
+            v[u] = x[((size_t)b * T + tc) * F + fc];
+            pad[u] = i * (PT - PW);
+            ok[u] = t >= 0 && t < T && f >= 0 && f < F && !((f >= mf0 && f < mf1) || (t >= mt0 && t < mt1));
         }
         // all BATCH loads are issued before the first value is touched: without the fence the scheduler pairs every load with its
         // use again, and without the pins the optimiser sinks each load back under its bounds predicate (a branch + a wait per load)
         sed_sched_fence();
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) sed_pin(v[k]);
+        for (int u = 0; u < BATCH; ++u) sed_pin(v[u]);
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            if (u0 + k < NPASS && f < F) {
-                const int i = 2 * (u0 + k) + rsel, t = t0 - 1 + i;
-                const bool ok = fok && t >= 0 && t < T && !(t >= mt0 && t < mt1);
-                tile[i * PT + 1 + f] = (ok ? v[k] : 0.f) - center;
-            }
+        for (int u = 0; u < BATCH; ++u) {
+            const int idx = base + 256 * u;
+            if (idx < n) tile[idx + pad[u]] = (ok[u] ? v[u] : 0.f) - center;
         }
     }
-    if (threadIdx.x < 2 * (B0_TR + 2)) tile[(threadIdx.x >> 1) * PT + ((threadIdx.x & 1) ? F + 1 : 0)] = 0.f - center;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -182,7 +178,7 @@ SED_API int sed_block0_fwd(const float* x, const float* W, const float* bias, co
 #define B0_NSUM 617         // entries [0, 617) are sums over the workgroup's pixels
 
 #ifndef B0_BWD_BATCH
-#define B0_BWD_BATCH 3
+#define B0_BWD_BATCH 4
 #endif
 #define B0_TS 20            // row pitch (floats) of the wave-private 16 x 16 transposition buffers: 16-byte rows, and the
                             // strided reads of a lane group (rows 4g + kk, column i) fall into 16 distinct banks per group
