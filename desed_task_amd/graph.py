@@ -208,13 +208,23 @@ def quiesce_collectives(dev):
     if not (dist.is_available() and dist.is_initialized()):
         return
     groups = list(getattr(dist.distributed_c10d._world, "pg_map", {}).keys()) or [dist.distributed_c10d._get_default_group()]
+    waited = True
     for pg in groups:
         try:
             nccl = dist.get_backend(pg) == "nccl"
         except Exception:  # noqa: BLE001 -- a group this rank is not part of
             continue
         if nccl:
-            pg._wait_for_pending_works()
+            wait = getattr(pg, "_wait_for_pending_works", None)
+            if wait is None:
+                waited = False
+            else:
+                wait()
+    if not waited:
+        # (a torch build without ProcessGroup._wait_for_pending_works: the device is idle, so every work item is complete and the
+        #  watchdog retires it at its next 100-ms poll -- give it three)
+        import time
+        time.sleep(0.3)
 
 
 class GraphedStepDriver:
