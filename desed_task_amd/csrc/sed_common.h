@@ -48,7 +48,7 @@ static inline void sed_zero4(hipStream_t s, float* p0, int n0, float* p1, int n1
 // Tuning overrides (tests and sweep tools only; all 0 = built-in choices).  Set explicitly through sed_set_tuning(): the entry
 // points never read the process environment.
 enum { SED_TUNE_GLU_GRID_CAP = 0, SED_TUNE_GLU_BWD128_SPLIT = 1, SED_TUNE_CONVB_CK = 2, SED_TUNE_CONVB_MP = 3, SED_TUNE_B0_NOCENTER = 4, SED_TUNE_GLU_FWD128 = 5, SED_TUNE_WGRAD_NARROW = 6, SED_TUNE_WGRAD_CAP = 7,
-       SED_TUNE_ATTN_VALU = 8, SED_TUNE_WGRAD_WIDE = 9, SED_TUNE_GRU_LDS_KB = 10, SED_TUNE_MEL_TAPS_MEM = 11, SED_TUNE_CONVB_TPW = 12, SED_TUNE_GRU_BWD_MAP = 13, SED_TUNE_COUNT = 16 };
+       SED_TUNE_ATTN_VALU = 8, SED_TUNE_WGRAD_WIDE = 9, SED_TUNE_GRU_LDS_KB = 10, SED_TUNE_MEL_TAPS_MEM = 11, SED_TUNE_CONVB_TPW = 12, SED_TUNE_COUNT = 16 };
 extern int sed_tuning[SED_TUNE_COUNT];
 
 static inline int sed_check_launch() {
@@ -239,17 +239,6 @@ __device__ __forceinline__ float sed_quad_sum(float v) {
     v += sed_quad_xor1(v);
     v += sed_quad_xor2(v);
     return v;
-}
-// sum over the eight lanes of a half row (lanes 8 m .. 8 m + 7), result in all eight: the quad sum, then the OTHER quad of the half row
-// through row_half_mirror (lane i <- lane 7 - i of its half row; after the quad sum every lane of a quad holds the same value, so the
-// mirrored order is immaterial).  Three DPP adds, no LDS crossbar; both quads add the same two numbers: identical bits in all eight.
-__device__ __forceinline__ float sed_oct_sum(float v) {
-    v = sed_quad_sum(v);
-#ifdef SED_EMU
-    return v + __shfl_xor(v, 4);
-#else
-    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-#endif
 }
 
 // ---- wave / block reductions -------------------------------------------------------------------

@@ -685,161 +685,6 @@ __global__ __launch_bounds__(256) void gru_bias_reduce_kernel(const float* __res
     if (j < 3 * H) { if (dbi) dbi[j] = v; }
     else if (dbh) dbh[j - 3 * H] = v;
 }
-// ---------------------------------------------------------------------------------------------
-// backward recurrence, H = 128, thread map (unit PAIR, EIGHTH of the gate rows)  [round 4, default for H = 128].
-// The map above -- thread (unit k, quarter of the gate rows) -- makes every thread read a quarter of each of the three gate-gradient
-// vectors per step: 24 ds_read_b128 per thread, 192 per workgroup, 768 LDS cycles between the barrier and the first FMA that can
-// retire -- ~ 270 of the 950 ns a step takes (the forward reads one vector: 8 reads, 90 ns of its 680).  Here a thread owns TWO units
-// (k, k + 64) and an EIGHTH of the gate rows: the same 48 packed FMAs from the same 96 weight registers, but 12 reads per thread, in
-// six shorter chains; the eight partial sums of a unit are combined by three DPP adds (sed_oct_sum) instead of two.  Everything
-// else -- chunked staging, quad stores of the seven result planes, bias records -- is the kernel above, lane for lane.
-// ---------------------------------------------------------------------------------------------
-template <int CH>
-__global__ __launch_bounds__(512) void gru_bwd_u2_kernel(const float* __restrict__ dout, const float* __restrict__ out,
-                                                         const float* __restrict__ saved, const float* __restrict__ whh0,
-                                                         const float* __restrict__ whh1, float* __restrict__ dgi,
-                                                         float* __restrict__ dgh, float* __restrict__ hprev_out,
-                                                         float* __restrict__ bpart, int B, int T) {
-    sed_wave_prio_high();
-    constexpr int H = 128, NT_ = 512, JS = H / 8;         // JS: gate rows per slice
-    // gbuf: three planes (da_r, da_z, dhn) of eight slices; the slices start EP floats apart (16 + 4: the eight slices a lane group
-    // reads with one ds_read_b128 fall into 16-byte slots 0, 5, 10, 15, 4, 9, 14, 3 of a bank row: distinct), the planes GP apart so
-    // that the three stores of a quad do not share banks.
-    constexpr int EP = JS + 4, GP = 8 * EP + 8;
-    constexpr int OBP = H + 8, OBS = 7 * OBP;
-    constexpr int IB_F = CH * 6 * H, OB_F = CH * OBS;
-    __shared__ __attribute__((aligned(16))) float gbuf[2][3 * GP];
-    SED_DYN_SMEM(smem);
-    float* ibuf = (float*)smem;                // [2][CH][6H] = r | z | n | hn | hprev | dout
-    float* obuf = ibuf + 2 * IB_F;             // [2][CH][7H] = dgi(3H) | dgh(3H) | hprev(H)
-    const int tid = threadIdx.x, e = tid & 7, pr = tid >> 3, half = e & 3;
-    const int k = (e & 4) ? pr + 64 : pr;      // the unit whose elementwise part (and result stores) this lane does
-    const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
-    const float* W = dir ? whh1 : whh0;
-    f32x2 wr[2][JS / 2], wz[2][JS / 2], wn[2][JS / 2];      // W^T slices: contributions of gate rows j of this lane's eighth to units pr, pr + 64
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int jj = 0; jj < JS / 2; ++jj) {
-            const int j = e * JS + 2 * jj, ku = pr + 64 * u;
-            wr[u][jj] = f32x2{W[(size_t)(0 * H + j) * H + ku], W[(size_t)(0 * H + j + 1) * H + ku]};
-            wz[u][jj] = f32x2{W[(size_t)(1 * H + j) * H + ku], W[(size_t)(1 * H + j + 1) * H + ku]};
-            wn[u][jj] = f32x2{W[(size_t)(2 * H + j) * H + ku], W[(size_t)(2 * H + j + 1) * H + ku]};
-        }
-    // (the W^T slices are complete before the recurrence starts: see sed_pin)
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int jj = 0; jj < JS / 2; ++jj) { sed_pin(wr[u][jj]); sed_pin(wz[u][jj]); sed_pin(wn[u][jj]); }
-    const int nchunks = (T + CH - 1) / CH;
-    constexpr int IV = (IB_F / 4 + NT_ - 1) / NT_;
-    float4 ireg[IV];
-    // chunk c covers reverse-order positions rs = c*CH .. c*CH+CH-1, forward step index = T-1-rs
-    auto load_chunk = [&](int c) {
-#pragma unroll
-        for (int u = 0; u < IV; ++u) {
-            const int e4 = tid + NT_ * u, s = e4 / (6 * H / 4), q = e4 - s * (6 * H / 4);
-            const int rs = c * CH + s;
-            ireg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e4 < IB_F / 4 && rs < T) {
-                const int step = T - 1 - rs;
-                const int t = dir ? T - 1 - step : step, tp = dir ? t + 1 : t - 1;
-                const size_t bt = (size_t)b * T + t;
-                if (q < H) ireg[u] = *(const float4*)(saved + (bt * 2 + dir) * 4 * H + 4 * q);
-                else if (q < H + H / 4) { if (step > 0) ireg[u] = *(const float4*)(out + ((size_t)b * T + tp) * 2 * H + dir * H + 4 * (q - H)); }
-                else ireg[u] = *(const float4*)(dout + bt * 2 * H + dir * H + 4 * (q - H - H / 4));
-            }
-        }
-    };
-    auto park_chunk = [&](int c) {
-#pragma unroll
-        for (int u = 0; u < IV; ++u)
-            if (tid + NT_ * u < IB_F / 4) *(float4*)(ibuf + (c & 1) * IB_F + 4 * (tid + NT_ * u)) = ireg[u];
-    };
-    auto flush_chunk = [&](int c) {
-        constexpr int PER = 7 * H / 4;
-        const float* ob = obuf + (c & 1) * OB_F;
-        for (int e4 = tid; e4 < CH * PER; e4 += NT_) {
-            const int s = e4 / PER, q = e4 - s * PER;
-            const int rs = c * CH + s;
-            if (rs >= T) break;
-            const int step = T - 1 - rs;
-            const int t = dir ? T - 1 - step : step;
-            const size_t bt = (size_t)b * T + t;
-            const int pl = q / (H / 4), w4 = 4 * (q - pl * (H / 4));
-            const float4 v = *(const float4*)(ob + s * OBS + pl * OBP + w4);
-            if (pl < 3) *(float4*)(dgi + (bt * 2 + dir) * 3 * H + pl * H + w4) = v;
-            else if (pl == 3) *(float4*)(hprev_out + (bt * 2 + dir) * H + w4) = v;
-            else *(float4*)(dgh + (bt * 2 + dir) * 3 * H + (pl - 4) * H + w4) = v;
-        }
-    };
-    load_chunk(0);
-    park_chunk(0);
-    __syncthreads();
-    float dh_carry = 0.f;
-    float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_hn = 0.f;     // bias gradients: sums over this clip's steps (off the chain)
-    const int gk = (k / JS) * EP + k % JS;                     // this unit's slot in a gbuf plane
-    int cur = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) load_chunk(c + 1);
-        if (c > 0) flush_chunk(c - 1);
-        const float* ich = ibuf + (c & 1) * IB_F;
-        float* och = obuf + (c & 1) * OB_F;
-        const int nsteps = min(CH, T - c * CH);
-        for (int s = 0; s < nsteps; ++s) {
-            const float* in = ich + s * 6 * H;
-            const float r = in[k], z = in[H + k], n = in[2 * H + k], hn = in[3 * H + k], hp = in[4 * H + k];
-            const float dh = in[5 * H + k] + dh_carry;
-            const float dn = dh * (1.0f - z);
-            const float dzg = dh * (hp - n);
-            const float da_n = dn * (1.0f - n * n);
-            const float da_z = dzg * z * (1.0f - z);
-            const float da_r = da_n * hn * r * (1.0f - r);
-            const float dhn = da_n * r;
-            sb_r += da_r; sb_z += da_z; sb_n += da_n; sb_hn += dhn;
-            float* o = och + s * OBS;
-            // the four lanes of a unit hold the same values: three store instructions on the chain instead of ten
-            const float g3 = half == 0 ? da_r : half == 1 ? da_z : dhn;
-            if (half < 3) gbuf[cur][half * GP + gk] = g3;
-            o[half * OBP + k] = half == 0 ? da_r : half == 1 ? da_z : half == 2 ? da_n : hp;
-            if (half < 3) o[(4 + half) * OBP + k] = g3;
-            __syncthreads();
-            const float* gv = gbuf[cur] + e * EP;
-            float4 ga[JS / 4], gc[JS / 4], gd[JS / 4];
-#pragma unroll
-            for (int q = 0; q < JS / 4; ++q) {
-                ga[q] = *(const float4*)(gv + 4 * q);
-                gc[q] = *(const float4*)(gv + GP + 4 * q);
-                gd[q] = *(const float4*)(gv + 2 * GP + 4 * q);
-            }
-            float acc[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f};     // three independent packed chains per unit
-#pragma unroll
-                for (int q = 0; q < JS / 4; ++q) {
-                    const f32x2 a0 = {ga[q].x, ga[q].y}, a1 = {ga[q].z, ga[q].w};
-                    const f32x2 c0 = {gc[q].x, gc[q].y}, c1 = {gc[q].z, gc[q].w};
-                    const f32x2 d0 = {gd[q].x, gd[q].y}, d1 = {gd[q].z, gd[q].w};
-                    p0 = pk_fma(wr[u][2 * q], a0, p0); p1 = pk_fma(wz[u][2 * q], c0, p1); p2 = pk_fma(wn[u][2 * q], d0, p2);
-                    p0 = pk_fma(wr[u][2 * q + 1], a1, p0); p1 = pk_fma(wz[u][2 * q + 1], c1, p1); p2 = pk_fma(wn[u][2 * q + 1], d1, p2);
-                }
-                acc[u] = sed_oct_sum(((p0.x + p0.y) + (p1.x + p1.y)) + (p2.x + p2.y));
-            }
-            dh_carry = dh * z + ((e & 4) ? acc[1] : acc[0]);
-            cur ^= 1;
-        }
-        __syncthreads();                       // all steps of the chunk done (gbuf/obuf/ibuf reads retired)
-        if (c + 1 < nchunks) park_chunk(c + 1);
-        __syncthreads();
-    }
-    flush_chunk(nchunks - 1);
-    if (bpart != nullptr) {
-        float* rec = bpart + (size_t)blockIdx.x * 6 * H;
-        if (half == 0) { rec[k] = sb_r; rec[H + k] = sb_z; rec[2 * H + k] = sb_n; }
-        if (half == 1) { rec[3 * H + k] = sb_r; rec[4 * H + k] = sb_z; rec[5 * H + k] = sb_hn; }
-    }
-}
 SED_API int sed_gru_bwd(const float* dout, const float* out, const float* saved, const float* whh0, const float* whh1,
                            float* dgi, float* dgh, float* hprev, float* dbi0, float* dbi1, float* dbh0, float* dbh1, int B, int T,
                            int H, float* scratch, void* stream) {
@@ -860,15 +705,7 @@ SED_API int sed_gru_bwd(const float* dout, const float* out, const float* saved,
         SED_LAUNCH((gru_bwd_kernel<h, ch>), dim3(2 * B), dim3(4 * h), smem, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh, \
                    hprev, bpart, B, T);                                                                                           \
     }
-    if (H == 128 && sed_tuning[SED_TUNE_GRU_BWD_MAP] != 1) {          // 1 = the (unit, quarter) map of the generic kernel (A/B runs)
-        int smem = (2 * GRU_CH * 6 * 128 + 2 * GRU_CH * 7 * (128 + 8)) * 4;
-        smem = gru_lds_claim(smem);
-        SED_MAX_SMEM((gru_bwd_u2_kernel<GRU_CH>), smem);
-        SED_LAUNCH((gru_bwd_u2_kernel<GRU_CH>), dim3(2 * B), dim3(512), smem, (hipStream_t)stream, dout, out, saved, whh0, whh1, dgi, dgh,
-                   hprev, bpart, B, T);
-    } else {
-        GRU_BWD_CASE(128, GRU_CH) GRU_BWD_CASE(192, 2)
-    }
+    GRU_BWD_CASE(128, GRU_CH) GRU_BWD_CASE(192, 2)
 #undef GRU_BWD_CASE
     if (sed_check_launch() != SED_OK) return SED_ERR_LAUNCH;
     if (want_bias)

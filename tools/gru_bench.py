@@ -4,13 +4,9 @@ import torch
 sys.path.insert(0, ".")
 from desed_task_amd.ops import BiGRULayerFn
 from desed_task_amd import _lib
-for a in sys.argv[1:]:                # A/B: another build of the C-ABI library (tools/_libsed_*.so), or key=value tuning overrides
-    if "=" not in a:
-        _lib.use_library(a, is_emulator=False)
+if len(sys.argv) > 1:                 # A/B: another build of the C-ABI library (tools/_libsed_*.so)
+    _lib.use_library(sys.argv[1], is_emulator=False)
 lib = _lib.get(); orig = lib.call
-for a in sys.argv[1:]:
-    if "=" in a:
-        _lib.set_tuning(a.split("=")[0], int(a.split("=")[1]))
 B, T = 48, 156
 for H, I in ((128, 128), (128, 256), (192, 128), (192, 384)):
     x = torch.randn(B, T, I, device="cuda", requires_grad=True)
@@ -23,10 +19,10 @@ for H, I in ((128, 128), (128, 256), (192, 128), (192, 384)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); orig(name, *a); e1.record()
         rec.setdefault(name, []).append((e0, e1))
-    for it in range(8):
+    for it in range(4):
         if it == 3:
             lib.call = timed
         out = BiGRULayerFn.apply(x, *ws)
         out.backward(torch.ones_like(out))
     torch.cuda.synchronize(); lib.call = orig
-    print("H=%d I=%d:" % (H, I), {k: round(sorted(a.elapsed_time(b) for a, b in v)[len(v) // 2] * 1e3, 1) for k, v in rec.items()})
+    print("H=%d I=%d:" % (H, I), {k: round(sum(a.elapsed_time(b) for a, b in v) * 1e3, 1) for k, v in rec.items()})
