@@ -359,6 +359,12 @@ def rccl_debug_lines(limit=12):
     return out[-limit:]
 
 
+def SHARE_GPU():
+    """SED_BENCH_SHARE_GPU=1 with SED_DIST_BACKEND=gloo: several ranks time-slice the visible GPU(s) (RCCL refuses two ranks per device).
+    A LAUNCH-PATH check of the N > 1 bench on a 1-GPU box (tests/test_gpu_ddp_graph.py) -- the JSON line then says so and is no measurement."""
+    return os.environ.get("SED_BENCH_SHARE_GPU") == "1" and os.environ.get("SED_DIST_BACKEND") == "gloo"
+
+
 def free_port():
     import socket
     sock = socket.socket()
@@ -376,7 +382,7 @@ def self_launch(n, dry_run):
     if not dry_run:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs the MI355X (no GPU visible); `--dry-run` checks the launch path on the CPU emulator")
-        if n > torch.cuda.device_count():
+        if n > torch.cuda.device_count() and not SHARE_GPU():
             raise SystemExit("--gpus %d but only %d GPU(s) visible" % (n, torch.cuda.device_count()))
     port = free_port()
     env = dict(os.environ)
@@ -461,7 +467,7 @@ def main():
                          % (sum(BATCH), N_SAMPLES))
     elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X (no GPU visible); `--dry-run` checks the launch path on the CPU emulator")
-    elif args.gpus > torch.cuda.device_count():
+    elif args.gpus > torch.cuda.device_count() and not SHARE_GPU():
         raise SystemExit("--gpus %d but only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
 
     from desed_task_amd import _lib
@@ -770,6 +776,11 @@ def main():
         if args.rehearse_exchange:
             out["dist"]["rehearsal"] = ("ONE rank: the N > 1 step structure (graph split, all-reduces over a one-rank communicator, eager "
                                         "Adam) on this GPU; bit-identical to the plain step, no link time -- NOT a scaling measurement")
+    if world > 1 and torch.cuda.is_available() and world > torch.cuda.device_count():
+        out["metric"] = "SHARED GPU (%d gloo ranks on %d device(s): launch-path check, NOT a measurement) " % (world, torch.cuda.device_count()) + out["metric"]
+        out["shared_gpu"] = True
+        if dist_info is not None:
+            out["dist"]["ranks_per_device"] = "%d ranks time-slice %d device(s) over gloo" % (world, torch.cuda.device_count())
     if dry:
         out["dry_run"] = True
         out["data"] = "synthetic, toy sizes (%d clips of %d samples per rank) on the CPU emulator" % (sum(BATCH), N_SAMPLES)

@@ -218,3 +218,29 @@ def _run_and_check(tmp_path, overlap, backend, dw_side, prefetch=None):
         assert diff.max().item() <= 2.5 * 1e-3 * 4, msg
         assert (diff > 5e-5).float().mean().item() <= 0.05, msg
     return d
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_sharing_the_gpu(tmp_path):
+    """`python bench.py --gpus 2` end to end ON THE GPU: self-launch under torch.distributed.run, two ranks, the pipelined hipGraph step
+    with the eager exchange tail, the exchange probe with HIP events, one JSON line from rank 0.  The ranks time-slice the one GPU over
+    gloo (RCCL refuses two ranks per device), so the numbers mean nothing -- the line says so -- but every line of the N > 1 bench path
+    except the collective backend runs on the hardware."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SED_BENCH_SHARE_GPU="1", SED_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "5", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out.get("shared_gpu") is True and out["metric"].startswith("SHARED GPU")
+    d = out["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and len(d["ms_per_step_per_rank"]) == 2
+    assert "hipGraph replay" in out["config"]["launch"] and "one graph" in d["graph_scheme"]
+    tail = d["exchange_tail_us"]
+    exposed = [k for k in tail if k.startswith("exposed_exchange")]
+    assert exposed and tail[exposed[0]]["device_us"] is not None and tail[exposed[0]]["device_us"] > 0
+    assert out["config"]["global_batch"] == 96 and out["roofline"] is not None
