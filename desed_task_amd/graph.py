@@ -22,6 +22,7 @@ import torch
 
 _active = None
 
+
 def active():
     """The DynArgs the current step runs under (None = plain eager launches with by-value arguments)."""
     return _active
@@ -301,7 +302,8 @@ class GraphedStepDriver:
         return self.static
 
     def next_label_buffer(self):
-        """prefetch "teacher": the static buffer of the NEXT batch's labels (mixed in place by the graph's prologue)."""
+        """prefetch "teacher": the static buffer of the NEXT batch's labels (only read by the graph's side branch, which copies them
+        into the step's hand-over buffer and mixes them there)."""
         return self.static_next_labels
 
     def next_extra_buffers(self):
