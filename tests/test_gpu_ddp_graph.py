@@ -194,6 +194,50 @@ def test_b48_pipelined_graph_step_vs_oracle_under_rccl_rehearsal(tmp_path):
     assert w["modes"] == ["eager", "capture", "replay"] and w["exchange"] is True
 
 
+def _capture_worker(rank, port, out_dir, reps):
+    """Regression test of graph.quiesce_collectives: a stream capture that starts while ProcessGroupNCCL's watchdog still polls the
+    end event of a just-issued collective used to abort the process (watchdog) or invalidate the capture (main thread) -- ~ 7 % of the
+    captures of round 3's build.  Here: all-reduce, then IMMEDIATELY quiesce + capture a few HIP kernels, `reps` times over."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      SED_DDP_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("SED_DIST_BACKEND", None)
+    from desed_task_amd import features
+    from desed_task_amd.graph import quiesce_collectives
+    from desed_task_amd.launcher import init_distributed
+    init_distributed()
+    assert dist.is_initialized() and dist.get_backend() == "nccl"
+    dev = torch.device("cuda", 0)
+    x = torch.rand(4, 64, 200, device=dev) + 0.1
+    big = torch.ones(8 << 20, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    ok = 0
+    for i in range(reps):
+        for _ in range(3):
+            dist.all_reduce(big)                      # work items the watchdog will be polling for the next ~ 100 ms
+        with torch.cuda.stream(stream):
+            stream.wait_stream(torch.cuda.current_stream(dev))
+            quiesce_collectives(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                y = features.take_log(x)
+                for _ in range(40):                   # (a capture long enough to span a watchdog poll now and then)
+                    y = features.minmax_scale(y)
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all()
+        ok += 1
+    torch.save(dict(ok=ok), os.path.join(out_dir, "capture.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_capture_next_to_live_rccl_collectives(tmp_path):
+    mp.spawn(_capture_worker, args=(_free_port(), str(tmp_path), 40), nprocs=1, join=True)
+    assert torch.load(os.path.join(str(tmp_path), "capture.pt"))["ok"] == 40
+
+
 def _run_and_check(tmp_path, overlap, backend, dw_side, prefetch=None):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path), overlap, backend, dw_side, prefetch), nprocs=2, join=True)
