@@ -195,38 +195,37 @@ def test_b48_pipelined_graph_step_vs_oracle_under_rccl_rehearsal(tmp_path):
 
 
 def _capture_worker(rank, port, out_dir, reps):
-    """Regression test of graph.quiesce_collectives: a stream capture that starts while ProcessGroupNCCL's watchdog still polls the
-    end event of a just-issued collective used to abort the process (watchdog) or invalidate the capture (main thread) -- ~ 7 % of the
-    captures of round 3's build.  Here: all-reduce, then IMMEDIATELY quiesce + capture a few HIP kernels, `reps` times over."""
+    """Regression test of graph.quiesce_collectives: the step's capture (three side streams forked and joined inside it, ~ 300 launches)
+    right behind live RCCL collectives, `reps` times in one process.  On round 3's build ~ 7 % of these captures killed the process --
+    ProcessGroupNCCL's watchdog polls the end event of the last collective from its own thread while the main thread captures
+    (tools/rehearsal_loop.py: 6 dead processes in 87 repetitions; tools/nodrain_check.py runs THIS worker with the drain disabled: 1 of 4 runs of 30 captures died)."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                       SED_DDP_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     os.environ.pop("SED_DIST_BACKEND", None)
-    from desed_task_amd import features
-    from desed_task_amd.graph import quiesce_collectives
+    os.environ.pop("SED_DDP_OVERLAP", None)
+    from oracle import sed_oracle as O
+    from tests import parity_cases as P
+    from desed_task_amd.graph import GraphedStepDriver
     from desed_task_amd.launcher import init_distributed
     init_distributed()
     assert dist.is_initialized() and dist.get_backend() == "nccl"
-    dev = torch.device("cuda", 0)
-    x = torch.rand(4, 64, 200, device=dev) + 0.1
-    big = torch.ones(8 << 20, device=dev)
-    stream = torch.cuda.Stream(device=dev)
+    dev = "cuda"
+    bs, n_samp = (1, 1, 2), 8192 + 1024
+    sd = O.make_state_dict(seed=7)
+    audio = P.to(dev, O.synth_audio(4, n_samp, seed=3))
+    labels = P.to(dev, O.synth_labels(bs, 10, (1 + n_samp // 256) // 4, seed=5))
     ok = 0
     for i in range(reps):
-        for _ in range(3):
-            dist.all_reduce(big)                      # work items the watchdog will be polling for the next ~ 100 ms
-        with torch.cuda.stream(stream):
-            stream.wait_stream(torch.cuda.current_stream(dev))
-            quiesce_collectives(dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                y = features.take_log(x)
-                for _ in range(40):                   # (a capture long enough to span a watchdog poll now and then)
-                    y = features.minmax_scale(y)
-            g.replay()
+        task = P.build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=5)
+        driver = GraphedStepDriver(task, 1, warmup=1, prefetch="teacher")
+        assert driver.eager.exchange
+        for step in range(3):                         # eager (all-reduce, eager Adam) -> capture right behind it -> one replay
+            driver.run_step((audio, labels, None, None), step, next_batch=(audio, labels, None, None))
         torch.cuda.synchronize()
-        assert torch.isfinite(y).all()
+        assert driver.graph is not None and torch.isfinite(task.sed_student.arena.flat).all()
         ok += 1
+        del driver, task
     torch.save(dict(ok=ok), os.path.join(out_dir, "capture.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -234,8 +233,8 @@ def _capture_worker(rank, port, out_dir, reps):
 
 @pytest.mark.timeout(600)
 def test_capture_next_to_live_rccl_collectives(tmp_path):
-    mp.spawn(_capture_worker, args=(_free_port(), str(tmp_path), 40), nprocs=1, join=True)
-    assert torch.load(os.path.join(str(tmp_path), "capture.pt"))["ok"] == 40
+    mp.spawn(_capture_worker, args=(_free_port(), str(tmp_path), 60), nprocs=1, join=True)
+    assert torch.load(os.path.join(str(tmp_path), "capture.pt"))["ok"] == 60
 
 
 def _run_and_check(tmp_path, overlap, backend, dw_side, prefetch=None):
