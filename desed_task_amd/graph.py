@@ -197,9 +197,10 @@ def quiesce_collectives(dev):
     """Called right before a stream capture: drain the device AND the collective backend's watchdog.
 
     ProcessGroupNCCL keeps every collective it issued in a work list that its watchdog thread polls with hipEventQuery every 100 ms
-    until the work has completed.  On this ROCm stack an event query from ANOTHER thread while this thread captures is refused
-    (`capture_error_mode="thread_local"` notwithstanding): the watchdog's query fails -- its exception aborts the process -- and the
-    capture is invalidated (the next launch returns hipErrorStreamCaptureInvalidated).  That, not a numeric race, was round 3's
+    until the work has completed.  On this ROCm stack such a query from ANOTHER thread while this thread captures the step (three
+    side streams forked and joined inside the capture) intermittently fails, `capture_error_mode="thread_local"` notwithstanding:
+    the watchdog's exception aborts the process, or the capture is invalidated (the next launch returns
+    hipErrorStreamCaptureInvalidated) -- 1 - 7 % of the captures; single-stream captures survived the same polls.  That, not a numeric race, was round 3's
     "one run in 43" of the one-rank RCCL rehearsal: tools/rehearsal_loop.py reproduced it as 6 dead processes in 87 repetitions,
     every survivor bit-identical.  With the device idle, `_wait_for_pending_works()` returns as soon as the watchdog has retired
     the last work item; after that it has no event left to query until the next collective -- and none is ever issued during a
