@@ -279,7 +279,9 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-1000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out.get("shared_gpu") is True and out["metric"].startswith("SHARED GPU")
+    assert out["n_gpus"] == 2
+    if torch.cuda.device_count() < 2:          # (on a multi-GPU node the two gloo ranks get a device each: no sharing to flag)
+        assert out.get("shared_gpu") is True and out["metric"].startswith("SHARED GPU")
     d = out["dist"]
     assert d["backend"] == "gloo" and d["world_size"] == 2 and len(d["ms_per_step_per_rank"]) == 2
     assert "hipGraph replay" in out["config"]["launch"] and "one graph" in d["graph_scheme"]
