@@ -4,6 +4,10 @@ import torch
 sys.path.insert(0, ".")
 from desed_task_amd.ops import HeadFn
 from desed_task_amd import _lib
+import os
+for a in sys.argv[1:]:
+    if a.startswith("lib="):                                   # A/B: another build of the C-ABI library (tools/build_variant.py)
+        _lib.use_library(os.path.abspath(a[4:]), is_emulator=False)
 lib = _lib.get(); orig = lib.call; rec = {}
 B, T, D, NC = 48, 156, 256, 10
 x = torch.randn(B, T, D, device="cuda", requires_grad=True)
