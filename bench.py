@@ -411,6 +411,7 @@ def main():
                          "(768 x 496 per clip) fused into the CRNN (confs/pretrained.yaml); not the headline metric")
     ap.add_argument("--gru-dw-atomic", action="store_true", help="A/B: BiGRU weight gradients through zero fill + atomic split-K")
     ap.add_argument("--no-gru-dw-side", action="store_true", help="A/B: BiGRU weight-gradient GEMMs on the main stream")
+    ap.add_argument("--no-cnn-prologue", action="store_true", help="A/B: SpecAugment bands, weight packs and the copy of the hand-over features as three launches")
     ap.add_argument("--no-overlap", action="store_true",
                     help="A/B at N > 1: ONE blocking all-reduce over the whole gradient arena after backward (one graph) instead of "
                          "bucket A under the CNN backward (two graphs); same as SED_DDP_OVERLAP=0")
@@ -537,6 +538,9 @@ def main():
         from desed_task_amd import ops as _ops_probe
         ts_probe = TsProbe(dev)
         _ops_probe.PROBE = ts_probe
+    if args.no_cnn_prologue:
+        from desed_task_amd.nnet.CNN import CNN as _CNN
+        _CNN.FUSE_PROLOGUE = False
     if args.no_gru_dw_side:
         from desed_task_amd import ops as _ops2
         _ops2.GRU_DW_SIDE_ALLOWED = False

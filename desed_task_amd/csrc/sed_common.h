@@ -284,6 +284,29 @@ __device__ __forceinline__ uint32_t sed_hash(uint32_t idx, uint32_t seed) {
     return x * 0x2C1B3C6Du;
 #endif
 }
+
+// SpecAugment bands of clip b from the counter-based generator: u_k(clip i) = top 24 bits of sed_hash(4 i + k, seed) / 2^24, k = 0 / 1
+// frequency-mask length / start, 2 / 3 time-mask length / start; torchaudio's mask_along_axis(_iid) float32 arithmetic
+// (sed_feat.hip: specaug_bounds_seeded_kernel; sed_conv_bf16.hip: the fused CNN prologue).  n == 1: one draw for the whole batch.
+__device__ __forceinline__ void sed_specaug_draw(int* __restrict__ bounds, int b, int n, int f_param, int n_freq, int t_param,
+                                                 int n_time, uint32_t seed) {
+    const int i = n == 1 ? 0 : b;
+    const float inv = 1.0f / 16777216.0f;
+    int f0 = 0, f1 = 0, t0 = 0, t1 = 0;
+    if (f_param >= 1) {
+        const float value = (float)(sed_hash(4u * i + 0u, seed) >> 8) * inv * (float)f_param;
+        const float min_value = (float)(sed_hash(4u * i + 1u, seed) >> 8) * inv * ((float)n_freq - value);
+        f0 = (int)min_value;
+        f1 = f0 + (int)value;
+    }
+    if (t_param >= 1) {
+        const float value = (float)(sed_hash(4u * i + 2u, seed) >> 8) * inv * (float)t_param;
+        const float min_value = (float)(sed_hash(4u * i + 3u, seed) >> 8) * inv * ((float)n_time - value);
+        t0 = (int)min_value;
+        t1 = t0 + (int)value;
+    }
+    bounds[4 * b] = f0; bounds[4 * b + 1] = f1; bounds[4 * b + 2] = t0; bounds[4 * b + 3] = t1;
+}
 // threshold = round(p * 2^24): keep when the top 24 bits are >= threshold.
 __device__ __forceinline__ bool sed_keep(uint32_t idx, uint32_t seed, uint32_t threshold24) {
     return (sed_hash(idx, seed) >> 8) >= threshold24;

@@ -47,8 +47,7 @@ struct PackBJobs {
     int ckf[8], ckd[8];                                  // channels per chunk of the forward / data-gradient slabs (convb_ck)
     int n;
 };
-__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(PackBJobs jobs) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_weights_bf16_one(const PackBJobs& jobs, int i) {
     if (i >= jobs.start[jobs.n]) return;
     int j = 0;
 #pragma unroll
@@ -70,6 +69,33 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(PackBJobs jobs) 
         d[(size_t)CIN * CK] = lo;
     }
 }
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(PackBJobs jobs) {
+    pack_weights_bf16_one(jobs, blockIdx.x * 256 + threadIdx.x);
+}
+// The CNN's prologue in ONE launch (round 4): everything a forward needs before its first convolution and that depends on nothing
+// but the weights, a seed and the input -- the weight packs (blocks [0, pack_blocks)), the SpecAugment bands of the batch (one block)
+// and, for a caller whose input buffer is rewritten before the backward pass reads it (the pipelined step's hand-over buffer), a
+// private copy of the input (the remaining blocks, grid-stride over 16-byte words).  They were three dependent launches of 4 - 12 us
+// at the head of the step's critical path.
+struct PrologueExtra {
+    int* bounds; int B, nb, f_param, n_freq, t_param, n_time; uint32_t seed; const unsigned* seed_dev;
+    const float4* src; float4* dst; size_t n4; const float* src_tail; float* dst_tail; int ntail;
+    int pack_blocks, copy_blocks;
+};
+__global__ __launch_bounds__(256) void cnn_prologue_bf16_kernel(PackBJobs jobs, PrologueExtra ex) {
+    const int blk = blockIdx.x;
+    if (blk < ex.pack_blocks) { pack_weights_bf16_one(jobs, blk * 256 + threadIdx.x); return; }
+    if (blk == ex.pack_blocks) {
+        if (ex.bounds) {
+            const uint32_t seed = ex.seed + (ex.seed_dev ? *ex.seed_dev : 0u);
+            for (int b = threadIdx.x; b < ex.B; b += 256) sed_specaug_draw(ex.bounds, b, ex.nb, ex.f_param, ex.n_freq, ex.t_param, ex.n_time, seed);
+        }
+        if ((int)threadIdx.x < ex.ntail) ex.dst_tail[threadIdx.x] = ex.src_tail[threadIdx.x];
+        return;
+    }
+    const size_t stride = (size_t)ex.copy_blocks * 256;
+    for (size_t i = (size_t)(blk - ex.pack_blocks - 1) * 256 + threadIdx.x; i < ex.n4; i += stride) ex.dst[i] = ex.src[i];
+}
 // Channels per weight chunk for a (CIN -> COUT) contraction: the packing and the kernel dispatch must agree, so both ask here.
 static inline int convb_ck(int CIN, int COUT) {
     const int e = sed_tuning[SED_TUNE_CONVB_CK];       // tuning override (tools/convb_mp_sweep.py)
@@ -79,11 +105,7 @@ static inline int convb_ck(int CIN, int COUT) {
     if (e && CIN >= 32) ck = e == 16 ? 16 : 32;
     return CIN < ck ? CIN : ck;
 }
-// n <= 8 layers; Wf / Wd buffers of 9*CIN*COUT*4 BYTES each (same size as the fp32 packs).
-SED_API int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout,
-                                        const int* cin, void* stream) {
-    if (n < 1 || n > 8) return SED_ERR_ARG;
-    PackBJobs jobs;
+static int packb_jobs(PackBJobs& jobs, int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout, const int* cin) {
     int tot = 0;
     for (int j = 0; j < n; ++j) {
         jobs.W[j] = (const float*)W[j]; jobs.Wf[j] = (unsigned short*)Wf[j]; jobs.Wd[j] = Wd ? (unsigned short*)Wd[j] : nullptr;
@@ -95,7 +117,40 @@ SED_API int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const* W
     jobs.start[n] = tot;
     jobs.start[8] = tot;
     jobs.n = n;
+    return tot;
+}
+// n <= 8 layers; Wf / Wd buffers of 9*CIN*COUT*4 BYTES each (same size as the fp32 packs).
+SED_API int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout,
+                                        const int* cin, void* stream) {
+    if (n < 1 || n > 8) return SED_ERR_ARG;
+    PackBJobs jobs;
+    const int tot = packb_jobs(jobs, n, W, Wf, Wd, cout, cin);
     SED_LAUNCH(pack_weights_bf16_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, jobs);
+    return sed_check_launch();
+}
+// The same packs + (bounds != null) the seeded SpecAugment bands of sed_specaug_bounds_seeded + (copy_dst != null) copy_n floats
+// copy_src -> copy_dst (both 16-byte aligned), one launch.  n == 0: no packs.
+SED_API int sed_cnn_prologue_bf16(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout, const int* cin,
+                                     int* bounds, int B, int nb, int f_param, int n_freq, int t_param, int n_time, unsigned seed,
+                                     const unsigned* seed_dev, const float* copy_src, float* copy_dst, long long copy_n, void* stream) {
+    if (n < 0 || n > 8) return SED_ERR_ARG;
+    if (bounds && B > 0 && nb != 1 && nb != B) return SED_ERR_ARG;
+    if (copy_dst && (!copy_src || copy_n < 0 || ((uintptr_t)copy_src & 15) || ((uintptr_t)copy_dst & 15))) return SED_ERR_ARG;
+    PackBJobs jobs;
+    const int tot = packb_jobs(jobs, n, W, Wf, Wd, cout, cin);
+    PrologueExtra ex;
+    ex.bounds = (bounds && B > 0) ? bounds : nullptr; ex.B = B; ex.nb = nb; ex.f_param = f_param; ex.n_freq = n_freq;
+    ex.t_param = t_param; ex.n_time = n_time; ex.seed = (uint32_t)seed; ex.seed_dev = seed_dev;
+    const size_t n4 = copy_dst ? (size_t)copy_n / 4 : 0;
+    ex.src = (const float4*)copy_src; ex.dst = (float4*)copy_dst; ex.n4 = n4;
+    ex.ntail = copy_dst ? (int)(copy_n % 4) : 0;
+    ex.src_tail = copy_src ? copy_src + 4 * n4 : nullptr; ex.dst_tail = copy_dst ? copy_dst + 4 * n4 : nullptr;
+    ex.pack_blocks = (tot + 255) / 256;
+    // four 16-byte words per thread: enough blocks to stream 15 MB in a few us, few enough not to delay the pack blocks
+    size_t cb = (n4 + 1023) / 1024;
+    ex.copy_blocks = (int)(cb > 4096 ? 4096 : cb);
+    if (ex.pack_blocks == 0 && !ex.bounds && n4 == 0 && ex.ntail == 0) return SED_OK;
+    SED_LAUNCH(cnn_prologue_bf16_kernel, dim3(ex.pack_blocks + 1 + ex.copy_blocks), dim3(256), 0, (hipStream_t)stream, jobs, ex);
     return sed_check_launch();
 }
 

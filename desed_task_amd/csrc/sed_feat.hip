@@ -254,22 +254,7 @@ __global__ __launch_bounds__(256) void specaug_bounds_seeded_kernel(int* __restr
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     if (seed_dev) seed += *seed_dev;
-    const int i = n == 1 ? 0 : b;
-    const float inv = 1.0f / 16777216.0f;
-    int f0 = 0, f1 = 0, t0 = 0, t1 = 0;
-    if (f_param >= 1) {
-        const float value = (float)(sed_hash(4u * i + 0u, seed) >> 8) * inv * (float)f_param;
-        const float min_value = (float)(sed_hash(4u * i + 1u, seed) >> 8) * inv * ((float)n_freq - value);
-        f0 = (int)min_value;
-        f1 = f0 + (int)value;
-    }
-    if (t_param >= 1) {
-        const float value = (float)(sed_hash(4u * i + 2u, seed) >> 8) * inv * (float)t_param;
-        const float min_value = (float)(sed_hash(4u * i + 3u, seed) >> 8) * inv * ((float)n_time - value);
-        t0 = (int)min_value;
-        t1 = t0 + (int)value;
-    }
-    bounds[4 * b] = f0; bounds[4 * b + 1] = f1; bounds[4 * b + 2] = t0; bounds[4 * b + 3] = t1;
+    sed_specaug_draw(bounds, b, n, f_param, n_freq, t_param, n_time, seed);
 }
 SED_API int sed_specaug_bounds_seeded(int* bounds, int B, int n, int f_param, int n_freq, int t_param, int n_time, unsigned seed,
                                          const unsigned* seed_dev, void* stream) {

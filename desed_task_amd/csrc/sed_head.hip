@@ -121,11 +121,15 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
 // (dW1 | dW2 | db1 | db2) and head_bwd_reduce_kernel sums the records in a fixed order (round 3: the 144 workgroups x 5 120 float
 // atomics on the same 5 120 addresses were most of the launch's 62 us, and made it irreproducible).
 // Grid = (clip, frame slice of HEAD_TS frames): nothing in the backward couples frames, so the slices fill the chip.
-// Phase 1: four lanes per frame as in the forward (logit gradients, then this lane's quarter of the dx row);
-// phase 2: thread k owns input feature k over the slice's frames.
+// Waves 0-3: four lanes per frame as in the forward (logit gradients, then this lane's quarter of the dx row);
+// waves 4-7: thread k owns input feature k over the slice's frames (weight gradients).  The two halves only share the logit
+// gradients (dl, behind one barrier) and ran one after the other on the same four waves until round 4: a slice is one wave per SIMD
+// of latency-bound work either way, so the second set of waves is free.
 #define HEAD_TS 64
+// (27 classes: 456 registers per thread -- one set of four waves does both halves in turn, as before)
+#define HEAD_BWD_THREADS(NC) ((NC) <= 10 ? 512 : 256)
 template <int NC, int D>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W1,
+__global__ __launch_bounds__(HEAD_BWD_THREADS(NC)) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W1,
                                                        const float* __restrict__ W2, const float* __restrict__ strong,
                                                        const float* __restrict__ psoft, const float* __restrict__ weak,
                                                        const float* __restrict__ den, const float* __restrict__ d_strong,
@@ -140,15 +144,31 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     float* w2 = w1 + NC * D;             // NC*D
     float* dl = w2 + NC * D;             // TS * 2*NC: (d logit1 | d logit2) per frame of the slice
     const int tid = threadIdx.x, b = blockIdx.y, tbeg = blockIdx.x * TS, tn = min(TS, T - tbeg), q = tid & 3;
-    for (int i = tid; i < NC * D; i += 256) { w1[i] = W1[i]; w2[i] = W2[i]; }
-    for (int i = tid; i < TS * 2 * NC; i += 256) dl[i] = 0.f;
+    constexpr int NTH = HEAD_BWD_THREADS(NC);
+    constexpr bool SPLIT = NTH == 512;
+    const bool rows = !SPLIT || tid < 256;                        // waves 0-3: frames; waves 4-7: input features
+    const int ft = SPLIT ? tid - 256 : tid;                       // feature thread index
+    for (int i = tid; i < NC * D; i += NTH) { w1[i] = W1[i]; w2[i] = W2[i]; }
+    for (int i = tid; i < TS * 2 * NC; i += NTH) dl[i] = 0.f;
     __syncthreads();
-    // ---- phase 1: per-frame logit gradients and dx rows (TS == 256 / 4 frames in one pass) ----
-    {
-        const int tl = tid >> 2, t = tbeg + tl;
-        if (tl < tn) {
-            const size_t bt = (size_t)b * T + t;
-            float g1[NC], g2[NC];
+    // ---- per-frame logit gradients (TS == 256 / 4 frames in one pass) ----
+    float g1[NC], g2[NC];
+    const int tl = (tid & 255) >> 2, t = tbeg + tl;
+    const size_t bt = (size_t)b * T + t;
+    // the feature threads fetch their first eight frames of x while the frame threads work out the logit gradients
+    constexpr int KPT = D / 256 + (D % 256 ? 1 : 0);             // input features per feature thread (k, k + 256)
+    float v[KPT][8];
+    auto first_round = [&]() {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = ft + 256 * j;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[j][u] = k < D ? x[((size_t)b * T + tbeg + (u < tn ? u : tn - 1)) * D + k] : 0.f;
+        }
+    };
+    if (SPLIT && !rows) first_round();
+    if (rows && tl < tn) {
+        {
             float dot = 0.f;
             const bool padded = pad && pad[bt];
 #pragma unroll
@@ -171,6 +191,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                 g2[c] = padded ? 0.f : psoft[bt * NC + c] * (g2[c] - dot);     // filled logits are constants
                 if (q == 0) { dl[tl * 2 * NC + c] = g1[c]; dl[tl * 2 * NC + NC + c] = g2[c]; }
             }
+        }
+    }
+    __syncthreads();
+    if (rows) {
+        if (tl < tn) {
+            // ---- dx rows ----
             float* dr = dx + bt * D;
 #pragma unroll 2
             for (int i = 0; i < D / 16; ++i) {
@@ -193,42 +219,48 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                 *(float4*)(dr + k) = acc;
             }
         }
+        if (tid < 2 * NC) {
+            float sm = 0.f;
+            for (int i = 0; i < tn; ++i) sm += dl[i * 2 * NC + tid];
+            mine[2 * NC * D + tid] = sm;
+        }
+        if (SPLIT) return;
     }
-    __syncthreads();
-    // ---- phase 2: weight gradients, thread k owns input feature k (and k + 256 when D = 384) ----
-    for (int k = tid; k < D; k += 256) {
+    // ---- weight gradients: thread k owns input feature k (and k + 256 when D = 384) ----
+    if (!SPLIT) first_round();
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int k = ft + 256 * j;
+        if (k >= D) break;
         float a1[NC], a2[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) { a1[c] = 0.f; a2[c] = 0.f; }
-        // eight frames per round: the loads of a round are all in flight before the first FMA (one load per iteration made this
-        // loop 64 dependent HBM round trips, most of the launch)
+        // eight frames per round, the NEXT round's loads in flight under this round's FMAs (one load per iteration made this loop 64
+        // dependent HBM round trips; eight loads and then their FMAs still exposed one round trip per round)
         for (int tl0 = 0; tl0 < tn; tl0 += 8) {
-            float v[8];
+            float vn[8];                                        // (v[j] holds this round: its first one was fetched before the barrier)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int tl = tl0 + u < tn ? tl0 + u : tn - 1;
-                v[u] = x[((size_t)b * T + tbeg + tl) * D + k];
+                const int nt = tl0 + 8 + u < tn ? tl0 + 8 + u : tn - 1;
+                vn[u] = tl0 + 8 < tn ? x[((size_t)b * T + tbeg + nt) * D + k] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int tl = tl0 + u;
-                const size_t bt = (size_t)b * T + tbeg + tl;
-                const float vv = (tl < tn && sed_keep((uint32_t)(bt * D + k), seed, thr24)) ? v[u] * dscale : 0.f;
-                const int tc = tl < tn ? tl : 0;
+                const int tl2 = tl0 + u;
+                const size_t bt2 = (size_t)b * T + tbeg + tl2;
+                const float vv = (tl2 < tn && sed_keep((uint32_t)(bt2 * D + k), seed, thr24)) ? v[j][u] * dscale : 0.f;
+                const int tc = tl2 < tn ? tl2 : 0;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     a1[c] = fmaf(dl[tc * 2 * NC + c], vv, a1[c]);
                     a2[c] = fmaf(dl[tc * 2 * NC + NC + c], vv, a2[c]);
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[j][u] = vn[u];
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) { mine[c * D + k] = a1[c]; mine[NC * D + c * D + k] = a2[c]; }
-    }
-    if (tid < 2 * NC) {
-        float s = 0.f;
-        for (int tl = 0; tl < tn; ++tl) s += dl[tl * 2 * NC + tid];
-        mine[2 * NC * D + tid] = s;
     }
 }
 // out[j] = sum over the nrec records of part[r][j], in a fixed order; j < NP = 2 NC D + 2 NC, laid out dW1 | dW2 | db1 | db2.
@@ -289,7 +321,7 @@ SED_API int sed_head_bwd(const float* x, const float* W1, const float* W2, const
     const int gx = (T + HEAD_TS - 1) / HEAD_TS, NP = 2 * NC * D + 2 * NC;
     int rc = SED_ERR_UNSUPPORTED;
 #define HEAD_CASE(nc, d) \
-    if (NC == nc && D == d) { SED_MAX_SMEM((head_bwd_kernel<nc, d>), smem); SED_LAUNCH((head_bwd_kernel<nc, d>), dim3(gx, B), dim3(256), smem, s, x, W1, W2, strong, psoft, weak, den, d_strong, d_weak, dx, scratch, T, seed, thr24, dscale, seed_dev, classes_valid, pad_mask); rc = sed_check_launch(); }
+    if (NC == nc && D == d) { SED_MAX_SMEM((head_bwd_kernel<nc, d>), smem); SED_LAUNCH((head_bwd_kernel<nc, d>), dim3(gx, B), dim3(HEAD_BWD_THREADS(nc)), smem, s, x, W1, W2, strong, psoft, weak, den, d_strong, d_weak, dx, scratch, T, seed, thr24, dscale, seed_dev, classes_valid, pad_mask); rc = sed_check_launch(); }
     HEAD_CASE(10, 256) HEAD_CASE(27, 256) HEAD_CASE(10, 384) HEAD_CASE(27, 384)
 #undef HEAD_CASE
     if (rc != SED_OK) return rc;

@@ -272,6 +272,27 @@ def specaug_bounds(batch, n_freq, n_time, f_l, f_p, t_l, t_p, device, iid_masks=
     return out
 
 
+def specaug_request(batch, n_freq, n_time, f_l, f_p, t_l, t_p, iid_masks, seed):
+    """The parameters of a seeded specaug_bounds() draw, for a consumer that makes it inside another launch (CNN prologue), or None
+    when neither mask can be longer than 0."""
+    params = [min(cap, int(axis_len * p)) for cap, p, axis_len in ((f_l, f_p, n_freq), (t_l, t_p, n_time))]
+    if params[0] < 1 and params[1] < 1:
+        return None
+    return dict(n=batch if iid_masks else 1, f_param=params[0], n_freq=n_freq, t_param=params[1], n_time=n_time, seed=seed)
+
+
+def specaug_bounds_from_request(batch, req, device):
+    """The stand-alone launch for a specaug_request (same arithmetic, same bits)."""
+    out = torch.empty(batch, 4, dtype=torch.int32, device=device)
+    if batch == 0:
+        return out
+    _lib.check_tensor(out, "specaug bounds")
+    seed = req["seed"]
+    _lib.get().call("sed_specaug_bounds_seeded", out.data_ptr(), batch, req["n"], req["f_param"], req["n_freq"], req["t_param"],
+                    req["n_time"], int(seed) & 0xFFFFFFFF, getattr(seed, "dev", None), _lib.stream_ptr(out))
+    return out
+
+
 def weak_labels(labels):
     """(labels (n, NC, T).sum(-1) > 0).float() in one launch (sed_trainer.py:292)."""
     labels = labels.contiguous().float()

@@ -62,6 +62,7 @@ class CNN(nn.Module):
         # checkpoints but bumped on the host and only written to the buffers when a state dict is requested
         # (7 tiny device launches per forward otherwise).
         self._pending_batches = [0] * n_layers
+        self.last_bounds = None
         self.register_state_dict_pre_hook(CNN._flush_batch_counters)
 
     @staticmethod
@@ -73,19 +74,46 @@ class CNN(nn.Module):
                     bn.num_batches_tracked += n
                 module._pending_batches[i] = 0
 
-    def _pack_weights(self, device, need_dgrad):
+    def _pack_weights(self, device, need_dgrad, prologue=None):
         """Repack the conv weights of blocks 1.. into the kernels' layouts, all layers in ONE launch -> {layer: (Wf, Wd)}."""
         mods = self.cnn._modules
         layers = list(range(1, len(self.nb_filters)))
-        packs = pack_conv_weights([mods["conv%d" % i].weight for i in layers], need_dgrad, self.conv_precision)
+        packs = pack_conv_weights([mods["conv%d" % i].weight for i in layers], need_dgrad, self.conv_precision, prologue)
         return dict(zip(layers, packs))
 
-    def forward(self, x, bounds=None, arena=None):
+    FUSE_PROLOGUE = True                # bench.py --no-cnn-prologue (A/B): separate bounds / pack launches + x.clone()
+
+    def can_fuse_prologue(self, x):
+        """The one-launch prologue (ops.pack_conv_weights(prologue=...)) exists for the split-bf16 packs of a CNN with >= 2 blocks."""
+        return (CNN.FUSE_PROLOGUE and self.conv_precision == "bf16x3" and len(self.nb_filters) > 1 and x.is_contiguous()
+                and x.dtype == torch.float32)
+
+    def forward(self, x, bounds=None, arena=None, specaug=None, private_input=False):
         """x: (B, T, F) scaled log-mel (channels-last with C = 1).  Returns (B, T', F', C_last) channels-last.
-        bounds: optional (B,4) int32 SpecAugment bands fused into the first conv's load."""
+        bounds: optional (B,4) int32 SpecAugment bands fused into the first conv's load.
+        specaug: instead of `bounds`, the parameters of a seeded draw (features.specaug_request) -- made by the weight-pack launch.
+        private_input: x's storage is rewritten before this forward's backward pass runs (the pipelined step's hand-over buffer):
+        work on a private copy -- made by the weight-pack launch as well when that exists, else x.clone()."""
         mods = self.cnn._modules
         p_drop = float(self.conv_dropout or 0.0)
-        packed = self._pack_weights(x.device, need_dgrad=torch.is_grad_enabled())
+        prologue = None
+        if (specaug is not None or private_input) and self.can_fuse_prologue(x):
+            prologue = {}
+            if specaug is not None:
+                bounds = torch.empty(x.shape[0], 4, dtype=torch.int32, device=x.device)
+                prologue["bounds"] = dict(specaug, out=bounds)
+            if private_input:
+                mine = torch.empty_like(x)
+                prologue["copy"] = (x, mine)
+                x = mine
+        else:
+            if specaug is not None:
+                from .. import features
+                bounds = features.specaug_bounds_from_request(x.shape[0], specaug, x.device)
+            if private_input:
+                x = x.clone()
+        packed = self._pack_weights(x.device, need_dgrad=torch.is_grad_enabled(), prologue=prologue)
+        self.last_bounds = bounds           # diagnostics / test recorders: the SpecAugment bands of the latest forward (or None)
         for i in range(len(self.nb_filters)):
             conv, bn, glu = mods["conv%d" % i], mods["batchnorm%d" % i], mods["glu%d" % i]
             drop = mods.get("dropout%d" % i)

@@ -138,13 +138,22 @@ class CRNN(nn.Module):
         return features.specaug_bounds(B, n_freq, n_time, self.specaugm_f_l, self.specaugm_f_p, self.specaugm_t_l,
                                        self.specaugm_t_p, device, iid_masks=self.specaugm_iid_masks, seed=_ops.new_seed())
 
-    def forward_cnn(self, x):
-        """First half of forward(): SpecAugment + the 7 CNN blocks.  x (B, n_mels, T) -> (B, T', C) channels-last."""
+    def forward_cnn(self, x, private_input=False):
+        """First half of forward(): SpecAugment + the 7 CNN blocks.  x (B, n_mels, T) -> (B, T', C) channels-last.
+        private_input: the caller rewrites x's storage before the backward pass (see nnet/CNN.py: forward)."""
         if x.dim() != 3:
             raise ValueError("expected (batch, n_mels, frames)")
         xt = features.as_btf(x)                                           # (B, T, F), no copy for our own views
-        bounds = self._specaug_bounds(xt.shape[0], xt.shape[2], xt.shape[1], xt.device) if self.training else None
-        h = self.cnn(xt, bounds=bounds, arena=self.arena)                 # (B, T', F', C)
+        request = None
+        if self.training:
+            # the seed is drawn here (the reference's order: apply_specaugment, then the CNN's dropouts); the draw itself happens in the
+            # CNN's one-launch prologue next to the weight packs (`_ops.new_seed`, not the module-level name: test recorders count
+            # the DROPOUT sites)
+            request = features.specaug_request(xt.shape[0], xt.shape[2], xt.shape[1], self.specaugm_f_l, self.specaugm_f_p,
+                                               self.specaugm_t_l, self.specaugm_t_p, self.specaugm_iid_masks, None)
+            if request is not None:
+                request["seed"] = _ops.new_seed()
+        h = self.cnn(xt, arena=self.arena, specaug=request, private_input=private_input)      # (B, T', F', C)
         bs, frames, freq, chan = h.shape
         if freq != 1:
             raise NotImplementedError("CNN output keeps %d frequency bins; the recurrent stage expects 1" % freq)

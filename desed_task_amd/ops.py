@@ -167,9 +167,10 @@ def _grad_buf(cfg, param):
     return torch.empty_like(param)
 
 
-def pack_conv_weights(weights, need_dgrad=True, precision="f32"):
+def pack_conv_weights(weights, need_dgrad=True, precision="f32", prologue=None):
     """Repack a list of nn.Conv2d weights (COUT,CIN,3,3) into the conv kernels' layouts, ALL layers in ONE launch.
     precision "f32": K-major fp32 (sed_conv3x3); "bf16x3": split-bf16 slabs (sed_conv3x3_bf16x3).
+    prologue (bf16x3 only): {"bounds": seeded SpecAugment draw, "copy": (src, dst)} done by the SAME launch (sed_cnn_prologue_bf16).
     -> [(Wf, Wd or None), ...] (views into one buffer; Wd = flipped/transposed pack for the data gradient)."""
     import ctypes
     n = len(weights)
@@ -191,6 +192,19 @@ def pack_conv_weights(weights, need_dgrad=True, precision="f32"):
         out.append((wf, wd))
         W[k] = w.data_ptr(); Wf[k] = wf.data_ptr(); Wd[k] = wd.data_ptr() if wd is not None else None
         co[k] = w.shape[0]; ci[k] = w.shape[1]
+    if prologue is not None:
+        if precision != "bf16x3":
+            raise ValueError("the fused CNN prologue is built for the split-bf16 packs")
+        b = prologue.get("bounds")                         # dict(out, n, f_param, n_freq, t_param, n_time, seed) or None
+        c = prologue.get("copy")                           # (src, dst) or None
+        seed = b["seed"] if b else 0
+        _lib.get().call("sed_cnn_prologue_bf16", n, W, Wf, Wd, co, ci,
+                        b["out"].data_ptr() if b else None, b["out"].shape[0] if b else 0, b["n"] if b else 1,
+                        b["f_param"] if b else 0, b["n_freq"] if b else 1, b["t_param"] if b else 0, b["n_time"] if b else 1,
+                        int(seed) & 0xFFFFFFFF, getattr(seed, "dev", None),
+                        c[0].data_ptr() if c else None, c[1].data_ptr() if c else None, c[0].numel() if c else 0,
+                        _lib.stream_ptr(buf))
+        return out
     entry = "sed_conv_pack_multi_bf16" if precision == "bf16x3" else "sed_conv_pack_multi"
     _lib.get().call(entry, n, W, Wf, Wd, co, ci, _lib.stream_ptr(buf))
     return out

@@ -364,10 +364,12 @@ class SEDTask4(_Base):
         x_out = self._pro_buffer("x", features_) if x_into_pro else None
         return self.scaled_logmel(features_, out=x_out), labels, labels_weak
 
-    def _forward_pair(self, x, ht=None, embeddings=None, **tail_kw):
+    def _forward_pair(self, x, ht=None, embeddings=None, volatile_x=False, **tail_kw):
         """Student (with grad) and teacher (no grad) forward on the same scaled features x -> (strong_s, weak_s, strong_t, weak_t).
         ht: the teacher's CNN output when the previous step already computed it (pipelined front half), else None.
         tail_kw: forward_tail keywords of the multi-data-set recipes (classes_mask, pad_mask).
+        volatile_x: x is the pipeline's hand-over buffer -- this step's backward still reads the features while the next prefetch
+        rewrites it, so the student works on a private copy (made by its CNN's one-launch prologue; it was a clone() launch).
         Both CNN encoders first (they fill the GPU), then the two latency-bound tails -- BiGRU recurrence (96 workgroups each) + head --
         side by side on two HIP streams: they are independent and together still leave CUs idle.  (Running the WHOLE teacher forward
         concurrently was measured to be a net loss.)  The teacher's CNN draws its dropout / SpecAugment seeds from its own private
@@ -375,10 +377,12 @@ class SEDTask4(_Base):
         from .nnet.CRNN import CRNN
         split = isinstance(self.sed_student, CRNN) and isinstance(self.sed_teacher, CRNN)
         tstream = self._tail_stream(x.device)
+        if volatile_x and not split:
+            x, volatile_x = x.clone(), False
         if tstream is None:
             self.launch_prefetch("tails")       # (single-stream / CPU path: the position of the fork is immaterial)
             if split:
-                strong_s, weak_s = self.sed_student.forward_tail(self.sed_student.forward_cnn(x), embeddings, **tail_kw)
+                strong_s, weak_s = self.sed_student.forward_tail(self.sed_student.forward_cnn(x, private_input=volatile_x), embeddings, **tail_kw)
             else:
                 strong_s, weak_s = self.sed_student(x, embeddings=embeddings, **tail_kw)
             with torch.no_grad():
@@ -390,7 +394,7 @@ class SEDTask4(_Base):
                 else:
                     strong_t, weak_t = self.sed_teacher(x, embeddings=embeddings, **tail_kw)
             return strong_s, weak_s, strong_t, weak_t
-        hs = self.sed_student.forward_cnn(x)
+        hs = self.sed_student.forward_cnn(x, private_input=volatile_x)
         if ht is None:
             with torch.no_grad(), _ops.seed_stream("teacher_cnn"):
                 ht = self.sed_teacher.forward_cnn(x)
@@ -417,12 +421,12 @@ class SEDTask4(_Base):
             pro["ready"] = False
             if pro["labels"].shape != labels.shape:
                 raise RuntimeError("the prefetched front half does not match this batch's shape")
-            x, ht = pro["x"].clone(), pro["ht"]       # (clone: this step's backward still reads x while the next prefetch rewrites it)
+            x, ht = pro["x"], pro["ht"]
             labels, labels_weak = pro["labels"], pro["labels_weak"]
         else:
             x, labels, labels_weak = self._front(audio, labels)
             ht = None
-        strong_s, weak_s, strong_t, weak_t = self._forward_pair(x, ht, embeddings)
+        strong_s, weak_s, strong_t, weak_t = self._forward_pair(x, ht, embeddings, volatile_x=pro is not None)
         sched = self.scheduler["scheduler"]
         const_max = self.hparams["training"]["const_max"]
         if dyn is not None:

@@ -125,13 +125,13 @@ class SEDTask4(_SEDTask4):
             pro["ready"] = False
             if pro["labels"].shape != labels.shape or pro["embeddings"].shape != embeddings.shape:
                 raise RuntimeError("the prefetched front half does not match this batch's shape")
-            x, ht = pro["x"].clone(), pro["ht"]       # (clone: this step's backward still reads x while the next prefetch rewrites it)
+            x, ht = pro["x"], pro["ht"]               # (x: volatile, the student's CNN copies it in its prologue launch)
             labels, labels_weak, embeddings = pro["labels"], pro["labels_weak"], pro["embeddings"]
         else:
             embeddings = self._dense_embeddings(embeddings)
             x, labels_weak = self._front_2024(audio, labels, embeddings)
             ht = None
-        strong_s, weak_s, strong_t, weak_t = self._forward_pair(x, ht, embeddings, classes_mask=valid)
+        strong_s, weak_s, strong_t, weak_t = self._forward_pair(x, ht, embeddings, volatile_x=pro is not None, classes_mask=valid)
 
         sched = self.scheduler["scheduler"]
         const_max = self.hparams["training"]["const_max"]

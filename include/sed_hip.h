@@ -104,6 +104,13 @@ int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const* Wf, void*
                              const int* cin, void* stream);
 int sed_conv3x3_bf16x3(const float* x, const void* Wp, const float* bias, float* y, float* partial, int B, int T, int F,
                        int CIN, int COUT, void* stream);
+/* The prologue of one CNN forward (desed_task/nnet/CRNN.py:207-232: apply_specaugment, then self.cnn) in ONE launch: the packs of
+ * sed_conv_pack_multi_bf16 (n = 0: none) + the SpecAugment bands of sed_specaug_bounds_seeded (bounds = null: none) + a private
+ * copy of copy_n floats copy_src -> copy_dst (null: none; both 16-byte aligned) for a caller whose input buffer is rewritten
+ * before the backward pass reads it. */
+int sed_cnn_prologue_bf16(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout, const int* cin,
+                          int* bounds, int B, int nb, int f_param, int n_freq, int t_param, int n_time, unsigned seed,
+                          const unsigned* seed_dev, const float* copy_src, float* copy_dst, long long copy_n, void* stream);
 
 /* The data gradient of a TRAINING-mode block with its BatchNorm backward (desed_task/nnet/CNN.py:76) folded into the operand
  * staging: dz (B,T,F,CIN) = dL/d(xhat) from sed_glu_bwd, ybn = the block's pre-BN conv output, stats = mean | invstd,

@@ -1432,7 +1432,7 @@ def case_mt_loss(dev):
 class StochasticRecorder:
     """Records what the HIP path drew in one training step so the oracle can be run on identical draws: the dropout seed of
     every call site (7 CNN blocks + post-GRU head [+ embcat] per model) and the SpecAugment bounds per model.  The draws
-    themselves are untouched -- `ops.new_seed` and `features.specaug_bounds` still produce them; the recorder only listens and
+    themselves are untouched -- `ops.new_seed` and the CNN's prologue still produce them; the recorder only listens and
     tags each draw with the model (student / teacher) whose forward asked for it (the two tails run in swapped order when they
     are overlapped on two HIP streams)."""
 
@@ -1468,10 +1468,17 @@ class StochasticRecorder:
             for meth in ("forward_cnn", "forward_tail"):
                 orig = getattr(model, meth)
 
-                def wrapped(*a, _o=orig, _n=name, **k):
+                def wrapped(*a, _o=orig, _n=name, _m=model, _meth=meth, **k):
                     prev, cur[0] = cur[0], _n
                     try:
-                        return _o(*a, **k)
+                        out = _o(*a, **k)
+                        if _meth == "forward_cnn" and _m.training:
+                            # the bands are drawn inside the CNN's one-launch prologue (no features.specaug_bounds call to listen to)
+                            b = _m.cnn.last_bounds
+                            if b is not None:
+                                rec[_n]["bounds"] = b
+                                rec[_n]["bounds_all"].append(b)
+                        return out
                     finally:
                         cur[0] = prev
                 object.__setattr__(model, meth, wrapped)

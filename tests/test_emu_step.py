@@ -163,11 +163,11 @@ def test_posconv_kernels(emu):
     P.case_posconv("cpu", B=1, T=33, groups=2, K=8)
 
 
-def test_pipelined_epoch_boundaries_and_reset(emu):
-    """Eager pipelined driver across epoch boundaries (no successor announced at an epoch's end) == the unpipelined order, and
-    reset_pipeline() between two steps recomputes the front half from UNMIXED labels (the hipGraph forms run on the GPU)."""
+def test_pipelined_epoch_boundaries(emu):
+    """Eager pipelined driver across epoch boundaries (no successor announced at an epoch's end) == the unpipelined order.  (The
+    hipGraph forms and the reset_pipeline() case -- graphed against eager pipelined -- run on the GPU: without a graph both sides of
+    the reset comparison would be the same driver.)"""
     P.case_pipelined_epoch_boundary("cpu", point="teacher", graph=False, epochs=2, per_epoch=2, n_samp=2048 + 1024)
-    P.case_pipelined_epoch_boundary("cpu", point="teacher", graph=False, epochs=2, per_epoch=3, n_samp=2048 + 1024, reset_after=0)
 
 
 def test_prefetched_2024_step_equals_unpipelined(emu):
