@@ -514,6 +514,13 @@ __global__ __launch_bounds__(256, 2) void glu32_bwd_kernel(const float* __restri
         }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) { if (!(GLU_ABL & 32)) P = mfma32(accd[ks], accx[ks], P); else P[ks] += accd[ks] * accx[ks]; }   // P[n' = S_hi[r]][c = lo] += sum_pixels dlin xn
+        // the frame that floor-mode time pooling drops (T odd: frame T - 1 of every clip) gets no gradient: the wave that owns the
+        // clip's last window row zeroes the 16 pixels x 32 channels below its tile (it was a launch of its own on the backward chain)
+        if ((T & 1) && to == To - 1) {
+            float4* zr = (float4*)(dz + (((size_t)b * T + (T - 1)) * F + 16 * tr) * C);
+            zr[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            zr[64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     // one partial per workgroup (plain stores), summed in a fixed order by glu_bwd_reduce_kernel: 4096 waves x 1024 device-scope
     // float atomics on the same 1 K addresses cost tens of microseconds
@@ -2141,7 +2148,8 @@ SED_API int sed_glu_bwd(const float* y, const float* stats, const float* gamma, 
         if (C == 128) return launch_glu_wide_bwd<128, false>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
         if (C == 64) return launch_glu_wide_bwd<64, false>(y, stats, gamma, beta, Wg, bg, gout, dz, dWg, dbg, dgamma, dbeta, scratch, B, T, F, seed, thr24, dscale, seed_dev, s);
     }
-    if (T % PT != 0) {
+    const bool lds_free32 = C == 32 && PT == 2 && PF == 2 && F % 16 == 0 && T >= 2;      // glu32_bwd_kernel zeroes the dropped frame itself
+    if (T % PT != 0 && !lds_free32) {
         // frames the floor-mode pooling drops get no gradient: zero just those rows (zeroing all of dz was a 123 MB memset
         // per step for block 1)
         const int tail = T % PT, rowf4 = F * C / 4;
