@@ -696,7 +696,7 @@ SED_API int sed_gru_bwd(const float* dout, const float* out, const float* saved,
         return SED_OK;
     }
     if (want_bias && scratch == nullptr) return SED_ERR_ARG;
-    float* bpart = want_bias ? scratch : nullptr;
+    float* bpart = scratch;                       // (scratch without bias pointers: records only, summed later by sed_gru_bias_reduce)
 #define GRU_BWD_CASE(h, ch)                                                                                                       \
     if (H == h) {                                                                                                                 \
         int smem = (2 * ch * 6 * h + 2 * ch * 7 * (GRU_QSTORE ? h + 8 : h)) * 4 + (h <= 128 ? 0 : 8 * 4 * h * 16);               \
@@ -711,5 +711,16 @@ SED_API int sed_gru_bwd(const float* dout, const float* out, const float* saved,
     if (want_bias)
         SED_LAUNCH(gru_bias_reduce_kernel, dim3((6 * H + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, (const float*)bpart, dbi0, dbi1,
                    dbh0, dbh1, B, H);
+    return sed_check_launch();
+}
+// The second half of sed_gru_bwd on its own: the bias gradients from the records a sed_gru_bwd call WITHOUT bias pointers left in
+// `scratch`.  Nothing on the backward chain reads them (the optimizer does), so a caller can run this beside the chain.
+SED_API int sed_gru_bias_reduce(const float* scratch, float* dbi0, float* dbi1, float* dbh0, float* dbh1, int B, int H, void* stream) {
+    if (H != 128 && H != 192) return SED_ERR_UNSUPPORTED;
+    if ((dbi0 == nullptr) != (dbi1 == nullptr) || (dbh0 == nullptr) != (dbh1 == nullptr)) return SED_ERR_ARG;
+    if (!dbi0 && !dbh0) return SED_OK;
+    if (B <= 0) { sed_zero4((hipStream_t)stream, dbi0, dbi0 ? 3 * H : 0, dbi1, dbi1 ? 3 * H : 0, dbh0, dbh0 ? 3 * H : 0, dbh1, dbh1 ? 3 * H : 0); return SED_OK; }
+    if (scratch == nullptr) return SED_ERR_ARG;
+    SED_LAUNCH(gru_bias_reduce_kernel, dim3((6 * H + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, scratch, dbi0, dbi1, dbh0, dbh1, B, H);
     return sed_check_launch();
 }

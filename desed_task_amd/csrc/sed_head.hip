@@ -315,7 +315,9 @@ SED_API int sed_head_bwd(const float* x, const float* W1, const float* W2, const
                             float* scratch, void* stream) {
     if (D != 256 && D != 384) return SED_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (B <= 0 || T <= 0) { sed_zero4(s, dW1, NC * D, dW2, NC * D, db1, NC, db2, NC); return SED_OK; }
+    const bool reduce = dW1 || dW2 || db1 || db2;          // all four null: records only, summed later by sed_head_bwd_reduce
+    if (reduce && !(dW1 && dW2 && db1 && db2)) return SED_ERR_ARG;
+    if (B <= 0 || T <= 0) { if (reduce) sed_zero4(s, dW1, NC * D, dW2, NC * D, db1, NC, db2, NC); return SED_OK; }
     if (!scratch) return SED_ERR_ARG;
     const int smem = (2 * NC * D + HEAD_TS * 2 * NC) * 4;
     const int gx = (T + HEAD_TS - 1) / HEAD_TS, NP = 2 * NC * D + 2 * NC;
@@ -324,8 +326,21 @@ SED_API int sed_head_bwd(const float* x, const float* W1, const float* W2, const
     if (NC == nc && D == d) { SED_MAX_SMEM((head_bwd_kernel<nc, d>), smem); SED_LAUNCH((head_bwd_kernel<nc, d>), dim3(gx, B), dim3(HEAD_BWD_THREADS(nc)), smem, s, x, W1, W2, strong, psoft, weak, den, d_strong, d_weak, dx, scratch, T, seed, thr24, dscale, seed_dev, classes_valid, pad_mask); rc = sed_check_launch(); }
     HEAD_CASE(10, 256) HEAD_CASE(27, 256) HEAD_CASE(10, 384) HEAD_CASE(27, 384)
 #undef HEAD_CASE
-    if (rc != SED_OK) return rc;
+    if (rc != SED_OK || !reduce) return rc;
     SED_LAUNCH(head_bwd_reduce_kernel, dim3((NP + 63) / 64), dim3(256), 0, s, (const float*)scratch, gx * B, NP, NC * D, dW1, dW2, db1, db2, NC);
+    return sed_check_launch();
+}
+// The second half of sed_head_bwd on its own: the weight / bias gradients from the records a sed_head_bwd call with null gradient
+// pointers left in `scratch` (same B, T, D, NC).  Nothing on the backward chain reads them.
+SED_API int sed_head_bwd_reduce(const float* scratch, float* dW1, float* dW2, float* db1, float* db2, int B, int T, int D, int NC,
+                                   void* stream) {
+    if (D != 256 && D != 384) return SED_ERR_UNSUPPORTED;
+    if (!(dW1 && dW2 && db1 && db2)) return SED_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (B <= 0 || T <= 0) { sed_zero4(s, dW1, NC * D, dW2, NC * D, db1, NC, db2, NC); return SED_OK; }
+    if (!scratch) return SED_ERR_ARG;
+    const int gx = (T + HEAD_TS - 1) / HEAD_TS, NP = 2 * NC * D + 2 * NC;
+    SED_LAUNCH(head_bwd_reduce_kernel, dim3((NP + 63) / 64), dim3(256), 0, s, scratch, gx * B, NP, NC * D, dW1, dW2, db1, db2, NC);
     return sed_check_launch();
 }
 

@@ -52,8 +52,44 @@ def side_stream(device):
 def join_side_stream(device):
     """The current stream waits for the weight-gradient GEMMs launched on the side stream (no-op if there were none)."""
     s = _side.get((device.type, device.index))
+    if _deferred:
+        if s is not None:
+            s.wait_stream(torch.cuda.current_stream(device))
+        flush_deferred(s)
     if s is not None:
         torch.cuda.current_stream(device).wait_stream(s)
+
+
+# Small reductions whose results only the optimizer reads (the head's weight gradients, the BiGRU bias gradients: 9 - 19 us each between
+# two kernels of the backward chain).  While GRU_DW_SIDE is on they are parked here and launched on the side stream at the next point
+# where that stream has already been forked from the chain -- the weight-gradient section of the next BiGRU layer backward, or
+# join_side_stream() at the latest.  (A fork of their own would cost what they save: a replayed graph keeps the first-captured
+# successor of a fork on the main hardware queue and starts the other late -- DESIGN.md, "A hipGraph finding".)
+_deferred = []
+DEFER_OFF_CHAIN = True           # bench.py --no-defer (A/B): launch them where they are produced, on the chain
+
+
+def defer_off_chain(device, launch, keep):
+    """launch(stream_ptr) now, or -- while the side stream is in use (GRU_DW_SIDE) -- later on that stream.  `keep`: the scratch tensors
+    the launch reads (held until then, and marked as used by the side stream).  Gradient OUTPUTS must be passed to `launch` as
+    addresses: they are returned to autograd, which only adopts a tensor nobody else references."""
+    if GRU_DW_SIDE and DEFER_OFF_CHAIN and device.type == "cuda":
+        _deferred.append((launch, keep))
+    else:
+        launch(_lib.stream_ptr(keep[0]))
+
+
+def flush_deferred(side):
+    """Launch what defer_off_chain() parked: on `side` (which the caller has made wait for the chain), or on the current stream."""
+    todo, _deferred[:] = list(_deferred), []
+    for launch, keep in todo:
+        if side is not None:
+            for t in keep:
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                launch(side.cuda_stream)
+        else:
+            launch(_lib.stream_ptr(keep[0]))
 
 
 def gemm_entry(cfg, pair=True):
@@ -421,9 +457,15 @@ class BiGRULayerFn(torch.autograd.Function):
         dbh = [_grad_buf(cfg, b_hh_f), _grad_buf(cfg, b_hh_r)]
         # the recurrence also emits the bias gradients (column sums of dgi / dgh)
         bscr = torch.empty(2 * B * 6 * H, **f32)          # per-(clip, direction) bias-gradient records, summed in clip order
+        # (records only: their sum -- sed_gru_bias_reduce -- feeds nothing but the optimizer and runs beside the chain, below)
         lib.call("sed_gru_bwd", dout.data_ptr(), out.data_ptr(), saved.data_ptr(), w_hh_f.data_ptr(), w_hh_r.data_ptr(),
-                 dgi.data_ptr(), dgh.data_ptr(), hprev.data_ptr(), dbi[0].data_ptr(), dbi[1].data_ptr(), dbh[0].data_ptr(),
-                 dbh[1].data_ptr(), B, T, H, bscr.data_ptr(), st)
+                 dgi.data_ptr(), dgh.data_ptr(), hprev.data_ptr(), None, None, None, None, B, T, H, bscr.data_ptr(), st)
+
+        def bias_sums(stream_ptr):
+            lib.call("sed_gru_bias_reduce", bscr.data_ptr(), dbi[0].data_ptr(), dbi[1].data_ptr(), dbh[0].data_ptr(),
+                     dbh[1].data_ptr(), B, H, stream_ptr)
+        if not DEFER_OFF_CHAIN:
+            bias_sums(st)
         BT = B * T
         split = max(1, min(32, BT // 256))
         dwi = [_grad_buf(cfg, w_ih_f), _grad_buf(cfg, w_ih_r)]
@@ -442,11 +484,16 @@ class BiGRULayerFn(torch.autograd.Function):
         side = side_stream(x.device) if GRU_DW_SIDE else None
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(x.device))          # after the recurrence and the dX product were enqueued
-            for t in (dgi, dgh, hprev, x):
+            flush_deferred(side)                                            # (the head's weight-gradient sums, parked by HeadFn)
+            for t in (dgi, dgh, hprev, x, bscr):
                 t.record_stream(side)
             with torch.cuda.stream(side):
+                if DEFER_OFF_CHAIN:
+                    bias_sums(side.cuda_stream)
                 BiGRULayerFn._weight_grads(lib, cfg, dgi, dgh, hprev, x, dwi, dwh, B, T, I, H, split, side.cuda_stream, f32)
         else:
+            if DEFER_OFF_CHAIN:
+                bias_sums(ws)
             BiGRULayerFn._weight_grads(lib, cfg, dgi, dgh, hprev, x, dwi, dwh, B, T, I, H, split, ws, f32)
         d_w_ih, d_w_hh, d_b_ih, d_b_hh = dwi, dwh, dbi, dbh
         return (dx, d_w_ih[0], d_w_hh[0], d_b_ih[0], d_b_hh[0], d_w_ih[1], d_w_hh[1], d_b_ih[1], d_b_hh[1], None)
@@ -609,10 +656,16 @@ class HeadFn(torch.autograd.Function):
         dw1, dw2 = _grad_buf(cfg, w1), _grad_buf(cfg, w2)
         db1, db2 = _grad_buf(cfg, b1), _grad_buf(cfg, b2)
         scratch = torch.empty(int(lib.value("sed_head_bwd_scratch_floats", B, T, D, NC)), device=x.device, dtype=torch.float32)
+        # dx now; the weight / bias gradients (sums of the per-workgroup records) feed nothing but the optimizer: beside the chain
         lib.call("sed_head_bwd", x.data_ptr(), w1.data_ptr(), w2.data_ptr(), strong.data_ptr(), psoft.data_ptr(), weak.data_ptr(),
-                 den.data_ptr(), d_strong.data_ptr(), d_weak.data_ptr(), dx.data_ptr(), dw1.data_ptr(), dw2.data_ptr(),
-                 db1.data_ptr(), db2.data_ptr(), B, T, D, NC, int(seed), thr24, dscale, _graph.seed_dev(seed), _p(ctx.masks[0]),
+                 den.data_ptr(), d_strong.data_ptr(), d_weak.data_ptr(), dx.data_ptr(), None, None, None, None,
+                 B, T, D, NC, int(seed), thr24, dscale, _graph.seed_dev(seed), _p(ctx.masks[0]),
                  _p(ctx.masks[1]), scratch.data_ptr(), _lib.stream_ptr(x))
+        # (the parked launch holds ADDRESSES of the gradient buffers, not the tensors: a second reference would keep autograd's
+        # AccumulateGrad from adopting them as .grad -- it would clone the not yet written buffers instead)
+        outs = (dw1.data_ptr(), dw2.data_ptr(), db1.data_ptr(), db2.data_ptr())
+        defer_off_chain(x.device, lambda stream_ptr: lib.call("sed_head_bwd_reduce", scratch.data_ptr(), outs[0], outs[1], outs[2], outs[3],
+                                                              B, T, D, NC, stream_ptr), (scratch,))
         return dx, dw1, db1, dw2, db2, None
 
 

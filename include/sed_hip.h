@@ -247,6 +247,10 @@ int sed_gru_fwd(const float* gi, const float* whh0, const float* whh1, const flo
 int sed_gru_bwd(const float* dout, const float* out, const float* saved, const float* whh0, const float* whh1,
                 float* dgi, float* dgh, float* hprev, float* dbi0, float* dbi1, float* dbh0, float* dbh1, int B, int T, int H,
                 float* scratch, void* stream);
+/* The bias-gradient half of sed_gru_bwd on its own: sed_gru_bwd with all four bias pointers null and a non-null scratch only
+ * leaves the records; this sums them (same order, same bits).  Nothing on the backward chain reads the bias gradients -- the
+ * optimizer does -- so the launcher runs this beside the chain, next to the weight-gradient GEMMs. */
+int sed_gru_bias_reduce(const float* scratch, float* dbi0, float* dbi1, float* dbh0, float* dbh1, int B, int H, void* stream);
 
 /* ---- K8 + K9: attention-pooling head (desed_task/nnet/CRNN.py:152-178, dropout :304) and losses ---------------- */
 
@@ -267,6 +271,10 @@ int sed_head_bwd(const float* x, const float* W1, const float* W2, const float* 
                  float* scratch, void* stream);
 /* floats of `scratch` for sed_head_bwd: one partial record (dW1 | dW2 | db1 | db2) per workgroup, summed in a fixed order. */
 long long sed_head_bwd_scratch_floats(int B, int T, int D, int NC);
+/* sed_head_bwd with dW1 = dW2 = db1 = db2 = null computes dx and leaves the records in `scratch`; this sums them (the second
+ * half of sed_head_bwd, same bits) -- off the backward chain, like sed_gru_bias_reduce. */
+int sed_head_bwd_reduce(const float* scratch, float* dW1, float* dW2, float* db1, float* db2, int B, int T, int D, int NC,
+                        void* stream);
 
 /* Mean-teacher losses of SEDTask4.training_step (recipes/dcase2023_task4_baseline/local/sed_trainer.py:309-342):
  * scalars[9] = BCE strong/weak (student), BCE strong/weak (teacher), MSE strong/weak, weight*(MSE_s + MSE_w), total, total again;
