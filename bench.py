@@ -606,6 +606,10 @@ def main():
             torch.cuda.synchronize()
 
     sync()
+    # the optimizer's one-launch path needs every gradient in the parameter arena (a gradient autograd had to clone would send Adam down
+    # the per-tensor path and, with side-stream producers, read stale values): checked on the warm-up steps' result, before the clock
+    if not task.sed_student.arena.grads_are_flat():
+        raise RuntimeError("bench: a parameter's .grad is not the arena's view after the warm-up steps")
     if grouped:
         dist.barrier()
     sync()
