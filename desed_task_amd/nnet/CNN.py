@@ -86,7 +86,7 @@ class CNN(nn.Module):
     def can_fuse_prologue(self, x):
         """The one-launch prologue (ops.pack_conv_weights(prologue=...)) exists for the split-bf16 packs of a CNN with >= 2 blocks."""
         return (CNN.FUSE_PROLOGUE and self.conv_precision == "bf16x3" and len(self.nb_filters) > 1 and x.is_contiguous()
-                and x.dtype == torch.float32)
+                and x.dtype == torch.float32 and x.data_ptr() % 16 == 0)       # (the copy moves 16-byte words)
 
     def forward(self, x, bounds=None, arena=None, specaug=None, private_input=False):
         """x: (B, T, F) scaled log-mel (channels-last with C = 1).  Returns (B, T', F', C_last) channels-last.

@@ -189,6 +189,103 @@ def np_hash_uniform(n, seed):
     return (x >> 8).to(torch.float32) * np.float32(1.0 / 16777216.0)
 
 
+def case_cnn_prologue(dev):
+    """sed_cnn_prologue_bf16 (one launch) == its three parts (weight packs, seeded SpecAugment bands, copy of the input), bit for bit --
+    every combination of the optional parts, a copy whose length is no multiple of four floats, one draw for the whole batch."""
+    from desed_task_amd import ops
+    shapes = [(32, 16), (64, 32), (128, 64), (128, 128)]
+    ws = [to(dev, O.lcg_fill((co, ci, 3, 3), 31 + i, 0.2)) for i, (co, ci) in enumerate(shapes)]
+    for need_dgrad in (True, False):
+        want = ops.pack_conv_weights(ws, need_dgrad, "bf16x3")
+        for (B, n_freq, n_time, iid, n_copy) in ((6, 128, 40, True, 6 * 40 * 128), (5, 64, 33, False, 5 * 33 * 64 + 3), (3, 16, 9, True, 0)):
+            seed = 424242 + B
+            req = Fh.specaug_request(B, n_freq, n_time, 10, 0.2, 5, 0.2, iid, seed)
+            want_b = Fh.specaug_bounds(B, n_freq, n_time, 10, 0.2, 5, 0.2, torch.device(dev), iid_masks=iid, seed=seed)
+            src = to(dev, O.lcg_fill((max(n_copy, 1),), 77, 1.0))[:n_copy]
+            for with_bounds in (True, False):
+                for with_copy in (True, False):
+                    if not (with_bounds or with_copy):
+                        continue
+                    pro = {}
+                    if with_bounds:
+                        got_b = torch.full((B, 4), -7, dtype=torch.int32, device=dev)
+                        pro["bounds"] = dict(req, out=got_b)
+                    if with_copy:
+                        dst = torch.full((n_copy + 5,), float("nan"), device=dev)
+                        pro["copy"] = (src, dst[:n_copy])
+                    got = ops.pack_conv_weights(ws, need_dgrad, "bf16x3", prologue=pro)
+                    for (gf, gd), (wf, wd) in zip(got, want):
+                        assert torch.equal(gf.cpu().view(torch.int32), wf.cpu().view(torch.int32))
+                        assert (gd is None) == (wd is None)
+                        if gd is not None:
+                            assert torch.equal(gd.cpu().view(torch.int32), wd.cpu().view(torch.int32))
+                    if with_bounds:
+                        assert torch.equal(got_b.cpu(), want_b.cpu()), (B, iid)
+                    if with_copy:
+                        assert torch.equal(dst[:n_copy].cpu(), src.cpu()) and bool(torch.isnan(dst[n_copy:]).all()), n_copy
+    assert Fh.specaug_request(4, 8, 4, 10, 0.0, 5, 0.2, True, 1) is None           # neither mask can be longer than 0: no draw, no seed
+
+
+def case_backward_entries_whole_and_split(dev):
+    """The two backward entry points whose optimizer-only half can run on its own (sed_head_bwd + sed_head_bwd_reduce, sed_gru_bwd +
+    sed_gru_bias_reduce): the one-call form a C caller binds == the split form the Python op layer launches, bit for bit."""
+    from desed_task_amd import _lib
+    lib = _lib.get()
+    f32 = dict(device=dev, dtype=torch.float32)
+    st = None if dev == "cpu" else torch.cuda.current_stream().cuda_stream
+    # ---- head ----
+    B, T, D, NC = 3, 70, 256, 10
+    x = to(dev, O.lcg_fill((B, T, D), 3, 1.0)); w1 = to(dev, O.lcg_fill((NC, D), 4, 0.05)); w2 = to(dev, O.lcg_fill((NC, D), 5, 0.05))
+    b1 = to(dev, O.lcg_fill((NC,), 6, 0.1)); b2 = to(dev, O.lcg_fill((NC,), 7, 0.1))
+    strong, psoft = torch.empty(B, T, NC, **f32), torch.empty(B, T, NC, **f32)
+    weak, den = torch.empty(B, NC, **f32), torch.empty(B, NC, **f32)
+    seed, thr24, dscale = 1234, 1 << 23, 2.0
+    lib.call("sed_head_fwd", x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), strong.data_ptr(), psoft.data_ptr(),
+             weak.data_ptr(), den.data_ptr(), B, T, D, NC, seed, thr24, dscale, None, None, None, st)
+    ds = to(dev, O.lcg_fill((B, T, NC), 8, 1.0)); dw = to(dev, O.lcg_fill((B, NC), 9, 1.0))
+    n_scr = int(lib.value("sed_head_bwd_scratch_floats", B, T, D, NC))
+    outs = []
+    for split in (False, True):
+        dx = torch.full((B, T, D), float("nan"), **f32)
+        g = [torch.full((NC, D), float("nan"), **f32), torch.full((NC, D), float("nan"), **f32), torch.full((NC,), float("nan"), **f32),
+             torch.full((NC,), float("nan"), **f32)]
+        scr = torch.full((n_scr,), float("nan"), **f32)
+        ptrs = [None] * 4 if split else [t.data_ptr() for t in g]
+        lib.call("sed_head_bwd", x.data_ptr(), w1.data_ptr(), w2.data_ptr(), strong.data_ptr(), psoft.data_ptr(), weak.data_ptr(),
+                 den.data_ptr(), ds.data_ptr(), dw.data_ptr(), dx.data_ptr(), ptrs[0], ptrs[1], ptrs[2], ptrs[3], B, T, D, NC, seed, thr24,
+                 dscale, None, None, None, scr.data_ptr(), st)
+        if split:
+            assert all(bool(torch.isnan(t).all()) for t in g)          # untouched until the second half runs
+            lib.call("sed_head_bwd_reduce", scr.data_ptr(), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), B, T, D, NC, st)
+        outs.append([dx.cpu()] + [t.cpu() for t in g])
+    for a, b_ in zip(*outs):
+        assert not bool(torch.isnan(a).any()) and torch.equal(a, b_)
+    # ---- BiGRU recurrence ----
+    B, T, H = 3, 9, 128
+    gi = to(dev, O.lcg_fill((B, T, 2, 3 * H), 11, 0.5))
+    whh = [to(dev, O.lcg_fill((3 * H, H), 12 + d, 0.08)) for d in range(2)]
+    bhh = [to(dev, O.lcg_fill((3 * H,), 14 + d, 0.1)) for d in range(2)]
+    out, saved = torch.empty(B, T, 2 * H, **f32), torch.empty(B, T, 2, 4, H, **f32)
+    lib.call("sed_gru_fwd", gi.data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), bhh[0].data_ptr(), bhh[1].data_ptr(), out.data_ptr(),
+             saved.data_ptr(), B, T, H, st)
+    dout = to(dev, O.lcg_fill((B, T, 2 * H), 16, 1.0))
+    outs = []
+    for split in (False, True):
+        dgi, dgh = torch.full((B, T, 2, 3 * H), float("nan"), **f32), torch.full((B, T, 2, 3 * H), float("nan"), **f32)
+        hprev = torch.full((B, T, 2, H), float("nan"), **f32)
+        db = [torch.full((3 * H,), float("nan"), **f32) for _ in range(4)]
+        scr = torch.full((2 * B * 6 * H,), float("nan"), **f32)
+        ptrs = [None] * 4 if split else [t.data_ptr() for t in db]
+        lib.call("sed_gru_bwd", dout.data_ptr(), out.data_ptr(), saved.data_ptr(), whh[0].data_ptr(), whh[1].data_ptr(), dgi.data_ptr(),
+                 dgh.data_ptr(), hprev.data_ptr(), ptrs[0], ptrs[1], ptrs[2], ptrs[3], B, T, H, scr.data_ptr(), st)
+        if split:
+            assert all(bool(torch.isnan(t).all()) for t in db)
+            lib.call("sed_gru_bias_reduce", scr.data_ptr(), db[0].data_ptr(), db[1].data_ptr(), db[2].data_ptr(), db[3].data_ptr(), B, H, st)
+        outs.append([dgi.cpu(), dgh.cpu(), hprev.cpu()] + [t.cpu() for t in db])
+    for a, b_ in zip(*outs):
+        assert not bool(torch.isnan(a).any()) and torch.equal(a, b_)
+
+
 def case_cnn_block(dev, layer, B, T, F, training=True, dropout_p=0.5, seed=1234, tol=2e-5, precision="f32", block0_fused=None):
     import torch.nn.functional as TF
     from desed_task_amd.ops import ConvBlockFn, pack_conv_weights

@@ -19,6 +19,16 @@ def test_mixup_and_specaug(emu):
     P.case_mixup_specaug("cpu")
 
 
+def test_backward_entries_whole_and_split(emu):
+    """sed_head_bwd / sed_gru_bwd in one call == kernel + sed_head_bwd_reduce / sed_gru_bias_reduce (what ops.py launches)."""
+    P.case_backward_entries_whole_and_split("cpu")
+
+
+def test_cnn_prologue_equals_its_three_launches(emu):
+    """sed_cnn_prologue_bf16: weight packs + seeded SpecAugment bands + the private copy of the input in one launch."""
+    P.case_cnn_prologue("cpu")
+
+
 def test_postprocess_median_threshold_events(emu):
     """K13: batched median filter / thresholds / event regions, bit-exact vs scipy and the oracle."""
     P.case_postprocess("cpu")

@@ -219,6 +219,15 @@ def test_step_ignores_uninitialised_memory():
     P.case_step_ignores_uninitialised_memory("cuda", n_samp=16000 + 1024, steps=3)
 
 
+def test_backward_entries_whole_and_split():
+    """sed_head_bwd / sed_gru_bwd in one call == kernel + sed_head_bwd_reduce / sed_gru_bias_reduce (what ops.py launches)."""
+    P.case_backward_entries_whole_and_split("cuda")
+
+
+def test_cnn_prologue_equals_its_three_launches():
+    P.case_cnn_prologue("cuda")
+
+
 def test_side_stream_backward_leaves_every_gradient_in_the_arena():
     """With the weight-gradient GEMMs and the parked small reductions on the side stream (ops.GRU_DW_SIDE / defer_off_chain) every
     parameter's .grad must still be the arena's own view after backward -- autograd only ADOPTS a returned gradient tensor that
