@@ -53,8 +53,6 @@ def join_side_stream(device):
     """The current stream waits for the weight-gradient GEMMs launched on the side stream (no-op if there were none)."""
     s = _side.get((device.type, device.index))
     if _deferred:
-        if s is not None:
-            s.wait_stream(torch.cuda.current_stream(device))
         flush_deferred(s)
     if s is not None:
         torch.cuda.current_stream(device).wait_stream(s)
@@ -74,16 +72,20 @@ def defer_off_chain(device, launch, keep):
     the launch reads (held until then, and marked as used by the side stream).  Gradient OUTPUTS must be passed to `launch` as
     addresses: they are returned to autograd, which only adopts a tensor nobody else references."""
     if GRU_DW_SIDE and DEFER_OFF_CHAIN and device.type == "cuda":
-        _deferred.append((launch, keep))
+        fork = torch.cuda.Event()
+        fork.record(torch.cuda.current_stream(device))         # the side stream forks HERE, whenever the launch is enqueued
+        _deferred.append((launch, keep, fork))
     else:
         launch(_lib.stream_ptr(keep[0]))
 
 
 def flush_deferred(side):
-    """Launch what defer_off_chain() parked: on `side` (which the caller has made wait for the chain), or on the current stream."""
+    """Launch what defer_off_chain() parked: on `side`, each behind the point of the chain where it was parked -- or on the current
+    stream (side = None)."""
     todo, _deferred[:] = list(_deferred), []
-    for launch, keep in todo:
+    for launch, keep, fork in todo:
         if side is not None:
+            side.wait_event(fork)
             for t in keep:
                 t.record_stream(side)
             with torch.cuda.stream(side):
@@ -361,6 +363,8 @@ class ConvBlockFn(torch.autograd.Function):
                  gout.data_ptr(), dz.data_ptr(), d_glu_w.data_ptr(), d_glu_b.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(),
                  _p(gscratch), B, T, F, COUT, PT, PF, int(seed), thr24, dscale, _graph.seed_dev(seed),
                  int(cfg.get("conv_precision", "f32") == "bf16x3"), st)
+        if _deferred:           # the last BiGRU layer's side section: enqueued now that the chain's next kernel is
+            flush_deferred(side_stream(dev) if GRU_DW_SIDE else None)
         d_bias = _grad_buf(cfg, conv_b)
         d_w = _grad_buf(cfg, conv_w)
         dx = None
@@ -461,9 +465,10 @@ class BiGRULayerFn(torch.autograd.Function):
         lib.call("sed_gru_bwd", dout.data_ptr(), out.data_ptr(), saved.data_ptr(), w_hh_f.data_ptr(), w_hh_r.data_ptr(),
                  dgi.data_ptr(), dgh.data_ptr(), hprev.data_ptr(), None, None, None, None, B, T, H, bscr.data_ptr(), st)
 
+        bptr = (dbi[0].data_ptr(), dbi[1].data_ptr(), dbh[0].data_ptr(), dbh[1].data_ptr())
+
         def bias_sums(stream_ptr):
-            lib.call("sed_gru_bias_reduce", bscr.data_ptr(), dbi[0].data_ptr(), dbi[1].data_ptr(), dbh[0].data_ptr(),
-                     dbh[1].data_ptr(), B, H, stream_ptr)
+            lib.call("sed_gru_bias_reduce", bscr.data_ptr(), bptr[0], bptr[1], bptr[2], bptr[3], B, H, stream_ptr)
         if not DEFER_OFF_CHAIN:
             bias_sums(st)
         BT = B * T
@@ -482,41 +487,50 @@ class BiGRULayerFn(torch.autograd.Function):
         # dW_ih[d] = dgi[d]^T . x   and   dW_hh[d] = dgh[d]^T . hprev[d]   (K = B*T, split-K, both directions per launch).
         ws = st
         side = side_stream(x.device) if GRU_DW_SIDE else None
-        if side is not None:
+        # (addresses, not tensors, go into anything that outlives this call: see defer_off_chain)
+        wptr = ([t.data_ptr() for t in dwi], [t.data_ptr() for t in dwh], [t.numel() for t in dwi], [t.numel() for t in dwh])
+
+        def side_section(stream_ptr):
+            if DEFER_OFF_CHAIN:
+                bias_sums(stream_ptr)
+            BiGRULayerFn._weight_grads(lib, cfg, dgi, dgh, hprev, x, wptr, B, T, I, H, split, stream_ptr, f32)
+        if side is not None and DEFER_OFF_CHAIN:
+            # what the nodes before this one parked (the head's sums, the other layer's side section) goes out now that THIS layer's
+            # recurrence and dX product -- the chain -- are enqueued; this layer's own side section waits for the next node's
+            flush_deferred(side)
+            defer_off_chain(x.device, side_section, (dgi, dgh, hprev, x, bscr))
+        elif side is not None:
             side.wait_stream(torch.cuda.current_stream(x.device))          # after the recurrence and the dX product were enqueued
-            flush_deferred(side)                                            # (the head's weight-gradient sums, parked by HeadFn)
             for t in (dgi, dgh, hprev, x, bscr):
                 t.record_stream(side)
             with torch.cuda.stream(side):
-                if DEFER_OFF_CHAIN:
-                    bias_sums(side.cuda_stream)
-                BiGRULayerFn._weight_grads(lib, cfg, dgi, dgh, hprev, x, dwi, dwh, B, T, I, H, split, side.cuda_stream, f32)
+                side_section(side.cuda_stream)
         else:
-            if DEFER_OFF_CHAIN:
-                bias_sums(ws)
-            BiGRULayerFn._weight_grads(lib, cfg, dgi, dgh, hprev, x, dwi, dwh, B, T, I, H, split, ws, f32)
+            side_section(ws)
         d_w_ih, d_w_hh, d_b_ih, d_b_hh = dwi, dwh, dbi, dbh
         return (dx, d_w_ih[0], d_w_hh[0], d_b_ih[0], d_b_hh[0], d_w_ih[1], d_w_hh[1], d_b_ih[1], d_b_hh[1], None)
 
     @staticmethod
-    def _weight_grads(lib, cfg, dgi, dgh, hprev, x, dwi, dwh, B, T, I, H, split, ws, f32):
+    def _weight_grads(lib, cfg, dgi, dgh, hprev, x, wptr, B, T, I, H, split, ws, f32):
+        """wptr = ([&dW_ih fwd, rev], [&dW_hh fwd, rev], their element counts x 2): the outputs by address (see defer_off_chain)."""
+        dwi, dwh, ni, nh = wptr
         BT, off = B * T, 3 * H * 4
-        if (gemm_entry(cfg).endswith("bf16x3") and I % 4 == 0 and H % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in dwi + dwh)
+        if (gemm_entry(cfg).endswith("bf16x3") and I % 4 == 0 and H % 4 == 0 and all(a % 16 == 0 for a in dwi + dwh)
                 and not (cfg or {}).get("gru_dw_atomic", GRU_DW_ATOMIC)):
             # deterministic split-K: dense per-slice partials + a fixed-order sum (no zero fill, no fp32 atomics: 5 M atomics on
             # 98 K addresses were most of these launches)
             scr = torch.empty(int(lib.value("sed_gemm_splitk_scratch_floats", 3 * H, max(I, H), BT, split)), **f32)
             lib.call("sed_gemm_pair_splitk_bf16x3", dgi.data_ptr(), dgi.data_ptr() + off, x.data_ptr(), x.data_ptr(),
-                     dwi[0].data_ptr(), dwi[1].data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, scr.data_ptr(), ws)
+                     dwi[0], dwi[1], 3 * H, I, BT, 6 * H, I, I, 1, 0, split, scr.data_ptr(), ws)
             lib.call("sed_gemm_pair_splitk_bf16x3", dgh.data_ptr(), dgh.data_ptr() + off, hprev.data_ptr(), hprev.data_ptr() + H * 4,
-                     dwh[0].data_ptr(), dwh[1].data_ptr(), 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, scr.data_ptr(), ws)
+                     dwh[0], dwh[1], 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, scr.data_ptr(), ws)
         else:
-            lib.call("sed_zero_buffers", dwi[0].data_ptr(), dwi[0].numel(), dwi[1].data_ptr(), dwi[1].numel(),
-                     dwh[0].data_ptr(), dwh[0].numel(), dwh[1].data_ptr(), dwh[1].numel(), ws)    # split-K GEMMs accumulate
+            lib.call("sed_zero_buffers", dwi[0], ni[0], dwi[1], ni[1],
+                     dwh[0], nh[0], dwh[1], nh[1], ws)    # split-K GEMMs accumulate
             lib.call(gemm_entry(cfg), dgi.data_ptr(), dgi.data_ptr() + off, x.data_ptr(), x.data_ptr(), None, None,
-                     dwi[0].data_ptr(), dwi[1].data_ptr(), 3 * H, I, BT, 6 * H, I, I, 1, 0, split, 0, ws)
+                     dwi[0], dwi[1], 3 * H, I, BT, 6 * H, I, I, 1, 0, split, 0, ws)
             lib.call(gemm_entry(cfg), dgh.data_ptr(), dgh.data_ptr() + off, hprev.data_ptr(), hprev.data_ptr() + H * 4, None, None,
-                     dwh[0].data_ptr(), dwh[1].data_ptr(), 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, 0, ws)
+                     dwh[0], dwh[1], 3 * H, H, BT, 6 * H, 2 * H, H, 1, 0, split, 0, ws)
 
 
 class EmbCatFn(torch.autograd.Function):
