@@ -461,6 +461,13 @@ __global__ __launch_bounds__(BNF_THREADS) void bn_finalize_kernel(const float* _
     __shared__ double r1[BNF_THREADS / 64], r2[BNF_THREADS / 64];
     const int c = blockIdx.x, tid = threadIdx.x;
     float mean, invstd;
+    // thread 0's four per-channel scalars are fetched NOW, under the reduction: read after the barrier they were one more exposed
+    // memory round trip in a launch that is nothing but latency (5 us, 14 launches per step, between two chip-wide kernels each)
+    float g_c = 0.f, b_c = 0.f, rm_c = 0.f, rv_c = 0.f;
+    if (tid == 0) {
+        g_c = gamma[c]; b_c = beta[c];
+        if (!training || update_running) { rm_c = running_mean[c]; rv_c = running_var[c]; }
+    }
     if (training) {
         // latency-bound launch (a few hundred to ~2000 partials per channel): 1024 threads so that every thread issues its one or
         // two loads at once instead of walking a dependent chain, then wave butterflies and one barrier
@@ -484,20 +491,20 @@ __global__ __launch_bounds__(BNF_THREADS) void bn_finalize_kernel(const float* _
         mean = (float)m;
         invstd = (float)(1.0 / sqrt(var + (double)eps));
         if (update_running) {
-            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+            running_mean[c] = (1.0f - momentum) * rm_c + momentum * mean;
             const float unbiased = (float)(var * ((double)count / ((double)count - 1.0)));
-            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+            running_var[c] = (1.0f - momentum) * rv_c + momentum * unbiased;
         }
     } else {
         if (tid != 0) return;
-        mean = running_mean[c];
-        invstd = 1.0f / sqrtf(running_var[c] + eps);
+        mean = rm_c;
+        invstd = 1.0f / sqrtf(rv_c + eps);
     }
-    const float sc = gamma[c] * invstd;
+    const float sc = g_c * invstd;
     stats[c] = mean;
     stats[C + c] = invstd;
     stats[2 * C + c] = sc;
-    stats[3 * C + c] = beta[c] - mean * sc;
+    stats[3 * C + c] = b_c - mean * sc;
 }
 SED_API int sed_bn_finalize(const float* partial, int nblocks, int C, float count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* stats, int training,

@@ -2029,7 +2029,7 @@ __global__ __launch_bounds__(GBR_THREADS) void glu_bwd_reduce_kernel(const float
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int fix) {
     // fix != 0 (split-bf16 kernel): the dWg slabs hold dWg' = dlin^T xhat; dWg[n][c] = gamma_c dWg'[n][c] + beta_c dbg[n]
     __shared__ float4 red[GBR_GROUPS][16];
-    __shared__ float sdb[GBR_THREADS];
+    __shared__ float sdb[GBR_THREADS / 64];
     const int tid = threadIdx.x, col = tid & 15, grp = tid >> 4, e = blockIdx.x * 64 + 4 * col;
     const int CC = C * C, PART = KS * CC + WMS * 3 * C;
     // outputs [0, CC) are dWg with KS slabs per partial; [CC, CC + 3C) the three vectors with WMS slabs (C % 4 == 0 keeps
@@ -2047,31 +2047,41 @@ __global__ __launch_bounds__(GBR_THREADS) void glu_bwd_reduce_kernel(const float
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
-    red[grp][col] = acc;
-    __syncthreads();
-    float dbn = 0.f;
-    if (fix && blockIdx.x * 64 < CC) {               // dbg[n] for this block's row n = (blockIdx.x * 64) / C   (C >= 64)
+    // Everything this launch reads is requested BEFORE its one barrier (round 4): dbg[n] of the block's row and the gamma / beta quads
+    // used to be fetched after it, behind a ten-barrier LDS tree -- two more exposed round trips in a launch that is nothing but
+    // latency (6 - 9 us, six of them on the backward chain between a GLU backward and its data-gradient convolution).
+    const bool need_dbn = fix && blockIdx.x * 64 < CC;     // dbg[n] for this block's row n = (blockIdx.x * 64) / C   (C >= 64)
+    float sacc = 0.f;
+    if (need_dbn) {
         const int nrow = (blockIdx.x * 64) / C;
-        float sacc = 0.f;
         for (int i = tid; i < nblk * WMS; i += GBR_THREADS) {
             const int b = i / WMS, k = i - b * WMS;
             sacc += part[(size_t)b * PART + (size_t)KS * CC + k * 3 * C + nrow];
         }
-        sdb[tid] = sacc;
-        __syncthreads();
-        for (int st = GBR_THREADS / 2; st > 0; st >>= 1) {
-            if (tid < st) sdb[tid] += sdb[tid + st];
-            __syncthreads();
-        }
-        dbn = sdb[0];
+    }
+    float4 gq = make_float4(0.f, 0.f, 0.f, 0.f), bq = gq;
+    if (fix && isw && grp == 0) {                        // (four scalar loads: a parameter is only guaranteed 4-byte alignment)
+        const int c = e % C;
+        gq = make_float4(gamma[c], gamma[c + 1], gamma[c + 2], gamma[c + 3]);
+        bq = make_float4(beta[c], beta[c + 1], beta[c + 2], beta[c + 3]);
+    }
+    red[grp][col] = acc;
+    if (need_dbn) {
+        sacc = wave_sum(sacc);
+        if ((tid & 63) == 0) sdb[tid >> 6] = sacc;
+    }
+    __syncthreads();
+    float dbn = 0.f;
+    if (need_dbn) {
+#pragma unroll
+        for (int w = 0; w < GBR_THREADS / 64; ++w) dbn += sdb[w];
     }
     if (grp == 0 && e < CC + 3 * C) {
 #pragma unroll
         for (int g = 1; g < GBR_GROUPS; ++g) { const float4 v = red[g][col]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
         if (fix && isw) {
-            const int c = e % C;
-            acc.x = fmaf(gamma[c], acc.x, beta[c] * dbn); acc.y = fmaf(gamma[c + 1], acc.y, beta[c + 1] * dbn);
-            acc.z = fmaf(gamma[c + 2], acc.z, beta[c + 2] * dbn); acc.w = fmaf(gamma[c + 3], acc.w, beta[c + 3] * dbn);
+            acc.x = fmaf(gq.x, acc.x, bq.x * dbn); acc.y = fmaf(gq.y, acc.y, bq.y * dbn);
+            acc.z = fmaf(gq.z, acc.z, bq.z * dbn); acc.w = fmaf(gq.w, acc.w, bq.w * dbn);
         }
         float* dst;
         if (isw) dst = dWg + e;
