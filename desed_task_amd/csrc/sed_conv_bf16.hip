@@ -47,23 +47,34 @@ struct PackBJobs {
     int ckf[8], ckd[8];                                  // channels per chunk of the forward / data-gradient slabs (convb_ck)
     int n;
 };
+// Thread i of [0, tot): one element of the FORWARD slabs, i = (tap, co, ci) with ci fastest -- a wave's stores are runs of CK
+// consecutive bf16 (32 - 64 B) per plane; thread tot + i: one element of the DATA-GRADIENT slabs, i = (tap, ci, co) with co fastest,
+// same.  The reads are then strided (36 B resp. 36 CIN B apart: the 2 MB of weights sit in L2); until round 4 the element order of W
+// was walked instead -- coalesced reads, but four 2-byte stores per thread each into a cache line of its own (2.1 M partial-line
+// writes: most of the launch's 12 us, at the head of the step's critical path).
 __device__ __forceinline__ void pack_weights_bf16_one(const PackBJobs& jobs, int i) {
-    if (i >= jobs.start[jobs.n]) return;
+    const int tot = jobs.start[jobs.n];
+    const bool dgrad = i >= tot;
+    if (dgrad) i -= tot;
+    if (i >= tot) return;
     int j = 0;
 #pragma unroll
     for (int q = 1; q < 8; ++q) j += (q < jobs.n && i >= jobs.start[q]) ? 1 : 0;
-    const int e = i - jobs.start[j], COUT = jobs.cout[j], CIN = jobs.cin[j];
-    const int b = e % 3, a = (e / 3) % 3, ci = (e / 9) % CIN, co = e / (9 * CIN);
+    if (dgrad && !jobs.Wd[j]) return;
+    const int r = i - jobs.start[j], COUT = jobs.cout[j], CIN = jobs.cin[j];
+    const int tap = r / (COUT * CIN), rem = r - tap * (COUT * CIN);
     unsigned short hi, lo;
-    bf16_split(jobs.W[j][e], hi, lo);
-    {
-        const int CK = jobs.ckf[j], NCH = CIN / CK, tap = a * 3 + b, cc = ci / CK, cl = ci % CK;
+    if (!dgrad) {
+        const int co = rem / CIN, ci = rem - co * CIN;
+        bf16_split(jobs.W[j][((size_t)co * CIN + ci) * 9 + tap], hi, lo);
+        const int CK = jobs.ckf[j], NCH = CIN / CK, cc = ci / CK, cl = ci % CK;
         unsigned short* d = jobs.Wf[j] + ((size_t)(tap * NCH + cc) * 2 * COUT + co) * CK + cl;
         d[0] = hi;
         d[(size_t)COUT * CK] = lo;
-    }
-    if (jobs.Wd[j]) {
-        const int CK = jobs.ckd[j], NCH = COUT / CK, tap = (2 - a) * 3 + (2 - b), cc = co / CK, cl = co % CK;
+    } else {
+        const int ci = rem / COUT, co = rem - ci * COUT;                // tap: the data-gradient slab index (kernel flipped: source tap 8 - tap)
+        bf16_split(jobs.W[j][((size_t)co * CIN + ci) * 9 + (8 - tap)], hi, lo);
+        const int CK = jobs.ckd[j], NCH = COUT / CK, cc = co / CK, cl = co % CK;
         unsigned short* d = jobs.Wd[j] + ((size_t)(tap * NCH + cc) * 2 * CIN + ci) * CK + cl;
         d[0] = hi;
         d[(size_t)CIN * CK] = lo;
@@ -119,12 +130,16 @@ static int packb_jobs(PackBJobs& jobs, int n, const void* const* W, void* const*
     jobs.n = n;
     return tot;
 }
+static inline bool packb_any_dgrad(const PackBJobs& jobs) {
+    for (int j = 0; j < jobs.n; ++j) if (jobs.Wd[j]) return true;
+    return false;
+}
 // n <= 8 layers; Wf / Wd buffers of 9*CIN*COUT*4 BYTES each (same size as the fp32 packs).
 SED_API int sed_conv_pack_multi_bf16(int n, const void* const* W, void* const* Wf, void* const* Wd, const int* cout,
                                         const int* cin, void* stream) {
     if (n < 1 || n > 8) return SED_ERR_ARG;
     PackBJobs jobs;
-    const int tot = packb_jobs(jobs, n, W, Wf, Wd, cout, cin);
+    const int tot = packb_jobs(jobs, n, W, Wf, Wd, cout, cin) * (packb_any_dgrad(jobs) ? 2 : 1);
     SED_LAUNCH(pack_weights_bf16_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, jobs);
     return sed_check_launch();
 }
@@ -137,7 +152,7 @@ SED_API int sed_cnn_prologue_bf16(int n, const void* const* W, void* const* Wf, 
     if (bounds && B > 0 && nb != 1 && nb != B) return SED_ERR_ARG;
     if (copy_dst && (!copy_src || copy_n < 0 || ((uintptr_t)copy_src & 15) || ((uintptr_t)copy_dst & 15))) return SED_ERR_ARG;
     PackBJobs jobs;
-    const int tot = packb_jobs(jobs, n, W, Wf, Wd, cout, cin);
+    const int tot = packb_jobs(jobs, n, W, Wf, Wd, cout, cin) * (packb_any_dgrad(jobs) ? 2 : 1);
     PrologueExtra ex;
     ex.bounds = (bounds && B > 0) ? bounds : nullptr; ex.B = B; ex.nb = nb; ex.f_param = f_param; ex.n_freq = n_freq;
     ex.t_param = t_param; ex.n_time = n_time; ex.seed = (uint32_t)seed; ex.seed_dev = seed_dev;
