@@ -262,6 +262,25 @@ SED_API int sed_gemm_kcat_bf16x3(const float* A, const float* B0, const float* B
                           (hipStream_t)stream, B1 - (size_t)ksplit * ldb, ksplit);
 }
 
+// The same product with a deterministic split-K (dense per-slice partials in `scratch`, sed_gemm_splitk_scratch_floats floats, summed
+// in slice order).  At the BiGRU dX shapes -- M = 7488, N = 128 / 256, K = 768 -- one slice is 118 / 236 workgroups walking 24
+// dependent K tiles each with the chip half empty (37 - 46 us, on the backward chain between two recurrences); 6 / 3 slices are ~ 700
+// workgroups of 4 / 8 tiles, three per CU.
+SED_API int sed_gemm_kcat_splitk_bf16x3(const float* A, const float* B0, const float* B1, float* Cm, int M, int N, int K, int ksplit,
+                                           int lda, int ldb, int ldc, int split_k, float* scratch, void* stream) {
+    if (ksplit % 32 != 0 || ksplit <= 0 || ksplit >= K) return SED_ERR_ARG;
+    if (M <= 0 || N <= 0) return SED_OK;
+    if (!scratch || N % 4 != 0 || ldc % 4 != 0) return SED_ERR_ARG;
+    if (((uintptr_t)Cm & 15) != 0) return SED_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = gemmb_dispatch(A, B0, nullptr, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, lda, ldb, ldc, 0, 0, split_k, 0, s,
+                                  B1 - (size_t)ksplit * ldb, ksplit, 0, scratch);
+    if (rc != SED_OK) return rc;
+    SED_LAUNCH(splitk_reduce_kernel, dim3((M * N / 4 + 255) / 256, 1), dim3(256), 0, s, (const float*)scratch, Cm, Cm,
+               splitk_slices(K, split_k), M, N, ldc);
+    return sed_check_launch();
+}
+
 // torch.nn.Linear forward with an optional fused activation: C[M][N] = act(A[M][K] . W[N][K]^T + bias[N]), act 0 = none, 1 = exact
 // GELU (the FFN of the BEATs encoder layers).  16-byte aligned operands, K % 4 == 0.
 SED_API int sed_linear_bf16x3(const float* A, const float* W, const float* bias, float* Cm, int M, int N, int K, int act,

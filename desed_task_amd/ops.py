@@ -24,6 +24,7 @@ GRU_DW_ATOMIC = False            # A/B switch (bench.py --gru-dw-atomic): the ze
 # the other layer's recurrence (96 workgroups: 160 CUs idle).  Only launcher.StepDriver.backward_joined() turns it on, for the
 # duration of its loss.backward(), and joins the side stream before returning (same-box step 4.17 -> 4.13 ms).
 GRU_DW_SIDE = False
+GRU_DX_SPLITK = True             # bench.py --no-dx-splitk (A/B): the BiGRU dX product as one K slice
 GRU_DW_SIDE_ALLOWED = True       # bench.py --no-gru-dw-side (A/B)
 _side = {}
 
@@ -483,7 +484,15 @@ class BiGRULayerFn(torch.autograd.Function):
             # zero fill)
             dx = torch.empty(B, T, I, **f32)
             kcat = "sed_gemm_kcat_bf16x3" if gemm_entry(cfg).endswith("bf16x3") else "sed_gemm_kcat"
-            lib.call(kcat, dgi.data_ptr(), w_ih_f.data_ptr(), w_ih_r.data_ptr(), dx.data_ptr(), BT, I, 6 * H, 3 * H, 6 * H, I, I, st)
+            # one slice is (I / 64) x (B T / 128) workgroups walking 6 H / 32 dependent K tiles with the chip half empty: aim at ~ 700
+            # workgroups (three resident per CU), slices of at least four tiles
+            nsl = min(max(1, round(700.0 / (((I + 63) // 64) * ((BT + 127) // 128)))), max(1, (6 * H) // 128)) if GRU_DX_SPLITK else 1
+            if kcat.endswith("bf16x3") and nsl > 1 and I % 4 == 0 and dx.data_ptr() % 16 == 0:
+                scr = torch.empty(int(lib.value("sed_gemm_splitk_scratch_floats", BT, I, 6 * H, nsl)) // 2, **f32)
+                lib.call("sed_gemm_kcat_splitk_bf16x3", dgi.data_ptr(), w_ih_f.data_ptr(), w_ih_r.data_ptr(), dx.data_ptr(), BT, I, 6 * H,
+                         3 * H, 6 * H, I, I, nsl, scr.data_ptr(), st)
+            else:
+                lib.call(kcat, dgi.data_ptr(), w_ih_f.data_ptr(), w_ih_r.data_ptr(), dx.data_ptr(), BT, I, 6 * H, 3 * H, 6 * H, I, I, st)
         # dW_ih[d] = dgi[d]^T . x   and   dW_hh[d] = dgh[d]^T . hprev[d]   (K = B*T, split-K, both directions per launch).
         ws = st
         side = side_stream(x.device) if GRU_DW_SIDE else None

@@ -216,6 +216,10 @@ int sed_gemm_kcat(const float* A, const float* B0, const float* B1, float* Cm, i
                   int ldb, int ldc, void* stream);
 int sed_gemm_kcat_bf16x3(const float* A, const float* B0, const float* B1, float* Cm, int M, int N, int K, int ksplit, int lda,
                          int ldb, int ldc, void* stream);
+/* sed_gemm_kcat_bf16x3 with a deterministic split-K: the slices go to `scratch` (sed_gemm_splitk_scratch_floats(M, N, K, split_k)
+ * floats) as dense partials and are summed in slice order -- no atomics, C needs no zero fill.  C 16-byte aligned, N % 4 == 0. */
+int sed_gemm_kcat_splitk_bf16x3(const float* A, const float* B0, const float* B1, float* Cm, int M, int N, int K, int ksplit,
+                                int lda, int ldb, int ldc, int split_k, float* scratch, void* stream);
 int sed_gemm_pair_bf16x3(const float* A0, const float* A1, const float* B0, const float* B1, const float* bias0,
                          const float* bias1, float* C0, float* C1, int M, int N, int K, int lda, int ldb, int ldc,
                          int transA, int transB, int split_k, int accumulate, void* stream);
