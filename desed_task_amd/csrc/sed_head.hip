@@ -121,11 +121,13 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(const float* __r
 // (dW1 | dW2 | db1 | db2) and head_bwd_reduce_kernel sums the records in a fixed order (round 3: the 144 workgroups x 5 120 float
 // atomics on the same 5 120 addresses were most of the launch's 62 us, and made it irreproducible).
 // Grid = (clip, frame slice of HEAD_TS frames): nothing in the backward couples frames, so the slices fill the chip.
-// Waves 0-3: four lanes per frame as in the forward (logit gradients, then this lane's quarter of the dx row);
+// Waves 0-3: HEAD_BL lanes per frame (logit gradients by all of them, then this lane's share of the dx row);
 // waves 4-7: thread k owns input feature k over the slice's frames (weight gradients).  The two halves only share the logit
 // gradients (dl, behind one barrier) and ran one after the other on the same four waves until round 4: a slice is one wave per SIMD
 // of latency-bound work either way, so the second set of waves is free.
-#define HEAD_TS 64
+#define HEAD_TS 32                // frames per slice: 256 frame threads = EIGHT lanes per frame (round 4: 64 frames x 4 lanes -- a slice is a
+                                  // latency chain per frame, so twice the lanes on half the features each and 240 instead of 144 workgroups)
+#define HEAD_BL 8                 // lanes per frame in the backward
 // (27 classes: 456 registers per thread -- one set of four waves does both halves in turn, as before)
 #define HEAD_BWD_THREADS(NC) ((NC) <= 10 ? 512 : 256)
 template <int NC, int D>
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS(NC)) void head_bwd_kernel(const fl
     float* w1 = (float*)smem;            // NC*D
     float* w2 = w1 + NC * D;             // NC*D
     float* dl = w2 + NC * D;             // TS * 2*NC: (d logit1 | d logit2) per frame of the slice
-    const int tid = threadIdx.x, b = blockIdx.y, tbeg = blockIdx.x * TS, tn = min(TS, T - tbeg), q = tid & 3;
+    const int tid = threadIdx.x, b = blockIdx.y, tbeg = blockIdx.x * TS, tn = min(TS, T - tbeg), q = tid & (HEAD_BL - 1);
+    static_assert(HEAD_TS * HEAD_BL == 256 && D % (4 * HEAD_BL) == 0, "256 frame threads: HEAD_BL lanes on interleaved feature quads per frame");
     constexpr int NTH = HEAD_BWD_THREADS(NC);
     constexpr bool SPLIT = NTH == 512;
     const bool rows = !SPLIT || tid < 256;                        // waves 0-3: frames; waves 4-7: input features
@@ -151,9 +154,9 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS(NC)) void head_bwd_kernel(const fl
     for (int i = tid; i < NC * D; i += NTH) { w1[i] = W1[i]; w2[i] = W2[i]; }
     for (int i = tid; i < TS * 2 * NC; i += NTH) dl[i] = 0.f;
     __syncthreads();
-    // ---- per-frame logit gradients (TS == 256 / 4 frames in one pass) ----
+    // ---- per-frame logit gradients (TS == 256 / HEAD_BL frames in one pass) ----
     float g1[NC], g2[NC];
-    const int tl = (tid & 255) >> 2, t = tbeg + tl;
+    const int tl = (tid & 255) / HEAD_BL, t = tbeg + tl;
     const size_t bt = (size_t)b * T + t;
     // the feature threads fetch their first eight frames of x while the frame threads work out the logit gradients
     constexpr int KPT = D / 256 + (D % 256 ? 1 : 0);             // input features per feature thread (k, k + 256)
@@ -199,8 +202,8 @@ __global__ __launch_bounds__(HEAD_BWD_THREADS(NC)) void head_bwd_kernel(const fl
             // ---- dx rows ----
             float* dr = dx + bt * D;
 #pragma unroll 2
-            for (int i = 0; i < D / 16; ++i) {
-                const int k = 16 * i + 4 * q;
+            for (int i = 0; i < D / (4 * HEAD_BL); ++i) {
+                const int k = 4 * HEAD_BL * i + 4 * q;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
