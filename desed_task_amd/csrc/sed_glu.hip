@@ -2054,6 +2054,7 @@ __global__ __launch_bounds__(GBR_THREADS) void glu_bwd_reduce_kernel(const float
     float sacc = 0.f;
     if (need_dbn) {
         const int nrow = (blockIdx.x * 64) / C;
+#pragma unroll 2
         for (int i = tid; i < nblk * WMS; i += GBR_THREADS) {
             const int b = i / WMS, k = i - b * WMS;
             sacc += part[(size_t)b * PART + (size_t)KS * CC + k * 3 * C + nrow];
@@ -2077,7 +2078,7 @@ __global__ __launch_bounds__(GBR_THREADS) void glu_bwd_reduce_kernel(const float
         for (int w = 0; w < GBR_THREADS / 64; ++w) dbn += sdb[w];
     }
     if (grp == 0 && e < CC + 3 * C) {
-#pragma unroll
+#pragma unroll 8
         for (int g = 1; g < GBR_GROUPS; ++g) { const float4 v = red[g][col]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
         if (fix && isw) {
             acc.x = fmaf(gq.x, acc.x, bq.x * dbn); acc.y = fmaf(gq.y, acc.y, bq.y * dbn);
