@@ -411,6 +411,7 @@ def main():
                          "(768 x 496 per clip) fused into the CRNN (confs/pretrained.yaml); not the headline metric")
     ap.add_argument("--gru-dw-atomic", action="store_true", help="A/B: BiGRU weight gradients through zero fill + atomic split-K")
     ap.add_argument("--no-gru-dw-side", action="store_true", help="A/B: BiGRU weight-gradient GEMMs on the main stream")
+    ap.add_argument("--no-park-loss", action="store_true", help="A/B: the eight loss sums inside the loss launch (fence + ticket) instead of beside the chain")
     ap.add_argument("--no-dx-splitk", action="store_true", help="A/B: the BiGRU dX products as one K slice (118 / 236 workgroups)")
     ap.add_argument("--no-defer", action="store_true", help="A/B: the head's weight-gradient sums and the BiGRU bias-gradient sums on the backward chain")
     ap.add_argument("--no-cnn-prologue", action="store_true", help="A/B: SpecAugment bands, weight packs and the copy of the hand-over features as three launches")
@@ -540,6 +541,9 @@ def main():
         from desed_task_amd import ops as _ops_probe
         ts_probe = TsProbe(dev)
         _ops_probe.PROBE = ts_probe
+    if args.no_park_loss:
+        from desed_task_amd import ops as _ops6
+        _ops6.PARK_LOSS_SUMS = False
     if args.no_dx_splitk:
         from desed_task_amd import ops as _ops4
         _ops4.GRU_DX_SPLITK = False

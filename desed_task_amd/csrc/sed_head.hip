@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
                                                    float* __restrict__ g_weak, int B, int T, int NC, int n_strong, int n_weak,
                                                    float weight, const float* __restrict__ weight_dev, int selfsup_bce,
                                                    int selfsup_from, const unsigned char* __restrict__ valid,
-                                                   float* __restrict__ work) {
+                                                   float* __restrict__ work, int finish) {
     if (weight_dev) weight = *weight_dev;       // consistency weight in device memory (hipGraph replays)
     // one workgroup per clip writes its eight pre-scaled per-clip sums to work[b][8]; the workgroup that draws the last ticket
     // (work[8 B], an integer counter it resets to 0) adds them up in clip order: no zero-fill launch, no float atomics,
@@ -443,6 +443,10 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ str
         const float v = tid < 6 ? part[tid] : (tid == 6 ? self_tot : part[0] + part[1] + self_tot);
         work[8 * b + tid] = v;
     }
+    // finish == 0 (sed_mt_loss_records): the per-clip records are all this launch leaves; loss_finish_kernel adds them later.  The
+    // gradient seeds above are complete per clip -- nothing on the backward chain needs the eight sums, and the agent-scope fence in
+    // front of the ticket makes every workgroup write its XCD's dirty L2 lines back (what such a hand-over costs).
+    if (!finish) return;
     __threadfence();
     __syncthreads();
     if (tid == 0) is_last = atomicAdd((unsigned*)(work + 8 * (size_t)B), 1u) == (unsigned)(B - 1);
@@ -475,6 +479,42 @@ SED_API int sed_mt_loss(const float* strong_s, const float* weak_s, const float*
     if (B <= 0 || T <= 0 || NC <= 0 || NC > 256 || n_strong + n_weak > B || selfsup_from < 0 || selfsup_from > B) return SED_ERR_ARG;
     if (work == nullptr) return SED_ERR_ARG;
     SED_LAUNCH(loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, strong_s, weak_s, strong_t, weak_t, labels, labels_weak,
-               scalars, g_strong, g_weak, B, T, NC, n_strong, n_weak, weight, weight_dev, selfsup_bce, selfsup_from, valid, work);
+               scalars, g_strong, g_weak, B, T, NC, n_strong, n_weak, weight, weight_dev, selfsup_bce, selfsup_from, valid, work, 1);
+    return sed_check_launch();
+}
+// The eight sums of sed_mt_loss from the per-clip records of a sed_mt_loss_records launch: one workgroup, clip order (the same order of
+// additions, the same bits as the one-call form).
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ work, float* __restrict__ scalars, int B) {
+    __shared__ float fin[8 * 256];
+    const int tid = threadIdx.x;
+    const bool staged = B <= 256;
+    if (staged) {
+        for (int idx = tid; idx < 8 * B; idx += 256) fin[idx] = work[idx];
+        __syncthreads();
+    }
+    if (tid < 8) {
+        float sum = 0.f;
+        if (staged) for (int i = 0; i < B; ++i) sum += fin[8 * i + tid];
+        else for (int i = 0; i < B; ++i) sum += work[8 * i + tid];
+        scalars[tid] = sum;
+        if (tid == 7) scalars[8] = sum;
+    }
+}
+// sed_mt_loss in two halves: this one writes the gradient seeds (all the backward pass needs) and the per-clip records into `work`
+// (8 B floats; the ticket word is not touched) -- no fence, no ticket; sed_mt_loss_finish adds the records up, on any stream ordered
+// after it.  Same arguments as sed_mt_loss (`scalars` is not written here).
+SED_API int sed_mt_loss_records(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
+                                   const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
+                                   int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, int selfsup_bce,
+                                   int selfsup_from, const unsigned char* valid, float* work, void* stream) {
+    if (B <= 0 || T <= 0 || NC <= 0 || NC > 256 || n_strong + n_weak > B || selfsup_from < 0 || selfsup_from > B) return SED_ERR_ARG;
+    if (work == nullptr) return SED_ERR_ARG;
+    SED_LAUNCH(loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, strong_s, weak_s, strong_t, weak_t, labels, labels_weak,
+               scalars, g_strong, g_weak, B, T, NC, n_strong, n_weak, weight, weight_dev, selfsup_bce, selfsup_from, valid, work, 0);
+    return sed_check_launch();
+}
+SED_API int sed_mt_loss_finish(const float* work, float* scalars, int B, void* stream) {
+    if (B <= 0 || work == nullptr || scalars == nullptr) return SED_ERR_ARG;
+    SED_LAUNCH(loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, work, scalars, B);
     return sed_check_launch();
 }

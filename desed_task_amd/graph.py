@@ -324,15 +324,8 @@ class GraphedStepDriver:
         d.arm_overlap()
         from . import ops as _ops
         _ops.probe("step_start")
-        loss = task.training_step(batch, 0)
+        loss = d.training_step_and_ema(batch, 0)         # (the EMA and the parked loss sums on the side stream)
         _ops.probe("loss_done")
-        if d.side is not None:
-            main = torch.cuda.current_stream()
-            d.side.wait_stream(main)
-            with torch.cuda.stream(d.side):
-                task.on_before_zero_grad()
-        else:
-            task.on_before_zero_grad()
         d.opt.zero_grad(set_to_none=True)
         from . import launcher as _launcher
         late = _launcher.PREFETCH_ENQUEUE_LATE

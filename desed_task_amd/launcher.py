@@ -358,18 +358,32 @@ class StepDriver:
             if self.probe is not None:
                 self.probe.end()
 
-    def _run_step(self, batch, batch_idx, next_batch, staged):
+    def training_step_and_ema(self, batch, batch_idx):
+        """training_step(), then `on_before_zero_grad` (the EMA) -- on the side stream when there is one, together with whatever the
+        forward pass parked for it (ops.AFTER_FORWARD: the loss sums, which feed the log and not the backward pass)."""
         task = self.task
-        self.announce(batch, next_batch, staged=staged)
-        self.arm_overlap()
-        loss = task.training_step(batch, batch_idx)
+        park = self.side is not None and _ops.PARK_LOSS_SUMS
+        prev, _ops.AFTER_FORWARD = _ops.AFTER_FORWARD, ([] if park else None)
+        try:
+            loss = task.training_step(batch, batch_idx)
+        finally:
+            parked, _ops.AFTER_FORWARD = _ops.AFTER_FORWARD, prev
         if self.side is not None:
             main = torch.cuda.current_stream()
             self.side.wait_stream(main)                       # teacher forward has finished reading theta_t
+            if parked:
+                _ops.run_after_forward(parked, self.side)
             with torch.cuda.stream(self.side):
                 task.on_before_zero_grad()
         else:
             task.on_before_zero_grad()
+        return loss
+
+    def _run_step(self, batch, batch_idx, next_batch, staged):
+        task = self.task
+        self.announce(batch, next_batch, staged=staged)
+        self.arm_overlap()
+        loss = self.training_step_and_ema(batch, batch_idx)
         self.opt.zero_grad(set_to_none=True)
         late = PREFETCH_ENQUEUE_LATE and loss.is_cuda
         fork = None

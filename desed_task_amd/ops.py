@@ -64,6 +64,22 @@ def join_side_stream(device):
 # where that stream has already been forked from the chain -- the weight-gradient section of the next BiGRU layer backward, or
 # join_side_stream() at the latest.  (A fork of their own would cost what they save: a replayed graph keeps the first-captured
 # successor of a fork on the main hardware queue and starts the other late -- DESIGN.md, "A hipGraph finding".)
+# The same idea for the FORWARD half of a step: launches whose results nothing on the chain reads (the eight loss sums) are parked here
+# while a step driver that has a side stream for the EMA runs training_step(), and go out on that stream with the EMA.  None: nobody
+# collects them -- launch in place.
+AFTER_FORWARD = None
+PARK_LOSS_SUMS = True            # bench.py --no-park-loss (A/B)
+
+
+def run_after_forward(parked, side):
+    """Launch what a training_step() parked in AFTER_FORWARD on `side` (the caller has made it wait for the main stream)."""
+    for launch, keep in parked:
+        for t in keep:
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            launch(side.cuda_stream)
+
+
 _deferred = []
 DEFER_OFF_CHAIN = True           # bench.py --no-defer (A/B): launch them where they are produced, on the chain
 
@@ -715,10 +731,16 @@ class MeanTeacherLossFn(torch.autograd.Function):
         scalars, total = buf[:8], buf[8]            # two views of one buffer: the kernel writes the total into slots 7 and 8
         g_strong = torch.empty(B, T, NC, **f32)
         g_weak = torch.empty(B, NC, **f32)
-        lib.call("sed_mt_loss", strong_s.data_ptr(), weak_s.data_ptr(), strong_t.data_ptr(), weak_t.data_ptr(), labels.data_ptr(),
-                 labels_weak.data_ptr(), buf.data_ptr(), g_strong.data_ptr(), g_weak.data_ptr(), B, T, NC, int(n_strong),
-                 int(n_weak), float(weight), getattr(weight, "dev", None), int(bool(selfsup_bce)), int(selfsup_from), _p(valid),
-                 loss_work(strong_s.device, B).data_ptr(), _lib.stream_ptr(strong_s))
+        work = loss_work(strong_s.device, B)
+        parked = AFTER_FORWARD is not None and strong_s.is_cuda
+        # parked: only the gradient seeds and the per-clip records here -- the eight sums feed the log, not the backward pass, and go
+        # out beside the chain (launcher.StepDriver.training_step_and_ema, next to the EMA)
+        lib.call("sed_mt_loss_records" if parked else "sed_mt_loss", strong_s.data_ptr(), weak_s.data_ptr(), strong_t.data_ptr(),
+                 weak_t.data_ptr(), labels.data_ptr(), labels_weak.data_ptr(), buf.data_ptr(), g_strong.data_ptr(), g_weak.data_ptr(),
+                 B, T, NC, int(n_strong), int(n_weak), float(weight), getattr(weight, "dev", None), int(bool(selfsup_bce)),
+                 int(selfsup_from), _p(valid), work.data_ptr(), _lib.stream_ptr(strong_s))
+        if parked:
+            AFTER_FORWARD.append((lambda stream_ptr: lib.call("sed_mt_loss_finish", work.data_ptr(), buf.data_ptr(), B, stream_ptr), (buf,)))
         ctx.save_for_backward(g_strong, g_weak)
         ctx.mark_non_differentiable(scalars)
         ctx.set_materialize_grads(False)

@@ -295,6 +295,15 @@ int sed_mt_loss(const float* strong_s, const float* weak_s, const float* strong_
                 const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
                 int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, int selfsup_bce,
                 int selfsup_from, const unsigned char* valid, float* work, void* stream);
+/* sed_mt_loss in two halves.  sed_mt_loss_records: the gradient seeds g_strong / g_weak (all the backward pass needs) and the per-clip
+ * records in work[0 .. 8 B) -- no fence, no ticket, `scalars` untouched; sed_mt_loss_finish: scalars[0 .. 8] from the records, in clip
+ * order (the same bits as the one-call form), on any stream ordered after the first half.  The launcher runs the second half beside
+ * the backward chain, next to the EMA. */
+int sed_mt_loss_records(const float* strong_s, const float* weak_s, const float* strong_t, const float* weak_t,
+                        const float* labels, const float* labels_weak, float* scalars, float* g_strong, float* g_weak, int B,
+                        int T, int NC, int n_strong, int n_weak, float weight, const float* weight_dev, int selfsup_bce,
+                        int selfsup_from, const unsigned char* valid, float* work, void* stream);
+int sed_mt_loss_finish(const float* work, float* scalars, int B, void* stream);
 
 /* ---- K13: inference post-processing, recipes/dcase2023_task4_baseline/local/utils.py:16-73 ----- */
 

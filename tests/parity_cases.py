@@ -260,6 +260,24 @@ def case_backward_entries_whole_and_split(dev):
         outs.append([dx.cpu()] + [t.cpu() for t in g])
     for a, b_ in zip(*outs):
         assert not bool(torch.isnan(a).any()) and torch.equal(a, b_)
+    # ---- losses: sed_mt_loss == sed_mt_loss_records + sed_mt_loss_finish ----
+    B, T, NC, ns, nw = 6, 11, 10, 2, 2
+    ss = torch.sigmoid(to(dev, O.lcg_fill((B, T, NC), 21, 2.0))); st_ = torch.sigmoid(to(dev, O.lcg_fill((B, T, NC), 22, 2.0)))
+    ws = torch.sigmoid(to(dev, O.lcg_fill((B, NC), 23, 2.0))); wt = torch.sigmoid(to(dev, O.lcg_fill((B, NC), 24, 2.0)))
+    lab = to(dev, (O.lcg_fill((B, NC, T), 25, 0.5, 0.5) < 0.3).float()); labw = to(dev, (O.lcg_fill((nw, NC), 26, 0.5, 0.5) < 0.3).float())
+    outs = []
+    for split in (False, True):
+        sc = torch.full((16,), float("nan"), **f32)
+        gs, gw = torch.full((B, T, NC), float("nan"), **f32), torch.full((B, NC), float("nan"), **f32)
+        work = torch.zeros(8 * B + 1, **f32)
+        lib.call("sed_mt_loss_records" if split else "sed_mt_loss", ss.data_ptr(), ws.data_ptr(), st_.data_ptr(), wt.data_ptr(), lab.data_ptr(),
+                 labw.data_ptr(), sc.data_ptr(), gs.data_ptr(), gw.data_ptr(), B, T, NC, ns, nw, 1.7, None, 0, 0, None, work.data_ptr(), st)
+        if split:
+            assert bool(torch.isnan(sc).all())                   # the first half leaves the scalars alone
+            lib.call("sed_mt_loss_finish", work.data_ptr(), sc.data_ptr(), B, st)
+        outs.append([sc[:9].cpu(), gs.cpu(), gw.cpu()])
+    for a, b_ in zip(*outs):
+        assert not bool(torch.isnan(a).any()) and torch.equal(a, b_)
     # ---- BiGRU recurrence ----
     B, T, H = 3, 9, 128
     gi = to(dev, O.lcg_fill((B, T, 2, 3 * H), 11, 0.5))
