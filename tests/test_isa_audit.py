@@ -20,13 +20,29 @@ CLEAN = {
 }
 
 
-@pytest.mark.timeout(600)
+_ASM = {}
+
+
+def gfx950_asm():
+    """{file name: ISA text} of every kernel source, compiled once per session (all files in parallel: both tests below read it)."""
+    if not _ASM:
+        import glob
+        from concurrent.futures import ThreadPoolExecutor
+        import isa_exposed_loads as A
+        srcs = sorted(glob.glob(os.path.join(ROOT, "desed_task_amd", "csrc", "*.hip")))
+        with ThreadPoolExecutor(max_workers=8) as ex:
+            for src, text in zip(srcs, ex.map(A.compile_asm, srcs)):
+                _ASM[os.path.basename(src)] = text
+    return _ASM
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("c++filt") is None, reason="needs hipcc and c++filt")
 @pytest.mark.parametrize("src", sorted(CLEAN))
 def test_no_load_is_waited_for_right_behind_its_issue(src):
     import isa_exposed_loads as A
     seen = set()
-    rows = A.audit_file(os.path.join(ROOT, "desed_task_amd", "csrc", src), min_dist=3, seen=seen)
+    rows = A.audit_file(os.path.join(ROOT, "desed_task_amd", "csrc", src), min_dist=3, seen=seen, asm_text=gfx950_asm()[src])
     missing = [k for k in CLEAN[src] if k not in seen]
     assert not missing, "kernels not found in the ISA (renamed?): %s" % missing
     bad = [r for r in rows if r[0] in CLEAN[src]]
@@ -41,14 +57,9 @@ MAY_SPILL = {"gru_fwd_kernel<192, 4>": 3, "gru_bwd_kernel<192, 2>": 38, "glu_wid
              "glu_wide_bwd_kernel<128>": 18, "head_fwd_kernel<27, 256>": 98, "head_fwd_kernel<27, 384>": 98}
 
 
-def _spills(src):
+def _spills(txt):
     import re
     import subprocess
-    import tempfile
-    out = os.path.join(tempfile.mkdtemp(), "k.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", "-std=c++17",
-                           "-I" + os.path.dirname(src), src, "-o", out], stderr=subprocess.DEVNULL)
-    txt = open(out).read()
     mangled = re.findall(r"\.name:\s+(\S+)", txt)
     names = dict(zip(mangled, subprocess.run(["c++filt"], input="\n".join(mangled), capture_output=True, text=True).stdout.split("\n")))
     rows = []
@@ -62,11 +73,7 @@ def _spills(src):
 @pytest.mark.timeout(900)
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("c++filt") is None, reason="needs hipcc and c++filt")
 def test_no_kernel_spills_registers_unannounced():
-    import glob
-    from concurrent.futures import ThreadPoolExecutor
-    srcs = sorted(glob.glob(os.path.join(ROOT, "desed_task_amd", "csrc", "*.hip")))
-    with ThreadPoolExecutor(max_workers=8) as ex:
-        rows = [r for part in ex.map(_spills, srcs) for r in part]
+    rows = [r for txt in gfx950_asm().values() for r in _spills(txt)]
     assert len(rows) > 100                                             # (the parser still finds the kernels)
     bad = [(n, s, scr) for n, s, scr in rows if s > MAY_SPILL.get(n, 0)]
     assert not bad, "kernels spilling registers (name, spilled VGPRs, scratch bytes): %s" % bad

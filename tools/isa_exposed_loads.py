@@ -39,11 +39,16 @@ def audit_kernel(insts, min_dist):
     return rows
 
 
-def audit_file(path, min_dist=12, seen=None):
-    """-> [(kernel, mnemonic, distance, mfmas, count)] for one .hip source (compiled to gfx950 ISA with the product's flags).
-    `seen` (a set) collects the names of all kernels found in the file."""
-    asm = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-I", CSRC,
-                          "-I", os.path.join(ROOT, "include"), path, "-o", "-"], capture_output=True, text=True).stdout.splitlines()
+def compile_asm(path):
+    """gfx950 ISA text of one .hip source, compiled with the product's flags."""
+    return subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-I", CSRC,
+                           "-I", os.path.join(ROOT, "include"), path, "-o", "-"], capture_output=True, text=True).stdout
+
+
+def audit_file(path, min_dist=12, seen=None, asm_text=None):
+    """-> [(kernel, mnemonic, distance, mfmas, count)] for one .hip source (compiled to gfx950 ISA with the product's flags, or taken
+    from `asm_text`).  `seen` (a set) collects the names of all kernels found in the file."""
+    asm = (asm_text if asm_text is not None else compile_asm(path)).splitlines()
     found, kern, insts = [], None, []
     for line in asm:
         s = line.split(";")[0].strip()
