@@ -3,6 +3,7 @@ C-ABI library).  Every case compares the HIP path against the CPU oracle on the 
 import math
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import sed_oracle as O
@@ -656,6 +657,48 @@ def case_edge_shapes(dev):
     empty = mel(to(dev, torch.zeros(0, 4096)))
     assert tuple(empty.shape) == (0, 128, 17)
     assert tuple(Fh.minmax_scale(empty, apply_log=True).shape) == (0, 128, 17)
+
+
+def case_edge_round4_entries(dev):
+    """Degenerate arguments of the entry points added in round 4: empty batches give zeroed (or untouched) outputs and SED_OK, bad
+    arguments the documented error -- never a launch on a null pointer."""
+    from desed_task_amd import _lib
+    lib = _lib.get()
+    f32 = dict(device=dev, dtype=torch.float32)
+    st = None if dev == "cpu" else torch.cuda.current_stream().cuda_stream
+    NC, D, H = 10, 256, 128
+    g = [torch.full((NC, D), 3.0, **f32), torch.full((NC, D), 3.0, **f32), torch.full((NC,), 3.0, **f32), torch.full((NC,), 3.0, **f32)]
+    lib.call("sed_head_bwd_reduce", None, g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), 0, 156, D, NC, st)
+    assert all(float(t.abs().max()) == 0.0 for t in g)                      # empty batch: zero gradients
+    with pytest.raises(RuntimeError, match="bad argument"):
+        lib.call("sed_head_bwd_reduce", None, g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), 2, 156, D, NC, st)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        lib.call("sed_head_bwd_reduce", None, g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), 2, 156, 100, NC, st)
+    db = [torch.full((3 * H,), 3.0, **f32) for _ in range(4)]
+    lib.call("sed_gru_bias_reduce", None, db[0].data_ptr(), db[1].data_ptr(), db[2].data_ptr(), db[3].data_ptr(), 0, H, st)
+    assert all(float(t.abs().max()) == 0.0 for t in db)
+    lib.call("sed_gru_bias_reduce", None, None, None, None, None, 4, H, st)                     # nothing asked for: nothing done
+    with pytest.raises(RuntimeError, match="bad argument"):
+        lib.call("sed_gru_bias_reduce", None, db[0].data_ptr(), None, db[2].data_ptr(), db[3].data_ptr(), 4, H, st)      # half a pair
+    with pytest.raises(RuntimeError, match="bad argument"):
+        lib.call("sed_gru_bias_reduce", None, db[0].data_ptr(), db[1].data_ptr(), db[2].data_ptr(), db[3].data_ptr(), 4, H, st)   # no records
+    # prologue: nothing to do at all is not an error; a misaligned copy and a draw for another batch size are
+    lib.call("sed_cnn_prologue_bf16", 0, None, None, None, None, None, None, 0, 1, 0, 1, 0, 1, 0, None, None, None, 0, st)
+    src = torch.zeros(64, **f32); dst = torch.zeros(64, **f32)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        lib.call("sed_cnn_prologue_bf16", 0, None, None, None, None, None, None, 0, 1, 0, 1, 0, 1, 0, None, src.data_ptr() + 4, dst.data_ptr(), 8, st)
+    b4 = torch.zeros(4, 4, dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        lib.call("sed_cnn_prologue_bf16", 0, None, None, None, None, None, b4.data_ptr(), 4, 3, 5, 128, 2, 40, 1, None, None, None, 0, st)
+    # split-K dX: empty problem fine, missing scratch / a K split point off the tile grid are not
+    a = torch.zeros(8, 64, **f32); b0 = torch.zeros(32, 16, **f32); c = torch.zeros(8, 16, **f32)
+    lib.call("sed_gemm_kcat_splitk_bf16x3", a.data_ptr(), b0.data_ptr(), b0.data_ptr(), c.data_ptr(), 0, 16, 64, 32, 64, 16, 16, 2, None, st)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        lib.call("sed_gemm_kcat_splitk_bf16x3", a.data_ptr(), b0.data_ptr(), b0.data_ptr(), c.data_ptr(), 8, 16, 64, 32, 64, 16, 16, 2, None, st)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        lib.call("sed_gemm_kcat_splitk_bf16x3", a.data_ptr(), b0.data_ptr(), b0.data_ptr(), c.data_ptr(), 8, 16, 64, 24, 64, 16, 16, 2, c.data_ptr(), st)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        lib.call("sed_mt_loss_finish", None, c.data_ptr(), 4, st)
 
 
 def case_dyn_args_step(dev, graph=False, steps=4, n_samp=16000 + 1024, seed0=0):

@@ -42,3 +42,7 @@ def test_dataset_scaler(emu, tmp_path):
 def test_mt_loss_modes(emu):
     """K9 losses, self_sup_loss mse and bce, against torch."""
     P.case_mt_loss("cpu")
+
+
+def test_round4_entry_points_on_degenerate_arguments(emu):
+    P.case_edge_round4_entries("cpu")
