@@ -155,7 +155,8 @@ class StepDriver:
         # GPU (the only multi-rank configuration that can be run here) the side-stream launches made a step 20 x slower (206 vs
         # 10 ms), unexplained -- under data parallelism the GEMMs stay on the compute stream until that is understood on RCCL
         # (SED_GRU_DW_SIDE=1 / bench.py --gru-dw-side turns it on at world > 1 for exactly that A/B on a real node)
-        self.gru_dw_side = bool(gru_dw_side) and dev.type == "cuda" and (not self.exchange or os.environ.get("SED_GRU_DW_SIDE") == "1")
+        self.gru_dw_side = (bool(gru_dw_side) and (dev.type == "cuda" or _ops.SIDE_ON_CPU)
+                            and (not self.exchange or os.environ.get("SED_GRU_DW_SIDE") == "1"))
         if hasattr(self.opt, "grad_scale"):
             self.opt.grad_scale = 1.0 / world_size
         if overlap_allreduce is None:
@@ -362,7 +363,7 @@ class StepDriver:
         """training_step(), then `on_before_zero_grad` (the EMA) -- on the side stream when there is one, together with whatever the
         forward pass parked for it (ops.AFTER_FORWARD: the loss sums, which feed the log and not the backward pass)."""
         task = self.task
-        park = self.side is not None and _ops.PARK_LOSS_SUMS
+        park = (self.side is not None or _ops.SIDE_ON_CPU) and _ops.PARK_LOSS_SUMS
         prev, _ops.AFTER_FORWARD = _ops.AFTER_FORWARD, ([] if park else None)
         try:
             loss = task.training_step(batch, batch_idx)
@@ -376,6 +377,8 @@ class StepDriver:
             with torch.cuda.stream(self.side):
                 task.on_before_zero_grad()
         else:
+            if parked:
+                _ops.run_after_forward(parked, None)
             task.on_before_zero_grad()
         return loss
 

@@ -72,8 +72,12 @@ PARK_LOSS_SUMS = True            # bench.py --no-park-loss (A/B)
 
 
 def run_after_forward(parked, side):
-    """Launch what a training_step() parked in AFTER_FORWARD on `side` (the caller has made it wait for the main stream)."""
+    """Launch what a training_step() parked in AFTER_FORWARD on `side` (the caller has made it wait for the main stream); side = None
+    (SIDE_ON_CPU test hook): in place."""
     for launch, keep in parked:
+        if side is None:
+            launch(_lib.stream_ptr(keep[0]))
+            continue
         for t in keep:
             t.record_stream(side)
         with torch.cuda.stream(side):
@@ -84,13 +88,19 @@ _deferred = []
 DEFER_OFF_CHAIN = True           # bench.py --no-defer (A/B): launch them where they are produced, on the chain
 
 
+SIDE_ON_CPU = False              # TEST HOOK (tests/test_emu_step.py): run the PARKING logic of the side-stream launches on the CPU emulator,
+                                 # where there are no streams -- parked launches then go out at the flush points, in place
+
+
 def defer_off_chain(device, launch, keep):
     """launch(stream_ptr) now, or -- while the side stream is in use (GRU_DW_SIDE) -- later on that stream.  `keep`: the scratch tensors
     the launch reads (held until then, and marked as used by the side stream).  Gradient OUTPUTS must be passed to `launch` as
     addresses: they are returned to autograd, which only adopts a tensor nobody else references."""
-    if GRU_DW_SIDE and DEFER_OFF_CHAIN and device.type == "cuda":
-        fork = torch.cuda.Event()
-        fork.record(torch.cuda.current_stream(device))         # the side stream forks HERE, whenever the launch is enqueued
+    if GRU_DW_SIDE and DEFER_OFF_CHAIN and (device.type == "cuda" or SIDE_ON_CPU):
+        fork = None
+        if device.type == "cuda":
+            fork = torch.cuda.Event()
+            fork.record(torch.cuda.current_stream(device))     # the side stream forks HERE, whenever the launch is enqueued
         _deferred.append((launch, keep, fork))
     else:
         launch(_lib.stream_ptr(keep[0]))
@@ -519,7 +529,7 @@ class BiGRULayerFn(torch.autograd.Function):
             if DEFER_OFF_CHAIN:
                 bias_sums(stream_ptr)
             BiGRULayerFn._weight_grads(lib, cfg, dgi, dgh, hprev, x, wptr, B, T, I, H, split, stream_ptr, f32)
-        if side is not None and DEFER_OFF_CHAIN:
+        if (side is not None or (SIDE_ON_CPU and GRU_DW_SIDE)) and DEFER_OFF_CHAIN:
             # what the nodes before this one parked (the head's sums, the other layer's side section) goes out now that THIS layer's
             # recurrence and dX product -- the chain -- are enqueued; this layer's own side section waits for the next node's
             flush_deferred(side)
@@ -732,7 +742,7 @@ class MeanTeacherLossFn(torch.autograd.Function):
         g_strong = torch.empty(B, T, NC, **f32)
         g_weak = torch.empty(B, NC, **f32)
         work = loss_work(strong_s.device, B)
-        parked = AFTER_FORWARD is not None and strong_s.is_cuda
+        parked = AFTER_FORWARD is not None and (strong_s.is_cuda or SIDE_ON_CPU)
         # parked: only the gradient seeds and the per-clip records here -- the eight sums feed the log, not the backward pass, and go
         # out beside the chain (launcher.StepDriver.training_step_and_ema, next to the EMA)
         lib.call("sed_mt_loss_records" if parked else "sed_mt_loss", strong_s.data_ptr(), weak_s.data_ptr(), strong_t.data_ptr(),

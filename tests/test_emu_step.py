@@ -60,6 +60,41 @@ def test_prefetched_teacher_forward_equals_unpipelined(emu):
     P.case_prefetch_equals_unpipelined("cpu", point="teacher", steps=3, n_samp=2048 + 1024, protocol=False)
 
 
+def test_parked_side_launches_keep_gradients_in_the_arena(emu):
+    """The PARKING logic of the launches that leave the critical chain (ops.defer_off_chain: the head's weight-gradient sums, the BiGRU
+    side sections; ops.AFTER_FORWARD: the loss sums) on the emulator, where parked launches go out at the flush points in place
+    (ops.SIDE_ON_CPU): the step must equal the unparked one bit for bit, every .grad must still be the arena's view -- autograd only
+    adopts a returned gradient nobody else references; round 4 shipped a parked launch that held the gradient tensors, for an hour --
+    and nothing may stay parked.  (The stream side of it runs on the GPU: test_side_stream_backward_leaves_every_gradient_in_the_arena.)"""
+    import random
+    import numpy as np
+    import torch
+    from desed_task_amd import ops
+    from desed_task_amd.launcher import StepDriver
+    O = P.O
+    bs, n_samp = (1, 1, 2), 22 * 256
+    out = []
+    for hook in (False, True):
+        ops.SIDE_ON_CPU = hook
+        try:
+            task = P.build_task("cpu", bs, O.make_state_dict(seed=7), dropout=0.5, specaug=True, rampup=5)
+            d = StepDriver(task, world_size=1)
+            assert d.gru_dw_side is hook
+            audio = O.synth_audio(sum(bs), n_samp, seed=100)
+            labels = O.synth_labels(bs, 10, (1 + n_samp // 256) // 4, seed=5)
+            random.seed(40); np.random.seed(100); torch.manual_seed(100)
+            ops.reseed_dropout()
+            losses = []
+            for step in range(2):
+                losses.append(float(d.run_step((audio, labels.clone(), None, None), step).detach()))
+                assert task.sed_student.arena.grads_are_flat(), (hook, step)
+                assert not ops._deferred and ops.AFTER_FORWARD is None
+            out.append((losses, task.sed_student.arena.flat.detach().clone(), task.sed_teacher.arena.flat.detach().clone()))
+        finally:
+            ops.SIDE_ON_CPU = False
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+
+
 def test_step_ignores_uninitialised_memory(emu):
     """Poisoned torch.empty buffers (NaN / 3e30) change no bit of two seeded training steps."""
     P.case_step_ignores_uninitialised_memory("cpu", n_samp=22 * 256)       # 23 frames -> 11 at block 1: an odd count in BOTH pooling blocks
