@@ -406,6 +406,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured hipGraph step")
+    ap.add_argument("--surface", choices=("lightning", "driver"), default="lightning",
+                    help="who drives the step.  'lightning' (default at N = 1): the reference's own surface -- Lightning 1.9's hook order "
+                         "(tests/lightning_order.Trainer: training_step -> on_before_zero_grad -> optimizer_zero_grad -> backward -> "
+                         "optimizer.step -> lr_scheduler_step) over train_dataloader(), a torch.optim.Adam built as train_sed.py:199-201 "
+                         "builds it; SEDTask4's whole-step mode runs the captured step behind training_step (with --no-graph: the hooks "
+                         "do their work one by one, eager launches).  'driver': desed_task_amd's own GraphedStepDriver / StepDriver "
+                         "called directly (what N > 1 always uses: the reference's trainer refuses more than one GPU)")
     ap.add_argument("--embeddings", action="store_true",
                     help="secondary workload (SURVEY 8f rank 3): the 2023 'pretrained' step, frozen BEATs-shaped embeddings "
                          "(768 x 496 per clip) fused into the CRNN (confs/pretrained.yaml); not the headline metric")
@@ -516,18 +523,31 @@ def main():
     student = CRNN(**config["net"]).to(dev)
     if grouped:                                     # identical initial weights on every rank
         dist.broadcast(student.arena.flat, src=0)
-    opt = FusedAdam(student.parameters(), lr=1e-3, betas=(0.9, 0.999), arena=student.arena)
+    lightning = args.surface == "lightning" and not grouped
+    if lightning:
+        opt = torch.optim.Adam(student.parameters(), 1e-3, betas=(0.9, 0.999))      # train_sed.py:199-201, verbatim; SEDTask4 adopts it
+    else:
+        opt = FusedAdam(student.parameters(), lr=1e-3, betas=(0.9, 0.999), arena=student.arena)
     sched = {"scheduler": ExponentialWarmup(opt, 1e-3, 50 * 118), "interval": "step"}
 
     class Enc:
         labels = list(range(10))
     task = SEDTask4(config, Enc(), student, opt=opt, scheduler=sched).to(dev)
+    if not isinstance(opt, FusedAdam):
+        raise RuntimeError("bench: SEDTask4 did not adopt the recipe's torch.optim.Adam")
     opt.arena = task.sed_student.arena
     task.train()
     if os.environ.get("SED_OVERLAP_TAILS") is not None:
         task.overlap_tails = os.environ["SED_OVERLAP_TAILS"] == "1"
     use_graph = not args.no_graph and not dry
-    if use_graph:
+    driver = None
+    if lightning:
+        # nobody builds a driver: SEDTask4.training_step does, at the first batch the trainer loop hands it (sed_trainer.py, "whole-step
+        # mode"); --no-graph: the hooks do their own work, one eager launch after the other, torch-free Adam still one launch
+        task.whole_step = bool(use_graph or dry) and not args.no_graph
+        task.whole_step_prefetch = args.prefetch
+        task.whole_step_warmup = 3
+    elif use_graph:
         # the step is captured once into a hipGraph (desed_task_amd/graph.py) and replayed: 3 eager steps, 1 capture step
         from desed_task_amd.graph import GraphedStepDriver
         driver = GraphedStepDriver(task, world_size=world, warmup=3, prefetch=args.prefetch)
@@ -575,31 +595,27 @@ def main():
     def one_step(i):
         # graph mode: the driver copies every batch tensor into its static input buffers, so `labels` (mixed in place by the
         # step) needs no clone; eager mode works on the tensors it is given
-        captured = use_graph and getattr(driver, "graph", None) is not None
-        batch = (inputs["audio"], labels if captured else labels.clone(), None, inputs["emb"])
+        captured = getattr(driver, "graph", None) is not None
+        if lightning:       # (the batch tuples train_dataloader() handed out: the captured step's static buffers have their arity)
+            tail = ([1.0] * sum(BATCH),) + ((inputs["emb"],) if emb is not None else ())
+            batch, nxt = (inputs["audio"], labels if captured else labels.clone()) + tail, (inputs["next_audio"], next_labels()) + tail
+        else:
+            batch, nxt = (inputs["audio"], labels if captured else labels.clone(), None, inputs["emb"]), (inputs["next_audio"], next_labels(), None, None)
         if pipelined:       # the loader hands over batch k and announces batch k + 1 (synthetic: the same clips again)
-            driver.run_step(batch, i, next_batch=(inputs["next_audio"], next_labels(), None, None))
+            driver.run_step(batch, i, next_batch=nxt)
         else:
             driver.run_step(batch, i)
 
-    # untimed: the W warm-up steps, plus (graph mode) whatever is still missing for the capture to lie outside the timed region
-    n_untimed = max(args.warmup, 5) if use_graph else args.warmup
-    graph_note = None
-    for i in range(n_untimed):
-        try:
-            one_step(i)
-        except RuntimeError as exc:             # a capture the runtime refuses must not cost the measurement: eager launches
-            if not use_graph or driver.graph is not None and driver.n > driver.warmup + 1:
-                raise
-            graph_note = "hipGraph capture failed (%s): eager launches" % str(exc).splitlines()[0][:120]
-            sys.stderr.write(graph_note + "\n")
-            use_graph = False
-            driver = driver.eager
-            one_step(i)
-    if use_graph and driver.input_buffers() is not None:
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
+    def adopt_static_buffers():
         # the synthetic clips already live in HBM: hand the graph's own input buffers back as the batch, like a loader that
         # writes its batches straight into them, so that no per-step staging copy of the 30 MB of audio is timed.  Round 4: the step
         # no longer mixes the announced labels in place, so they are staged once as well (round 3 re-staged 300 KB every step).
+        if getattr(driver, "graph", None) is None or driver.input_buffers() is None:
+            return
         bufs = driver.input_buffers()
         inputs["audio"] = bufs[0]
         if emb is not None:
@@ -609,32 +625,115 @@ def main():
             inputs["next_labels"] = driver.next_label_buffer()
             if inputs["next_labels"] is not None:
                 inputs["next_labels"].copy_(labels)
-    def sync():
-        if not dry:
-            torch.cuda.synchronize()
 
-    sync()
-    # the optimizer's one-launch path needs every gradient in the parameter arena (a gradient autograd had to clone would send Adam down
-    # the per-tensor path and, with side-stream producers, read stale values): checked on the warm-up steps' result, before the clock
-    if not task.sed_student.arena.grads_are_flat():
-        raise RuntimeError("bench: a parameter's .grad is not the arena's view after the warm-up steps")
-    if grouped:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-    sync()
-    dt_local = time.perf_counter() - t0             # this rank's own K steps (before it waits for the others)
+    # untimed: the W warm-up steps, plus (graph mode) whatever is still missing for the capture to lie outside the timed region
+    n_untimed = max(args.warmup, 5) if use_graph else args.warmup
+    graph_note = None
+    surface_info = None
+    if lightning:
+        # ---- the reference's surface: a Lightning-1.9-order loop over train_dataloader(); ONE epoch of n_untimed + K + 1 resident batches:
+        # the K timed steps are steps n_untimed .. n_untimed + K - 1 of it, the epoch's last batch (no successor: the driver's eager
+        # fall-back) lies behind the timed region.
+        from desed_task_amd.lookahead import BatchList
+        from tests.lightning_order import Trainer
+        n_untimed = max(n_untimed, 8)
+        pad = [1.0] * sum(BATCH)
+
+        class Resident(BatchList):
+            def __getitem__(self, i):
+                lab = inputs.get("next_labels")
+                return (inputs["audio"], labels.clone() if lab is None else lab, pad) + ((inputs["emb"],) if emb is not None else ())
+
+        task.train_data = Resident([None] * (n_untimed + args.steps + 1))
+        marks = {}
+
+        def on_step(tr, model, i):
+            nonlocal driver
+            n = i + 1
+            driver = task._driver
+            if n == n_untimed - 3:
+                adopt_static_buffers()              # (batches the look-ahead has already fetched still carry the old tensors: 2 steps)
+            if n == n_untimed:
+                sync()
+                if not task.sed_student.arena.grads_are_flat():
+                    raise RuntimeError("bench: a parameter's .grad is not the arena's view after the warm-up steps")
+                sync()
+                if getattr(driver, "graph", None) is not None:
+                    marks["fb0"], marks["rp0"] = driver.eager_fallbacks, driver.reprimes
+                marks["t0"] = time.perf_counter()
+            elif n == n_untimed + args.steps:
+                sync()
+                marks["t1"] = time.perf_counter()
+                if driver is not None and getattr(driver, "graph", None) is not None:
+                    marks["fallbacks"], marks["reprimes"] = driver.eager_fallbacks, driver.reprimes
+
+        Trainer(max_epochs=1, on_step=on_step).fit(task)
+        sync()
+        dt = dt_local = marks["t1"] - marks["t0"]
+        driver = task._driver
+        use_graph = driver is not None and getattr(driver, "graph", None) is not None
+        if task.whole_step and not dry and not use_graph:
+            raise RuntimeError("bench: the whole-step mode never captured its graph")
+        surface_info = {"surface": "lightning",
+                        "loop": "tests/lightning_order.Trainer: Lightning 1.9's automatic-optimisation hook order over train_dataloader() "
+                                "(one epoch of %d resident batches), optimizer built as torch.optim.Adam(student.parameters(), 1e-3, "
+                                "betas=(0.9, 0.999))" % (n_untimed + args.steps + 1),
+                        "whole_step": bool(task.whole_step),
+                        "eager_fallbacks_in_timed_region": marks["fallbacks"] - marks["fb0"] if "fb0" in marks else None,
+                        "reprimes_in_timed_region": marks["reprimes"] - marks["rp0"] if "rp0" in marks else None}
+        if driver is None:
+            # hooks mode (--no-graph): the per-launch timing below still needs a StepDriver for its eager steps
+            driver = StepDriver(task, world_size=1, prefetch="off")
+            pipelined = False
+        else:
+            # the same captured step driven by hand (StepDriver protocol, what --surface driver times): K more steps, after the epoch's
+            # last batch has been run eagerly -- 3 untimed steps re-prime the pipeline
+            for i in range(3):
+                one_step(i)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                one_step(i)
+            sync()
+            surface_info["driver_surface_ms_per_step"] = round((time.perf_counter() - t0) / args.steps * 1e3, 3)
+            surface_info["lightning_over_driver"] = round(dt / args.steps * 1e3 / surface_info["driver_surface_ms_per_step"], 4)
+    else:
+        for i in range(n_untimed):
+            try:
+                one_step(i)
+            except RuntimeError as exc:             # a capture the runtime refuses must not cost the measurement: eager launches
+                if not use_graph or driver.graph is not None and driver.n > driver.warmup + 1:
+                    raise
+                graph_note = "hipGraph capture failed (%s): eager launches" % str(exc).splitlines()[0][:120]
+                sys.stderr.write(graph_note + "\n")
+                use_graph = False
+                driver = driver.eager
+                one_step(i)
+        if use_graph:
+            adopt_static_buffers()
+        sync()
+        # the optimizer's one-launch path needs every gradient in the parameter arena (a gradient autograd had to clone would send Adam
+        # down the per-tensor path and, with side-stream producers, read stale values): checked on the warm-up steps' result, before the clock
+        if not task.sed_student.arena.grads_are_flat():
+            raise RuntimeError("bench: a parameter's .grad is not the arena's view after the warm-up steps")
+        if grouped:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + i)
+        sync()
+        dt_local = time.perf_counter() - t0             # this rank's own K steps (before it waits for the others)
     ts_rows = None
     if ts_probe is not None:
         ts_rows = ts_probe.read()
         from desed_task_amd import ops as _ops_probe
         _ops_probe.PROBE = None
-    if grouped:
-        dist.barrier()
-    sync()
-    dt = time.perf_counter() - t0
+    if not lightning:
+        if grouped:
+            dist.barrier()
+        sync()
+        dt = time.perf_counter() - t0
     # Data-parallel runs: PROBE_STEPS more steps of the SAME launch path (graph replays + eager exchange tail, or eager steps) with
     # marks around the exchange tail -- after the timed region, so the K timed steps carry no extra events.
     exchange_probe = None
@@ -765,6 +864,13 @@ def main():
                    "global_batch": sum(BATCH) * world, "parallelism": "dp%d" % world, "last_loss_strong": round(loss_val, 5),
                    "launch": "hipGraph replay of the captured step (3 eager + 1 capture step before the timed region)" if use_graph
                              else (graph_note or "eager launches"), "untimed_steps": n_untimed,
+                   "surface": surface_info if surface_info is not None else {
+                       "surface": "driver", "loop": "desed_task_amd.graph.GraphedStepDriver / launcher.StepDriver.run_step(batch, i, "
+                                                    "next_batch) called directly" + (" (N > 1 or the one-rank rehearsal: the reference's own "
+                                                    "trainer refuses more than one GPU, train_sed.py:269-276)" if grouped else "")},
+                   # the synthetic labels of the announced batch live in the graph's static next-label buffer (staged once,
+                   # like the waveforms); a real loader pays one ~300 KB host-to-device copy per step on top of the 30.7 MB of audio
+                   "labels_resident": bool(use_graph and args.prefetch == "teacher"),
                    "backend": backend_name, "world_size": world,
                    "front_end": ("mel of batch k at the head of step k" if not pipelined else
                                  "pipelined: front half of step k+1 (mel, mixup, log/min-max) + the teacher's CNN forward on a side stream "

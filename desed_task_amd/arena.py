@@ -120,6 +120,35 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_scale = grad_scale
         self._flat_state = None
 
+    # ---- a torch.optim.Adam handed in by the recipe (train_sed.py:199-201) --------------------------------------------
+    served = False      # set by SEDTask4's whole-step mode: the update of this step() call has already run (inside the closure)
+
+    @classmethod
+    def adopt(cls, opt, model):
+        """Turn `opt` -- the `torch.optim.Adam(sed_student.parameters(), lr, betas=(0.9, 0.999))` of recipes/dcase2023_task4_baseline/
+        train_sed.py:199-201 -- into this class IN PLACE, so that every reference to it (the recipe's ExponentialWarmup, Lightning's
+        wrapper, `configure_optimizers`) keeps pointing at the same object while step() becomes the one-launch arena update.
+        `param_groups` (with torch's own keys: the state dict stays loadable by torch.optim.Adam) and any existing per-parameter
+        state are kept.  -> True when `opt` now is (or already was) a FusedAdam; False -- `opt` untouched -- when it is not a plain
+        Adam over exactly `model.parameters()` (weight decay, amsgrad, maximize, several groups, a tensor lr ...)."""
+        if isinstance(opt, cls):
+            if opt._arena_src is None:
+                opt._arena_src = model
+            return True
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1 or not hasattr(model, "arena"):
+            return False
+        g = opt.param_groups[0]
+        if (g.get("weight_decay", 0) != 0 or g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable")
+                or torch.is_tensor(g["lr"])):
+            return False
+        params = list(model.parameters())
+        if len(g["params"]) != len(params) or any(a is not b for a, b in zip(g["params"], params)):
+            return False
+        opt.__class__ = cls
+        opt._arena_src, opt.grad_scale, opt._flat_state = model, 1.0, None
+        opt._patch_step_function()          # (what Optimizer.__init__ / __setstate__ do for a class: the profiler-hooked step)
+        return True
+
     # ---- arena lookup ---------------------------------------------------------------------------------
     @property
     def arena(self):
@@ -208,6 +237,10 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self.served:
+            # SEDTask4's whole-step mode: the closure's training_step ran the whole optimisation step -- this update included
+            self.served = False
+            return loss
         arena = self.arena
         if self._flat_ok(arena) and arena.grads_are_flat():
             st = self._flat(arena)

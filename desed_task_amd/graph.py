@@ -398,6 +398,10 @@ class GraphedStepDriver:
                 return self.eager.run_step(batch, batch_idx, None, staged=self.static_next)
             if not self._primed():
                 self._reprime(batch, teacher_level)
+        if pipelined and self.graph is None and (next_batch is None or not self._primed()):
+            # the capture needs both halves of the pipeline in hand: a successor to announce and a front half an eager step left for
+            # this batch.  An epoch end inside the warm-up (or a loop that cannot announce) postpones it: one more eager step
+            return self.eager.run_step(batch, batch_idx, next_batch)
         if pipelined:
             self.eager.announce(batch, next_batch, staged=self.static_next)
             nxt, nxt_lab, nxt_ext = task._next_audio, task._next_labels, (task._next_extras or {})

@@ -143,6 +143,7 @@ class StepDriver:
             task.prefetch_point = None if prefetch in ("off", False) else ("backward" if prefetch == "teacher" else prefetch)
             task.prefetch_level = "teacher" if prefetch == "teacher" else "features"
         self._announced = None
+        self.check_announced = True     # False: the caller vouches for the order of the batches (SEDTask4's whole-step mode: loader keys)
         self.world = world_size
         # the gradient exchange runs at world > 1 -- and on a one-rank process group when rehearsing (see rehearsing())
         self.exchange = world_size > 1 or (rehearsing() and dist.is_initialized())
@@ -337,7 +338,7 @@ class StepDriver:
         if getattr(task, "_feat_ready", False) or (getattr(task, "_pro", None) or {}).get("ready"):
             key = (batch[0].data_ptr(), tuple(batch[0].shape))
             staged_key = (staged.data_ptr(), tuple(staged.shape)) if staged is not None else None
-            if self._announced is not None and key != self._announced and key != staged_key:
+            if self.check_announced and self._announced is not None and key != self._announced and key != staged_key:
                 raise RuntimeError("run_step got another batch than the one announced as next_batch by the previous step")
         nxt = next_batch[0] if next_batch is not None else None
         self._announced = (nxt.data_ptr(), tuple(nxt.shape)) if nxt is not None else None
@@ -365,10 +366,12 @@ class StepDriver:
         task = self.task
         park = (self.side is not None or _ops.SIDE_ON_CPU) and _ops.PARK_LOSS_SUMS
         prev, _ops.AFTER_FORWARD = _ops.AFTER_FORWARD, ([] if park else None)
+        inside, task._in_driver = getattr(task, "_in_driver", False), True      # (SEDTask4.training_step: the step BODY, not the surface)
         try:
             loss = task.training_step(batch, batch_idx)
         finally:
             parked, _ops.AFTER_FORWARD = _ops.AFTER_FORWARD, prev
+            task._in_driver = inside
         if self.side is not None:
             main = torch.cuda.current_stream()
             self.side.wait_stream(main)                       # teacher forward has finished reading theta_t

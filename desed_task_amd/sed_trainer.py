@@ -11,6 +11,7 @@ SURVEY 8f rank 1-2 rows: `validation_step`, `validation_epoch_end`, `test_step`,
 It subclasses pytorch_lightning.LightningModule when Lightning is importable, else a minimal stand-in with
 `hparams`/`log` so the step can be driven by desed_task_amd.launcher (one process per GPU).
 """
+import os
 import random
 from copy import deepcopy
 
@@ -19,7 +20,8 @@ import torch
 from . import features
 from . import graph as _graph
 from . import ops as _ops
-from .arena import ema_update_
+from .arena import FusedAdam, ema_update_
+from .lookahead import LookaheadLoader
 from .data_augm import MixupBatch, mixup_inplace_
 from .ops import MeanTeacherLossFn
 from .utils.scaler import TorchScaler
@@ -40,6 +42,33 @@ except Exception:  # noqa: BLE001
 
         def log(self, name, value, **kwargs):
             self.logged[name] = value
+
+        # Lightning 1.9's defaults of the hooks its automatic-optimisation loop calls (pytorch_lightning/core/module.py), so that a
+        # hand-written loop in that order (tests/lightning_order.py, bench.py --surface lightning) drives this class and the real one alike
+        trainer = None
+
+        def optimizer_step(self, epoch, batch_idx, optimizer, optimizer_idx=0, optimizer_closure=None, **kwargs):
+            optimizer.step(closure=optimizer_closure)
+
+        def optimizer_zero_grad(self, epoch, batch_idx, optimizer, optimizer_idx=0):
+            optimizer.zero_grad()
+
+        def backward(self, loss, optimizer=None, optimizer_idx=None, *args, **kwargs):
+            loss.backward(*args, **kwargs)
+
+        def transfer_batch_to_device(self, batch, device, dataloader_idx=0):
+            return _move_to_device(batch, device)
+
+
+def _move_to_device(batch, device):
+    """lightning's move_data_to_device for the containers a DataLoader's default collate produces."""
+    if torch.is_tensor(batch):
+        return batch.to(device, non_blocking=True)
+    if isinstance(batch, (list, tuple)) and not hasattr(batch, "_fields"):
+        return type(batch)(_move_to_device(b, device) for b in batch)
+    if isinstance(batch, dict):
+        return {k: _move_to_device(v, device) for k, v in batch.items()}
+    return batch
 
 
 class SEDTask4(_Base):
@@ -72,6 +101,9 @@ class SEDTask4(_Base):
             raise NotImplementedError
         self.selfsup_bce = sup == "bce"
         self.scaler = self._init_scaler()
+        # train_sed.py:199-201 hands in torch.optim.Adam(sed_student.parameters(), lr, betas=(0.9, 0.999)): same object, one-launch step
+        if opt is not None and os.environ.get("SED_ADOPT_ADAM", "1") != "0":
+            FusedAdam.adopt(opt, self.sed_student)
 
     # ---- feature pipeline ------------------------------------------------------------------------
     def _init_scaler(self):
@@ -119,6 +151,8 @@ class SEDTask4(_Base):
 
     # ---- optimisation hooks -----------------------------------------------------------------------
     def lr_scheduler_step(self, scheduler, optimizer_idx=None, metric=None):
+        if self._take("scheduler"):
+            return
         dyn = _graph.active()
         if dyn is not None:
             dyn.host(scheduler.step)            # pure host arithmetic: re-run before every graph replay
@@ -131,6 +165,8 @@ class SEDTask4(_Base):
                     getattr(ema_model, "arena", None), getattr(model, "arena", None))
 
     def on_before_zero_grad(self, *args, **kwargs):
+        if self._take("ema"):
+            return
         factor = self.hparams["training"]["ema_factor"]
         sched = self.scheduler["scheduler"]
         dyn = _graph.active()
@@ -150,9 +186,177 @@ class SEDTask4(_Base):
         return checkpoint
 
     def train_dataloader(self):
-        self.train_loader = torch.utils.data.DataLoader(self.train_data, batch_sampler=self.train_sampler,
-                                                        num_workers=self.num_workers)
+        # sed_trainer.py:913-920's DataLoader, as the subclass that stays one batch ahead (lookahead.py): the whole-step mode below
+        # learns the NEXT batch from it.  A data set of ready batches (lookahead.BatchList) is iterated as it is.
+        if self.train_sampler is None and getattr(self.train_data, "yields_batches", False):
+            self.train_loader = LookaheadLoader(self.train_data, batch_size=None, num_workers=0)
+        else:
+            self.train_loader = LookaheadLoader(self.train_data, batch_sampler=self.train_sampler, num_workers=self.num_workers)
         return self.train_loader
+
+    # ---- whole-step mode: the benchmarked launch path behind Lightning's own loop ---------------------------------------------------
+    # `pl.Trainer.fit` (train_sed.py:278-299) drives one batch through   training_step -> on_before_zero_grad -> optimizer_zero_grad ->
+    # backward -> optimizer.step -> lr_scheduler_step   (Lightning 1.9's closure).  Run hook by hook that is ~330 launches
+    # from one Python thread plus a 62-tensor Adam: host-bound.  In whole-step mode `training_step` hands the batch to the step
+    # driver -- graph.GraphedStepDriver on the GPU: the captured hipGraph of the WHOLE optimisation step (both forwards, the losses,
+    # the EMA, backward, the one-launch Adam, the scheduler's host arithmetic), with the next batch's front half pipelined under this
+    # batch's backward; launcher.StepDriver on a CPU device (the test emulator) -- and returns the (detached) loss; the hooks
+    # Lightning calls afterwards for the same batch find their work done (`_take`) and return.  The optimizer Lightning steps is the
+    # adopted FusedAdam: its step() runs the closure -- which is where training_step is called -- and skips the update once (`served`).
+    # The next batch comes from `train_dataloader()`'s look-ahead loader; epoch ends, checkpoint loads and batches the loader does not
+    # know fall back to eager launches / an inline front half inside the driver (GraphedStepDriver._run_step).  Same kernels, same
+    # host draws in the same order: bit-identical to driving GraphedStepDriver by hand (tests/lightning_order.py).
+    #   SED_WHOLE_STEP = 0 | 1 | auto (default: on when the student is on a GPU and nothing below blocks it);  `whole_step` overrides.
+    whole_step = None
+    whole_step_prefetch = None              # None: SED_PREFETCH or "teacher"; "off" | "tails" | "backward" | "teacher"
+    whole_step_warmup = 3                   # eager steps before the capture (GraphedStepDriver)
+    _driver = None
+    _in_driver = False                      # launcher.StepDriver sets it around ITS call of training_step
+    _served = None
+    _static_logs = None
+    _cur_batch = None                       # (loader key, device batch) noted by transfer_batch_to_device
+    _uploaded = None                        # (loader key, device batch) of the batch announced as NEXT (uploaded once, used twice)
+    _whole_ok = None
+
+    def _take(self, what):
+        """Has the whole-step driver already done `what` for the current batch?  (One-shot: a second call does the work.)"""
+        s = self._served
+        if s and what in s:
+            s.discard(what)
+            return True
+        return False
+
+    def _whole_step_blockers(self):
+        from .nnet.CRNN import CRNN
+        tr = self.hparams["training"]
+        if not (isinstance(self.sed_student, CRNN) and isinstance(self.sed_teacher, CRNN)):
+            return "student / teacher are not desed_task_amd.nnet.CRNN"
+        if not isinstance(self.opt, FusedAdam) or self.scheduler is None:
+            return "the optimizer is not a plain Adam over sed_student.parameters() (arena.FusedAdam.adopt), or there is no scheduler"
+        if tr.get("accumulate_batches", 1) != 1:
+            return "accumulate_batches != 1 (one optimizer step per training_step is what a whole step is)"
+        if (tr.get("gradient_clip") or 0) > 0:
+            return "gradient_clip > 0 (clipping sits between backward and the optimizer step)"
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return "a process group with more than one rank is up: data-parallel runs go through desed_task_amd.launcher"
+        return None
+
+    def _whole_step_on(self):
+        if self._whole_ok is None:
+            mode = self.whole_step
+            if mode is None:
+                mode = {"0": False, "1": True}.get(os.environ.get("SED_WHOLE_STEP", "auto"))
+            if mode is False:
+                self._whole_ok = False
+            else:
+                why = self._whole_step_blockers()
+                if why and mode is True:
+                    raise RuntimeError("whole-step mode was asked for but cannot run: " + why)
+                on_gpu = next(self.sed_student.parameters()).device.type == "cuda"
+                self._whole_ok = (not why) and (mode is True or on_gpu)
+        return self._whole_ok and self.training
+
+    def _step_driver(self, pipelined):
+        if self._driver is None:
+            pf = self.whole_step_prefetch or os.environ.get("SED_PREFETCH", "teacher")
+            if not pipelined:
+                pf = "off"              # nobody can announce a next batch (no look-ahead loader): the unpipelined step
+            elif pf == "teacher" and not self.prefetch_teacher_ok:
+                pf = "backward"
+            dev = next(self.sed_student.parameters()).device
+            if dev.type == "cuda":
+                self._driver = _graph.GraphedStepDriver(self, world_size=1, warmup=self.whole_step_warmup, prefetch=pf)
+                self._driver.eager.check_announced = False
+            else:
+                from .launcher import StepDriver
+                self._driver = StepDriver(self, world_size=1, prefetch=pf)
+                self._driver.check_announced = False    # this class tracks the identity of the batches itself (loader keys)
+        return self._driver
+
+    def _epoch_limit(self):
+        """Batches the trainer runs per epoch when it is fewer than the loader holds (`limit_train_batches`, train_sed.py:256)."""
+        try:
+            n = getattr(self.trainer, "num_training_batches", None)
+        except Exception:  # noqa: BLE001 -- real Lightning raises when no trainer is attached
+            n = None
+        return n if isinstance(n, int) else None
+
+    def transfer_batch_to_device(self, batch, device, dataloader_idx=0):
+        """Lightning's hook, called once per batch right before training_step.  A training batch of the look-ahead loader that was
+        already uploaded as the announced successor of the previous batch is not uploaded again."""
+        loader = getattr(self, "train_loader", None)
+        if self.training and isinstance(loader, LookaheadLoader):
+            key = loader.find(batch)
+            if key is not None:
+                up = self._uploaded
+                dev_batch = up[1] if (up is not None and up[0] == key) else _move_to_device(batch, device)
+                self._cur_batch = (key, dev_batch)
+                return dev_batch
+        return super().transfer_batch_to_device(batch, device, dataloader_idx)
+
+    def _next_from_loader(self, batch):
+        """The batch that follows `batch` in the look-ahead loader's epoch, on the device -- or None (no such loader, a batch it does not
+        know, the end of the epoch)."""
+        loader = getattr(self, "train_loader", None)
+        if not isinstance(loader, LookaheadLoader):
+            return None
+        cur = self._cur_batch
+        key = cur[0] if (cur is not None and batch[0] is cur[1][0]) else loader.find(batch)
+        self._cur_batch = None
+        if key is None:
+            return None
+        loader.release(key)
+        limit = self._epoch_limit()
+        nxt = loader.batch_after(key) if (limit is None or key[1] + 1 < limit) else None
+        if nxt is None:
+            self._uploaded = None
+            return None
+        dev_next = _move_to_device(nxt, batch[0].device)
+        self._uploaded = ((key[0], key[1] + 1), dev_next)
+        return dev_next
+
+    def training_step(self, batch, batch_indx):
+        if self._in_driver or not self._whole_step_on():
+            return self._training_step(batch, batch_indx)
+        nxt = self._next_from_loader(batch)
+        drv = self._step_driver(pipelined=nxt is not None)
+        self._served = None
+        graph_before = getattr(drv, "graph", None)
+        rec = []
+        object.__setattr__(self, "log", lambda name, value, **kw: rec.append((name, value, kw)))    # (no self.log inside a capture)
+        try:
+            loss = drv.run_step(batch, batch_indx, next_batch=nxt)
+        finally:
+            object.__delattr__(self, "log")
+        if any(name == "train/student/loss_strong" for name, _, _ in rec):
+            # an eager or the capture step: every key was logged; after a capture the tensors are the graph's static outputs
+            if graph_before is None and getattr(drv, "graph", None) is not None:
+                self._static_logs = list(rec)
+        elif self._static_logs is not None:
+            # a replay ran no Python but the host half (train/step, train/lr): the rest are the static tensors it just rewrote
+            fresh = {name: (value, kw) for name, value, kw in rec}
+            rec = [(name,) + fresh.get(name, (value, kw)) for name, value, kw in self._static_logs]
+        for name, value, kw in rec:
+            self.log(name, value, **kw)
+        self._served = {"ema", "zero_grad", "backward", "scheduler"}
+        self.opt.served = True
+        # "0-d loss tensor with grad" (SURVEY 8b): a leaf, so that Lightning's `loss / accumulate_grad_batches` and a hand-written
+        # `loss.backward()` both work -- there is nothing left to differentiate
+        return loss.detach().requires_grad_(True)
+
+    def optimizer_zero_grad(self, epoch, batch_idx, optimizer, *args, **kwargs):
+        if not self._take("zero_grad"):
+            super().optimizer_zero_grad(epoch, batch_idx, optimizer, *args, **kwargs)
+
+    def backward(self, loss, *args, **kwargs):
+        if not self._take("backward"):
+            super().backward(loss, *args, **kwargs)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        out = super().load_state_dict(state_dict, *args, **kwargs)
+        self.reset_pipeline()           # a front half prefetched with the previous weights must not be consumed (launcher.load_checkpoint)
+        return out
 
     # ---- the hot path -----------------------------------------------------------------------------
     overlap_tails = True            # student / teacher GRU+head tails on two HIP streams (GPU only)
@@ -410,7 +614,8 @@ class SEDTask4(_Base):
         weak_t.record_stream(main)
         return strong_s, weak_s, strong_t, weak_t
 
-    def training_step(self, batch, batch_indx):
+    def _training_step(self, batch, batch_indx):
+        """sed_trainer.py:269-356: the step body (what `training_step` is when the hooks run one by one)."""
         audio, labels = batch[0], batch[1]
         embeddings = self._batch_embeddings(batch)        # NOT mixed up with the features (sed_trainer_pretrained.py:320-330)
         indx_synth, indx_weak, indx_unlabelled = self.hparams["training"]["batch_size"]

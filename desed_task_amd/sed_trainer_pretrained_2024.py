@@ -114,7 +114,7 @@ class SEDTask4(_SEDTask4):
         emb.copy_(src)
         return self._front_2024(audio, lab, emb, fresh=True, x_into_pro=True)
 
-    def training_step(self, batch, batch_indx):
+    def _training_step(self, batch, batch_indx):
         audio, labels, padded_indxs, embeddings, valid_class_mask = self._unpack_batch(batch)
         indx_maestro, indx_synth, indx_strong, indx_weak, indx_unlabelled = self._group_bounds()
         valid = (valid_class_mask != 0).to(torch.uint8).contiguous()

@@ -460,7 +460,9 @@ def recipe_config(batch_sizes=(12, 12, 24)):
     }
 
 
-def build_task(dev, batch_sizes, sd, dropout=None, specaug=True, rampup=100, lr=1e-3, pretrained=False):
+def build_task(dev, batch_sizes, sd, dropout=None, specaug=True, rampup=100, lr=1e-3, pretrained=False, torch_adam=False, whole_step=False,
+               train_data=None):
+    """torch_adam: the optimizer is built as train_sed.py:199-201 builds it (torch.optim.Adam; SEDTask4 adopts it)."""
     from desed_task_amd.nnet.CRNN import CRNN
     from desed_task_amd.arena import FusedAdam
     from desed_task_amd.utils.schedulers import ExponentialWarmup
@@ -479,12 +481,18 @@ def build_task(dev, batch_sizes, sd, dropout=None, specaug=True, rampup=100, lr=
     if sd is not None:
         student.load_state_dict({k: v.clone() for k, v in sd.items()})
     student = student.to(dev) if dev != "cpu" else student
-    opt = FusedAdam(student.parameters(), lr=lr, betas=(0.9, 0.999), arena=student.arena)
+    if torch_adam:
+        opt = torch.optim.Adam(student.parameters(), lr, betas=(0.9, 0.999))
+    else:
+        opt = FusedAdam(student.parameters(), lr=lr, betas=(0.9, 0.999), arena=student.arena)
     sched = {"scheduler": ExponentialWarmup(opt, lr, rampup), "interval": "step"}
 
     class Enc:
         labels = list(range(10))
-    task = SEDTask4(config, Enc(), student, opt=opt, scheduler=sched)
+    task = SEDTask4(config, Enc(), student, opt=opt, scheduler=sched, train_data=train_data)
+    assert isinstance(opt, FusedAdam)
+    # most cases call training_step / the drivers themselves; the whole-step surface has its own cases (case_lightning_surface)
+    task.whole_step = whole_step
     task.train()
     if dev != "cpu":
         task.to(dev)
@@ -917,6 +925,98 @@ def case_pipelined_epoch_boundary(dev, point="teacher", graph=True, epochs=3, pe
     assert l0 == l1, (l0, l1)
     assert torch.equal(s0, s1) and torch.equal(t0, t1) and torch.equal(b0, b1)
     return l0
+
+
+def case_lightning_surface(dev, epochs=3, per_epoch=3, n_samp=16000 + 1024, limit_train_batches=None, warmup=1, pretrained=False):
+    """The whole-step mode of SEDTask4 behind Lightning 1.9's hook order (tests/lightning_order.Trainer: training_step ->
+    on_before_zero_grad -> optimizer_zero_grad -> backward -> optimizer.step -> lr_scheduler_step, the optimizer a plain
+    torch.optim.Adam as train_sed.py:199-201 builds it, the batches from `train_dataloader()`) must equal, BIT FOR BIT,
+      (a) the step driver driven by hand with explicit next_batch announcements -- graph.GraphedStepDriver on the GPU (eager warm-up,
+          capture, replays, the eager fall-back at every epoch end, the inline front half after it), launcher.StepDriver on the
+          emulator -- and
+      (b) the same Trainer loop with the hooks doing their work one by one (whole_step = False: the unpipelined eager order);
+    compared: every step's loss, the student and teacher weights, the BatchNorm statistics of both, Adam's moments and step count,
+    the scheduler's step_num, and the logged keys of the last step.  limit_train_batches: the trainer stops an epoch early
+    (train_sed.py:256, fast_dev_run) -- the step before the cut must not announce a batch nobody trains on."""
+    import random
+    from desed_task_amd import graph as G
+    from desed_task_amd import ops as _ops
+    from desed_task_amd.launcher import StepDriver
+    from desed_task_amd.lookahead import BatchList
+    from tests.lightning_order import Trainer
+    bs = (1, 1, 2)
+    B = sum(bs)
+    sd = O.make_state_dict(seed=7, **({"embedding_size": 768} if pretrained else {}))
+    n_out = (1 + n_samp // 256) // 4
+    audios = [to(dev, O.synth_audio(B, n_samp, seed=700 + 7 * i)) for i in range(per_epoch)]
+    labelss = [to(dev, O.synth_labels(bs, 10, n_out, seed=80 + i)) for i in range(per_epoch)]
+    embs = [to(dev, torch.randn(B, 768, 31, generator=torch.Generator().manual_seed(5 + i))) for i in range(per_epoch)] if pretrained else None
+    used = per_epoch if limit_train_batches is None else limit_train_batches
+
+    class Clips(BatchList):             # a loader hands out fresh tensors every time: the step mixes the labels in place
+        def __getitem__(self, i):
+            return (audios[i], labelss[i].clone(), [1.0] * B) + ((embs[i],) if pretrained else ())
+
+    def state(task):
+        out = [task.sed_student.arena.flat.detach().cpu().clone(), task.sed_teacher.arena.flat.detach().cpu().clone()]
+        for model in (task.sed_student, task.sed_teacher):
+            for i in range(7):
+                bn = getattr(model.cnn.cnn, "batchnorm%d" % i)
+                out += [bn.running_mean.detach().cpu().clone(), bn.running_var.detach().cpu().clone()]
+        osd = task.opt.state_dict()
+        assert set(osd["param_groups"][0]) >= {"lr", "betas", "eps", "params"}
+        out += [torch.cat([osd["state"][i]["exp_avg"].reshape(-1).cpu() for i in sorted(osd["state"])]),
+                torch.cat([osd["state"][i]["exp_avg_sq"].reshape(-1).cpu() for i in sorted(osd["state"])]),
+                torch.tensor([float(osd["state"][0]["step"]), float(task.scheduler["scheduler"].step_num)])]
+        return out
+
+    def seed():
+        random.seed(41); np.random.seed(101); torch.manual_seed(101)
+        if dev != "cpu":
+            torch.cuda.manual_seed(101)
+        _ops.reseed_dropout()
+
+    results = {}
+    for mode in ("driver", "whole", "hooks"):
+        task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=5, torch_adam=mode != "driver", whole_step=mode == "whole",
+                          train_data=Clips([None] * per_epoch), pretrained=pretrained)
+        task.whole_step_warmup = warmup
+        seed()
+        losses = []
+        if mode == "driver":
+            driver = (G.GraphedStepDriver(task, world_size=1, warmup=warmup, prefetch="teacher") if dev != "cpu"
+                      else StepDriver(task, world_size=1, prefetch="teacher"))
+            data = Clips([None] * per_epoch)
+            for epoch in range(epochs):
+                epoch_batches = [data[i] for i in range(used)]
+                for i in range(used):
+                    nxt = epoch_batches[i + 1] if i + 1 < used else None
+                    losses.append(float(driver.run_step(epoch_batches[i], i, next_batch=nxt).detach()))
+        else:
+            tr = Trainer(max_epochs=epochs, limit_train_batches=1.0 if limit_train_batches is None else limit_train_batches)
+            tr.fit(task)
+            losses = [float(l) for l in tr.losses]
+            assert tr.global_step == epochs * used
+            if mode == "whole":
+                drv = task._driver
+                assert drv is not None and not task._served and task.opt.served is False
+                if dev != "cpu":
+                    assert drv.graph is not None and drv.eager_fallbacks >= epochs - 1 and drv.reprimes >= epochs - 1
+            else:
+                assert task._driver is None
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        logged = {k: float(v) for k, v in task.logged.items()}
+        assert len(logged) == 11 and logged["train/step"] == epochs * used, logged          # (logged BEFORE the scheduler's step)
+        results[mode] = (losses, state(task), logged)
+    ref = results["driver"]
+    for mode in ("whole", "hooks"):
+        got = results[mode]
+        assert got[0] == ref[0], (mode, got[0], ref[0])
+        for a, b in zip(got[1], ref[1]):
+            assert torch.equal(a, b), mode
+        assert got[2] == ref[2], (mode, got[2], ref[2])
+    return ref[0]
 
 
 def case_step_bit_reproducible(dev, steps=3, n_samp=16000 + 1024):
@@ -1944,7 +2044,7 @@ def case_b48_forward_vs_oracle(dev, bs=(12, 12, 24)):
     return out
 
 
-def case_b48_graph_step_vs_oracle(dev, bs=(12, 12, 24), n_samp=160000, warmup=1, replays=1, tol_scale=1.0, prefetch=None):
+def case_b48_graph_step_vs_oracle(dev, bs=(12, 12, 24), n_samp=160000, warmup=1, replays=1, tol_scale=1.0, prefetch=None, surface="driver"):
     """The benchmarked configuration THROUGH THE BENCHMARKED LAUNCH PATH, with the backward pass: B = 48 (12/12/24) clips of 10 s,
     dropout + SpecAugment + mixup on, student != teacher, run by graph.GraphedStepDriver -- `warmup` eager steps, the capture step,
     `replays` replayed steps -- and EVERY step compared with OracleTrainer on the draws the HIP path made: logged scalars <= 2e-4
@@ -1958,50 +2058,66 @@ def case_b48_graph_step_vs_oracle(dev, bs=(12, 12, 24), n_samp=160000, warmup=1,
     and the teacher's CNN forward ran under step k - 1's backward, so the draws that belong to step k's oracle step were made at
     three different times -- mixup and the teacher's CNN seeds / SpecAugment bounds during step k - 1, the student's and the
     teacher head's during step k -- and are carried over accordingly.  Runs unchanged under SED_DDP_REHEARSE=1 with a one-rank
-    process group (graph up to the end of backward + RCCL all-reduce + eager Adam: the N > 1 structure)."""
+    process group (graph up to the end of backward + RCCL all-reduce + eager Adam: the N > 1 structure).
+
+    surface="lightning" (with prefetch="teacher"): the same steps, but nobody calls the driver -- tests/lightning_order.Trainer runs
+    Lightning 1.9's hook order over `train_dataloader()` with a torch.optim.Adam, and SEDTask4's whole-step mode does the rest
+    (its own GraphedStepDriver, the next batch from the look-ahead loader).  The epoch's last batch has no successor: one more step,
+    run eagerly by the driver's fall-back, compared like the others."""
     from desed_task_amd.graph import GraphedStepDriver
+    from desed_task_amd.lookahead import BatchList
     torch.set_num_threads(min(64, torch.get_num_threads()))
     B = sum(bs)
     n_frames = 1 + n_samp // 256
-    n_steps = warmup + 1 + replays
+    lightning = surface == "lightning"
+    n_steps = warmup + 1 + replays + (1 if lightning else 0)
     pipelined = prefetch is not None
-    assert prefetch in (None, "teacher")
+    assert prefetch in (None, "teacher") and (pipelined or not lightning)
     sd, sd_t = O.make_state_dict(seed=13), O.make_state_dict(seed=14)
-    n_batches = n_steps + 1 if pipelined else 1                 # (the last step announces one more batch so that it is a replay too)
+    # (driven by hand, the last step announces one more batch so that it is a replay too)
+    n_batches = (n_steps if lightning else n_steps + 1) if pipelined else 1
     audios = [O.synth_audio(B, n_samp, seed=5 + 31 * i) for i in range(n_batches)]
     labelss = [O.synth_labels(bs, 10, n_frames // 4, seed=6 + i) for i in range(n_batches)]
-    task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=100)
+    audio_d = [to(dev, a) for a in audios]
+    loader_batches = [(audio_d[i], to(dev, labelss[i].clone()), [1.0] * B) for i in range(n_batches)] if lightning else None
+    task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=100, torch_adam=lightning, whole_step=lightning,
+                      train_data=BatchList(loader_batches) if lightning else None)
+    task.whole_step_warmup = warmup
     task.sed_teacher.load_state_dict({k: v.clone() for k, v in sd_t.items()})
-    driver = GraphedStepDriver(task, world_size=1, warmup=warmup, prefetch=prefetch)
+    driver = None if lightning else GraphedStepDriver(task, world_size=1, warmup=warmup, prefetch=prefetch)
     orc = O.OracleTrainer(sd, batch_sizes=bs, lr=1e-3, rampup_len=100, teacher_sd=sd_t)
     flat0 = task.sed_student.arena.flat.detach().clone()
     rec = StochasticRecorder(task)
-    audio_d = [to(dev, a) for a in audios]
-    worst = {"post": 0.0, "scalar": 0.0, "grad_max": 0.0, "grad_med": 0.0, "modes": [], "exchange": bool(driver.eager.exchange)}
+    worst = {"post": 0.0, "scalar": 0.0, "grad_max": 0.0, "grad_med": 0.0, "modes": [],
+             "exchange": bool(driver.eager.exchange) if driver is not None else False}
     mixes, t_cnn = {}, {}           # pipelined: per step, the mixup draws / (teacher CNN seeds, bounds) made one step early
-    try:
-        for step in range(n_steps):
-            mode = "eager" if step < warmup else ("capture" if step == warmup else "replay")
+    ctx = {}
+
+    def mode_of(step):
+        if step < warmup:
+            return "eager"
+        return "capture" if step == warmup else ("replay" if step < warmup + 1 + replays else "eager-last")
+
+    def before(step):
+        seeds = (4 + step, 100 + step, 100 + step)                       # seeds 4 -> mixup on, 5 -> off, 6 -> on
+        if not pipelined:
+            ctx["mix"] = _mixup_draws(bs, seeds)
+        elif step == 0:
+            mixes[0], mixes[1] = _mixup_draws_n(bs, seeds, 2)            # inline front half of step 0, then step 1's prefetch
+        else:
+            mixes[step + 1] = _mixup_draws_n(bs, seeds, 1)[0]
+        if mode_of(step) != "replay":
+            rec.reset()                         # a replay re-runs no Python: the capture's call sites stay valid
+
+    def after(step, loss):
+            driver = ctx["driver"]
+            mode = mode_of(step)
             bi = step if pipelined else 0
             audio, labels = audios[bi], labelss[bi]
-            seeds = (4 + step, 100 + step, 100 + step)                       # seeds 4 -> mixup on, 5 -> off, 6 -> on
-            if not pipelined:
-                mix = _mixup_draws(bs, seeds)
-            elif step == 0:
-                mixes[0], mixes[1] = _mixup_draws_n(bs, seeds, 2)            # inline front half of step 0, then step 1's prefetch
-            else:
-                mixes[step + 1] = _mixup_draws_n(bs, seeds, 1)[0]
-            if mode != "replay":
-                rec.reset()                         # a replay re-runs no Python: the capture's call sites stay valid
-            if pipelined:       # (protocol: the batch IS the tensor announced one step earlier)
-                batch = (audio_d[bi], to(dev, labels.clone()), None, None)
-                nxt = (audio_d[bi + 1], to(dev, labelss[bi + 1].clone()), None, None)
-                loss = driver.run_step(batch, step, next_batch=nxt)
-            else:
-                loss = driver.run_step((audio_d[bi].clone(), to(dev, labels.clone()), None, None), step)
+            mix = ctx.get("mix")
             torch.cuda.synchronize()
             assert (driver.graph is not None) == (mode != "eager")
-            dyn = driver.dyn if mode != "eager" else None
+            dyn = driver.dyn if mode in ("capture", "replay") else None
             aug_s, drop_s = rec.oracle_draws("student", B, n_frames, dyn=dyn)
             if not pipelined:
                 aug_t, drop_t = rec.oracle_draws("teacher", B, n_frames, dyn=dyn)
@@ -2013,11 +2129,14 @@ def case_b48_graph_step_vs_oracle(dev, bs=(12, 12, 24), n_samp=160000, warmup=1,
                     assert len(tv) == 15 and len(tb) == 2, (len(tv), len(tb))
                     t_cnn[0] = (tv[0:7], tb[0].cpu().clone())
                     head, t_cnn[1] = tv[7], (tv[8:15], tb[1].cpu().clone())
+                elif mode == "eager-last":          # no successor: the eager fall-back, [head (k)] only
+                    assert len(tv) == 1 and len(tb) == 0, (len(tv), len(tb))
+                    head = tv[0]
                 else:                               # [head (k)] then the prefetch's [7 CNN seeds (k + 1)]; bounds: the graph's static tensor
                     assert len(tv) == 8 and len(tb) == 1, (len(tv), len(tb))
                     head, t_cnn[step + 1] = tv[0], (tv[1:8], tb[0].cpu().clone())
                 aug_t, drop_t = StochasticRecorder.draws_from(list(t_cnn[step][0]) + [head], t_cnn[step][1], B, n_frames)
-                assert driver.eager_fallbacks == 0 and driver.reprimes == 0
+                assert driver.eager_fallbacks == (1 if mode == "eager-last" else 0) and driver.reprimes == 0
             tot, logs = orc.training_step(audio, labels, mix=mix, aug_s=aug_s, aug_t=aug_t, drop_s=drop_s, drop_t=drop_t)
             ref_grads = orc.optimizer_step(tot)
             got = {k: (float(v) if not torch.is_tensor(v) else float(v.detach().cpu())) for k, v in task.logged.items()}
@@ -2055,6 +2174,30 @@ def case_b48_graph_step_vs_oracle(dev, bs=(12, 12, 24), n_samp=160000, warmup=1,
                 for k in orc.keys:
                     orc.student[k].copy_(sd[k])
             worst["modes"].append(mode)
+
+    try:
+        if lightning:
+            from tests.lightning_order import Trainer
+            task.on_train_batch_start = lambda batch, i: before(i)
+
+            def batch_end(out, batch, i):
+                ctx["driver"] = task._driver
+                after(i, out["loss"])
+            task.on_train_batch_end = batch_end
+            Trainer(max_epochs=1).fit(task)
+            assert worst["modes"][-1] == "eager-last" and type(task.opt).__name__ == "FusedAdam"
+        else:
+            ctx["driver"] = driver
+            for step in range(n_steps):
+                before(step)
+                bi = step if pipelined else 0
+                if pipelined:       # (protocol: the batch IS the tensor announced one step earlier)
+                    batch = (audio_d[bi], to(dev, labelss[bi].clone()), None, None)
+                    nxt = (audio_d[bi + 1], to(dev, labelss[bi + 1].clone()), None, None)
+                    loss = driver.run_step(batch, step, next_batch=nxt)
+                else:
+                    loss = driver.run_step((audio_d[bi].clone(), to(dev, labelss[bi].clone()), None, None), step)
+                after(step, loss)
         assert worst["modes"].count("replay") == replays and "capture" in worst["modes"]
         if pipelined:
             assert any(m is not None for m in mixes.values()) and any(m is None for m in list(mixes.values())[:n_steps])
@@ -2311,6 +2454,7 @@ def build_task_2024(dev, bs=(2, 1, 1, 2, 2), nclass=27, dropout=0.5, dropstep=0.
     class Enc:
         labels = list(range(nclass))
     task = SEDTask4(config, Enc(), student, None, opt=opt, scheduler=sched)
+    task.whole_step = False
     task.train()
     if dev != "cpu":
         task.to(dev)

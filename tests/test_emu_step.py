@@ -208,3 +208,15 @@ def test_pipelined_epoch_boundaries(emu):
 def test_prefetched_2024_step_equals_unpipelined(emu):
     """The 2024 five-data-set step, front half + teacher CNN forward one step early == the unpipelined order, bit for bit."""
     P.case_prefetch_2024_equals_unpipelined("cpu", graph=False, steps=3, n_samp=2048 + 1024, te=9)
+
+
+def test_lightning_hook_order_whole_step_equals_driver(emu):
+    """SEDTask4's whole-step mode driven by Lightning 1.9's hook order (tests/lightning_order.py: torch.optim.Adam, batches from
+    train_dataloader()'s look-ahead loader) == the pipelined step driver driven by hand == the hooks run one by one, bit for bit,
+    across epoch ends.  (The hipGraph form of the same comparison runs on the GPU.)"""
+    P.case_lightning_surface("cpu", epochs=2, per_epoch=3, n_samp=2048 + 1024)
+
+
+def test_lightning_hook_order_limit_train_batches(emu):
+    """`limit_train_batches` (train_sed.py:256): the batch before the cut announces no successor."""
+    P.case_lightning_surface("cpu", epochs=2, per_epoch=3, n_samp=2048 + 1024, limit_train_batches=2)
