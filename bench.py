@@ -138,6 +138,7 @@ def _glu_bwd_work(k):
 
 ENTRIES = {
     "sed_mel_fwd": ("mel_kernel", "mel", 6, lambda k: ("hbm", 4.0 * k[1] * (k[2] + k[3] * k[6]))),      # (B,N,T,n_fft,hop,n_mels)
+    "sed_mel_fwd_wave": ("mel_wave_kernel", "mel", 6, lambda k: ("hbm", 4.0 * k[1] * (k[2] + k[3] * k[6]))),
     "sed_logscale_fwd": ("minmax_partial/apply_kernel", "mel", 2, lambda k: ("hbm", 8.0 * k[1] * k[2])),
     "sed_conv0_fwd": ("conv0_kernel", "block0", 4, lambda k: ("hbm", 4.0 * k[1] * k[2] * k[3] * (1 + k[4]))),
     "sed_conv0_wgrad": ("conv0_wgrad_kernel", "block0", 4, lambda k: ("hbm", 4.0 * k[1] * k[2] * k[3] * (1 + 2 * k[4]))),

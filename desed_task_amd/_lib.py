@@ -83,12 +83,21 @@ def use_library(path, is_emulator=True):
     return _lib
 
 
-TUNING_KEYS = {"glu_grid_cap": 0, "glu_bwd128_split": 1, "convb_ck": 2, "convb_mp": 3, "block0_nocenter": 4, "glu_fwd128": 5, "wgrad_narrow": 6, "wgrad_cap": 7, "attn_valu": 8, "wgrad_wide": 9, "gru_lds_kb": 10, "mel_taps_mem": 11, "convb_tpw": 12}
+TUNING_KEYS = {"glu_grid_cap": 0, "glu_bwd128_split": 1, "convb_ck": 2, "convb_mp": 3, "block0_nocenter": 4, "glu_fwd128": 5, "wgrad_narrow": 6, "wgrad_cap": 7, "attn_valu": 8, "wgrad_wide": 9, "gru_lds_kb": 10, "mel_taps_mem": 11, "convb_tpw": 12, "mel_wave": 13}
+
+
+_tuning = {}
 
 
 def set_tuning(key, value):
     """Tests / sweep tools: override a kernel tuning choice of the bound library (0 = built-in choice).  See sed_set_tuning."""
     get().call("sed_set_tuning", TUNING_KEYS[key], int(value))
+    _tuning[key] = int(value)
+
+
+def get_tuning(key):
+    """The value last given to set_tuning (0 = built-in choice): for choices made on the host side of an entry point."""
+    return _tuning.get(key, 0)
 
 
 def check_tensor(t, name="tensor"):

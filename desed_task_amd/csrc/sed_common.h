@@ -48,7 +48,7 @@ static inline void sed_zero4(hipStream_t s, float* p0, int n0, float* p1, int n1
 // Tuning overrides (tests and sweep tools only; all 0 = built-in choices).  Set explicitly through sed_set_tuning(): the entry
 // points never read the process environment.
 enum { SED_TUNE_GLU_GRID_CAP = 0, SED_TUNE_GLU_BWD128_SPLIT = 1, SED_TUNE_CONVB_CK = 2, SED_TUNE_CONVB_MP = 3, SED_TUNE_B0_NOCENTER = 4, SED_TUNE_GLU_FWD128 = 5, SED_TUNE_WGRAD_NARROW = 6, SED_TUNE_WGRAD_CAP = 7,
-       SED_TUNE_ATTN_VALU = 8, SED_TUNE_WGRAD_WIDE = 9, SED_TUNE_GRU_LDS_KB = 10, SED_TUNE_MEL_TAPS_MEM = 11, SED_TUNE_CONVB_TPW = 12, SED_TUNE_COUNT = 16 };
+       SED_TUNE_ATTN_VALU = 8, SED_TUNE_WGRAD_WIDE = 9, SED_TUNE_GRU_LDS_KB = 10, SED_TUNE_MEL_TAPS_MEM = 11, SED_TUNE_CONVB_TPW = 12, SED_TUNE_MEL_WAVE = 13, SED_TUNE_COUNT = 16 };
 extern int sed_tuning[SED_TUNE_COUNT];
 
 static inline int sed_check_launch() {
@@ -148,6 +148,16 @@ __device__ __forceinline__ void sed_opaque(int& x) {
     asm volatile("" : "+v"(x));
 #else
     (void)x;
+#endif
+}
+
+// A value that is the same in all 64 lanes of a wave (e.g. the wave's index in its workgroup), moved to a scalar register: what is
+// derived from it -- loop counters, frame indices, base addresses, branch conditions -- then lives in SGPRs and on the scalar ALU.
+__device__ __forceinline__ int sed_wave_uniform(int x) {
+#ifdef SED_EMU
+    return x;
+#else
+    return __builtin_amdgcn_readfirstlane(x);
 #endif
 }
 

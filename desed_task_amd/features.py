@@ -92,6 +92,9 @@ class MelSpectrogram(torch.nn.Module):
             state_dict.pop(prefix + k, None)
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
+    TAPS_FLOATS = (4 + 12) * 64 * 4     # sed_mel_taps / mel_wave_kernel: MEL_GA + MEL_GB groups of four taps per lane
+    _taps = None
+
     def _tables_to(self, device):
         if self.window.device != device:
             self.to(device)
@@ -111,9 +114,23 @@ class MelSpectrogram(torch.nn.Module):
             out = torch.empty(B, T, self.n_mels, device=audio.device, dtype=torch.float32)
         elif tuple(out.shape) != (B, T, self.n_mels) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != audio.device:
             raise ValueError("frames_major: `out` must be a contiguous fp32 (B, T, n_mels) tensor on the audio's device")
-        _lib.get().call("sed_mel_fwd", audio.data_ptr(), out.data_ptr(), B, N, T, self.n_fft, self.hop_length, self.n_mels,
-                        self.window.data_ptr(), self.tw1024.data_ptr(), self.tw2048.data_ptr(), self.fb_start.data_ptr(),
-                        self.fb_len.data_ptr(), self.fb_w.data_ptr(), self.fb_stride, int(apply_log), _lib.stream_ptr(audio))
+        lib = _lib.get()
+        if _lib.get_tuning("mel_wave") == 2 or _lib.get_tuning("mel_taps_mem"):
+            # the round-1..4 kernel: one frame per 256-thread workgroup (kept as the generic form and for A/B runs)
+            lib.call("sed_mel_fwd", audio.data_ptr(), out.data_ptr(), B, N, T, self.n_fft, self.hop_length, self.n_mels,
+                     self.window.data_ptr(), self.tw1024.data_ptr(), self.tw2048.data_ptr(), self.fb_start.data_ptr(),
+                     self.fb_len.data_ptr(), self.fb_w.data_ptr(), self.fb_stride, int(apply_log), _lib.stream_ptr(audio))
+            return out
+        taps = self._taps
+        if taps is None or taps.device != audio.device:
+            # the filterbank in the wave kernel's LDS layout: one tiny launch per device, outside any captured step
+            taps = torch.zeros(self.TAPS_FLOATS, device=audio.device, dtype=torch.float32)
+            lib.call("sed_mel_taps", self.fb_start.data_ptr(), self.fb_len.data_ptr(), self.fb_w.data_ptr(), self.fb_stride,
+                     self.n_mels, taps.data_ptr(), _lib.stream_ptr(audio))
+            self._taps = taps
+        lib.call("sed_mel_fwd_wave", audio.data_ptr(), out.data_ptr(), B, N, T, self.n_fft, self.hop_length, self.n_mels,
+                 self.window.data_ptr(), self.tw1024.data_ptr(), self.tw2048.data_ptr(), self.fb_start.data_ptr(),
+                 self.fb_len.data_ptr(), self.fb_w.data_ptr(), self.fb_stride, taps.data_ptr(), int(apply_log), _lib.stream_ptr(audio))
         return out
 
     def forward(self, audio):

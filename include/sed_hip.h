@@ -28,6 +28,15 @@ int sed_mel_fwd(const float* audio, float* out, int B, int N, int T, int n_fft, 
                 const float* window, const float* tw1024, const float* tw2048, const int* fb_start,
                 const int* fb_len, const float* fb_w, int fb_stride, int apply_log, void* stream);
 
+/* K1, round 5: the same transform with one WAVE per frame (1024-point packed FFT as 16 x 16 x 4 in registers, two wave-private LDS
+ * exchanges, no workgroup barrier in the frame loop; runs of consecutive frames of a clip stay on one XCD).  `taps`: the filterbank in
+ * the kernel's LDS layout, (4 + 12) * 64 * 4 floats written once by sed_mel_taps from the same sparse filterbank arrays.  Same
+ * reference call site as sed_mel_fwd (local/sed_trainer.py:80-91, :282), which remains as the generic one-frame-per-workgroup form. */
+int sed_mel_taps(const int* fb_start, const int* fb_len, const float* fb_w, int fb_stride, int n_mels, float* taps, void* stream);
+int sed_mel_fwd_wave(const float* audio, float* out, int B, int N, int T, int n_fft, int hop, int n_mels,
+                     const float* window, const float* tw1024, const float* tw2048, const int* fb_start,
+                     const int* fb_len, const float* fb_w, int fb_stride, const float* taps, int apply_log, void* stream);
+
 /* K3+K4: SEDTask4.take_log (sed_trainer.py:253-264) + TorchScaler("instance","minmax") forward
  * (desed_task/utils/scaler.py:114-120) on (B, L) clips.  partial: B*64 floats scratch; minmax: optional (B,2). */
 int sed_logscale_fwd(const float* x, float* logbuf, float* out, float* partial, float* minmax, int B, int L,

@@ -9,6 +9,17 @@ def test_mfma_maps(emu):
 
 def test_mel_matches_oracle(emu):
     P.case_mel("cpu")
+    P.case_mel("cpu", batch=3, n_samples=256 * 21 + 100)       # ragged clip length, a batch the XCD walk does not divide
+
+
+def test_mel_generic_kernel_matches_oracle(emu):
+    """The one-frame-per-workgroup kernel of rounds 1-4 (`sed_mel_fwd`), kept as the generic form."""
+    from desed_task_amd import _lib
+    _lib.set_tuning("mel_wave", 2)
+    try:
+        P.case_mel("cpu")
+    finally:
+        _lib.set_tuning("mel_wave", 0)
 
 
 def test_logscale_generic(emu):

@@ -26,6 +26,16 @@ def test_mfma_maps():
 
 def test_mel_small():
     P.case_mel("cuda")
+    P.case_mel("cuda", batch=5, n_samples=256 * 40 + 100)      # a batch that is no multiple of the XCD count, a ragged clip length
+
+
+def test_mel_generic_kernel():
+    """The one-frame-per-workgroup kernel of rounds 1-4 (`sed_mel_fwd`), kept as the generic form."""
+    _lib.set_tuning("mel_wave", 2)
+    try:
+        P.case_mel("cuda")
+    finally:
+        _lib.set_tuning("mel_wave", 0)
 
 
 def test_mel_full_clip_and_golden():
