@@ -22,6 +22,7 @@ from . import _lib
 
 
 POSCONV_MFMA = True             # position convolution on the split-bf16 MFMA (False: the f32 vector-pipe kernel, A/B and tests)
+LINEAR_PACKED = True            # the large Linear layers through the packed-weight 256 x 128-tile kernel (False: sed_linear_bf16x3, A/B and tests)
 
 
 class BEATsConfig:
@@ -258,8 +259,23 @@ class BEATs(nn.Module):
         R = B * T
         f32 = dict(device=fb.device, dtype=torch.float32)
 
+        packed = pk.setdefault("linear", {})
+
         def linear(x, w, b, n, k, act=0):
             y = torch.empty(x.shape[0], n, **f32)
+            if LINEAR_PACKED and n >= 2048 and n % 128 == 0 and k % 32 == 0 and x.shape[0] >= 256:
+                # frozen weight: split into bf16 hi / lo planes once, then the 256 x 128-tile kernel (sed_gemm_bf16.hip, round 5).  Wide
+                # outputs only: at N = 768 its 558 tiles on 512 resident workgroups lose to the 128-row tiles (gpurun_out/linear_r05a.txt)
+                key = (w.data_ptr(), n, k)
+                wp = packed.get(key)
+                if wp is None or wp.device != x.device:
+                    wp = torch.empty(2 * n * k, device=x.device, dtype=torch.int16)
+                    wsrc = w.detach().float().contiguous()
+                    lib.call("sed_pack_weights_bf16x3", wsrc.data_ptr(), wp.data_ptr(), n, k, st)
+                    packed[key] = wp
+                lib.call("sed_linear_packed_bf16x3", x.data_ptr(), wp.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(),
+                         x.shape[0], n, k, act, st)
+                return y
             lib.call("sed_linear_bf16x3", x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(),
                      x.shape[0], n, k, act, st)
             return y

@@ -281,6 +281,159 @@ SED_API int sed_gemm_kcat_splitk_bf16x3(const float* A, const float* B0, const f
     return sed_check_launch();
 }
 
+// ---- round 5: the large frozen-weight linears of the BEATs encoder (M = 23 808 tokens, N, K in {768, 2304, 3072}) -------------------
+// gemm_bf16x3_kernel above stages BOTH operands through LDS as split planes it forms on the fly: per 32-wide K tile 16 ds_write_b64
+// per thread (~6 LDS cycles each) next to the fragment reads -- the LDS pipe, not the matrix pipe, set its pace (235 - 260 TFLOP/s =
+// 28 - 31 % of the 833 TFLOP/s that three bf16 MFMAs per product allow).  Here
+//   * W is split ONCE (frozen weights: sed_pack_weights_bf16x3 -> [hi | lo][N][K] bf16 planes), so its tiles travel HBM -> LDS as plain
+//     16-byte copies, double-buffered: one workgroup barrier per K tile;
+//   * A never touches LDS: a wave owns 64 rows x all 128 columns of the 256 x 128 tile, and the MFMA A fragment of lane (row, k-half) is
+//     8 consecutive floats of that row -- two 16-byte global loads, split into hi / lo in registers (5 VALU per pair, hidden behind
+//     the 24 MFMAs of the k-step), prefetched one k-step ahead;
+//   * per k-step (16 k) a wave issues 24 MFMAs against 8 ds_read_b128 (B) + 4 global_load_dwordx4 (A);
+//   * tiles are walked so that the workgroups of one XCD share an A row panel (its L2) while they sweep the N tiles.
+namespace {
+constexpr int LB_BM = 256, LB_BN = 128, LB_BK = 32, LB_RS = 40;     // LDS row pitch 40 bf16 = 80 B = 5 sixteen-byte slots (odd)
+
+__device__ __forceinline__ void split8(const float4 p, const float4 q, s16x8& h, s16x8& l) {
+    uint4 hh, ll;
+    bf16_split2(p.x, p.y, hh.x, ll.x); bf16_split2(p.z, p.w, hh.y, ll.y);
+    bf16_split2(q.x, q.y, hh.z, ll.z); bf16_split2(q.z, q.w, hh.w, ll.w);
+    h = __builtin_bit_cast(s16x8, hh); l = __builtin_bit_cast(s16x8, ll);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void linear_big_kernel(const float* __restrict__ A, const unsigned short* __restrict__ Wp,
+                                                         const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K,
+                                                         int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][2 * LB_BN * LB_RS];        // [stage][hi | lo][n][k]
+    const int tid = threadIdx.x, lane = tid & 63, w = sed_wave_uniform(tid >> 6), lo = lane & 31, hi = lane >> 5;
+    // tile walk: workgroup g runs on XCD g & 7; XCD x takes the row panels tm = x (mod 8) and sweeps their N tiles back to back
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int panels_here = (tiles_m - xcd + 7) >> 3;
+    for (int tile = slot; tile < panels_here * tiles_n; tile += per_xcd) {
+        const int tm = xcd + 8 * (tile / tiles_n), tn = tile % tiles_n;
+        const int m0 = tm * LB_BM, n0 = tn * LB_BN;
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x16_zero();
+        // B tile copy: 2 planes x 128 rows x 64 B = 1024 sixteen-byte chunks, 4 per thread: chunk c = tid + 256 u ->
+        // plane c >> 9, row (c >> 2) & 127, 16-byte piece c & 3 of the row's 64 bytes
+        const int brow = (tid >> 2) & 63, bq = tid & 3;          // u = 0..3: plane = u >> 1, row = brow + 64 (u & 1)
+        const unsigned short* bsrc = Wp + ((size_t)(n0 + brow)) * K + 8 * bq;
+        const size_t bplane = (size_t)N * K, brow64 = (size_t)64 * K;
+        const int bdst = brow * LB_RS + 8 * bq;
+        uint4 b0, b1, b2, b3;
+#define LB_BLOAD(k0_) { b0 = *(const uint4*)(bsrc + (k0_)); b1 = *(const uint4*)(bsrc + brow64 + (k0_)); \
+                        b2 = *(const uint4*)(bsrc + bplane + (k0_)); b3 = *(const uint4*)(bsrc + bplane + brow64 + (k0_)); }
+#define LB_BSTORE(st_) { unsigned short* d_ = &Bs[st_][bdst]; *(uint4*)d_ = b0; *(uint4*)(d_ + 64 * LB_RS) = b1; \
+                         *(uint4*)(d_ + LB_BN * LB_RS) = b2; *(uint4*)(d_ + LB_BN * LB_RS + 64 * LB_RS) = b3; }
+        // A fragments: rows m0 + 64 w + 32 rb + lo (clamped: rows past M are computed and dropped).  One 32-wide K tile of a row is
+        // one 128-byte line; lane (row, k-half hi) needs its bytes [32 hi, 32 hi + 32) (k-step 0) and [64 + 32 hi, ...) (k-step 1).  All four
+        // 16-byte loads of a row block go out TOGETHER, so a line is fetched into the CU once (requested per k-step, 768 MFMA-cycles apart,
+        // every line came over from L2 twice: the eight waves' lines of one k-step alone are 64 KB) -- and they go out one row block ahead:
+        // while block rb computes its 24 MFMAs, the other block's lines (same K tile, or the next one) are in flight.
+        int r0 = m0 + 64 * w + lo, r1 = r0 + 32;
+        r0 = r0 < M ? r0 : M - 1;
+        r1 = r1 < M ? r1 : M - 1;
+        const float* arow0 = A + (size_t)r0 * K + 8 * hi;
+        const float* arow1 = A + (size_t)r1 * K + 8 * hi;
+        float4 a0, a1, a2, a3;              // k-step 0: a0 a1, k-step 1: a2 a3 of the row block in flight
+#define LB_ALOAD(row_, k_) { a0 = *(const float4*)((row_) + (k_)); a1 = *(const float4*)((row_) + (k_) + 4); \
+                             a2 = *(const float4*)((row_) + (k_) + 16); a3 = *(const float4*)((row_) + (k_) + 20); }
+#define LB_RB(rb_, next_row_, next_k_) { \
+            s16x8 ah0, al0, ah1, al1; \
+            split8(a0, a1, ah0, al0); \
+            split8(a2, a3, ah1, al1); \
+            LB_ALOAD(next_row_, next_k_) \
+            sed_sched_fence(); \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
+                const s16x8 ah = ks ? ah1 : ah0, al = ks ? al1 : al0; \
+                s16x8 bh[4], bl[4]; \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) { \
+                    const unsigned short* bp = &Bs[stage][(nt * 32 + lo) * LB_RS + 16 * ks + 8 * hi]; \
+                    bh[nt] = *(const s16x8*)bp; \
+                    bl[nt] = *(const s16x8*)(bp + LB_BN * LB_RS); \
+                } \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[rb_][nt] = mfma32_bf16(al, bh[nt], acc[rb_][nt]); \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[rb_][nt] = mfma32_bf16(ah, bl[nt], acc[rb_][nt]); \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[rb_][nt] = mfma32_bf16(ah, bh[nt], acc[rb_][nt]); \
+            } }
+        __syncthreads();                    // (the previous tile's last reads of both stages)
+        LB_BLOAD(0)
+        LB_ALOAD(arow0, 0)
+        LB_BSTORE(0)
+        __syncthreads();
+        const int nk = K / LB_BK;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int stage = kt & 1;
+            if (kt + 1 < nk) LB_BLOAD((kt + 1) * LB_BK)
+            const int k0 = kt * LB_BK;
+            const int k1 = kt + 1 < nk ? k0 + LB_BK : k0;       // (past the end: the last tile again, unused)
+            LB_RB(0, arow1, k0)
+            LB_RB(1, arow0, k1)
+            if (kt + 1 < nk) LB_BSTORE(stage ^ 1)
+            __syncthreads();                // stage ^ 1 is complete; everybody is done with `stage` before iteration kt + 2 rewrites it
+        }
+#undef LB_RB
+#undef LB_BLOAD
+#undef LB_BSTORE
+#undef LB_ALOAD
+        // epilogue: bias (+ exact GELU); lane holds column n0 + 32 nt + lo, rows mfma32_row(r, lane)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int gn = n0 + nt * 32 + lo;
+            const float bv = bias != nullptr ? bias[gn] : 0.f;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = m0 + 64 * w + 32 * rb + mfma32_row(r, lane);
+                    float v = acc[rb][nt][r] + bv;
+                    if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                    if (gm < M) Cm[(size_t)gm * N + gn] = v;
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* __restrict__ W, unsigned short* __restrict__ Wp, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned short h, l;
+    bf16_split(W[i], h, l);
+    Wp[i] = h;
+    Wp[n + i] = l;
+}
+}  // namespace
+
+// Frozen weights W[N][K] -> Wp[2][N][K] bf16 bit patterns: plane 0 = bf16(w), plane 1 = bf16(w - plane 0)  (done once per weight).
+SED_API int sed_pack_weights_bf16x3(const float* W, unsigned short* Wp, int N, int K, void* stream) {
+    const long long n = (long long)N * K;
+    if (n <= 0) return SED_OK;
+    SED_LAUNCH(pack_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, Wp, n);
+    return sed_check_launch();
+}
+
+// torch.nn.Linear forward on packed weights: C[M][N] = act(A[M][K] . W[N][K]^T + bias[N]) -- every Linear of the BEATs encoder
+// (recipes/dcase2023_task4_baseline/local/beats/backbone.py:286-330 q/k/v/out projections, :214-276 fc1 (GELU) / fc2).
+// N % 128 == 0, K % 32 == 0, 16-byte aligned A and Wp.
+SED_API int sed_linear_packed_bf16x3(const float* A, const unsigned short* Wp, const float* bias, float* Cm, int M, int N, int K, int act,
+                                     void* stream) {
+    if (act < 0 || act > 1) return SED_ERR_ARG;
+    if (M <= 0 || N <= 0) return SED_OK;
+    if (N % LB_BN != 0 || K % LB_BK != 0 || K <= 0 || ((uintptr_t)A & 15) || ((uintptr_t)Wp & 15)) return SED_ERR_UNSUPPORTED;
+    const int tiles_m = (M + LB_BM - 1) / LB_BM, tiles_n = N / LB_BN;
+    long long tiles = (long long)tiles_m * tiles_n;
+    int grid = tiles < 512 ? (int)tiles : 512;          // two resident workgroups per CU
+    grid = (grid + 7) & ~7;
+    if (act) SED_LAUNCH((linear_big_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, A, Wp, bias, Cm, M, N, K, tiles_m, tiles_n);
+    else SED_LAUNCH((linear_big_kernel<0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, A, Wp, bias, Cm, M, N, K, tiles_m, tiles_n);
+    return sed_check_launch();
+}
+
 // torch.nn.Linear forward with an optional fused activation: C[M][N] = act(A[M][K] . W[N][K]^T + bias[N]), act 0 = none, 1 = exact
 // GELU (the FFN of the BEATs encoder layers).  16-byte aligned operands, K % 4 == 0.
 SED_API int sed_linear_bf16x3(const float* A, const float* W, const float* bias, float* Cm, int M, int N, int K, int act,

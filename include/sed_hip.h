@@ -366,6 +366,14 @@ int sed_zero_buffers(float* p0, long long n0, float* p1, long long n1, float* p2
  * act 0 = none, 1 = exact GELU (backbone.py:279-283: the encoder layers' fc1).  16-byte aligned, K % 4 == 0. */
 int sed_linear_bf16x3(const float* A, const float* W, const float* bias, float* Cm, int M, int N, int K, int act, void* stream);
 
+/* Round 5: the same Linear for the large frozen-weight products of the BEATs encoder (backbone.py:214-276 fc1 / fc2, :286-330 the
+ * q / k / v / out projections; M = 23 808 tokens at 48 clips).  The weight is split into bf16 hi / lo planes once
+ * (sed_pack_weights_bf16x3: Wp = 2 * N * K bf16 bit patterns); 256 x 128 tiles, A fragments straight from HBM into registers, W tiles
+ * double-buffered in LDS.  N % 128 == 0, K % 32 == 0. */
+int sed_pack_weights_bf16x3(const float* W, unsigned short* Wp, int N, int K, void* stream);
+int sed_linear_packed_bf16x3(const float* A, const unsigned short* Wp, const float* bias, float* C, int M, int N, int K, int act,
+                             void* stream);
+
 /* torchaudio.compliance.kaldi.fbank(waveform * 2^15, num_mel_bins, 16 kHz, 25 ms frames, 10 ms shift) with that function's
  * defaults (povey window, pre-emphasis 0.97, DC removal, snip_edges, 512-point FFT, power spectrum, log) followed by
  * (x - norm_mean) * norm_inv -- BEATs.preprocess, BEATs.py:109-133.  audio (B,N) -> out (B, 1 + (N - 400) / 160, n_mels).

@@ -442,6 +442,38 @@ def case_gemm(dev, entry="sed_gemm"):
         assert err < 1e-4 * max(1.0, ref.abs().max().item()), (kcat, M, N, K, err)
 
 
+def case_linear_packed(dev, shapes=((300, 128, 64, 0), (513, 256, 96, 1), (256, 128, 32, 1))):
+    """sed_pack_weights_bf16x3 + sed_linear_packed_bf16x3 (the BEATs encoder's large Linear layers: frozen weight split into bf16
+    hi / lo planes once, 256 x 128 tiles, A fragments straight from HBM, optional exact-GELU epilogue) vs float64: ragged M (rows
+    past M are computed and dropped), several K tiles, more tiles than one XCD's share."""
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(11)
+    for (M, N, K, act) in shapes:
+        A, W, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+        ref = A.double() @ W.double().t() + bias.double()
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        Ad, Wd, bd = to(dev, A, W, bias)
+        Wp = torch.empty(2 * N * K, dtype=torch.int16, device=Ad.device)
+        lib.call("sed_pack_weights_bf16x3", Wd.data_ptr(), Wp.data_ptr(), N, K, _lib.stream_ptr(Ad))
+        hi = Wp[:N * K].view(torch.bfloat16).float().cpu().view(N, K)
+        lo = Wp[N * K:].view(torch.bfloat16).float().cpu().view(N, K)
+        assert (hi + lo - W).abs().max().item() <= 2.0 ** -16 * W.abs().max().item()
+        C = torch.full((M, N), 7.0, device=Ad.device)
+        lib.call("sed_linear_packed_bf16x3", Ad.data_ptr(), Wp.data_ptr(), bd.data_ptr(), C.data_ptr(), M, N, K, act, _lib.stream_ptr(Ad))
+        err = (C.cpu().double() - ref).abs().max().item()
+        assert err < 3e-5 * max(1.0, ref.abs().max().item()), (M, N, K, act, err)
+        # no bias; shapes the kernel does not take are refused, not mangled
+        lib.call("sed_linear_packed_bf16x3", Ad.data_ptr(), Wp.data_ptr(), None, C.data_ptr(), M, N, K, 0, _lib.stream_ptr(Ad))
+        err = (C.cpu().double() - A.double() @ W.double().t()).abs().max().item()
+        assert err < 3e-5 * max(1.0, ref.abs().max().item()), (M, N, K, "nobias", err)
+    try:
+        lib.call("sed_linear_packed_bf16x3", Ad.data_ptr(), Wp.data_ptr(), None, C.data_ptr(), M, 100, K, 0, _lib.stream_ptr(Ad))
+        raise AssertionError("N % 128 != 0 must be refused")
+    except RuntimeError:
+        pass
+
+
 # ------------------------------------------------------------------------------------------------
 # whole mean-teacher step (a16): SEDTask4.training_step + EMA + backward + Adam + scheduler
 # ------------------------------------------------------------------------------------------------

@@ -314,7 +314,7 @@ def test_rank_sharded_batch_sampler():
     assert a[0].epoch == a[1].epoch == 2 and e1 != e0
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(1500)
 def test_bench_self_launch_dry_run():
     """`python bench.py --gpus 2` from a plain shell (no torchrun environment) starts its own two ranks; here as the dry run on the
     CPU emulator over gloo.  The JSON line must say which backend / world size ran and carry the gradient-bucket log."""
@@ -341,6 +341,18 @@ def test_bench_self_launch_dry_run():
     assert exposed and tail[exposed[0]]["host_us"] > 0 and tail[exposed[0]]["device_us"] is None
     assert "backward_done -> exchange_done" in tail and "exchange_done -> adam_done" in tail
     assert "falsified by" in d["expected"] and "rccl_debug" in d
+    # the SAME launch at the node's size -- eight ranks (only two had ever been started): rank-local seeds / port /
+    # the JSON line from rank 0 only, one all-reduce over the whole arena per step on every rank
+    r8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "1", "--warmup", "1"],
+                        cwd=ROOT, env=dict(env, SED_EMU_THREADS="2"), capture_output=True, text=True, timeout=900)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    lines = [ln for ln in r8.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r8.stdout[-1000:]
+    out8 = json.loads(lines[0])
+    d8 = out8["dist"]
+    assert out8["n_gpus"] == 8 and d8["world_size"] == 8 and len(d8["ms_per_step_per_rank"]) == 8
+    assert out8["config"]["global_batch"] == 8 * out["config"]["global_batch"] // 2 and "cpu_baseline" not in out8
+    assert out8["config"]["surface"]["surface"] == "driver"
     # without a GPU and without --dry-run the bench refuses loudly instead of producing a number
     if not torch.cuda.is_available():
         r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, capture_output=True,

@@ -8,6 +8,11 @@ def test_gemm(emu):
     P.case_gemm("cpu", entry="sed_gemm_bf16x3")
 
 
+def test_linear_packed(emu):
+    """The BEATs encoder's packed-weight Linear (round 5)."""
+    P.case_linear_packed("cpu", shapes=((300, 128, 64, 0), (257, 256, 32, 1)))
+
+
 def test_bigru_layer0(emu):
     P.case_bigru("cpu", B=2, T=7, I=128)
 

@@ -74,6 +74,12 @@ def test_gemm():
     P.case_gemm("cuda", entry="sed_gemm_bf16x3")
 
 
+def test_linear_packed():
+    """The BEATs encoder's packed-weight Linear (256 x 128 tiles) incl. one production-width shape (K = 3072, 24 N tiles)."""
+    P.case_linear_packed("cuda")
+    P.case_linear_packed("cuda", shapes=((1000, 768, 3072, 0), (700, 3072, 768, 1)))
+
+
 def test_bigru_production_shape():
     P.case_bigru("cuda", B=4, T=156, I=128, tol=5e-5)
     P.case_bigru("cuda", B=3, T=156, I=256, tol=5e-5)

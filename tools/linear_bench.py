@@ -1,0 +1,32 @@
+"""The BEATs encoder's Linear shapes alone (M = 23 808 tokens): packed-weight kernel vs the generic split-bf16 GEMM, HIP-event time per launch,
+algorithmic TFLOP/s and the fraction of the 833 TFLOP/s that three bf16 MFMAs per product allow.  python tools/linear_bench.py [packed|generic]"""
+import sys, torch
+sys.path.insert(0, '.')
+from desed_task_amd import _lib
+lib = _lib.get()
+which = sys.argv[1:] or ["packed", "generic"]
+M = 23808
+g = torch.Generator(device="cuda").manual_seed(1)
+for (N, K, act, name) in ((2304, 768, 0, "qkv"), (768, 768, 0, "out"), (3072, 768, 1, "fc1+gelu"), (768, 3072, 0, "fc2")):
+    A = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    C = torch.empty(M, N, device="cuda")
+    Wp = torch.empty(2 * N * K, dtype=torch.int16, device="cuda")
+    st = _lib.stream_ptr(A)
+    lib.call("sed_pack_weights_bf16x3", W.data_ptr(), Wp.data_ptr(), N, K, st)
+    for kind in which:
+        def run():
+            if kind == "packed":
+                lib.call("sed_linear_packed_bf16x3", A.data_ptr(), Wp.data_ptr(), b.data_ptr(), C.data_ptr(), M, N, K, act, st)
+            else:
+                lib.call("sed_linear_bf16x3", A.data_ptr(), W.data_ptr(), b.data_ptr(), C.data_ptr(), M, N, K, act, st)
+        for _ in range(2): run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        tf = 2.0 * M * N * K / ms / 1e9
+        print("%-9s %-8s N %4d K %4d: %7.1f us  %6.1f TFLOP/s  = %.3f of 833" % (name, kind, N, K, ms * 1e3, tf, tf / 833.3))
