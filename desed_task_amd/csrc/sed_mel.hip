@@ -189,13 +189,23 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
 // reads l + 64 m + 256 r) and the conjugate-pair exchange of the real-FFT step are contiguous per lane group as they are.  All LDS
 // addresses are a per-lane base + an immediate.  Mel stage: lane l owns bands l and 127 - l (3 + 42 ... 13 + 13 taps: balanced), taps
 // in registers (MEL_WA + MEL_WB), magnitudes read from the wave's buffer; longer bands finish from memory (no recipe has any).
-#define MEL_RUN 8
+// MEL_RUN = frames of a run = MEL_WAVES: every wave transforms ONE frame per run.  Longer runs (8, 16: a wave walks t, t + 4, ...
+// with the next frame's samples prefetched under the mel stage) measure the same 79 us alone, but are NOT safe: replayed inside a hipGraph
+// next to the BiGRU tails (the "tails" side branch of the pipelined step) the last frames a wave transforms came out wrong in ~5 % of
+// the replays -- a handful of neighbouring bins k and their mirror bins 1024 - k, i.e. one register of a few neighbouring lanes
+// between pass 3 and the real-FFT step; never in eager launches (2 000 launches beside the same kernels), never with one frame per
+// run (3 000 replays).  tools/mel_graph_race.py reproduces it (build with -DMEL_RUN=8); explicit s_waitcnt vmcnt(0) / lgkmcnt(0) at
+// every exchange, no prefetch, plain (non-asm) arithmetic, -O1, a vector wave index and 48 KB of LDS padding (no BiGRU workgroup on
+// the CU) all still fail.  Cause not found; DESIGN.md section 12.
+#ifndef MEL_RUN
+#define MEL_RUN 4
+#endif
 #define MEL_XPAD 1088          // 1024 + 64 padding slots (exchange 1)
 
 // Complex arithmetic on the packed-fp32 pipe: a complex number is one 64-bit VGPR pair, and VOP3P's op_sel / neg modifiers pick and
 // negate the halves, so that a rotation by +-i folds into the add and a complex product is two instructions (the compiler's own
 // lowering of the float2 formulas spent 18 % of the frame loop on v_mov shuffles between scalar and packed forms).
-#ifdef SED_EMU
+#if defined(SED_EMU) || defined(MEL_PLAIN_MATH)
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cadd_mi(float2 a, float2 b) { return make_float2(a.x + b.y, a.y - b.x); }     // a - i b

@@ -226,6 +226,11 @@ def quiesce_collectives(dev):
         # (a torch build without ProcessGroup._wait_for_pending_works: the device is idle, so every work item is complete and the
         #  watchdog retires it at its next 100-ms poll -- give it three)
         import time
+        import warnings
+        warnings.warn("graph.quiesce_collectives: this torch build has no ProcessGroup._wait_for_pending_works; falling back to a 0.3 s "
+                      "pause before the stream capture.  If the RCCL watchdog still invalidates the capture it fails loudly (hipErrorStreamCapture"
+                      "Invalidated / an aborted process): it is NOT retried -- the capture pass runs the step's host half (RNG draws, "
+                      "scheduler, Adam's step count), which a second attempt would run twice")
         time.sleep(0.3)
 
 
@@ -294,6 +299,14 @@ class GraphedStepDriver:
 
     def _device(self):
         return next(self.task.sed_student.parameters()).device
+
+    def _freeze_handover_buffers(self):
+        """From the capture on, the graph reads the task's hand-over buffers (`_pro`, `_feat_buf`) at FIXED addresses: a silent
+        reallocation -- another shape, stride or dtype while nothing is ready -- would leave the replays on the old storage (ADVICE
+        r04).  Frozen buffers raise instead."""
+        pro = getattr(self.task, "_pro", None)
+        if pro is not None:
+            pro["frozen"] = True
 
     def input_buffers(self):
         """The static device tensors the captured graph reads (one per tensor of the batch tuple, None elsewhere), available
@@ -444,6 +457,7 @@ class GraphedStepDriver:
                 _ops.loss_work(dev, B)              # (scratch the loss kernel caches per device: allocated OUTSIDE the capture pool)
             quiesce_collectives(dev)
             self.graph = torch.cuda.CUDAGraph()
+            self._freeze_handover_buffers()
             with dyn_step(self.dyn, record=True):
                 # thread_local: calls other threads make (allocator, a collective backend's housekeeping) must not fail this capture;
                 # the one that does fail on this stack -- the RCCL watchdog's event query -- has been drained by quiesce_collectives()

@@ -138,7 +138,7 @@ class StepDriver:
         min-max) AND the teacher's CNN forward run under this step's backward (SEDTask4.launch_prefetch).  The next run_step must
         be given exactly the announced batch."""
         self.task = task
-        _ops.reset_loss_work()
+        _ops.reset_loss_work(next(task.sed_student.parameters()).device)
         if prefetch is not None:
             task.prefetch_point = None if prefetch in ("off", False) else ("backward" if prefetch == "teacher" else prefetch)
             task.prefetch_level = "teacher" if prefetch == "teacher" else "features"

@@ -221,6 +221,20 @@ def new_seed(generator=None):
     return draw()
 
 
+def _arena_views(cfg, *grads):
+    """Are all these gradient buffers views into the parameter arena's flat gradient tensor?  Only then may their producer be launched
+    LATER, off the chain, through raw addresses: autograd adopts such a view as .grad, so the address stays valid and is
+    what the optimizer reads.  A buffer that is a fresh tensor instead -- the parameter already had a .grad (a second backward without
+    zero_grad: AccumulateGrad adds it at once, on the main stream) or is frozen (the tensor is dropped after backward) -- must be
+    written before this node returns."""
+    arena = cfg.get("arena") if cfg else None
+    if arena is None:
+        return False
+    lo = arena.flat_grad.data_ptr()
+    hi = lo + 4 * arena.flat_grad.numel()
+    return all(lo <= g.data_ptr() < hi for g in grads)
+
+
 def _grad_buf(cfg, param):
     """Gradient output buffer for `param`: a view into the parameter arena's flat gradient buffer when the
     parameter lives in one (so the optimizer / all-reduce see ONE contiguous tensor), else a fresh tensor."""
@@ -529,7 +543,10 @@ class BiGRULayerFn(torch.autograd.Function):
             if DEFER_OFF_CHAIN:
                 bias_sums(stream_ptr)
             BiGRULayerFn._weight_grads(lib, cfg, dgi, dgh, hprev, x, wptr, B, T, I, H, split, stream_ptr, f32)
-        if (side is not None or (SIDE_ON_CPU and GRU_DW_SIDE)) and DEFER_OFF_CHAIN:
+        off_chain_ok = _arena_views(cfg, *dwi, *dwh, *dbi, *dbh)
+        if not off_chain_ok:
+            side_section(ws)                    # some gradient buffer is not the arena's: written before this node returns
+        elif (side is not None or (SIDE_ON_CPU and GRU_DW_SIDE)) and DEFER_OFF_CHAIN:
             # what the nodes before this one parked (the head's sums, the other layer's side section) goes out now that THIS layer's
             # recurrence and dX product -- the chain -- are enqueued; this layer's own side section waits for the next node's
             flush_deferred(side)
@@ -713,8 +730,12 @@ class HeadFn(torch.autograd.Function):
         # (the parked launch holds ADDRESSES of the gradient buffers, not the tensors: a second reference would keep autograd's
         # AccumulateGrad from adopting them as .grad -- it would clone the not yet written buffers instead)
         outs = (dw1.data_ptr(), dw2.data_ptr(), db1.data_ptr(), db2.data_ptr())
-        defer_off_chain(x.device, lambda stream_ptr: lib.call("sed_head_bwd_reduce", scratch.data_ptr(), outs[0], outs[1], outs[2], outs[3],
-                                                              B, T, D, NC, stream_ptr), (scratch,))
+        reduce = lambda stream_ptr: lib.call("sed_head_bwd_reduce", scratch.data_ptr(), outs[0], outs[1], outs[2], outs[3],    # noqa: E731
+                                             B, T, D, NC, stream_ptr)
+        if _arena_views(cfg, dw1, dw2, db1, db2):
+            defer_off_chain(x.device, reduce, (scratch,))
+        else:
+            reduce(_lib.stream_ptr(x))
         return dx, dw1, db1, dw2, db2, None
 
 
@@ -798,8 +819,13 @@ def loss_work(device, B):
     return _LOSS_WORK[key]
 
 
-def reset_loss_work():
-    """Zero every cached loss scratch (its ticket word in particular): a launch that faulted mid-way would otherwise leave a stale
-    ticket behind for every later step.  Called when a step driver is constructed."""
-    for t in _LOSS_WORK.values():
-        t.zero_()
+def reset_loss_work(device=None):
+    """Zero the cached loss scratch (its ticket word in particular): a launch that faulted mid-way would otherwise leave a stale ticket
+    behind for every later step.  Called when a step driver is constructed -- for ITS device, after synchronising it: the entries are
+    keyed per stream, and zeroing another driver's scratch while its step is in flight would race with that step's ticket (ADVICE
+    r04).  device None: every entry (tests)."""
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+    for key, t in _LOSS_WORK.items():
+        if device is None or (key[0], key[1]) == (torch.device(device).type, torch.device(device).index):
+            t.zero_()

@@ -473,9 +473,15 @@ class SEDTask4(_Base):
         if p is None:
             p = self._pro = {"ready": False}
         t = p.get(key)
-        if t is None or t.shape != like.shape or t.stride() != like.stride() or t.device != like.device or t.dtype != like.dtype:
+        if t is None or t.shape != like.shape or t.device != like.device or t.dtype != like.dtype or (
+                t.stride() != like.stride() and t.stride() != torch.empty_like(like).stride()):
+            # (the second stride test: a non-dense `like` -- sliced labels -- gets a dense buffer from empty_like; comparing it with
+            #  like's own strides would reallocate on every call)
             if p["ready"]:
                 raise RuntimeError("the batch shape changed between a prefetch and the step that consumes it")
+            if p.get("frozen") and t is not None:
+                raise RuntimeError("hand-over buffer %r changed shape / layout after the step was captured into a hipGraph: the replays "
+                                   "read the old address (build a new GraphedStepDriver for another batch shape)" % key)
             t = p[key] = torch.empty_like(like)      # (preserve_format: x is a (B, n_mels, T) VIEW of frame-major storage and must stay one)
         return t
 

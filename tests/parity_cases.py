@@ -72,6 +72,61 @@ def case_mel(dev, batch=2, n_samples=256 * 12):
     return got
 
 
+def case_mel_in_graph_beside_tails(dev, replays=300):
+    """The wave-per-frame mel kernel as a hipGraph node on a side stream beside the student's and the teacher's BiGRU + head tails (the
+    "tails" fork of the pipelined step), replayed `replays` times on changing waveforms: every output bit-equal to the solo launch.
+    (Round 5: with runs of 8 frames per workgroup -- two frames per wave -- ~5 % of such replays had a few mirror-paired bins of a
+    wave's last frame wrong; never eager.  One frame per wave per run: clean.  tools/mel_graph_race.py is the same loop with a library
+    argument for variant builds.)"""
+    task = build_task(dev, (1, 1, 2), O.make_state_dict(seed=7), dropout=0.5, specaug=True, rampup=5)
+    mel = task.mel_spec
+    B, N = 4, 16000 + 1024
+    g = torch.Generator().manual_seed(1)
+    audios = [to(dev, 0.1 * torch.randn(B, N, generator=g)) for _ in range(8)]
+    refs = [mel.frames_major(a).clone() for a in audios]
+    static_audio = audios[0].clone()
+    out = torch.empty_like(refs[0])
+    x = task.scaled_logmel(mel(audios[0]))
+    with torch.no_grad():
+        h = task.sed_student.forward_cnn(x)
+    torch.cuda.synchronize()
+    main, s_mel, s_t = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+
+    def body():
+        with torch.no_grad():
+            hs = task.sed_student.forward_cnn(x)
+            cur = torch.cuda.current_stream()
+            s_mel.wait_stream(cur)
+            with torch.cuda.stream(s_mel):
+                mel.frames_major(static_audio, out=out)
+            s_t.wait_stream(cur)
+            with torch.cuda.stream(s_t):
+                task.sed_teacher.forward_tail(h)
+            task.sed_student.forward_tail(hs)
+            cur.wait_stream(s_t)
+            cur.wait_stream(s_mel)
+
+    with torch.cuda.stream(main):
+        body(); body()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=main, capture_error_mode="thread_local"):
+        body()
+    bad = []
+    for rep in range(replays):
+        i = rep % 8
+        with torch.cuda.stream(main):
+            static_audio.copy_(audios[i], non_blocking=True)
+            out.fill_(-777.0)
+            graph.replay()
+        torch.cuda.synchronize()
+        ne = out != refs[i]
+        if ne.any():
+            bad.append((rep, int(ne.sum()), sorted({(int(b), int(t)) for b, t, m in ne.nonzero().tolist()})[:4]))
+    assert not bad, (len(bad), bad[:5])
+    return replays
+
+
 def case_logscale_generic(dev):
     x = O.lcg_fill((3, 16, 9), 55, 30.0, -10.0)
     got, mm = Fh.minmax_scale(to(dev, x), return_minmax=True)

@@ -29,6 +29,11 @@ def test_mel_small():
     P.case_mel("cuda", batch=5, n_samples=256 * 40 + 100)      # a batch that is no multiple of the XCD count, a ragged clip length
 
 
+def test_mel_in_graph_beside_tails():
+    """Regression for the round-5 finding: the mel kernel replayed in a hipGraph next to the BiGRU tails must give the solo launch's bits."""
+    P.case_mel_in_graph_beside_tails("cuda", replays=300)
+
+
 def test_mel_generic_kernel():
     """The one-frame-per-workgroup kernel of rounds 1-4 (`sed_mel_fwd`), kept as the generic form."""
     _lib.set_tuning("mel_wave", 2)
