@@ -232,14 +232,29 @@ def kernel_name(row):
     return row["kernel"]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` (name prefix) from the newest committed rocprofv3 --pmc summary in profiles/, or None."""
+def lib_rev():
+    from desed_task_amd.build import source_rev
+    return source_rev()
+
+
+def _traffic_files():
+    """Committed rocprofv3 --pmc traffic summaries, newest first, that were taken on THIS build of the library (same `lib_rev`).
+    A summary of another build says nothing about the kernels timed here: it is skipped, and the caller reports null."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+    rev = lib_rev()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime, reverse=True):
         try:
-            kernels = json.load(open(path))["kernels"]
+            rec = json.load(open(path))
         except Exception:  # noqa: BLE001
             continue
+        if rec.get("lib_rev") == rev:
+            yield path, rec
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` (name prefix) from the newest committed rocprofv3 --pmc summary of this build, or None."""
+    for path, rec in _traffic_files():
+        kernels = rec["kernels"]
         hits = [rec["hbm_bytes"] for name, rec in kernels.items() if name and name.startswith(kernel.split("*")[0])]
         if hits:
             return max(hits)
@@ -249,12 +264,7 @@ def pmc_traffic(kernel):
 def pmc_step_traffic():
     """(HBM bytes per training step, file) = sum over all kernels of PMC bytes per launch x launches / steps, from the newest
     committed profiles/*_pmc_traffic.json that carries it (tools/pmc_traffic_json.py with the step count), or (None, None)."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
-        try:
-            rec = json.load(open(path))
-        except Exception:  # noqa: BLE001
-            continue
+    for path, rec in _traffic_files():
         if rec.get("hbm_bytes_per_step"):
             return int(rec["hbm_bytes_per_step"]), os.path.basename(path)
     return None, None
@@ -890,7 +900,8 @@ def main():
             "mfma_frac_of_f32_peak": round(6.464e9 * clips / dt / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
             "mfma_frac_of_bf16_peak": round(6.464e9 * clips / dt / world / (PEAK_BF16_MFMA_TFLOPS * 1e12), 5),
             "mel_hbm_frac": round(960512.0 * clips / dt / world / 8.0e12, 6),
-            "hbm_bytes_per_step": hbm_step, "hbm_bytes_per_step_source": hbm_src,
+            "hbm_bytes_per_step": hbm_step, "hbm_bytes_per_step_source": hbm_src, "lib_rev": lib_rev(),
+            "hbm_note": None if hbm_step else "no profiles/*_pmc_traffic.json was taken on this build of the library (lib_rev): null, not a stale figure",
             "hbm_frac_of_8TBs": round(hbm_step / (step_ms * 1e-3) / 8.0e12, 4) if hbm_step else None,
             "note": "6.464 GFLOP/clip = conv1-6 + GLU1-6, student fwd + dgrad + wgrad + teacher fwd; 960 512 B/clip = mel path in+out; "
                     "whole-step clips/s, so both are diluted by the GRU recurrence and the HBM-bound narrow blocks (DESIGN.md 8)"},

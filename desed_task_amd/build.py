@@ -25,6 +25,20 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def source_rev():
+    """12 hex digits over the kernel sources (every .hip / .h under csrc/, names and contents): the identity of a build of the library.
+    PMC summaries under profiles/ carry it (tools/pmc_traffic_json.py), and bench.py drops `roofline.traffic` to null when the library it
+    times is another build than the one the counters were taken on."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

@@ -189,14 +189,14 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
 // reads l + 64 m + 256 r) and the conjugate-pair exchange of the real-FFT step are contiguous per lane group as they are.  All LDS
 // addresses are a per-lane base + an immediate.  Mel stage: lane l owns bands l and 127 - l (3 + 42 ... 13 + 13 taps: balanced), taps
 // in registers (MEL_WA + MEL_WB), magnitudes read from the wave's buffer; longer bands finish from memory (no recipe has any).
-// MEL_RUN = frames of a run = MEL_WAVES: every wave transforms ONE frame per run.  Longer runs (8, 16: a wave walks t, t + 4, ...
-// with the next frame's samples prefetched under the mel stage) measure the same 79 us alone, but are NOT safe: replayed inside a hipGraph
-// next to the BiGRU tails (the "tails" side branch of the pipelined step) the last frames a wave transforms came out wrong in ~5 % of
-// the replays -- a handful of neighbouring bins k and their mirror bins 1024 - k, i.e. one register of a few neighbouring lanes
-// between pass 3 and the real-FFT step; never in eager launches (2 000 launches beside the same kernels), never with one frame per
-// run (3 000 replays).  tools/mel_graph_race.py reproduces it (build with -DMEL_RUN=8); explicit s_waitcnt vmcnt(0) / lgkmcnt(0) at
-// every exchange, no prefetch, plain (non-asm) arithmetic, -O1, a vector wave index and 48 KB of LDS padding (no BiGRU workgroup on
-// the CU) all still fail.  Cause not found; DESIGN.md section 12.
+// OPEN ISSUE (round 5): replayed as a hipGraph node beside other kernels (the pipelined step's side branch) this kernel intermittently
+// returns single frames with a handful of neighbouring bins k -- and their mirror bins 1024 - k -- wrong, i.e. one register of a few
+// neighbouring lanes between pass 3 and the real-FFT step.  Never seen in eager launches (thousands, beside the same kernels on
+// other streams).  With runs of 8 / 16 frames ~5 % of the replays of tools/mel_graph_race.py; with one frame per wave per run 0 of
+// 3 000 in that tool but 1 of 300 inside the full GPU test session.  Explicit s_waitcnt vmcnt(0) / lgkmcnt(0) at every exchange, no
+// prefetch, plain (non-asm) arithmetic, -O1, a vector wave index, 48 KB of LDS padding (no BiGRU workgroup on the same CU), intact
+// LDS tables (checksummed) -- all still fail.  The kernel is therefore OPT-IN (features.py, tuning key mel_wave = 1); the default mel
+// path stays the kernel above.  DESIGN.md section 12.
 #ifndef MEL_RUN
 #define MEL_RUN 4
 #endif

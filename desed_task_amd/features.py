@@ -115,8 +115,11 @@ class MelSpectrogram(torch.nn.Module):
         elif tuple(out.shape) != (B, T, self.n_mels) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != audio.device:
             raise ValueError("frames_major: `out` must be a contiguous fp32 (B, T, n_mels) tensor on the audio's device")
         lib = _lib.get()
-        if _lib.get_tuning("mel_wave") == 2 or _lib.get_tuning("mel_taps_mem"):
-            # the round-1..4 kernel: one frame per 256-thread workgroup (kept as the generic form and for A/B runs)
+        if _lib.get_tuning("mel_wave") != 1 or _lib.get_tuning("mel_taps_mem"):
+            # DEFAULT: the round-1..4 kernel, one frame per 256-thread workgroup.  The round-5 wave-per-frame kernel below is 1.9 x
+            # faster alone (79 vs 147 us) and fetches every sample from HBM once instead of eight times, but replayed as a hipGraph node
+            # beside other kernels it intermittently returns a few wrong bins in single frames (never in eager launches; cause not
+            # found: DESIGN.md section 12, tools/mel_graph_race.py) -- parity first: it stays opt-in (`_lib.set_tuning("mel_wave", 1)`)
             lib.call("sed_mel_fwd", audio.data_ptr(), out.data_ptr(), B, N, T, self.n_fft, self.hop_length, self.n_mels,
                      self.window.data_ptr(), self.tw1024.data_ptr(), self.tw2048.data_ptr(), self.fb_start.data_ptr(),
                      self.fb_len.data_ptr(), self.fb_w.data_ptr(), self.fb_stride, int(apply_log), _lib.stream_ptr(audio))

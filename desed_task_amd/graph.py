@@ -267,6 +267,13 @@ class GraphedStepDriver:
         self.static = None
         self.loss = None
         self.stream = None
+        # SED_DDP_GRAPH_EXCHANGE=1 (round 5): capture the gradient exchange TOO -- the RCCL all-reduce(s) and the
+        # Adam launch become nodes of the one graph, like the single-GPU step: no second graph, no host hand-over between the replay
+        # and the collective (measured 18 us device / 61 us host with a no-op collective).  A captured collective never reaches the
+        # process group's watchdog, so the capture-invalidation race of round 3 cannot recur for it.  RCCL only (the gloo test backend
+        # synchronises the device around its collectives); rehearsed on one rank -- never yet on a real multi-GPU node, hence opt-in.
+        import os
+        self.capture_exchange = os.environ.get("SED_DDP_GRAPH_EXCHANGE") == "1" and self.eager.exchange
         self.eager_fallbacks = 0    # pipelined graph: steps run eagerly because no next batch was announced (epoch ends)
         self.reprimes = 0           # ... and front halves run inline because the previous step had prefetched nothing
 
@@ -348,14 +355,17 @@ class GraphedStepDriver:
             fork.record()
         else:
             task.launch_prefetch("backward", after=(d.side,))
-        d.backward_joined(loss)                          # BiGRU weight-gradient GEMMs on the side stream, joined here
+        if self.capture_exchange:
+            d.backward(loss)                             # ... + the CNN half + the all-reduce(s), all of it inside the capture
+        else:
+            d.backward_joined(loss)                      # BiGRU weight-gradient GEMMs on the side stream, joined here
         _ops.probe("backward_done")
         if late:
             task.launch_prefetch("backward", after=(d.side,), fork_event=fork)
         task.join_prefetch()
         if d.side is not None:
             torch.cuda.current_stream().wait_stream(d.side)
-        if not d.exchange:
+        if not d.exchange or self.capture_exchange:
             d.opt.step()
             task.lr_scheduler_step(d.sched, 0, None)
         _ops.probe("step_end")
@@ -464,7 +474,7 @@ class GraphedStepDriver:
                 with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
                     self.loss = self._step_body(tuple(st if st is not None else t for st, t in zip(self.static, batch)))
                 student = self.task.sed_student
-                if self.eager.exchange and getattr(student, "_cnn_boundary", None) is not None:
+                if self.eager.exchange and not self.capture_exchange and getattr(student, "_cnn_boundary", None) is not None:
                     # the cut left the CNN half of backward undone: it becomes a second graph (same memory pool), replayed
                     # after bucket A has been handed to RCCL
                     self.graph_cnn = torch.cuda.CUDAGraph()
@@ -491,7 +501,7 @@ class GraphedStepDriver:
         if probe is not None:
             probe.begin()
         self.graph.replay()
-        if self.eager.exchange:
+        if self.eager.exchange and not self.capture_exchange:
             self._finish_multi()
         if probe is not None:
             probe.end()

@@ -2082,10 +2082,16 @@ def case_head_dropout(dev, B=3, T=39, p=0.5, seed=4242, D=256, NC=10):
     assert abs(kept - (1 - p)) < 0.05 if p > 0 else kept > 0.99
 
 
-def case_b48_forward_vs_oracle(dev, bs=(12, 12, 24)):
+def case_b48_forward_vs_oracle(dev, bs=(12, 12, 24), single_bf16=False):
     """BASELINE config C2 itself -- 48 clips (12/12/24) of 10 s, dropout + SpecAugment + mixup ON, student != teacher weights --
     compared with the oracle, forward pass: student and teacher posteriors (1e-3 abs), the six loss scalars, all 7 + 7
-    BatchNorm running statistics (batch-size dependent reductions) and the per-clip min/max of the scaler."""
+    BatchNorm running statistics (batch-size dependent reductions) and the per-clip min/max of the scaler.
+
+    single_bf16=True: the same forward with the numerics of a ONE-product bf16 convolution (what a plain `bf16` line would compute):
+    the 3 x 3 weights of blocks 1-6 and the activations entering those convolutions are rounded to bf16 first, so the lo planes of the
+    split operands are zero and hi*hi + hi*lo + lo*hi collapses to the single product hi*hi (fp32 accumulation, everything else as
+    shipped).  Nothing is asserted but finiteness: the posterior errors against the fp32 oracle are RETURNED -- the number DESIGN.md
+    quotes for why the contractions are issued as three MFMAs per product."""
     torch.set_num_threads(min(64, torch.get_num_threads()))
     B, n_samp = sum(bs), 160000
     n_frames = 1 + n_samp // 256
@@ -2097,6 +2103,21 @@ def case_b48_forward_vs_oracle(dev, bs=(12, 12, 24)):
     assert task.sed_teacher.arena.is_intact()
     orc = O.OracleTrainer(sd, batch_sizes=bs, lr=1e-3, rampup_len=100, teacher_sd=sd_t)
     rec = StochasticRecorder(task)
+    import importlib
+    cnn_mod = importlib.import_module("desed_task_amd.nnet.CNN")
+    orig_block = cnn_mod.ConvBlockFn
+    if single_bf16:
+        with torch.no_grad():
+            for model in (task.sed_student, task.sed_teacher):
+                for i in range(1, 7):
+                    w = getattr(model.cnn.cnn, "conv%d" % i).weight
+                    w.copy_(w.to(torch.bfloat16).float())
+
+        class _RoundedInput:
+            @staticmethod
+            def apply(x, *a):
+                return orig_block.apply(x.to(torch.bfloat16).float() if x.dim() == 4 else x, *a)
+        cnn_mod.ConvBlockFn = _RoundedInput
     try:
         mix = _mixup_draws(bs, (4, 100, 100))
         assert mix is not None
@@ -2108,6 +2129,7 @@ def case_b48_forward_vs_oracle(dev, bs=(12, 12, 24)):
         aug_t, drop_t = rec.oracle_draws("teacher", B, n_frames)
     finally:
         rec.close()
+        cnn_mod.ConvBlockFn = orig_block
     with torch.no_grad():
         logm = O.take_log(O.mel_spectrogram(audio))
         tot, logs = orc.training_step(audio, labels, mix=mix, aug_s=aug_s, aug_t=aug_t, drop_s=drop_s, drop_t=drop_t)
@@ -2116,9 +2138,13 @@ def case_b48_forward_vs_oracle(dev, bs=(12, 12, 24)):
     out = {}
     for a, name in zip([t.detach().cpu() for t in task.last_outputs], ("strong_s", "weak_s", "strong_t", "weak_t")):
         out[name] = (a - orc.last[name]).abs().max().item()
-        assert out[name] < 1e-3, "%s: %.3e" % (name, out[name])
+        assert single_bf16 or out[name] < 1e-3, "%s: %.3e" % (name, out[name])
+        assert math.isfinite(out[name])
     got = {k: (float(v) if not torch.is_tensor(v) else float(v.detach().cpu())) for k, v in task.logged.items()}
     got["loss"] = float(loss.detach().cpu()); logs["loss"] = tot.item()
+    if single_bf16:
+        out["loss_rel"] = abs(got["loss"] - logs["loss"]) / abs(logs["loss"])
+        return out
     for k in sorted(logs):
         assert abs(got[k] - logs[k]) <= 2e-5 + 2e-4 * abs(logs[k]), "%s: hip %.8g oracle %.8g" % (k, got[k], logs[k])
     for who, model, ref in (("student", task.sed_student, orc.student), ("teacher", task.sed_teacher, orc.teacher)):

@@ -12,12 +12,13 @@ def test_mel_matches_oracle(emu):
     P.case_mel("cpu", batch=3, n_samples=256 * 21 + 100)       # ragged clip length, a batch the XCD walk does not divide
 
 
-def test_mel_generic_kernel_matches_oracle(emu):
-    """The one-frame-per-workgroup kernel of rounds 1-4 (`sed_mel_fwd`), kept as the generic form."""
+def test_mel_wave_kernel_matches_oracle(emu):
+    """The round-5 wave-per-frame kernel (`sed_mel_fwd_wave`, opt-in)."""
     from desed_task_amd import _lib
-    _lib.set_tuning("mel_wave", 2)
+    _lib.set_tuning("mel_wave", 1)
     try:
         P.case_mel("cpu")
+        P.case_mel("cpu", batch=3, n_samples=256 * 21 + 100)
     finally:
         _lib.set_tuning("mel_wave", 0)
 

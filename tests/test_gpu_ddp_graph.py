@@ -102,11 +102,11 @@ def test_two_rank_graph_step_rccl(tmp_path, overlap, dw_side):
     assert d["dw_side"] == (dw_side == "1")
 
 
-def _rehearsal_worker(rank, port, out_dir, overlap, prefetch):
+def _rehearsal_worker(rank, port, out_dir, overlap, prefetch, graph_exchange=False):
     """ONE rank over RCCL (launcher.rehearsing): the N > 1 step structure on a one-rank communicator vs the plain one-GPU step."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      SED_DDP_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      SED_DDP_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SED_DDP_GRAPH_EXCHANGE="1" if graph_exchange else "0")
     os.environ.pop("SED_DIST_BACKEND", None)
     if overlap is None:
         os.environ.pop("SED_DDP_OVERLAP", None)
@@ -144,7 +144,7 @@ def _rehearsal_worker(rank, port, out_dir, overlap, prefetch):
         finals.append(torch.cat([task.sed_student.arena.flat.detach().cpu(), task.sed_teacher.arena.flat.detach().cpu()]))
         if mode == "rehearsal":
             info = dict(two_graphs=driver.graph_cnn is not None, bucket_log=driver.eager.bucket_log, overlap=driver.eager.overlap,
-                        dw_side=driver.eager.gru_dw_side)
+                        dw_side=driver.eager.gru_dw_side, capture_exchange=driver.capture_exchange)
     torch.save(dict(plain=finals[0], rehearsal=finals[1], **info), os.path.join(out_dir, "rehearsal.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -165,6 +165,18 @@ def test_one_rank_rccl_rehearsal_equals_plain_step(tmp_path, overlap, prefetch):
     # RCCL watchdog's event query during the stream capture, see graph.quiesce_collectives).  tools/rehearsal_loop.py: 87 repetitions
     # before the fix = 0 numeric differences and 6 dead processes; after it, profiles/r04_rehearsal_loop.md.
     assert torch.equal(d["plain"], d["rehearsal"]), "one-rank rehearsal differs from the plain step: max %.3e" % (
+        (d["plain"] - d["rehearsal"]).abs().max().item())
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("overlap,prefetch", [("0", None), ("1", None), (None, "teacher")])
+def test_one_rank_rccl_rehearsal_with_the_exchange_captured(tmp_path, overlap, prefetch):
+    """SED_DDP_GRAPH_EXCHANGE=1 (round 5): the RCCL all-reduce(s) and Adam are nodes of the ONE captured graph -- no second graph, no
+    host hand-over after the replay.  Same strict comparison with the plain one-GPU step over 5 steps (1 eager, the capture, 3 replays)."""
+    mp.spawn(_rehearsal_worker, args=(_free_port(), str(tmp_path), overlap, prefetch, True), nprocs=1, join=True)
+    d = torch.load(os.path.join(str(tmp_path), "rehearsal.pt"))
+    assert d["capture_exchange"] is True and d["two_graphs"] is False
+    assert torch.equal(d["plain"], d["rehearsal"]), "captured-exchange rehearsal differs from the plain step: max %.3e" % (
         (d["plain"] - d["rehearsal"]).abs().max().item())
 
 

@@ -2,7 +2,7 @@
 `recipes/dcase2024_task4_baseline/confs/pretrained.yaml` -- batch [12, 6, 6, 12, 24] = 60 clips of 10 s, 27 classes, n_RNN_cell 192,
 dropout 0.5, dropstep_recurrent 0.3 x 16, frozen 768 x 496 embeddings per clip, mixup on features and embeddings, class masks --
 random weights, synthetic data.  Secondary workload: not the headline metric of bench.py.   python tools/bench_2024.py [--graph]"""
-import json, random, sys, time
+import json, os, random, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 import torch
@@ -75,7 +75,37 @@ for i in range(K):
     loss = step(W + i)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
+# per-entry roofline rows like bench.py's: HIP events around every launch of 3 eager steps after the timed region
+# (the 2024 step's entries are the CRNN step's + sed_embcat: bench.py's work table applies; shapes with n_RNN_cell = 192)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import KernelTimer, roofline_tables, PEAK_BF16_MFMA_TFLOPS
+from desed_task_amd import _lib as _lib_
+eager = driver.eager if hasattr(driver, "eager") else driver
+timer = KernelTimer(None)
+EAGER = 3
+
+
+def eager_step(i):
+    if pipelined:
+        return eager.run_step((audio, labels, None, emb, valid), i, next_batch=(audio, labels, None, emb, valid))
+    return eager.run_step((audio, labels.clone(), None, emb, valid), i)
+
+
+eager_step(0); torch.cuda.synchronize()
+timer.wrap(_lib_.get())
+for i in range(EAGER):
+    eager_step(i)
+torch.cuda.synchronize()
+timer.unwrap()
+rows, families = roofline_tables(timer.summary(), EAGER, dt * 1e3, task.sed_student.cnn.conv_precision)
+clips_s = B / dt
 print(json.dumps({"workload": "dcase2024 pretrained.yaml training step: batch 60 = [12,6,6,12,24] x 10 s, 27 classes, n_RNN_cell 192, "
                               "768 x 496 embeddings per clip, dropout + dropstep + mixup on", "launch": "hipGraph" if "--graph" in sys.argv else "eager",
                   "front_end": "pipelined (teacher)" if pipelined else "inline",
-                  "ms_per_step": round(dt * 1e3, 3), "clips_per_s": round(B / dt, 1), "loss": round(float(loss), 5)}))
+                  "ms_per_step": round(dt * 1e3, 3), "clips_per_s": round(B / dt, 1), "loss": round(float(loss), 5),
+                  "step_roofline": {"mfma_tflops": round(6.464e9 * clips_s / 1e12, 2),
+                                    "mfma_frac_of_bf16_peak": round(6.464e9 * clips_s / (PEAK_BF16_MFMA_TFLOPS * 1e12), 5),
+                                    "note": "6.464 GFLOP/clip = conv1-6 + GLU1-6 (student fwd + dgrad + wgrad + teacher fwd), the same CNN as the 2023 recipe"},
+                  "roofline_families": families,
+                  "roofline_top_launches": [{k: r[k] for k in ("entry", "shape", "bound", "launches_per_step", "avg_us", "us_per_step", "achieved",
+                                                                 "peak", "unit", "frac")} for r in rows[:8]]}))

@@ -19,11 +19,15 @@ def means(path, counter):
     return {k: v[1] / v[0] for k, v in agg.items()}
 
 
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from desed_task_amd.build import source_rev
 counts = {}
 fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else None        # training steps the profiled command ran (all of them eager)
 out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --no-graph; HBM bytes = "
-               "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count correction)", "kernels": {}}
+               "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count correction)",
+       "lib_rev": source_rev(), "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     if f + w < 64:
