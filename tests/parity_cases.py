@@ -1014,7 +1014,8 @@ def case_pipelined_epoch_boundary(dev, point="teacher", graph=True, epochs=3, pe
     return l0
 
 
-def case_lightning_surface(dev, epochs=3, per_epoch=3, n_samp=16000 + 1024, limit_train_batches=None, warmup=1, pretrained=False):
+def case_lightning_surface(dev, epochs=3, per_epoch=3, n_samp=16000 + 1024, limit_train_batches=None, warmup=1, pretrained=False,
+                           recipe2024=False):
     """The whole-step mode of SEDTask4 behind Lightning 1.9's hook order (tests/lightning_order.Trainer: training_step ->
     on_before_zero_grad -> optimizer_zero_grad -> backward -> optimizer.step -> lr_scheduler_step, the optimizer a plain
     torch.optim.Adam as train_sed.py:199-201 builds it, the batches from `train_dataloader()`) must equal, BIT FOR BIT,
@@ -1031,17 +1032,33 @@ def case_lightning_surface(dev, epochs=3, per_epoch=3, n_samp=16000 + 1024, limi
     from desed_task_amd.launcher import StepDriver
     from desed_task_amd.lookahead import BatchList
     from tests.lightning_order import Trainer
-    bs = (1, 1, 2)
+    bs = (2, 1, 1, 2, 2) if recipe2024 else (1, 1, 2)
     B = sum(bs)
     sd = O.make_state_dict(seed=7, **({"embedding_size": 768} if pretrained else {}))
     n_out = (1 + n_samp // 256) // 4
     audios = [to(dev, O.synth_audio(B, n_samp, seed=700 + 7 * i)) for i in range(per_epoch)]
-    labelss = [to(dev, O.synth_labels(bs, 10, n_out, seed=80 + i)) for i in range(per_epoch)]
-    embs = [to(dev, torch.randn(B, 768, 31, generator=torch.Generator().manual_seed(5 + i))) for i in range(per_epoch)] if pretrained else None
+    if recipe2024:      # recipes/dcase2024_task4_baseline: 27 classes, five data sets, embeddings + valid_class_mask in the batch
+        ns = bs[0] + bs[1] + bs[2]
+        labelss = []
+        for i in range(per_epoch):
+            lab = (O.lcg_fill((B, 27, n_out), 50 + i, 0.5, 0.5) < 0.1).float()
+            lab[ns:ns + bs[3], :, 1:] = 0.0
+            lab[ns + bs[3]:] = 0.0
+            labelss.append(to(dev, lab))
+        valid = torch.zeros(B, 27, dtype=torch.bool)
+        valid[:bs[0], 10:] = True
+        valid[bs[0]:, :10] = True
+        valid = to(dev, valid)
+    else:
+        labelss = [to(dev, O.synth_labels(bs, 10, n_out, seed=80 + i)) for i in range(per_epoch)]
+    embs = ([to(dev, torch.randn(B, 768, 31, generator=torch.Generator().manual_seed(5 + i))) for i in range(per_epoch)]
+            if (pretrained or recipe2024) else None)
     used = per_epoch if limit_train_batches is None else limit_train_batches
 
-    class Clips(BatchList):             # a loader hands out fresh tensors every time: the step mixes the labels in place
+    class Clips(BatchList):             # a loader hands out fresh tensors every time: the step mixes labels (2024: embeddings too) in place
         def __getitem__(self, i):
+            if recipe2024:
+                return (audios[i], labelss[i].clone(), [1.0] * B, embs[i].clone(), valid)
             return (audios[i], labelss[i].clone(), [1.0] * B) + ((embs[i],) if pretrained else ())
 
     def state(task):
@@ -1065,8 +1082,11 @@ def case_lightning_surface(dev, epochs=3, per_epoch=3, n_samp=16000 + 1024, limi
 
     results = {}
     for mode in ("driver", "whole", "hooks"):
-        task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=5, torch_adam=mode != "driver", whole_step=mode == "whole",
-                          train_data=Clips([None] * per_epoch), pretrained=pretrained)
+        if recipe2024:
+            task = build_task_2024(dev, bs, 27, torch_adam=mode != "driver", whole_step=mode == "whole", train_data=Clips([None] * per_epoch))
+        else:
+            task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=5, torch_adam=mode != "driver", whole_step=mode == "whole",
+                              train_data=Clips([None] * per_epoch), pretrained=pretrained)
         task.whole_step_warmup = warmup
         seed()
         losses = []
@@ -1075,7 +1095,9 @@ def case_lightning_surface(dev, epochs=3, per_epoch=3, n_samp=16000 + 1024, limi
                       else StepDriver(task, world_size=1, prefetch="teacher"))
             data = Clips([None] * per_epoch)
             for epoch in range(epochs):
-                epoch_batches = [data[i] for i in range(used)]
+                # (through a DataLoader like the trainer's: creating its iterator draws the epoch's base seed from torch's global
+                #  generator -- the reference's own loop does the same --, which moves the mixup permutations that follow)
+                epoch_batches = list(torch.utils.data.DataLoader(data, batch_size=None))[:used]
                 for i in range(used):
                     nxt = epoch_batches[i + 1] if i + 1 < used else None
                     losses.append(float(driver.run_step(epoch_batches[i], i, next_batch=nxt).detach()))
@@ -1094,7 +1116,7 @@ def case_lightning_surface(dev, epochs=3, per_epoch=3, n_samp=16000 + 1024, limi
         if dev != "cpu":
             torch.cuda.synchronize()
         logged = {k: float(v) for k, v in task.logged.items()}
-        assert len(logged) == 11 and logged["train/step"] == epochs * used, logged          # (logged BEFORE the scheduler's step)
+        assert len(logged) == (9 if recipe2024 else 11) and logged["train/step"] == epochs * used, logged     # (logged BEFORE the scheduler's step)
         results[mode] = (losses, state(task), logged)
     ref = results["driver"]
     for mode in ("whole", "hooks"):
@@ -2545,7 +2567,8 @@ def case_training_step_2024(dev, golden):
 # ------------------------------------------------------------------------------------------------
 # frozen BEATs extractor
 # ------------------------------------------------------------------------------------------------
-def build_task_2024(dev, bs=(2, 1, 1, 2, 2), nclass=27, dropout=0.5, dropstep=0.3, seed=7):
+def build_task_2024(dev, bs=(2, 1, 1, 2, 2), nclass=27, dropout=0.5, dropstep=0.3, seed=7, torch_adam=False, whole_step=False,
+                    train_data=None):
     """The 2024 recipe's task (27 classes, n_RNN_cell 192, frozen 768-d embeddings, dropstep_recurrent) on closed-form weights."""
     from desed_task_amd.arena import FusedAdam
     from desed_task_amd.nnet.CRNN import CRNN
@@ -2561,13 +2584,16 @@ def build_task_2024(dev, bs=(2, 1, 1, 2, 2), nclass=27, dropout=0.5, dropstep=0.
     student = CRNN(**config["net"])
     student.load_state_dict({k: v.clone() for k, v in sd.items()})
     student = student.to(dev) if dev != "cpu" else student
-    opt = FusedAdam(student.parameters(), lr=1e-3, betas=(0.9, 0.999), arena=student)
+    if torch_adam:
+        opt = torch.optim.Adam(student.parameters(), 1e-3, betas=(0.9, 0.999))
+    else:
+        opt = FusedAdam(student.parameters(), lr=1e-3, betas=(0.9, 0.999), arena=student)
     sched = {"scheduler": ExponentialWarmup(opt, 1e-3, 5), "interval": "step"}
 
     class Enc:
         labels = list(range(nclass))
-    task = SEDTask4(config, Enc(), student, None, opt=opt, scheduler=sched)
-    task.whole_step = False
+    task = SEDTask4(config, Enc(), student, None, opt=opt, scheduler=sched, train_data=train_data)
+    task.whole_step = whole_step
     task.train()
     if dev != "cpu":
         task.to(dev)

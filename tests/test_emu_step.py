@@ -220,3 +220,9 @@ def test_lightning_hook_order_whole_step_equals_driver(emu):
 def test_lightning_hook_order_limit_train_batches(emu):
     """`limit_train_batches` (train_sed.py:256): the batch before the cut announces no successor."""
     P.case_lightning_surface("cpu", epochs=2, per_epoch=3, n_samp=2048 + 1024, limit_train_batches=2)
+
+
+def test_lightning_hook_order_2024_recipe(emu):
+    """The 2024 five-data-set trainer (27 classes, embeddings + valid_class_mask in the batch, labels AND embeddings mixed in the
+    hand-over buffers) through the same three routes: whole-step behind Lightning's hook order == the driver by hand == hook by hook."""
+    P.case_lightning_surface("cpu", epochs=2, per_epoch=2, n_samp=2048 + 1024, recipe2024=True)

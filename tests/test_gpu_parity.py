@@ -347,6 +347,12 @@ def test_lightning_hook_order_pretrained_recipe():
     P.case_lightning_surface("cuda", epochs=2, per_epoch=3, pretrained=True)
 
 
+@pytest.mark.timeout(600)
+def test_lightning_hook_order_2024_recipe():
+    """... and the 2024 five-data-set trainer (labels and embeddings mixed in the hand-over buffers)."""
+    P.case_lightning_surface("cuda", epochs=2, per_epoch=3, recipe2024=True)
+
+
 @pytest.mark.timeout(1500)
 def test_long_horizon_training_vs_oracle():
     """300 consecutive optimiser steps (fresh batch each step, dropout + SpecAugment + mixup, warm-up, ramp-up, EMA, Adam), HIP vs
