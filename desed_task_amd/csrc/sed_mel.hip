@@ -189,13 +189,16 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
 // reads l + 64 m + 256 r) and the conjugate-pair exchange of the real-FFT step are contiguous per lane group as they are.  All LDS
 // addresses are a per-lane base + an immediate.  Mel stage: lane l owns bands l and 127 - l (3 + 42 ... 13 + 13 taps: balanced), taps
 // in registers (MEL_WA + MEL_WB), magnitudes read from the wave's buffer; longer bands finish from memory (no recipe has any).
-// OPEN ISSUE (round 5): replayed as a hipGraph node beside other kernels (the pipelined step's side branch) this kernel intermittently
-// returns single frames with a handful of neighbouring bins k -- and their mirror bins 1024 - k -- wrong, i.e. one register of a few
-// neighbouring lanes between pass 3 and the real-FFT step.  Never seen in eager launches (thousands, beside the same kernels on
-// other streams).  With runs of 8 / 16 frames ~5 % of the replays of tools/mel_graph_race.py; with one frame per wave per run 0 of
-// 3 000 in that tool but 1 of 300 inside the full GPU test session.  Explicit s_waitcnt vmcnt(0) / lgkmcnt(0) at every exchange, no
-// prefetch, plain (non-asm) arithmetic, -O1, a vector wave index, 48 KB of LDS padding (no BiGRU workgroup on the same CU), intact
-// LDS tables (checksummed) -- all still fail.  The kernel is therefore OPT-IN (features.py, tuning key mel_wave = 1); the default mel
+// OPEN ISSUE (round 5): replayed as a hipGraph node while `gemm_bf16x3_kernel` (the BiGRU input projection) runs on another branch,
+// this kernel intermittently returns single frames with a handful of neighbouring bins k -- and their mirror bins 1024 - k -- wrong,
+// i.e. one register of a few neighbouring lanes between pass 3 and the real-FFT step (sometimes a whole frame).  What is known
+// (tools/mel_graph_race.py, profiles/r05_mel_graph_race.md): never in eager launches (thousands, beside the same kernels on other
+// streams); never beside the convolutions, the BiGRU recurrence, the heads or a rocBLAS GEMM -- only beside the split-bf16 GEMM, and
+// not when that GEMM's v_mfma_f32_32x32x16_bf16 are compiled out (its LDS traffic and stores alone are harmless); only in frames of a
+// workgroup's SECOND and later runs (one run per workgroup: 0 of 800 replays; persistent walk with runs of 8: ~7 %; runs of 4: 0 of
+// 3 000 in the tool, 1 of 300 inside the full GPU test session).  Still failing with: s_waitcnt vmcnt(0) / lgkmcnt(0) at every
+// exchange, no prefetch, plain (non-asm) arithmetic, -O1, a vector wave index, no s_setprio in the recurrences, 8 / 48 KB of LDS
+// padding, intact LDS tables (checksummed).  The kernel is therefore OPT-IN (features.py, tuning key mel_wave = 1); the default mel
 // path stays the kernel above.  DESIGN.md section 12.
 #ifndef MEL_RUN
 #define MEL_RUN 4

@@ -72,7 +72,7 @@ def case_mel(dev, batch=2, n_samples=256 * 12):
     return got
 
 
-def case_mel_in_graph_beside_tails(dev, replays=300):
+def case_mel_in_graph_beside_tails(dev, replays=300, beside="tails"):
     """The wave-per-frame mel kernel as a hipGraph node on a side stream beside the student's and the teacher's BiGRU + head tails (the
     "tails" fork of the pipelined step), replayed `replays` times on changing waveforms: every output bit-equal to the solo launch.
     (Round 5: with runs of 8 frames per workgroup -- two frames per wave -- ~5 % of such replays had a few mirror-paired bins of a
@@ -91,6 +91,23 @@ def case_mel_in_graph_beside_tails(dev, replays=300):
         h = task.sed_student.forward_cnn(x)
     torch.cuda.synchronize()
     main, s_mel, s_t = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.randn(1024, 1024, device=out.device)
+    # direct launches of the two kernels of a BiGRU layer (diagnostics: beside = "gemm" / "gru")
+    Bq, Tq, Hq = h.shape[0], h.shape[1], 128
+    rnn0 = task.sed_student.rnn.rnn
+    gi_buf = torch.zeros(Bq, Tq, 2, 3 * Hq, device=out.device)
+    go_buf = torch.empty(Bq, Tq, 2 * Hq, device=out.device)
+
+    def gemm_only(stream):
+        lib = _lib.get()
+        lib.call("sed_gemm_pair_bf16x3", h.data_ptr(), h.data_ptr(), rnn0.weight_ih_l0.data_ptr(), rnn0.weight_ih_l0_reverse.data_ptr(),
+                 rnn0.bias_ih_l0.data_ptr(), rnn0.bias_ih_l0_reverse.data_ptr(), gi_buf.data_ptr(), gi_buf.data_ptr() + 3 * Hq * 4,
+                 Bq * Tq, 3 * Hq, Hq, Hq, Hq, 6 * Hq, 0, 1, 1, 0, stream.cuda_stream)
+
+    def gru_only(stream):
+        lib = _lib.get()
+        lib.call("sed_gru_fwd", gi_buf.data_ptr(), rnn0.weight_hh_l0.data_ptr(), rnn0.weight_hh_l0_reverse.data_ptr(),
+                 rnn0.bias_hh_l0.data_ptr(), rnn0.bias_hh_l0_reverse.data_ptr(), go_buf.data_ptr(), None, Bq, Tq, Hq, stream.cuda_stream)
 
     def body():
         with torch.no_grad():
@@ -101,8 +118,26 @@ def case_mel_in_graph_beside_tails(dev, replays=300):
                 mel.frames_major(static_audio, out=out)
             s_t.wait_stream(cur)
             with torch.cuda.stream(s_t):
-                task.sed_teacher.forward_tail(h)
-            task.sed_student.forward_tail(hs)
+                if beside == "tails":
+                    task.sed_teacher.forward_tail(h)
+                elif beside == "matmul":
+                    big @ big
+                elif beside == "rnn":
+                    task.sed_teacher.rnn(h, arena=task.sed_teacher.arena)
+                elif beside == "cnn":
+                    task.sed_teacher.forward_cnn(x)
+                elif beside == "gemm":
+                    gemm_only(s_t); gemm_only(s_t)
+                elif beside == "gru":
+                    gru_only(s_t); gru_only(s_t)
+            if beside == "tails":
+                task.sed_student.forward_tail(hs)
+            elif beside == "matmul":
+                big @ big
+            elif beside == "rnn":
+                task.sed_student.rnn(hs, arena=task.sed_student.arena)
+            elif beside == "cnn":
+                task.sed_student.forward_cnn(x)
             cur.wait_stream(s_t)
             cur.wait_stream(s_mel)
 
