@@ -190,19 +190,25 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
 // addresses are a per-lane base + an immediate.  Mel stage: lane l owns bands l and 127 - l (3 + 42 ... 13 + 13 taps: balanced), taps
 // in registers (MEL_WA + MEL_WB), magnitudes read from the wave's buffer; longer bands finish from memory (no recipe has any).
 // OPEN ISSUE (round 5): replayed as a hipGraph node while `gemm_bf16x3_kernel` (the BiGRU input projection) runs on another branch,
-// this kernel intermittently returns single frames with a handful of neighbouring bins k -- and their mirror bins 1024 - k -- wrong,
-// i.e. one register of a few neighbouring lanes between pass 3 and the real-FFT step (sometimes a whole frame).  What is known
-// (tools/mel_graph_race.py, profiles/r05_mel_graph_race.md): never in eager launches (thousands, beside the same kernels on other
-// streams); never beside the convolutions, the BiGRU recurrence, the heads or a rocBLAS GEMM -- only beside the split-bf16 GEMM, and
-// not when that GEMM's v_mfma_f32_32x32x16_bf16 are compiled out (its LDS traffic and stores alone are harmless); only in frames of a
-// workgroup's SECOND and later runs (one run per workgroup: 0 of 800 replays; persistent walk with runs of 8: ~7 %; runs of 4: 0 of
-// 3 000 in the tool, 1 of 300 inside the full GPU test session).  Still failing with: s_waitcnt vmcnt(0) / lgkmcnt(0) at every
-// exchange, no prefetch, plain (non-asm) arithmetic, -O1, a vector wave index, no s_setprio in the recurrences, 8 / 48 KB of LDS
-// padding, intact LDS tables (checksummed).  The kernel is therefore OPT-IN (features.py, tuning key mel_wave = 1); the default mel
-// path stays the kernel above.  DESIGN.md section 12.
+// this kernel intermittently returns single frames with a handful of neighbouring bins k -- and their mirror bins 1024 - k -- wrong
+// (plausible magnitudes, not garbage), i.e. one register of a few neighbouring lanes between pass 3 and the real-FFT step; sometimes a
+// whole frame.  What is known (tools/mel_graph_race.py, profiles/r05_mel_graph_race.md):
+//   * never in eager launches (thousands, beside the same kernels on other streams);
+//   * never beside the convolutions, the BiGRU recurrence, the heads or a rocBLAS GEMM -- only beside the split-bf16 GEMM, and not when
+//     that GEMM's v_mfma_f32_32x32x16_bf16 are compiled out (its LDS traffic and global stores alone are harmless);
+//   * only in the SECOND and later frames a wave transforms, never its first: persistent walk with runs of 8 frames ~7 % of the replays,
+//     one run of 8 per workgroup (this build) 0.2 - 0.5 % beside the GEMM and 0 of 3 000 beside the full BiGRU + head tails, runs of 4
+//     (one frame per wave per run, persistent) 0 of 3 000 in the tool but 1 of 300 inside the full GPU test session;
+//   * still failing with: s_waitcnt vmcnt(0) / lgkmcnt(0) at every exchange (MORE often), drained stores before s_endpgm, no prefetch,
+//     plain (non-asm) arithmetic, -O1, a vector wave index, no s_setprio in the recurrences, 8 / 48 KB of LDS padding; the LDS tables stay
+//     intact (checksummed).
+// Cause not found.  The kernel is therefore OPT-IN (features.py: tuning key mel_wave = 1 or SED_MEL_WAVE=1); the default mel path stays
+// the kernel above, which passes the same graph test (tests/test_gpu_parity.py::test_mel_in_graph_beside_tails).  DESIGN.md section 12.
 #ifndef MEL_RUN
-#define MEL_RUN 4
+#define MEL_RUN 8
 #endif
+// MEL_PERSISTENT: workgroups walk several runs (grid capped at two workgroups per CU) -- the form in which the open issue above shows.
+// Default: ONE run per workgroup (grid = all runs; the 26 KB of tables are re-read from L2 per run).
 #define MEL_XPAD 1088          // 1024 + 64 padding slots (exchange 1)
 
 // Complex arithmetic on the packed-fp32 pipe: a complex number is one 64-bit VGPR pair, and VOP3P's op_sel / neg modifiers pick and
@@ -489,8 +495,15 @@ SED_API int sed_mel_fwd_wave(const float* audio, float* out, int B, int N, int T
     int segs_per_clip = B >= 32 ? 1 : 32 / B;       // small batches: several stretches per clip, so that all eight XCDs work
     if (segs_per_clip > runs_per_clip) segs_per_clip = runs_per_clip;
     long long runs = (long long)B * runs_per_clip;
-    int grid = runs < 512 ? (int)runs : 512;        // 2 resident workgroups (12 waves) on each of the 256 CUs
+#ifdef MEL_PERSISTENT
+    int grid = runs < 512 ? (int)runs : 512;        // 2 resident workgroups on each of the 256 CUs
     grid = (grid + 7) & ~7;                         // every XCD gets the same number of slots
+#else
+    // one run per workgroup: every XCD gets as many slots as it has runs (its segments x runs per segment)
+    const int rps_ = (runs_per_clip + segs_per_clip - 1) / segs_per_clip;
+    const int grid = 8 * ((B * segs_per_clip + 7) / 8) * rps_;
+    (void)runs;
+#endif
 #define MELW_LAUNCH(LOG) SED_LAUNCH((mel_wave_kernel<LOG>), dim3(grid), dim3(64 * MEL_WAVES), 0, (hipStream_t)stream, audio, out, B, N, T, hop, \
                                     n_mels, window, (const float2*)tw1024, (const float2*)tw2048, fb_start, fb_len, fb_w, fb_stride,             \
                                     (const float4*)taps, runs_per_clip, segs_per_clip)

@@ -7,6 +7,7 @@ is frame-major (B, T, n_mels) and handed out as a transposed view, so every kern
 frames and conv0 consumes it without a permute.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -115,7 +116,7 @@ class MelSpectrogram(torch.nn.Module):
         elif tuple(out.shape) != (B, T, self.n_mels) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != audio.device:
             raise ValueError("frames_major: `out` must be a contiguous fp32 (B, T, n_mels) tensor on the audio's device")
         lib = _lib.get()
-        if _lib.get_tuning("mel_wave") != 1 or _lib.get_tuning("mel_taps_mem"):
+        if (_lib.get_tuning("mel_wave") != 1 and os.environ.get("SED_MEL_WAVE") != "1") or _lib.get_tuning("mel_taps_mem"):
             # DEFAULT: the round-1..4 kernel, one frame per 256-thread workgroup.  The round-5 wave-per-frame kernel below is 1.9 x
             # faster alone (79 vs 147 us) and fetches every sample from HBM once instead of eight times, but replayed as a hipGraph node
             # beside other kernels it intermittently returns a few wrong bins in single frames (never in eager launches; cause not
