@@ -286,11 +286,14 @@ __device__ __forceinline__ void dft16(float2* v) {
 // first bin rounded DOWN to a multiple of four (leading / trailing zeros), stored [group][lane] -- every lane reads its 16 bytes of group
 // g at the same offset (conflict-free), and the magnitudes as aligned 16-byte reads too: 32 ds_read_b128 per frame instead of 120 b32.
 #define MEL_WAVES 4
+#ifndef MEL_OCC
+#define MEL_OCC 2
+#endif
 #define MEL_GA 4
 #define MEL_GB 12
 
 template <bool LOG>
-__global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_wave_kernel(const float* __restrict__ audio, float* __restrict__ out,
+__global__ __launch_bounds__(64 * MEL_WAVES, MEL_OCC) void mel_wave_kernel(const float* __restrict__ audio, float* __restrict__ out,
                                                        int B, int N, int T, int hop, int n_mels,
                                                        const float* __restrict__ window, const float2* __restrict__ tw1024,
                                                        const float2* __restrict__ tw2048, const int* __restrict__ fb_start,

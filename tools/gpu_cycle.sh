@@ -16,7 +16,7 @@ trace) timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_$tag -o $tag -- p
        python tools/step_timeline.py gpurun_out/prof_$tag/${tag}_results.db 0 8 > gpurun_out/timeline_$tag.md 2>&1; tail -1 gpurun_out/timeline_$tag.md ;;
 pmc) for pass in "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "fetch FETCH_SIZE" "write WRITE_SIZE"; do
        set -- $pass; name=$1; shift
-       timeout 400 rocprofv3 --kernel-trace --pmc $@ -d gpurun_out/pmc_${tag}_$name -o $name -- python bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > gpurun_out/pmc_${tag}_$name.log 2>&1
+       timeout 400 rocprofv3 --kernel-trace --pmc $@ -d gpurun_out/pmc_${tag}_$name -o $name -- python bench.py --surface driver --steps 2 --warmup 1 --no-graph --no-cpu-baseline > gpurun_out/pmc_${tag}_$name.log 2>&1
      done
      python tools/pmc_ratio_summary.py gpurun_out/pmc_${tag}_mfma/mfma_results.db > gpurun_out/pmc_${tag}_mfma.md 2>&1
      python tools/pmc_summary.py gpurun_out/pmc_${tag}_fetch/fetch_results.db > gpurun_out/pmc_${tag}_fetch.md 2>&1
@@ -30,6 +30,9 @@ surf) # the four launch paths of the same step, same box: Lightning-order whole-
         n=$(echo $v | tr -d ' -'); timeout 300 python bench.py --surface $v --steps 50 --warmup 10 --no-cpu-baseline 2>gpurun_out/surf_${tag}_$n.err | tail -1 > gpurun_out/surf_${tag}_$n.json
         python -c "import json;d=json.load(open('gpurun_out/surf_${tag}_$n.json'));print('$v', d['ms_per_step'], d['config']['surface'].get('driver_surface_ms_per_step'), d['config']['launch'][:40])" 2>&1 | tail -1
       done ;;
+beats) timeout 300 python tools/beats_bench.py 2>/dev/null | tail -1 > gpurun_out/beats_$tag.json; cut -c1-400 gpurun_out/beats_$tag.json ;;
+host) timeout 300 python bench.py --host-batches --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/host_$tag.json; python -c "import json;d=json.load(open('gpurun_out/host_$tag.json'));print('host batches (PCIe-inclusive)', d['ms_per_step'], d['value'])" ;;
+melpmc) bash tools/pmc_mel.sh $tag 2>&1 | tail -3 | cut -c1-300 ;;
 smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
 second) timeout 300 python tools/bench_2024.py --graph --prefetch 2>/dev/null | tail -1 > gpurun_out/bench2024_$tag.json; cut -c1-80,330- gpurun_out/bench2024_$tag.json
         timeout 300 python tools/bench_2024.py --graph 2>/dev/null | tail -1 > gpurun_out/bench2024_inline_$tag.json
