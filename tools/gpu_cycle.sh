@@ -4,6 +4,7 @@ tag=${1:-x}; shift
 what=${@:-tests bench}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+# rocprofv3 databases are summarised on the box and then deleted: gpurun merges at most 64 MiB of gpurun_out/ back
 for w in $what; do
 case $w in
 tests) timeout 2400 python -m pytest tests -m gpu -q -s --durations=8 2>&1 | grep -v "^$" | tail -40 | cut -c1-400 | tee gpurun_out/tests_$tag.log ;;
@@ -13,7 +14,8 @@ reh) timeout 300 env NCCL_DEBUG=INFO python bench.py --steps 50 --warmup 10 --no
      python -c "import json;d=json.load(open('gpurun_out/reh_$tag.json'));print('rehearsal', d['ms_per_step']);print(json.dumps(d['dist']['exchange_tail_us'],indent=0));print(d['dist']['rccl_debug'])" ;;
 trace) timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_$tag -o $tag -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline $BENCH_ARGS > gpurun_out/prof_$tag.log 2>&1
        python tools/rocpd_summary.py gpurun_out/prof_$tag/${tag}_results.db 0.75 > gpurun_out/prof_$tag.md 2>&1; head -60 gpurun_out/prof_$tag.md | cut -c1-120
-       python tools/step_timeline.py gpurun_out/prof_$tag/${tag}_results.db 0 8 > gpurun_out/timeline_$tag.md 2>&1; tail -1 gpurun_out/timeline_$tag.md ;;
+       python tools/step_timeline.py gpurun_out/prof_$tag/${tag}_results.db 0 8 > gpurun_out/timeline_$tag.md 2>&1; tail -1 gpurun_out/timeline_$tag.md
+       rm -rf gpurun_out/prof_$tag ;;
 pmc) for pass in "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "fetch FETCH_SIZE" "write WRITE_SIZE"; do
        set -- $pass; name=$1; shift
        timeout 400 rocprofv3 --kernel-trace --pmc $@ -d gpurun_out/pmc_${tag}_$name -o $name -- python bench.py --surface driver --steps 2 --warmup 1 --no-graph --no-cpu-baseline > gpurun_out/pmc_${tag}_$name.log 2>&1
@@ -22,8 +24,10 @@ pmc) for pass in "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" 
      python tools/pmc_summary.py gpurun_out/pmc_${tag}_fetch/fetch_results.db > gpurun_out/pmc_${tag}_fetch.md 2>&1
      python tools/pmc_summary.py gpurun_out/pmc_${tag}_write/write_results.db > gpurun_out/pmc_${tag}_write.md 2>&1
      python tools/pmc_traffic_json.py gpurun_out/pmc_${tag}_fetch/fetch_results.db gpurun_out/pmc_${tag}_write/write_results.db 9 > gpurun_out/pmc_${tag}_traffic.json 2>gpurun_out/pmc_${tag}_traffic.err
-     head -30 gpurun_out/pmc_${tag}_mfma.md | cut -c1-200 ;;
-pmcw) bash tools/pmc_wait.sh $tag > /dev/null 2>&1; grep -E "block0|conv0_kernel|glu128|kernel \|" gpurun_out/pmcw_$tag.md | cut -c1-110 ;;
+     head -30 gpurun_out/pmc_${tag}_mfma.md | cut -c1-200
+     rm -rf gpurun_out/pmc_${tag}_mfma gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write ;;
+pmcw) bash tools/pmc_wait.sh $tag > /dev/null 2>&1; grep -E "block0|conv0_kernel|glu128|kernel \|" gpurun_out/pmcw_$tag.md | cut -c1-110
+      rm -rf gpurun_out/pmcw_${tag}_a gpurun_out/pmcw_${tag}_b gpurun_out/pmcw_${tag}_c ;;
 lt) timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "lightning" 2>&1 | grep -v "^$" | tail -30 | cut -c1-400 | tee gpurun_out/tests_lt_$tag.log ;;
 surf) # the four launch paths of the same step, same box: Lightning-order whole-step (headline), driver by hand, and the two eager forms
       for v in "lightning" "driver" "lightning --no-graph" "driver --no-graph --prefetch off"; do
@@ -32,7 +36,7 @@ surf) # the four launch paths of the same step, same box: Lightning-order whole-
       done ;;
 beats) timeout 300 python tools/beats_bench.py 2>/dev/null | tail -1 > gpurun_out/beats_$tag.json; cut -c1-400 gpurun_out/beats_$tag.json ;;
 host) timeout 300 python bench.py --host-batches --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/host_$tag.json; python -c "import json;d=json.load(open('gpurun_out/host_$tag.json'));print('host batches (PCIe-inclusive)', d['ms_per_step'], d['value'])" ;;
-melpmc) bash tools/pmc_mel.sh $tag 2>&1 | tail -3 | cut -c1-300 ;;
+melpmc) bash tools/pmc_mel.sh $tag 2>&1 | tail -3 | cut -c1-300; rm -rf gpurun_out/pmcmel_${tag}_[abcfw] ;;
 smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
 second) timeout 300 python tools/bench_2024.py --graph --prefetch 2>/dev/null | tail -1 > gpurun_out/bench2024_$tag.json; cut -c1-80,330- gpurun_out/bench2024_$tag.json
         timeout 300 python tools/bench_2024.py --graph 2>/dev/null | tail -1 > gpurun_out/bench2024_inline_$tag.json
