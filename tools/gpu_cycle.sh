@@ -14,7 +14,7 @@ reh) timeout 300 env NCCL_DEBUG=INFO python bench.py --steps 50 --warmup 10 --no
      python -c "import json;d=json.load(open('gpurun_out/reh_$tag.json'));print('rehearsal', d['ms_per_step']);print(json.dumps(d['dist']['exchange_tail_us'],indent=0));print(d['dist']['rccl_debug'])" ;;
 trace) timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_$tag -o $tag -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline $BENCH_ARGS > gpurun_out/prof_$tag.log 2>&1
        python tools/rocpd_summary.py gpurun_out/prof_$tag/${tag}_results.db 0.75 > gpurun_out/prof_$tag.md 2>&1; head -60 gpurun_out/prof_$tag.md | cut -c1-120
-       python tools/step_timeline.py gpurun_out/prof_$tag/${tag}_results.db 0 8 > gpurun_out/timeline_$tag.md 2>&1; tail -1 gpurun_out/timeline_$tag.md
+       python tools/step_timeline.py gpurun_out/prof_$tag/${tag}_results.db 0 0 > gpurun_out/timeline_$tag.md 2>&1; tail -1 gpurun_out/timeline_$tag.md
        rm -rf gpurun_out/prof_$tag ;;
 pmc) for pass in "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "fetch FETCH_SIZE" "write WRITE_SIZE"; do
        set -- $pass; name=$1; shift

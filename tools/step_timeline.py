@@ -16,6 +16,17 @@ def main(path, min_us=0.0, back=8):
     adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
     if len(adam) < 3:
         print("need >= 3 steps"); return
+    if back == 0:
+        # auto: among the last 16 steps, the replayed one with the shortest span (a tracer-induced host stall inside a step -- the
+        # host is several times slower under rocprofv3 -- stretches its span but not its kernels)
+        best = None
+        for k in range(2, min(17, len(adam))):
+            a, b_ = adam[-k - 1], adam[-k]
+            if b_ - a >= 100:
+                span_ = rows[b_][2] - rows[a + 1][1]
+                if best is None or span_ < best[0]:
+                    best = (span_, k)
+        back = best[1] if best else 8
     lo, hi = adam[-back - 1] + 1, adam[-back] + 1
     step = rows[lo:hi]
     t0 = rows[adam[-back - 1]][2]
