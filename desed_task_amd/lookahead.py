@@ -14,6 +14,9 @@ batches it has handed out, in order, until the module releases them, and fetches
     release(key)       -> forget everything up to and including `key`
 
 Nothing else changes: an epoch yields exactly the batches the plain DataLoader would, the worker processes and the sampler are torch's.
+(SEDTask4 asks two batches ahead: k + 1 for the step's side branch, k + 2 to upload it while step k runs.  With `num_workers = 0` a data
+set that draws random numbers in `__getitem__` -- the reference's random crop of over-long clips -- therefore draws them up to two
+batches earlier relative to the step's own draws than under a plain loop; with worker processes, the recipes' setting, nothing moves.)
 """
 import collections
 
@@ -76,7 +79,7 @@ class _LookaheadIter:
 
 
 class LookaheadLoader(DataLoader):
-    MAX_HELD = 4            # a trainer that prefetches one batch holds two; the look-ahead adds one
+    MAX_HELD = 6            # a trainer that prefetches one batch holds two; the look-ahead adds two (next batch + the one being uploaded)
 
     _cur = None
     _epochs = 0

@@ -34,6 +34,17 @@ except Exception:  # noqa: BLE001
 from ._lightning_standin import move_to_device as _move_to_device
 
 
+def _tensors(batch):
+    if torch.is_tensor(batch):
+        yield batch
+    elif isinstance(batch, (list, tuple)):
+        for b in batch:
+            yield from _tensors(b)
+    elif isinstance(batch, dict):
+        for b in batch.values():
+            yield from _tensors(b)
+
+
 class SEDTask4(_Base):
     def __init__(self, hparams, encoder, sed_student, opt=None, train_data=None, valid_data=None, test_data=None,
                  train_sampler=None, scheduler=None, fast_dev_run=False, evaluation=False, sed_teacher=None):
@@ -255,22 +266,64 @@ class SEDTask4(_Base):
             n = None
         return n if isinstance(n, int) else None
 
+    # Host batches (what a DataLoader hands out): batch k + 1 must be on the device before step k's replay starts (its side branch reads
+    # it), so uploading it at step k would put 30.7 MB of PCIe traffic in front of every replay.  Batch k + 2 is therefore uploaded
+    # DURING step k, on an upload stream of its own (pinned memory: asynchronous; pageable: the host thread blocks, the GPU does not),
+    # and step k + 1 merely waits for that upload's event.  Device-resident batches pass through untouched.
+    _staged = None                          # {loader key: (device batch, upload-done event or None)}
+    _up_stream = None
+
+    def _stage(self, key, host_batch, device):
+        st = self._staged
+        if st is None:
+            st = self._staged = {}
+        for k in [k for k in st if k[0] != key[0] or k[1] < key[1] - 2]:
+            del st[k]                       # (another epoch's, or batches nobody asked for)
+        if key in st:
+            return
+        on_host = [t for t in _tensors(host_batch) if t.device != device]
+        if not on_host or device.type != "cuda":
+            st[key] = (_move_to_device(host_batch, device), None)
+            return
+        if self._up_stream is None:
+            self._up_stream = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(self._up_stream):
+            dev_batch = _move_to_device(host_batch, device)
+            ev = torch.cuda.Event()
+            ev.record()
+        st[key] = (dev_batch, ev)
+
+    def _take_staged(self, key, device):
+        dev_batch, ev = self._staged.pop(key)
+        if ev is not None:
+            cur = torch.cuda.current_stream(device)
+            cur.wait_event(ev)
+            for t in _tensors(dev_batch):
+                if t.is_cuda:
+                    t.record_stream(cur)    # allocated on the upload stream, read on this one
+        return dev_batch
+
     def transfer_batch_to_device(self, batch, device, dataloader_idx=0):
         """Lightning's hook, called once per batch right before training_step.  A training batch of the look-ahead loader that was
-        already uploaded as the announced successor of the previous batch is not uploaded again."""
+        already uploaded -- as the announced successor of the previous batch, or one step further ahead -- is not uploaded again."""
         loader = getattr(self, "train_loader", None)
         if self.training and isinstance(loader, LookaheadLoader):
             key = loader.find(batch)
             if key is not None:
                 up = self._uploaded
-                dev_batch = up[1] if (up is not None and up[0] == key) else _move_to_device(batch, device)
+                if up is not None and up[0] == key:
+                    dev_batch = up[1]
+                elif self._staged and key in self._staged:
+                    dev_batch = self._take_staged(key, torch.device(device))
+                else:
+                    dev_batch = _move_to_device(batch, device)
                 self._cur_batch = (key, dev_batch)
                 return dev_batch
         return super().transfer_batch_to_device(batch, device, dataloader_idx)
 
     def _next_from_loader(self, batch):
         """The batch that follows `batch` in the look-ahead loader's epoch, on the device -- or None (no such loader, a batch it does not
-        know, the end of the epoch)."""
+        know, the end of the epoch).  Also starts the upload of the batch after that."""
         loader = getattr(self, "train_loader", None)
         if not isinstance(loader, LookaheadLoader):
             return None
@@ -281,12 +334,18 @@ class SEDTask4(_Base):
             return None
         loader.release(key)
         limit = self._epoch_limit()
-        nxt = loader.batch_after(key) if (limit is None or key[1] + 1 < limit) else None
+        device = batch[0].device
+        k1, k2 = (key[0], key[1] + 1), (key[0], key[1] + 2)
+        nxt = loader.batch_after(key) if (limit is None or k1[1] < limit) else None
         if nxt is None:
             self._uploaded = None
             return None
-        dev_next = _move_to_device(nxt, batch[0].device)
-        self._uploaded = ((key[0], key[1] + 1), dev_next)
+        self._stage(k1, nxt, device)
+        dev_next = self._take_staged(k1, device)
+        self._uploaded = (k1, dev_next)
+        nxt2 = loader.batch_after(k1) if (limit is None or k2[1] < limit) else None
+        if nxt2 is not None:
+            self._stage(k2, nxt2, device)
         return dev_next
 
     def training_step(self, batch, batch_indx):
