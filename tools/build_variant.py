@@ -10,9 +10,11 @@ name, extra = sys.argv[1], sys.argv[2:]
 obj_dir = os.path.join(HERE, "_obj_" + name)
 os.makedirs(obj_dir, exist_ok=True)
 objs = []
+only = os.environ.get("ONLY")        # ONLY=sed_mel.hip: the extra flags go to that source alone
 def cc(src):
     obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
-    subprocess.check_call([B.HIPCC] + B.FLAGS + extra + ["-c", src, "-o", obj])
+    ex = extra if (only is None or os.path.basename(src) == only) else []
+    subprocess.check_call([B.HIPCC] + B.FLAGS + ex + ["-c", src, "-o", obj])
     return obj
 with ThreadPoolExecutor(max_workers=8) as ex:
     objs = list(ex.map(cc, B.sources()))
