@@ -17,7 +17,7 @@ per = collections.defaultdict(lambda: collections.defaultdict(list))
 names, starts = {}, {}
 for did, name, start, c, v in cur.execute("select dispatch_id, name, start, counter_name, counter_value from pmc_events"):
     per[did][c].append(v)
-    names[did] = re.sub(r"\(.*$", "", re.sub(r"^void ", "", name))[:90]
+    names[did] = re.sub(r"\(.*$", "", re.sub(r"^void ", "", name).replace("(anonymous namespace)::", ""))[:90]
     starts[did] = start
 if not per:
     print("no pmc events"); sys.exit(0)

@@ -2,7 +2,7 @@
 """Per-kernel average of one PMC counter from a rocprofv3 rocpd database (value units as reported; FETCH_SIZE / WRITE_SIZE are KiB)."""
 import re, sqlite3, sys, collections
 def short(n):
-    return re.sub(r"\(.*$", "", re.sub(r"^void ", "", n))[:90]
+    return re.sub(r"\(.*$", "", re.sub(r"^void ", "", n).replace("(anonymous namespace)::", ""))[:90]
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 agg = collections.defaultdict(lambda: [0, 0.0])
 for name, cname, val in cur.execute("select name, counter_name, counter_value from pmc_events"):

@@ -6,7 +6,7 @@ import collections, json, re, sqlite3, sys
 
 
 def short(n):
-    return re.sub(r"\(.*$", "", re.sub(r"^void ", "", n))[:90]
+    return re.sub(r"\(.*$", "", re.sub(r"^void ", "", n).replace("(anonymous namespace)::", ""))[:90]
 
 
 def means(path, counter):

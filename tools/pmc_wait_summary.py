@@ -4,7 +4,7 @@ kernel's waves wait for: WAIT_ANY / WAVE_CYCLES (waves stalled on any counter), 
 slot), WAIT_INST_LDS / WAVE_CYCLES, LDS_BANK_CONFLICT / LDS_IDX_ACTIVE.   python tools/pmc_wait_summary.py a.db [b.db ...]"""
 import re, sqlite3, sys, collections
 def short(n):
-    return re.sub(r"\(.*$", "", re.sub(r"^void ", "", n))[:72]
+    return re.sub(r"\(.*$", "", re.sub(r"^void ", "", n).replace("(anonymous namespace)::", ""))[:72]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for path in sys.argv[1:]:
     cur = sqlite3.connect(path).cursor()
