@@ -433,6 +433,7 @@ def main():
                          "(768 x 496 per clip) fused into the CRNN (confs/pretrained.yaml); not the headline metric")
     ap.add_argument("--gru-dw-atomic", action="store_true", help="A/B: BiGRU weight gradients through zero fill + atomic split-K")
     ap.add_argument("--no-gru-dw-side", action="store_true", help="A/B: BiGRU weight-gradient GEMMs on the main stream")
+    ap.add_argument("--no-cnn-dw-side", action="store_true", help="A/B: the weight-gradient GEMMs of CNN blocks 1-6 on the backward chain (= SED_CNN_DW_SIDE=0)")
     ap.add_argument("--no-park-loss", action="store_true", help="A/B: the eight loss sums inside the loss launch (fence + ticket) instead of beside the chain")
     ap.add_argument("--no-dx-splitk", action="store_true", help="A/B: the BiGRU dX products as one K slice (118 / 236 workgroups)")
     ap.add_argument("--no-defer", action="store_true", help="A/B: the head's weight-gradient sums and the BiGRU bias-gradient sums on the backward chain")
@@ -591,6 +592,9 @@ def main():
     if args.no_gru_dw_side:
         from desed_task_amd import ops as _ops2
         _ops2.GRU_DW_SIDE_ALLOWED = False
+    if args.no_cnn_dw_side:
+        from desed_task_amd import ops as _ops7
+        _ops7.CNN_DW_SIDE = False
     audio, labels = synthetic_batch(dev, 1234 + rank)
     emb = None
     if args.embeddings:

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
                                                   int B, int N, int T, int hop, int n_mels,
                                                   const float* __restrict__ window, const float2* __restrict__ tw1024,
                                                   const float2* __restrict__ tw2048, const int* __restrict__ fb_start,
-                                                  const int* __restrict__ fb_len, const float* __restrict__ fb_w, int fb_stride) {
+                                                  const int* __restrict__ fb_len, const float* __restrict__ fb_w, int fb_stride, int S, int fps) {
     __shared__ float2 buf0[MEL_M];
     __shared__ float2 buf1[MEL_M];
     // per-pass twiddle tables [pass 1..4][j = 1..3][k < Ns]: w^(j k 256/Ns), contiguous in k.  (Indexing one 1024-entry table
@@ -69,12 +69,10 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
             wr[j] = (mband < n_mels && i < fln) ? fb_w[(size_t)mband * fb_stride + i] : 0.f;
         }
     }
-    const int n_frames = B * T;
     // the next frame's samples are fetched into registers while the current frame is transformed (a workgroup would
     // otherwise expose one L2/HBM latency per frame in front of ~10 short barrier-separated phases)
     float2 smp[4];
-    auto load_frame = [&](int frame_) {
-        const int b_ = frame_ / T, t_ = frame_ - b_ * T;
+    auto load_frame = [&](int b_, int t_) {
         const float* clip = audio + (size_t)b_ * N;
         const int base = t_ * hop - MEL_NFFT / 2;
 #pragma unroll
@@ -87,14 +85,33 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
             smp[q] = make_float2(clip[s0], clip[s1]);
         }
     };
-    int frame = blockIdx.x;
-    if (frame < n_frames) load_frame(frame);
-    for (; frame < n_frames; frame += gridDim.x) {
-        const int b = frame / T, t = frame - b * T;
+    // Work list, XCD-aware: workgroup w runs on XCD w & 7 (round-robin dispatch), and the 8 frames that overlap one hop of audio
+    // must meet in ONE L2 -- with frame = blockIdx + n * gridDim they sat on 8 XCDs, every L2 fetched every clip and the launch
+    // read 246 MB for 31 MB of audio (profiles/r05f_pmc_mel.md).  Clips are cut into S segments of fps frames (S = 1 when 8 | B),
+    // segment sg belongs to XCD sg & 7, and the workgroups of an XCD walk its segments' frames in order, slot-strided, so the
+    // workgroups resident together read one moving window of a clip.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, n_slots = gridDim.x >> 3;
+    const int n_segs = B * S;
+    const int n_local = xcd < n_segs ? ((n_segs - xcd + 7) >> 3) * fps : 0;
+    auto locate = [&](int i_, int& b_, int& t_) {
+        const int j = i_ / fps, sg = xcd + 8 * j;
+        b_ = sg / S;
+        t_ = (sg - b_ * S) * fps + (i_ - j * fps);
+        return t_ < T;
+    };
+    int li = slot, b = 0, t = 0;
+    bool have = false;
+    while (li < n_local && !(have = locate(li, b, t))) li += n_slots;
+    if (have) load_frame(b, t);
+    while (have) {
         // ---- reflect-padded, windowed samples packed as z[n] = x[2n] + i x[2n+1] ----
 #pragma unroll
         for (int q = 0; q < 4; ++q) buf0[mel_sw(tid + 256 * q)] = make_float2(smp[q].x * win[q].x, smp[q].y * win[q].y);
-        if (frame + (int)gridDim.x < n_frames) load_frame(frame + gridDim.x);
+        int nb = 0, nt = 0;
+        bool nhave = false;
+        li += n_slots;
+        while (li < n_local && !(nhave = locate(li, nb, nt))) li += n_slots;
+        if (nhave) load_frame(nb, nt);
         __syncthreads();
         // ---- 5 Stockham radix-4 passes, Ns = 1,4,16,64,256; result lands in buf1 ----
         float2* src = buf0;
@@ -170,6 +187,7 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
             }
         }
         __syncthreads();
+        b = nb; t = nt; have = nhave;
     }
 }
 
@@ -520,9 +538,13 @@ SED_API int sed_mel_fwd(const float* audio, float* out, int B, int N, int T, int
                            const int* fb_len, const float* fb_w, int fb_stride, int apply_log, void* stream) {
     if (n_fft != MEL_NFFT || n_mels > 128 || n_mels < 1 || N < n_fft / 2 + 1 || T != 1 + N / hop) return SED_ERR_UNSUPPORTED;
     if (B <= 0) return SED_OK;
-    int grid = B * T < 4096 ? B * T : 4096;
+    int S = 1;                                    // segments per clip: the smallest count that makes B * S a multiple of 8 XCDs
+    while ((B * S) & 7) S <<= 1;
+    const int fps = (T + S - 1) / S;
+    const long long slots = ((long long)B * T + 7) / 8;
+    const int grid = 8 * (int)(slots < 512 ? slots : 512);
 #define MEL_LAUNCH(LOG, WPT) SED_LAUNCH((mel_kernel<LOG, WPT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, audio, out, B, N, T, hop, \
-                                        n_mels, window, (const float2*)tw1024, (const float2*)tw2048, fb_start, fb_len, fb_w, fb_stride)
+                                        n_mels, window, (const float2*)tw1024, (const float2*)tw2048, fb_start, fb_len, fb_w, fb_stride, S, fps)
     if (fb_stride <= 48 && !sed_tuning[SED_TUNE_MEL_TAPS_MEM]) {      // the recipes' filterbank (128 HTK bands up to 8 kHz: widest band 46 bins)
         if (apply_log) MEL_LAUNCH(true, 24); else MEL_LAUNCH(false, 24);
     } else {

@@ -26,6 +26,9 @@ GRU_DW_ATOMIC = False            # A/B switch (bench.py --gru-dw-atomic): the ze
 GRU_DW_SIDE = False
 GRU_DX_SPLITK = True             # bench.py --no-dx-splitk (A/B): the BiGRU dX product as one K slice
 GRU_DW_SIDE_ALLOWED = True       # bench.py --no-gru-dw-side (A/B)
+# Round 5: the weight-gradient GEMMs of CNN blocks 1-6 take the same way out (they were ~390 us of a backward chain that ran one kernel
+# at a time).  Needs the side stream, i.e. only acts while GRU_DW_SIDE is on; bench.py --no-cnn-dw-side / SED_CNN_DW_SIDE=0 (A/B).
+CNN_DW_SIDE = os.environ.get("SED_CNN_DW_SIDE", "1") != "0"
 _side = {}
 
 
@@ -385,6 +388,8 @@ class ConvBlockFn(torch.autograd.Function):
                      bn_b.data_ptr(), glu_w.data_ptr(), glu_b.data_ptr(), gout.data_ptr(), d_w.data_ptr(), d_bias.data_ptr(),
                      d_gamma.data_ptr(), d_beta.data_ptr(), d_glu_w.data_ptr(), d_glu_b.data_ptr(), scratch.data_ptr(), B, T, F,
                      int(seed), thr24, dscale, _graph.seed_dev(seed), st)
+            if _deferred:           # block 1's weight gradient: beside this kernel
+                flush_deferred(side_stream(x.device) if GRU_DW_SIDE else None)
             return None, d_w, d_bias, d_gamma, d_beta, d_glu_w, d_glu_b, None, None, None
         x, y, stats, conv_w, bn_w, bn_b, glu_w, glu_b, conv_b = ctx.saved_tensors
         first, B, T, F, CIN, COUT, PT, PF, training, seed, thr24, dscale, bounds = ctx.meta
@@ -424,7 +429,17 @@ class ConvBlockFn(torch.autograd.Function):
             lib.call("sed_conv3x3_bf16x3_bnbwd", dz.data_ptr(), y.data_ptr(), stats.data_ptr(), bn_w.data_ptr(), d_gamma.data_ptr(),
                      d_beta.data_ptr(), packed[1].data_ptr(), dx.data_ptr(), dy.data_ptr(), d_bias.data_ptr(), B, T, F, COUT, CIN, st)
             scratch = torch.empty(int(lib.value("sed_conv_wgrad_scratch_floats", B, T, F, CIN, COUT)), **f32)
-            lib.call("sed_conv_wgrad_bf16x3", x.data_ptr(), dy.data_ptr(), scratch.data_ptr(), d_w.data_ptr(), B, T, F, CIN, COUT, st)
+            d_w_ptr = d_w.data_ptr()            # (an address, not the tensor, goes into what outlives this call: see defer_off_chain)
+
+            def wgrad(stream_ptr):
+                lib.call("sed_conv_wgrad_bf16x3", x.data_ptr(), dy.data_ptr(), scratch.data_ptr(), d_w_ptr, B, T, F, CIN, COUT, stream_ptr)
+            if CNN_DW_SIDE and _arena_views(cfg, d_w):
+                # the chain goes on with the block below (its GLU backward reads dx); dW only feeds the optimizer.  Parked until that
+                # block's first kernel is enqueued, then launched on the side stream beside it (block 1's goes out beside block 0's
+                # backward, which had the end of the step to itself)
+                defer_off_chain(dev, wgrad, (x, dy, scratch))
+            else:
+                wgrad(st)
             return dx, d_w, d_bias, d_gamma, d_beta, d_glu_w, d_glu_b, None, None, None
         lib.call("sed_bn_bwd_apply", y.data_ptr(), dz.data_ptr(), stats.data_ptr(), bn_w.data_ptr(), d_gamma.data_ptr(),
                  d_beta.data_ptr(), d_bias.data_ptr(), B * T * F, COUT, int(training), st)

@@ -10,6 +10,8 @@ def test_mfma_maps(emu):
 def test_mel_matches_oracle(emu):
     P.case_mel("cpu")
     P.case_mel("cpu", batch=3, n_samples=256 * 21 + 100)       # ragged clip length, a batch the XCD walk does not divide
+    P.case_mel("cpu", batch=8, n_samples=256 * 6)               # one clip per XCD (S = 1)
+    P.case_mel("cpu", batch=9, n_samples=256 * 5 + 17)          # 9 clips in 8 segments each
 
 
 def test_mel_wave_kernel_matches_oracle(emu):
