@@ -11,6 +11,7 @@
 // The Linear layers (86 % of the extractor's FLOPs), the attention and the position convolution all run on the split-bf16 MFMA
 // (vector-pipe versions of the last two are kept as sed_posconv and behind sed_set_tuning).
 #include "sed_common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
 // K-B1: one workgroup (256 threads) per frame.  audio (B, N) in [-1, 1) -> out (B, M, n_mels), M = 1 + (N - 400) / 160.
@@ -437,41 +438,63 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 }
 // ---------------------------------------------------------------------------------------------
 // K-B5 on the matrix cores (default): the same attention, Q K^T and P V on v_mfma_f32_16x16x32_bf16 with split operands (three
-// MFMAs per product: fp32-level accuracy, the extractor's parity bound is 2e-4).  Workgroup = 64 queries of one (b, h), wave w =
-// queries 16 w .. 16 w + 15 (one 16-row MFMA block), key tiles of 64.
-//   scores:  A = Q (the wave's 16 queries x 64 dims, scaled, as bf16 hi / lo fragments in 16 VGPRs for the whole kernel),
-//            B = K^T from [key][dim] hi / lo planes -> four 16 x 16 blocks, D[q = 4 g + r][key = i16]
-//   softmax: a score row lives in the 16 lanes of a lane row: max / sum by quad_perm + row_ror DPP, online rescaling per lane's
-//            four rows; the gated relative-position bias is added in the accumulator layout (gate per row from a 16-float
-//            wave-private exchange, bias row of the head in LDS)
-//   P V:     A = P through wave-private [q][key] hi / lo planes (accumulator layout -> operand layout), B = V from TRANSPOSED
-//            [dim][key] planes (staged from 4 key x 4 dim register blocks), D[q][dim block] = 4 accumulators per wave.
-// All plane pitches are 80 bf16 = 10 sixteen-byte slots (= 2 mod 4: conflict-free ds_read_b128 for the 16x16x32 lane groups).
+// MFMAs per product: fp32-level accuracy, the extractor's parity bound is 2e-4).  Round 5: the TRANSPOSED products, so that the
+// probabilities never leave the registers (rounds 2-4 computed S = Q K^T, whose accumulator layout had to go through wave-private
+// LDS planes -- 32 two-byte stores per lane and tile -- to become the A operand of P V; with the 4-rows-per-lane softmax and IEEE
+// expf the vector pipe did ~550 instructions per 48 MFMAs: MFMA-busy 0.10, profiles/r05g_pmc_beats_mfma_busy.md).
+//   Workgroup = 128 queries of one (b, h); wave w = queries 32 w .. 32 w + 31 as TWO 16-query blocks j that share every K / V
+//   fragment read (LDS operand traffic per MFMA halves); key tiles of 64.
+//   S^T[key][query] = K Q^T:  A = K rows from [key][dim] hi / lo planes, B = Q (lane (i16, g) = query i16, dims 8 g + e of a
+//            32-dim half; scaled by log2(e) / sqrt(d), as bf16 hi / lo fragments in registers for the whole kernel).
+//            D[key = 16 kb + 4 g + r][query = i16]: a lane holds 16 scores OF ONE QUERY per block.
+//   softmax: per query = per lane: max / sum over the lane's 16 values, then over the 4 lanes of the column (xor 16, xor 32); ONE
+//            running maximum, sum and correction per lane and block; base-2 exponentials (v_exp_f32); the gated relative-position
+//            bias (pre-multiplied by log2 e when staged) is one LDS base + 16 immediate offsets per lane.
+//   O^T[dim][query] = V^T P^T: B = P^T comes STRAIGHT from the score accumulators -- the contraction index of an MFMA may be any
+//            permutation of the keys as long as both operands use it: slot (g, e) of K-half ks := key 16 (2 ks + (e >> 2)) + 4 g +
+//            (e & 3), which is exactly what lane (query, g) holds; A = V^T from [dim][slot] hi / lo planes staged in that order.
+//            D[dim = 16 db + 4 g + r][query = i16]: the result leaves as 16-byte stores.
+// Plane pitch 80 bf16 = 10 sixteen-byte slots (= 2 mod 4: conflict-free ds_read_b128 for the 16x16x32 lane groups).
 // ---------------------------------------------------------------------------------------------
 #define ATM_P 80
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ relb,
+#define ATM_QG 128
+__device__ __forceinline__ float atm_exp2(float x) {
+#ifdef SED_EMU
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);
+#endif
+}
+template <bool BIAS>
+__global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ relb,
                                                              const float* __restrict__ grep_w, const float* __restrict__ grep_b,
                                                              const float* __restrict__ grep_a, float* __restrict__ out, int T, int H,
-                                                             float scaling) {
+                                                             int n_pairs, float scaling) {
     SED_DYN_SMEM(smem);
-    unsigned short* kh = (unsigned short*)smem;           // K  [64 keys][ATM_P] hi | lo
+    unsigned short* kh = (unsigned short*)smem;           // K   [64 keys][ATM_P] hi | lo
     unsigned short* kl = kh + 64 * ATM_P;
-    unsigned short* vh = kl + 64 * ATM_P;                 // V^T [64 dims][ATM_P] hi | lo
+    unsigned short* vh = kl + 64 * ATM_P;                 // V^T [64 dims][ATM_P] hi | lo, keys in MFMA-slot order
     unsigned short* vl = vh + 64 * ATM_P;
-    unsigned short* pbase = vl + 64 * ATM_P;              // P  per wave: [16 q][ATM_P] hi | lo
-    float* gsh = (float*)(pbase + 4 * 2 * 16 * ATM_P);    // gate per query: [4 waves][16]
-    float* rb = gsh + 64;                                 // [2 T - 1] bias row of this head
+    float* rb = (float*)(vl + 64 * ATM_P);                // [2 T - 1 (+ 64 zeros)] bias row of this head, times log2 e
+    const float LOG2E = 1.44269504088896341f;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z, D = H * AT_HD, LD = 3 * D;
-    unsigned short* ph = pbase + w * 2 * 16 * ATM_P;
-    unsigned short* pl = ph + 16 * ATM_P;
-    if (relb)
-        for (int i = tid; i < 2 * T - 1; i += 256) rb[i] = relb[(size_t)h * (2 * T - 1) + i];
-    // ---- Q fragments: lane (i16, g) = query 16 w + i16, dims 32 ks + 8 g + e; the gate from the same 16 values per lane ----
-    s16x8 qh[2], ql[2];
-    {
-        const int tq = q0 + 16 * w + i16;
-        const float* qr = qkv + ((size_t)b * T + (tq < T ? tq : T - 1)) * LD + h * AT_HD;
+    // XCD-aware walk: workgroup n runs on XCD n & 7; the query tiles of one (b, h) are consecutive workgroups OF ONE XCD, so that head's
+    // K / V rows (254 KB) are fetched into one L2 once instead of into four
+    const int nq = (T + ATM_QG - 1) / ATM_QG, mloc = blockIdx.x >> 3, pair = (blockIdx.x & 7) + 8 * (mloc / nq);
+    if (pair >= n_pairs) return;
+    const int q0 = (mloc % nq) * ATM_QG, h = pair % H, b = pair / H, D = H * AT_HD, LD = 3 * D;
+    if (BIAS)
+        for (int i = tid; i < 2 * T - 1 + 64; i += 256) rb[i] = i < 2 * T - 1 ? relb[(size_t)h * (2 * T - 1) + i] * LOG2E : 0.f;
+    // ---- Q fragments and gates: lane (i16, g) = query q0 + 32 w + 16 j + i16, dims 32 ks + 8 g + e ----
+    s16x8 qh[2][2], ql[2][2];
+    float gate[2], m2[2], l2[2];
+    int tq[2], rbase[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        tq[j] = q0 + 32 * w + 16 * j + i16;
+        const int tc = tq[j] < T ? tq[j] : T - 1;                      // dead queries compute on a clamped row and are not stored
+        rbase[j] = T - 1 - tc + 4 * g;
+        const float* qr = qkv + ((size_t)b * T + tc) * LD + h * AT_HD;
         float qv[16];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -479,8 +502,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
             qv[8 * ks] = a.x; qv[8 * ks + 1] = a.y; qv[8 * ks + 2] = a.z; qv[8 * ks + 3] = a.w;
             qv[8 * ks + 4] = c.x; qv[8 * ks + 5] = c.y; qv[8 * ks + 6] = c.z; qv[8 * ks + 7] = c.w;
         }
-        float gate = relb ? 1.0f : 0.0f;
-        if (relb && grep_w) {
+        float gt = BIAS ? 1.0f : 0.0f;
+        if (BIAS && grep_w) {
             float ga = 0.f, gb = 0.f;
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
@@ -495,69 +518,69 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
                 if (o < 4) ga += a; else gb += a;
             }
             ga = sed_sigmoid(ga); gb = sed_sigmoid(gb);
-            gate = ga * (gb * grep_a[h] - 1.0f) + 2.0f;
+            gt = ga * (gb * grep_a[h] - 1.0f) + 2.0f;
         }
-        if (g == 0) gsh[16 * w + i16] = gate;
+        gate[j] = gt;
+        m2[j] = -INFINITY; l2[j] = 0.f;
+        const float qs = scaling * LOG2E;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             unsigned hv[4], lv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bf16_split2(qv[8 * ks + 2 * e] * scaling, qv[8 * ks + 2 * e + 1] * scaling, hv[e], lv[e]);
+            for (int e = 0; e < 4; ++e) bf16_split2(qv[8 * ks + 2 * e] * qs, qv[8 * ks + 2 * e + 1] * qs, hv[e], lv[e]);
             uint4 hq, lq;
             hq.x = hv[0]; hq.y = hv[1]; hq.z = hv[2]; hq.w = hv[3];
             lq.x = lv[0]; lq.y = lv[1]; lq.z = lv[2]; lq.w = lv[3];
-            qh[ks] = __builtin_bit_cast(s16x8, hq);
-            ql[ks] = __builtin_bit_cast(s16x8, lq);
+            qh[j][ks] = __builtin_bit_cast(s16x8, hq);
+            ql[j][ks] = __builtin_bit_cast(s16x8, lq);
         }
     }
-    sed_wave_sync();
-    float gate4[4], m4[4], l4[4];
-    int trow[4];
+    f32x4 o[2][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        gate4[r] = gsh[16 * w + 4 * g + r];
-        m4[r] = -INFINITY; l4[r] = 0.f;
-        const int t = q0 + 16 * w + 4 * g + r;
-        trow[r] = t < T ? t : T - 1;                                  // dead query rows compute on a clamped index and are not stored
-    }
-    f32x4 o[4];
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int db = 0; db < 4; ++db) o[j][db] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int kq = tid & 15, dq = tid >> 4;                            // staging block: keys 4 kq .. +3, dims 4 dq .. +3
+    // keys 4 kq .. 4 kq + 3 = (kb = kq >> 2, g = kq & 3, r = 0..3) sit at MFMA slots 32 (kb >> 1) + 8 g + 4 (kb & 1) + r of V^T
+    const int vpos = 32 * (kq >> 3) + 8 * (kq & 3) + 4 * ((kq >> 2) & 1);
     // The K / V rows of the NEXT key tile are fetched into registers under this tile's MFMAs and softmax (unconditional loads on
-    // clamped rows; keys past T are zeroed when the tile is parked in LDS).  Loaded at the top of their own tile -- each inside an
-    // `if (s < T)` -- every tile exposed a full memory latency in front of its first barrier (tools/isa_exposed_loads.py).
+    // clamped rows; keys past T are zeroed when the tile is parked in LDS).
     float4 kr[4], vr[4];
+    // (K needs no transposition, so its rows are fetched and parked row-contiguously: lanes = 16 dim quads of key dq + 16 j.  With
+    // V's 4 x 4 blocks the 8-byte LDS stores of 16 lanes fell on two bank groups: lds_conflict 0.61 of the LDS cycles)
     auto load_kv = [&](int s0_) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int s = s0_ + 4 * kq + j;
-            const float* base = qkv + ((size_t)b * T + (s < T ? s : T - 1)) * LD + h * AT_HD + 4 * dq;
-            kr[j] = *(const float4*)(base + D);
-            vr[j] = *(const float4*)(base + 2 * D);
+            const int s = s0_ + 4 * kq + j, sk = s0_ + dq + 16 * j;
+            vr[j] = *(const float4*)(qkv + ((size_t)b * T + (s < T ? s : T - 1)) * LD + h * AT_HD + 4 * dq + 2 * D);
+            kr[j] = *(const float4*)(qkv + ((size_t)b * T + (sk < T ? sk : T - 1)) * LD + h * AT_HD + 4 * kq + D);
         }
     };
     load_kv(0);
     for (int s0 = 0; s0 < T; s0 += 64) {
         __syncthreads();                                               // previous tile consumed (first pass: rb staged)
         {
+            if (s0 + 64 > T) {                                         // (uniform: the ragged last tile only)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (s0 + 4 * kq + j >= T) { kr[j] = make_float4(0.f, 0.f, 0.f, 0.f); vr[j] = kr[j]; }
+                for (int j = 0; j < 4; ++j) {
+                    if (s0 + 4 * kq + j >= T) vr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (s0 + dq + 16 * j >= T) kr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {                              // K rows: 4 dims of key 4 kq + j
+            for (int j = 0; j < 4; ++j) {                              // K rows: dims 4 kq .. + 3 of key dq + 16 j
                 uint2 hv, lv;
                 bf16_split2(kr[j].x, kr[j].y, hv.x, lv.x);
                 bf16_split2(kr[j].z, kr[j].w, hv.y, lv.y);
-                *(uint2*)(kh + (4 * kq + j) * ATM_P + 4 * dq) = hv;
-                *(uint2*)(kl + (4 * kq + j) * ATM_P + 4 * dq) = lv;
+                *(uint2*)(kh + (dq + 16 * j) * ATM_P + 4 * kq) = hv;
+                *(uint2*)(kl + (dq + 16 * j) * ATM_P + 4 * kq) = lv;
             }
             auto vt = [&](float a, float c, float e, float f, int d) {  // V^T rows: 4 keys of dim d
                 uint2 hv, lv;
                 bf16_split2(a, c, hv.x, lv.x);
                 bf16_split2(e, f, hv.y, lv.y);
-                *(uint2*)(vh + d * ATM_P + 4 * kq) = hv;
-                *(uint2*)(vl + d * ATM_P + 4 * kq) = lv;
+                *(uint2*)(vh + d * ATM_P + vpos) = hv;
+                *(uint2*)(vl + d * ATM_P + vpos) = lv;
             };
             vt(vr[0].x, vr[1].x, vr[2].x, vr[3].x, 4 * dq);
             vt(vr[0].y, vr[1].y, vr[2].y, vr[3].y, 4 * dq + 1);
@@ -566,100 +589,128 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         }
         __syncthreads();
         if (s0 + 64 < T) load_kv(s0 + 64);
-        // ---- scores: four 16-key blocks ----
-        f32x4 sc[4];
+        // ---- scores, transposed: four 16-key blocks x two query blocks ----
+        f32x4 sc[2][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const unsigned short* bp = kh + (16 * kb + i16) * ATM_P + 32 * ks + 8 * g;
-                const s16x8 bh = *(const s16x8*)bp, bl = *(const s16x8*)(bp + 64 * ATM_P);
-                a = mfma16_bf16(ql[ks], bh, a);
-                a = mfma16_bf16(qh[ks], bl, a);
-                a = mfma16_bf16(qh[ks], bh, a);
+                const unsigned short* ap = kh + (16 * kb + i16) * ATM_P + 32 * ks + 8 * g;
+                const s16x8 ah = *(const s16x8*)ap, al = *(const s16x8*)(ap + 64 * ATM_P);
+                a0 = mfma16_bf16(al, qh[0][ks], a0);
+                a1 = mfma16_bf16(al, qh[1][ks], a1);
+                a0 = mfma16_bf16(ah, ql[0][ks], a0);
+                a1 = mfma16_bf16(ah, ql[1][ks], a1);
+                a0 = mfma16_bf16(ah, qh[0][ks], a0);
+                a1 = mfma16_bf16(ah, qh[1][ks], a1);
             }
-            sc[kb] = a;
+            sc[0][kb] = a0;
+            sc[1][kb] = a1;
         }
-        // ---- bias, mask, online softmax (row r of the lane = query 4 g + r; its 64 scores sit in this lane row's 16 lanes x 4 blocks) ----
-        float corr[4];
+        // ---- bias, mask, online softmax in base 2: everything of a query is in its lane column ----
+        s16x8 ph[2][2], pl[2][2];
+        // (BIAS and the ragged last tile are compile-time / loop-versioned: as per-element conditions they became 32 basic blocks,
+        // each one LDS read waited for on its own)
+        auto soft = [&](auto ragged_c) {
+            constexpr bool RAGGED = decltype(ragged_c)::value;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float mx = -INFINITY;
+            for (int j = 0; j < 2; ++j) {
+                float bias[16];
+                if (BIAS) {
+                    const float* rbj = rb + rbase[j] + s0;
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const int s = s0 + 16 * kb + i16;
-                float v = sc[kb][r];
-                if (relb && s < T) v = fmaf(gate4[r], rb[s - trow[r] + T - 1], v);
-                v = s < T ? v : -INFINITY;
-                sc[kb][r] = v;
-                mx = fmaxf(mx, v);
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bias[4 * kb + r] = rbj[16 * kb + r];
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = sc[j][kb][r];
+                        if (BIAS) v = fmaf(gate[j], bias[4 * kb + r], v);
+                        if (RAGGED) v = (s0 + 16 * kb + 4 * g + r) < T ? v : -INFINITY;
+                        sc[j][kb][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mn = fmaxf(m2[j], mx);
+                const float corr = atm_exp2(m2[j] - mn);               // m = -inf on the first tile: exp2(-inf) = 0
+                float ls = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = atm_exp2(sc[j][kb][r] - mn);
+                        sc[j][kb][r] = e;
+                        ls += e;
+                    }
+                ls += __shfl_xor(ls, 16);
+                ls += __shfl_xor(ls, 32);
+                l2[j] = l2[j] * corr + ls;
+                m2[j] = mn;
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[j][db][r] *= corr;
+                // P^T fragments: slot e of K-half ks = sc[2 ks + (e >> 2)][e & 3]
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    uint4 hq, lq;
+                    bf16_split2(sc[j][2 * ks][0], sc[j][2 * ks][1], hq.x, lq.x);
+                    bf16_split2(sc[j][2 * ks][2], sc[j][2 * ks][3], hq.y, lq.y);
+                    bf16_split2(sc[j][2 * ks + 1][0], sc[j][2 * ks + 1][1], hq.z, lq.z);
+                    bf16_split2(sc[j][2 * ks + 1][2], sc[j][2 * ks + 1][3], hq.w, lq.w);
+                    ph[j][ks] = __builtin_bit_cast(s16x8, hq);
+                    pl[j][ks] = __builtin_bit_cast(s16x8, lq);
+                }
             }
-            mx = sed_row16_max(mx);
-            const float mn = fmaxf(m4[r], mx);
-            corr[r] = expf(m4[r] - mn);                                // m = -inf on the first tile: exp(-inf) = 0
-            float ls = 0.f;
+        };
+        if (s0 + 64 > T) soft(std::true_type{}); else soft(std::false_type{});
+        // ---- O^T += V^T P^T ----
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const float e = expf(sc[kb][r] - mn);
-                sc[kb][r] = e;
-                ls += e;
-            }
-            ls = sed_row16_sum(ls);
-            l4[r] = l4[r] * corr[r] + ls;
-            m4[r] = mn;
-        }
-        // ---- P: accumulator layout -> [q][key] hi / lo planes of this wave ----
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                unsigned short hh, ll;
-                bf16_split(sc[kb][r], hh, ll);
-                ph[(4 * g + r) * ATM_P + 16 * kb + i16] = hh;
-                pl[(4 * g + r) * ATM_P + 16 * kb + i16] = ll;
-            }
-        sed_wave_sync();
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[db][r] *= corr[r];
-        // ---- O += P V ----
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const unsigned short* ap = ph + i16 * ATM_P + 32 * ks + 8 * g;
-            const s16x8 ah = *(const s16x8*)ap, al = *(const s16x8*)(ap + 16 * ATM_P);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const unsigned short* bp = vh + (16 * db + i16) * ATM_P + 32 * ks + 8 * g;
-                const s16x8 bh = *(const s16x8*)bp, bl = *(const s16x8*)(bp + 64 * ATM_P);
-                o[db] = mfma16_bf16(al, bh, o[db]);
-                o[db] = mfma16_bf16(ah, bl, o[db]);
-                o[db] = mfma16_bf16(ah, bh, o[db]);
+                const unsigned short* ap = vh + (16 * db + i16) * ATM_P + 32 * ks + 8 * g;
+                const s16x8 ah = *(const s16x8*)ap, al = *(const s16x8*)(ap + 64 * ATM_P);
+                o[0][db] = mfma16_bf16(al, ph[0][ks], o[0][db]);
+                o[1][db] = mfma16_bf16(al, ph[1][ks], o[1][db]);
+                o[0][db] = mfma16_bf16(ah, pl[0][ks], o[0][db]);
+                o[1][db] = mfma16_bf16(ah, pl[1][ks], o[1][db]);
+                o[0][db] = mfma16_bf16(ah, ph[0][ks], o[0][db]);
+                o[1][db] = mfma16_bf16(ah, ph[1][ks], o[1][db]);
             }
-        }
-        sed_wave_sync();                                               // P planes free for the next tile
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int t = q0 + 16 * w + 4 * g + r;
-        if (t < T) {
-            const float inv = 1.0f / l4[r];
-            float* dst = out + ((size_t)b * T + t) * D + h * AT_HD + i16;
+    for (int j = 0; j < 2; ++j)
+        if (tq[j] < T) {
+            const float inv = 1.0f / l2[j];
+            float* dst = out + ((size_t)b * T + tq[j]) * D + h * AT_HD + 4 * g;
 #pragma unroll
-            for (int db = 0; db < 4; ++db) dst[16 * db] = o[db][r] * inv;
+            for (int db = 0; db < 4; ++db)
+                *(float4*)(dst + 16 * db) = make_float4(o[j][db][0] * inv, o[j][db][1] * inv, o[j][db][2] * inv, o[j][db][3] * inv);
         }
-    }
 }
 SED_API int sed_attention_relpos(const float* qkv, const float* relb, const float* grep_w, const float* grep_b,
                                     const float* grep_a, float* out, int B, int T, int H, int head_dim, void* stream) {
     if (head_dim != AT_HD || T > 4096) return SED_ERR_UNSUPPORTED;
     if (B <= 0 || T <= 0) return SED_OK;
     if (sed_tuning[SED_TUNE_ATTN_VALU] == 0) {          // default: the matrix-core kernel
-        const int smem_m = (4 * 64 * ATM_P + 4 * 2 * 16 * ATM_P) * 2 + (64 + 2 * T) * 4;
-        SED_MAX_SMEM(attention_mfma_kernel, smem_m);
-        SED_LAUNCH(attention_mfma_kernel, dim3((T + 63) / 64, H, B), dim3(256), smem_m, (hipStream_t)stream, qkv, relb, grep_w, grep_b,
-                   grep_a, out, T, H, 1.0f / sqrtf((float)head_dim));
+        const int smem_m = 4 * 64 * ATM_P * 2 + (64 + 2 * T) * 4;
+        const int nwg = ((T + ATM_QG - 1) / ATM_QG) * ((H * B + 7) / 8) * 8;
+        if (relb) {
+            SED_MAX_SMEM(attention_mfma_kernel<true>, smem_m);
+            SED_LAUNCH(attention_mfma_kernel<true>, dim3(nwg), dim3(256), smem_m, (hipStream_t)stream, qkv, relb,
+                       grep_w, grep_b, grep_a, out, T, H, H * B, 1.0f / sqrtf((float)head_dim));
+        } else {
+            SED_MAX_SMEM(attention_mfma_kernel<false>, smem_m);
+            SED_LAUNCH(attention_mfma_kernel<false>, dim3(nwg), dim3(256), smem_m, (hipStream_t)stream, qkv, relb,
+                       grep_w, grep_b, grep_a, out, T, H, H * B, 1.0f / sqrtf((float)head_dim));
+        }
         return sed_check_launch();
     }
     const int smem = (3 * AT_TQ * AT_P + 2 * T) * 4;
