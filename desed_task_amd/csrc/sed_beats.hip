@@ -264,14 +264,31 @@ __global__ __launch_bounds__(256) void posconv_mfma_kernel(const float* __restri
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const size_t plane = (size_t)G * K * PC_CG * PC_CG;                         // elements per hi / lo plane of the weights
+    // The next chunk's weights travel HBM -> registers under this chunk's MFMAs (round 5; they used to be copied global -> LDS between
+    // the two barriers, one exposed memory latency per 54 MFMAs: wait_any 0.68, profiles/r05i_pmc_beats_wait.md)
+    // (nine named registers: as an array the compiler kept them in scratch memory -- loads waited for one by one)
+    static_assert(2 * (PCM_KC * PC_CG * PC_CG / 8) == 9 * 256, "nine 16-byte pieces per thread and chunk");
+#define PCM_EACH(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#define PCM_DECL(q)                                                                                                          \
+    uint4 w##q;                                                                                                              \
+    const int wp##q = (tid + 256 * q) / (WPL / 8), we##q = (tid + 256 * q) - wp##q * (WPL / 8);                              \
+    const unsigned short* const ws##q = wsplit + (size_t)grp * K * PC_CG * PC_CG + wp##q * plane + 8 * (size_t)we##q;        \
+    unsigned short* const wd##q = wh + wp##q * WPL + 8 * we##q;
+    PCM_EACH(PCM_DECL)
+#define PCM_LOAD(q) w##q = *(const uint4*)(ws##q + koff);
+#define PCM_PARK(q) *(uint4*)wd##q = w##q;
+    {
+        const size_t koff = 0;
+        PCM_EACH(PCM_LOAD)
+    }
     for (int k0 = 0; k0 < K; k0 += PCM_KC) {
         __syncthreads();                                                         // previous chunk consumed (first pass: x staged)
-        const uint4* src = (const uint4*)(wsplit + ((size_t)grp * K + k0) * PC_CG * PC_CG);
-        for (int i = tid; i < 2 * (WPL / 8); i += 256) {
-            const int p = i / (WPL / 8), e = i - p * (WPL / 8);
-            *((uint4*)(wh + p * WPL) + e) = *(const uint4*)((const unsigned short*)src + p * plane + 8 * (size_t)e);
-        }
+        PCM_EACH(PCM_PARK)
         __syncthreads();
+        if (k0 + PCM_KC < K) {
+            const size_t koff = (size_t)(k0 + PCM_KC) * PC_CG * PC_CG;
+            PCM_EACH(PCM_LOAD)
+        }
 #pragma unroll
         for (int ks = 0; ks < PCM_KC * PC_CG / 32; ++ks) {                       // 6 k-steps of 32 = 4 octets of (tap, 8 channels)
             const int o = 4 * ks + g, tapl = o / (PC_CG / 8), c8 = o - tapl * (PC_CG / 8);
