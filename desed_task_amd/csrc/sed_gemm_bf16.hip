@@ -29,12 +29,19 @@ template <int ROWS, bool KC>
 struct OperandTile {
     static constexpr int NV = ROWS * GB_BK / 4 / 256;
     float4 r[NV];
+    // k-contiguous staging: eight lanes cover the 32 k of a row; the two rows of a 16-lane ds_write_b64 group are r and r + 4, whose
+    // 64-byte pieces sit 320 B = 16 banks (mod 32) apart -- with rows r and r + 1 (80 B apart) four banks of every store were hit
+    // twice (lds_conflict 0.31 of the LDS cycles, profiles/r05i_pmc_beats_wait.md)
+    static __device__ __forceinline__ int kc_row(int i) {
+        const int grp = i >> 4;
+        return ((grp >> 2) << 3) + (grp & 3) + ((i >> 1) & 4);
+    }
     __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int nrows, int k0, int kend, int tid) {
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (KC) {
-                const int i = tid + 256 * u, row = i / (GB_BK / 4), kq = i % (GB_BK / 4);
+                const int i = tid + 256 * u, row = kc_row(i), kq = i & 7;
                 const int gr = row0 + row, gk = k0 + 4 * kq;
                 if (gr < nrows && gk < kend) r[u] = *(const float4*)(base + (size_t)gr * ld + gk);
             } else {
@@ -50,7 +57,7 @@ struct OperandTile {
         if (KC) {
 #pragma unroll
             for (int u = 0; u < NV; ++u) {
-                const int i = tid + 256 * u, row = i / (GB_BK / 4), kq = i % (GB_BK / 4);
+                const int i = tid + 256 * u, row = kc_row(i), kq = i & 7;
                 uint2 h, l;
                 split4(r[u], h, l);
                 *(uint2*)(hi_plane + row * GB_RS + 4 * kq) = h;
@@ -321,7 +328,8 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(const float* __restr
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x16_zero();
         // B tile copy: 2 planes x 128 rows x 64 B = 1024 sixteen-byte chunks, 4 per thread: chunk c = tid + 256 u ->
         // plane c >> 9, row (c >> 2) & 127, 16-byte piece c & 3 of the row's 64 bytes
-        const int brow = (tid >> 2) & 63, bq = tid & 3;          // u = 0..3: plane = u >> 1, row = brow + 64 (u & 1)
+        // (the two rows of an 8-lane ds_write_b128 group are r and r + 4: 320 B apart = 16 banks mod 32, see OperandTile::kc_row)
+        const int brow = (((tid >> 3) >> 2) << 3) + ((tid >> 3) & 3) + (tid & 4), bq = tid & 3;     // u = 0..3: plane = u >> 1, row = brow + 64 (u & 1)
         const unsigned short* bsrc = Wp + ((size_t)(n0 + brow)) * K + 8 * bq;
         const size_t bplane = (size_t)N * K, brow64 = (size_t)64 * K;
         const int bdst = brow * LB_RS + 8 * bq;
