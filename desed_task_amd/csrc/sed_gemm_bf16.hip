@@ -94,13 +94,25 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x3_kernel(const float* __rest
                                                           int lda, int ldb, int ldc, int k_per_slice, int atomic,
                                                           const float* __restrict__ A1, const float* __restrict__ B1,
                                                           const float* __restrict__ bias1, float* __restrict__ C1, int nbatch,
-                                                          const float* __restrict__ Bsw, int ksw, int act, float* __restrict__ part) {
+                                                          const float* __restrict__ Bsw, int ksw, int act, float* __restrict__ part,
+                                                          int walk_nt) {
     // Bsw != null: K-concatenated B -- rows k >= ksw come from Bsw (already offset by -ksw rows); ksw % 32 == 0
     constexpr int BM = GB_BM, BN = 32 * NTN, BK = GB_BK, RS = GB_RS;
     __shared__ __attribute__((aligned(16))) unsigned short As[2 * BM * RS];     // hi plane, lo plane
     __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * BN * RS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lo = lane & 31, hi = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // walk_nt > 0 (the BEATs linears: one problem, no K slices, 1-D grid): XCD-aware tile walk.  Workgroup g runs on XCD g & 7; with
+    // the N tile as the fastest grid index the walk_nt workgroups that share a 128-row panel of A sat on as many XCDs, each L2 fetched
+    // the panel for itself (FC2: 6 x 292 MB per launch -- the launch ran at HBM speed, not at the matrix pipe's).  Now XCD x takes the
+    // panels x, x + 8, ... and its consecutive workgroups sweep one panel's N tiles.
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    if (walk_nt > 0) {
+        const int ml = blockIdx.x >> 3;
+        tile_m = (blockIdx.x & 7) + 8 * (ml / walk_nt);
+        tile_n = ml % walk_nt;
+        if (tile_m * BM >= M) return;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int zb = nbatch == 2 ? (blockIdx.z & 1) : 0, zs = nbatch == 2 ? (blockIdx.z >> 1) : blockIdx.z;
     if (zb) { A = A1; Bm = B1; bias = bias1; Cm = C1; }          // second problem of a batch of two
     if (part) { Cm = part + (size_t)blockIdx.z * M * N; ldc = N; }  // split-K slices as dense [z][M][N] partials (plain stores), summed
@@ -166,7 +178,7 @@ SED_API int sed_gemm_pair(const float* A0, const float* A1, const float* B0, con
 static int gemmb_dispatch(const float* A, const float* Bm, const float* bias, float* Cm, const float* A1, const float* B1,
                           const float* bias1, float* C1, int nbatch, int M, int N, int K, int lda, int ldb, int ldc, int transA,
                           int transB, int split_k, int accumulate, hipStream_t s, const float* Bsw = nullptr, int ksw = 0, int act = 0,
-                          float* part = nullptr) {
+                          float* part = nullptr, bool act_linear = false) {
     if (M <= 0 || N <= 0 || K <= 0) return SED_OK;
     bool ok = ((uintptr_t)A % 16 == 0) && ((uintptr_t)Bm % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 &&
               ((transA ? M : K) % 4 == 0) && ((transB ? K : N) % 4 == 0) && !(transA && transB);
@@ -182,10 +194,26 @@ static int gemmb_dispatch(const float* A, const float* Bm, const float* bias, fl
     const int atomic = (!part && (split_k > 1 || accumulate)) ? 1 : 0;
     int ntn = N > 64 ? 4 : 2;
     if (ntn == 4 && ((N + 127) / 128) * ((M + 127) / 128) * split_k * nbatch < 400) ntn = 2;     // too few workgroups for 512 resident slots
+    if (ntn == 4 && !transA && transB && N % 96 == 0) {
+        // more than one round of the 768 resident workgroups (3 per CU): take the tile width whose last round is fuller.  BEATs out-proj /
+        // FC2 (M = 23 808, N = 768): 1 116 tiles of 128 x 128 = 1.45 rounds, 1 488 of 128 x 96 = 1.94
+        const long long rows = (M + 127) / 128, z = (long long)split_k * nbatch, slots = 768;
+        const long long t4 = rows * ((N + 127) / 128) * z, t3 = rows * (N / 96) * z;
+        if (sed_tuning[SED_TUNE_GEMM_NTN] == 3) ntn = 3;              // (tests: the 128 x 96 tile at small sizes)
+        else if (t4 > slots) {
+            const double e4 = (double)t4 / (double)(((t4 + slots - 1) / slots) * slots), e3 = (double)t3 / (double)(((t3 + slots - 1) / slots) * slots);
+            if (e3 > e4 + 0.1) ntn = 3;
+        }
+    }
     dim3 grid((N + 32 * ntn - 1) / (32 * ntn), (M + 127) / 128, split_k * nbatch);
+    int walk_nt = 0;
+    if (act_linear && split_k * nbatch == 1 && grid.y >= 16) {        // (act_linear: the call came through sed_linear_bf16x3)
+        walk_nt = (int)grid.x;
+        grid = dim3(grid.x * ((grid.y + 7) / 8) * 8, 1, 1);
+    }
 #define GEMMB_CASE(ta, tb, nn) \
-    if (transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_bf16x3_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic, A1, B1, bias1, C1, nbatch, Bsw, ksw, act, part); return sed_check_launch(); }
-    GEMMB_CASE(0, 0, 2) GEMMB_CASE(0, 0, 4) GEMMB_CASE(0, 1, 2) GEMMB_CASE(0, 1, 4) GEMMB_CASE(1, 0, 2) GEMMB_CASE(1, 0, 4)
+    if (transA == ta && transB == tb && ntn == nn) { SED_LAUNCH((gemm_bf16x3_kernel<ta, tb, nn>), grid, dim3(256), 0, s, A, Bm, bias, Cm, M, N, K, lda, ldb, ldc, kps, atomic, A1, B1, bias1, C1, nbatch, Bsw, ksw, act, part, walk_nt); return sed_check_launch(); }
+    GEMMB_CASE(0, 0, 2) GEMMB_CASE(0, 0, 4) GEMMB_CASE(0, 1, 2) GEMMB_CASE(0, 1, 3) GEMMB_CASE(0, 1, 4) GEMMB_CASE(1, 0, 2) GEMMB_CASE(1, 0, 4)
 #undef GEMMB_CASE
     return SED_ERR_UNSUPPORTED;
 }
@@ -448,5 +476,5 @@ SED_API int sed_linear_bf16x3(const float* A, const float* W, const float* bias,
                                  void* stream) {
     if (act < 0 || act > 1) return SED_ERR_ARG;
     return gemmb_dispatch(A, W, bias, Cm, nullptr, nullptr, nullptr, nullptr, 1, M, N, K, K, K, N, 0, 1, 1, 0, (hipStream_t)stream,
-                          nullptr, 0, act);
+                          nullptr, 0, act, nullptr, true);
 }

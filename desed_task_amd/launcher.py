@@ -241,11 +241,13 @@ class StepDriver:
     def backward_joined(self, loss):
         """loss.backward() with the BiGRU weight-gradient GEMMs on the side stream (ops.GRU_DW_SIDE), joined before returning."""
         prev, _ops.GRU_DW_SIDE = _ops.GRU_DW_SIDE, self.gru_dw_side and _ops.GRU_DW_SIDE_ALLOWED
+        prev_c, _ops.CNN_DW_SIDE_NOW = _ops.CNN_DW_SIDE_NOW, not self.exchange
         del _ops._deferred[:]               # (nothing may be left over from a backward pass that raised)
         try:
             torch.autograd.backward(loss, _ops.unit_grad(loss.device))       # = loss.backward() without the ones_like fill
         finally:
             _ops.GRU_DW_SIDE = prev
+            _ops.CNN_DW_SIDE_NOW = prev_c
         _ops.join_side_stream(loss.device)  # also launches what ops.defer_off_chain() still holds
 
     def launch_bucket_a(self):

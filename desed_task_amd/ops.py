@@ -29,6 +29,8 @@ GRU_DW_SIDE_ALLOWED = True       # bench.py --no-gru-dw-side (A/B)
 # Round 5: the weight-gradient GEMMs of CNN blocks 1-6 take the same way out (they were ~390 us of a backward chain that ran one kernel
 # at a time).  Needs the side stream, i.e. only acts while GRU_DW_SIDE is on; bench.py --no-cnn-dw-side / SED_CNN_DW_SIDE=0 (A/B).
 CNN_DW_SIDE = os.environ.get("SED_CNN_DW_SIDE", "1") != "0"
+CNN_DW_SIDE_NOW = True           # set by the step driver around its backward(): off under a gradient exchange (the buckets of an overlapped
+                                 # all-reduce are issued from inside the backward pass; nothing there waits for the side stream)
 CNN_DW_LANE = int(os.environ.get("SED_CNN_DW_LANE", "0"))      # 0: behind the BiGRU's sections; 1: a side stream of their own (A/B)
 CNN_DW_SIDE_F = {int(f) for f in os.environ.get("SED_CNN_DW_SIDE_F", "2,4,8,16,32,64").split(",") if f}   # which blocks, by their F
 _side = {}
@@ -447,7 +449,7 @@ class ConvBlockFn(torch.autograd.Function):
 
             def wgrad(stream_ptr):
                 lib.call("sed_conv_wgrad_bf16x3", x.data_ptr(), dy.data_ptr(), scratch.data_ptr(), d_w_ptr, B, T, F, CIN, COUT, stream_ptr)
-            if CNN_DW_SIDE and F in CNN_DW_SIDE_F and _arena_views(cfg, d_w):
+            if CNN_DW_SIDE and CNN_DW_SIDE_NOW and F in CNN_DW_SIDE_F and _arena_views(cfg, d_w):
                 # the chain goes on with the block below (its GLU backward reads dx); dW only feeds the optimizer.  Parked until that
                 # block's first kernel is enqueued, then launched on the side stream beside it (block 1's goes out beside block 0's
                 # backward, which had the end of the step to itself)

@@ -532,6 +532,27 @@ def case_gemm(dev, entry="sed_gemm"):
         assert err < 1e-4 * max(1.0, ref.abs().max().item()), (kcat, M, N, K, err)
 
 
+def case_linear_n96_tile(dev, shapes=((300, 192, 64, 0), (513, 96, 96, 1), (130, 768, 32, 0))):
+    """sed_linear_bf16x3 through the 128 x 96 tile of the split-bf16 GEMM (picked on its own for BEATs' N = 768 layers at M = 23 808,
+    where 128 x 128 tiles leave the second round of resident workgroups half empty; forced here with the tuning key) vs float64."""
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(12)
+    _lib.set_tuning("gemm_ntn", 3)
+    try:
+        for (M, N, K, act) in shapes:
+            A, W, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+            ref = A.double() @ W.double().t() + bias.double()
+            if act:
+                ref = torch.nn.functional.gelu(ref)
+            Ad, Wd, bd = to(dev, A, W, bias)
+            C = torch.full((M, N), 7.0, device=Ad.device)
+            lib.call("sed_linear_bf16x3", Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), C.data_ptr(), M, N, K, act, _lib.stream_ptr(Ad))
+            err = (C.cpu().double() - ref).abs().max().item()
+            assert err < 3e-5 * max(1.0, ref.abs().max().item()), (M, N, K, act, err)
+    finally:
+        _lib.set_tuning("gemm_ntn", 0)
+
+
 def case_linear_packed(dev, shapes=((300, 128, 64, 0), (513, 256, 96, 1), (256, 128, 32, 1))):
     """sed_pack_weights_bf16x3 + sed_linear_packed_bf16x3 (the BEATs encoder's large Linear layers: frozen weight split into bf16
     hi / lo planes once, 256 x 128 tiles, A fragments straight from HBM, optional exact-GELU epilogue) vs float64: ragged M (rows

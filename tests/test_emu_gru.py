@@ -13,6 +13,11 @@ def test_linear_packed(emu):
     P.case_linear_packed("cpu", shapes=((300, 128, 64, 0), (257, 256, 32, 1)))
 
 
+def test_linear_n96_tile(emu):
+    """The 128 x 96 tile of the split-bf16 GEMM (BEATs N = 768 layers)."""
+    P.case_linear_n96_tile("cpu", shapes=((300, 192, 64, 0), (130, 96, 96, 1), (2100, 192, 32, 0)))     # last: 17 row panels -> the XCD-aware walk
+
+
 def test_bigru_layer0(emu):
     P.case_bigru("cpu", B=2, T=7, I=128)
 

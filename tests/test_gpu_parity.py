@@ -87,6 +87,12 @@ def test_linear_packed():
     P.case_linear_packed("cuda", shapes=((1000, 768, 3072, 0), (700, 3072, 768, 1)))
 
 
+def test_linear_n96_tile():
+    """The 128 x 96 tile of the split-bf16 GEMM, forced at small sizes and picked by the dispatch at BEATs' out-proj / FC2 shapes."""
+    P.case_linear_n96_tile("cuda")
+    P.case_linear_n96_tile("cuda", shapes=((23808, 768, 768, 0),))
+
+
 def test_bigru_production_shape():
     P.case_bigru("cuda", B=4, T=156, I=128, tol=5e-5)
     P.case_bigru("cuda", B=3, T=156, I=256, tol=5e-5)
