@@ -152,12 +152,7 @@ class StepDriver:
         self.arena = getattr(task.sed_student, "arena", None)
         dev = next(task.sed_student.parameters()).device
         self.side = torch.cuda.Stream(device=dev) if (ema_side_stream and dev.type == "cuda") else None
-        # see ops.GRU_DW_SIDE: on only inside this driver's backward(), and only without a process group: with two gloo ranks on one
-        # GPU (the only multi-rank configuration that can be run here) the side-stream launches made a step 20 x slower (206 vs
-        # 10 ms), unexplained -- under data parallelism the GEMMs stay on the compute stream until that is understood on RCCL
-        # (SED_GRU_DW_SIDE=1 / bench.py --gru-dw-side turns it on at world > 1 for exactly that A/B on a real node)
-        self.gru_dw_side = (bool(gru_dw_side) and (dev.type == "cuda" or _ops.SIDE_ON_CPU)
-                            and (not self.exchange or os.environ.get("SED_GRU_DW_SIDE") == "1"))
+        self._gru_dw_side_arg = bool(gru_dw_side)
         if hasattr(self.opt, "grad_scale"):
             self.opt.grad_scale = 1.0 / world_size
         if overlap_allreduce is None:
@@ -169,6 +164,19 @@ class StepDriver:
             env = os.environ.get("SED_DDP_OVERLAP")
             overlap_allreduce = (env != "0") if env is not None else getattr(task, "prefetch_level", "features") != "teacher"
         self.overlap = bool(overlap_allreduce) and self.exchange and self.arena is not None
+        # see ops.GRU_DW_SIDE / CNN_DW_SIDE: the weight-gradient GEMMs beside the backward chain, on only inside this driver's backward().
+        # Under a gradient exchange (round 5): on when the gradients go out as ONE all-reduce after backward_joined() has joined the side
+        # stream (the default of the pipelined step), over RCCL -- one-rank rehearsal 3.05 vs 3.22 ms, strict-equal to the plain step;
+        # off with the bucketed overlap (bucket A is issued from inside the backward pass: a side section would still be running --
+        # the rehearsal test fails with it) and over gloo (two ranks sharing ONE GPU, the only multi-rank configuration this container
+        # can run, went 20 x slower with the side-stream launches, unexplained).  SED_GRU_DW_SIDE=1 / 0 forces it (A/B on a real node).
+        env_side = os.environ.get("SED_GRU_DW_SIDE")
+        side_ok = not self.exchange
+        if self.exchange and not self.overlap and dist.is_initialized():
+            side_ok = dist.get_backend() == "nccl"
+        if env_side is not None and self.exchange:
+            side_ok = env_side == "1"
+        self.gru_dw_side = self._gru_dw_side_arg and (dev.type == "cuda" or _ops.SIDE_ON_CPU) and side_ok
         self.bucket_log = []            # [(tag, first float, number of floats)] of the collectives of the last step (tests)
         self._work_a = None
         self.probe = None               # an ExchangeProbe while bench.py times the tail of the step
@@ -241,7 +249,7 @@ class StepDriver:
     def backward_joined(self, loss):
         """loss.backward() with the BiGRU weight-gradient GEMMs on the side stream (ops.GRU_DW_SIDE), joined before returning."""
         prev, _ops.GRU_DW_SIDE = _ops.GRU_DW_SIDE, self.gru_dw_side and _ops.GRU_DW_SIDE_ALLOWED
-        prev_c, _ops.CNN_DW_SIDE_NOW = _ops.CNN_DW_SIDE_NOW, not self.exchange
+        prev_c, _ops.CNN_DW_SIDE_NOW = _ops.CNN_DW_SIDE_NOW, not (self.exchange and self.overlap)     # (bucket A goes out from inside backward)
         del _ops._deferred[:]               # (nothing may be left over from a backward pass that raised)
         try:
             torch.autograd.backward(loss, _ops.unit_grad(loss.device))       # = loss.backward() without the ones_like fill
