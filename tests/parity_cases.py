@@ -72,6 +72,24 @@ def case_mel(dev, batch=2, n_samples=256 * 12):
     return got
 
 
+def case_mel_walk_batch_independent(dev, batch=48, n_samples=160000, probe=(0, 7, 8, 23, 47)):
+    """Size-independent property of the XCD-aware frame walk at the BASELINE batch: every frame of every clip is produced exactly once
+    and does not depend on which workgroup / XCD / segment it fell to -- the batched launch (one segment per clip when 8 | B) equals,
+    bit for bit, the launches of single clips (eight segments per clip) and of a 12-clip batch (two segments per clip)."""
+    g = torch.Generator().manual_seed(5)
+    audio = to(dev, 0.1 * torch.randn(batch, n_samples, generator=g))
+    mel = make_mel()
+    out = torch.full((batch, mel.n_mels, 1 + n_samples // 256), float("nan"), device=audio.device)
+    whole = mel(audio)
+    assert tuple(whole.shape) == tuple(out.shape) and bool(torch.isfinite(whole).all())
+    for i in probe:
+        if i < batch:
+            assert torch.equal(mel(audio[i:i + 1])[0], whole[i]), i
+    if batch >= 12:
+        assert torch.equal(mel(audio[:12]), whole[:12])
+    return whole
+
+
 def case_mel_in_graph_beside_tails(dev, replays=300, beside="tails"):
     """The wave-per-frame mel kernel as a hipGraph node on a side stream beside the student's and the teacher's BiGRU + head tails (the
     "tails" fork of the pipelined step), replayed `replays` times on changing waveforms: every output bit-equal to the solo launch.

@@ -14,6 +14,10 @@ def test_mel_matches_oracle(emu):
     P.case_mel("cpu", batch=9, n_samples=256 * 5 + 17)          # 9 clips in 8 segments each
 
 
+def test_mel_walk_batch_independent(emu):
+    P.case_mel_walk_batch_independent("cpu", batch=13, n_samples=256 * 9 + 40, probe=(0, 5, 12))
+
+
 def test_mel_wave_kernel_matches_oracle(emu):
     """The round-5 wave-per-frame kernel (`sed_mel_fwd_wave`, opt-in)."""
     from desed_task_amd import _lib

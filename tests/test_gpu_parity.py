@@ -29,6 +29,10 @@ def test_mel_small():
     P.case_mel("cuda", batch=5, n_samples=256 * 40 + 100)      # a batch that is no multiple of the XCD count, a ragged clip length
 
 
+def test_mel_walk_batch_independent_at_baseline_size():
+    P.case_mel_walk_batch_independent("cuda")
+
+
 def test_mel_in_graph_beside_tails():
     """The (default) mel kernel replayed as a hipGraph node next to the BiGRU tails gives the solo launch's bits, 300 replays.  (The
     round-5 wave-per-frame kernel does NOT pass this reliably -- which is why it is opt-in; tools/mel_graph_race.py wave.)"""
