@@ -31,10 +31,9 @@ GRU_DW_SIDE_ALLOWED = True       # bench.py --no-gru-dw-side (A/B)
 CNN_DW_SIDE = os.environ.get("SED_CNN_DW_SIDE", "1") != "0"
 CNN_DW_SIDE_NOW = True           # set by the step driver around its backward(): off under a gradient exchange (the buckets of an overlapped
                                  # all-reduce are issued from inside the backward pass; nothing there waits for the side stream)
-CNN_DW_LANE = int(os.environ.get("SED_CNN_DW_LANE", "0"))      # 0: behind the BiGRU's sections; 1: a side stream of their own (A/B)
-CNN_DW_SIDE_F = {int(f) for f in os.environ.get("SED_CNN_DW_SIDE_F", "2,4,8,16,32,64").split(",") if f}   # which blocks, by their F
+# (Measured and removed again: a side stream of their own -- a replayed graph ran the two lanes one after the other, 3.17 vs 3.04 ms --
+#  and deferring only some of the six blocks: all six was best.  DESIGN.md 12.6.)
 _side = {}
-_lane_used = set()
 
 
 
@@ -49,28 +48,22 @@ def probe(tag):
         PROBE(tag)
 
 
-def side_stream(device, lane=0):
-    """Lane 0: the BiGRU weight-gradient sections and the small parked reductions; lane 1 (round 5): the CNN weight gradients -- on one
-    stream the two families ran one after the other and ended 170 us after the chain."""
+def side_stream(device):
     if device.type != "cuda":
         return None
-    key = (device.type, device.index, lane)
+    key = (device.type, device.index)
     if key not in _side:
         _side[key] = torch.cuda.Stream(device=device)
     return _side[key]
 
 
 def join_side_stream(device):
-    """The current stream waits for the weight-gradient GEMMs launched on the side streams (no-op if there were none)."""
-    s = _side.get((device.type, device.index, 0))
+    """The current stream waits for the weight-gradient GEMMs launched on the side stream (no-op if there were none)."""
+    s = _side.get((device.type, device.index))
     if _deferred:
         flush_deferred(s)
     if s is not None:
         torch.cuda.current_stream(device).wait_stream(s)
-    key1 = (device.type, device.index, 1)
-    if key1 in _lane_used:
-        _lane_used.discard(key1)
-        torch.cuda.current_stream(device).wait_stream(_side[key1])
 
 
 # Small reductions whose results only the optimizer reads (the head's weight gradients, the BiGRU bias gradients: 9 - 19 us each between
@@ -106,36 +99,31 @@ SIDE_ON_CPU = False              # TEST HOOK (tests/test_emu_step.py): run the P
                                  # where there are no streams -- parked launches then go out at the flush points, in place
 
 
-def defer_off_chain(device, launch, keep, lane=0):
-    """launch(stream_ptr) now, or -- while the side stream is in use (GRU_DW_SIDE) -- later on that stream (`lane`: see side_stream).
-    `keep`: the scratch tensors the launch reads (held until then, and marked as used by the side stream).  Gradient OUTPUTS must be
-    passed to `launch` as addresses: they are returned to autograd, which only adopts a tensor nobody else references."""
+def defer_off_chain(device, launch, keep):
+    """launch(stream_ptr) now, or -- while the side stream is in use (GRU_DW_SIDE) -- later on that stream.  `keep`: the scratch tensors
+    the launch reads (held until then, and marked as used by the side stream).  Gradient OUTPUTS must be passed to `launch` as
+    addresses: they are returned to autograd, which only adopts a tensor nobody else references."""
     if GRU_DW_SIDE and DEFER_OFF_CHAIN and (device.type == "cuda" or SIDE_ON_CPU):
         fork = None
         if device.type == "cuda":
             fork = torch.cuda.Event()
             fork.record(torch.cuda.current_stream(device))     # the side stream forks HERE, whenever the launch is enqueued
-        _deferred.append((launch, keep, fork, lane))
+        _deferred.append((launch, keep, fork))
     else:
         launch(_lib.stream_ptr(keep[0]))
 
 
 def flush_deferred(side):
-    """Launch what defer_off_chain() parked: on `side` (lane 0) or its sibling (lane 1), each behind the point of the chain where it
-    was parked -- or on the current stream (side = None)."""
+    """Launch what defer_off_chain() parked: on `side`, each behind the point of the chain where it was parked -- or on the current
+    stream (side = None)."""
     todo, _deferred[:] = list(_deferred), []
-    for launch, keep, fork, lane in todo:
+    for launch, keep, fork in todo:
         if side is not None:
-            s = side
-            if lane:
-                dev = keep[0].device
-                s = side_stream(dev, lane)
-                _lane_used.add((dev.type, dev.index, lane))
-            s.wait_event(fork)
+            side.wait_event(fork)
             for t in keep:
-                t.record_stream(s)
-            with torch.cuda.stream(s):
-                launch(s.cuda_stream)
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                launch(side.cuda_stream)
         else:
             launch(_lib.stream_ptr(keep[0]))
 
@@ -449,11 +437,11 @@ class ConvBlockFn(torch.autograd.Function):
 
             def wgrad(stream_ptr):
                 lib.call("sed_conv_wgrad_bf16x3", x.data_ptr(), dy.data_ptr(), scratch.data_ptr(), d_w_ptr, B, T, F, CIN, COUT, stream_ptr)
-            if CNN_DW_SIDE and CNN_DW_SIDE_NOW and F in CNN_DW_SIDE_F and _arena_views(cfg, d_w):
+            if CNN_DW_SIDE and CNN_DW_SIDE_NOW and _arena_views(cfg, d_w):
                 # the chain goes on with the block below (its GLU backward reads dx); dW only feeds the optimizer.  Parked until that
                 # block's first kernel is enqueued, then launched on the side stream beside it (block 1's goes out beside block 0's
                 # backward, which had the end of the step to itself)
-                defer_off_chain(dev, wgrad, (x, dy, scratch), lane=CNN_DW_LANE)
+                defer_off_chain(dev, wgrad, (x, dy, scratch))
             else:
                 wgrad(st)
             return dx, d_w, d_bias, d_gamma, d_beta, d_glu_w, d_glu_b, None, None, None
