@@ -217,6 +217,75 @@ def test_two_rank_multi_step_semantics(tmp_path):
     assert d["ok"] and d["steps"] == 3
 
 
+def _side_worker(rank, world, port, out_dir):
+    """Two ranks, the weight-gradient side sections ON under the exchange (round 5: the default over RCCL when the gradients leave as one
+    all-reduce; forced here with SED_GRU_DW_SIDE=1 and run through the emulator's parking logic, ops.SIDE_ON_CPU): every parked launch
+    -- BiGRU sections, head sums, CNN weight gradients -- must have gone out before the arena is handed to the collective, i.e. two
+    steps end in the same bits as with everything on the chain."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from tests.emu_support import bind_emulator
+    bind_emulator()
+    import random
+    from oracle import sed_oracle as O
+    from tests import parity_cases as P
+    from desed_task_amd import ops as _ops
+    from desed_task_amd.launcher import StepDriver, init_distributed
+    init_distributed(backend="gloo")
+    bs, n_samp = (1, 1, 1), 4096 + 1024
+    sd = O.make_state_dict(seed=7)
+    n_out = (1 + n_samp // 256) // 4
+    out = {}
+    for mode in ("chain", "side"):
+        if mode == "side":
+            os.environ["SED_GRU_DW_SIDE"] = "1"
+            _ops.SIDE_ON_CPU = True
+        else:
+            os.environ["SED_GRU_DW_SIDE"] = "0"
+            _ops.SIDE_ON_CPU = False
+        task = P.build_task("cpu", bs, sd, dropout=0.5, specaug=True, rampup=5)
+        driver = StepDriver(task, world_size=world, overlap_allreduce=False)
+        assert driver.exchange and not driver.overlap and driver.gru_dw_side == (mode == "side")
+        random.seed(4); np.random.seed(7 + rank); torch.manual_seed(7 + rank)
+        _ops.reseed_dropout()
+        parked = []
+        if mode == "side":
+            real = _ops.defer_off_chain
+
+            def spy(device, launch, keep):
+                parked.append(len(_ops._deferred))
+                return real(device, launch, keep)
+            _ops.defer_off_chain = spy
+        try:
+            for step in range(2):
+                audio = O.synth_audio(3, n_samp, seed=300 + 10 * step + rank)
+                labels = O.synth_labels(bs, 10, n_out, seed=40 + 10 * step + rank)
+                driver.run_step((audio, labels, None, None), step)
+                assert not _ops._deferred
+        finally:
+            if mode == "side":
+                _ops.defer_off_chain = real
+                _ops.SIDE_ON_CPU = False
+        out[mode] = task.sed_student.arena.flat.detach().clone()
+        out[mode + "_parked"] = len(parked)
+    flats = [torch.zeros_like(out["side"]) for _ in range(world)]
+    dist.all_gather(flats, out["side"])
+    if rank == 0:
+        torch.save(dict(equal=bool(torch.equal(out["chain"], out["side"])), ranks_equal=bool(torch.equal(flats[0], flats[1])),
+                        parked=out["side_parked"]), os.path.join(out_dir, "side.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_side_sections_under_exchange(tmp_path):
+    mp.spawn(_side_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    d = torch.load(os.path.join(str(tmp_path), "side.pt"))
+    assert d["parked"] >= 2 * (2 + 1 + 6), d          # per step: two BiGRU sections, the head's sums, six CNN weight gradients
+    assert d["equal"] and d["ranks_equal"], d
+
+
 def _rehearsal_worker(rank, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", SED_DDP_REHEARSE="1")
