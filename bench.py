@@ -9,7 +9,8 @@
 `torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one process per GPU, rank r -> device r, RCCL).
 The JSON line then carries a `dist` object: backend, world size, the gradient-bucket log of the last step, which graph scheme
 ran, and the per-rank step times.  A/B switches for a real node: --no-overlap (= SED_DDP_OVERLAP=0: one blocking all-reduce,
-one graph), --gru-dw-side (= SED_GRU_DW_SIDE=1: BiGRU weight-gradient GEMMs on the side stream also at world > 1), --no-graph.
+one graph), --gru-dw-side (= SED_GRU_DW_SIDE=1: force the BiGRU / CNN weight-gradient GEMMs beside the backward chain at world > 1;
+unset they are there over RCCL whenever the gradients leave as ONE all-reduce, SED_GRU_DW_SIDE=0 puts them back on the chain), --no-graph.
 `--dry-run` (no GPU needed): the same program on the CPU fiber emulator of the kernels over gloo, at toy sizes -- a plumbing
 check of the launch path only; its numbers mean nothing and the line says so.
 
@@ -445,8 +446,9 @@ def main():
                     help="A/B at N > 1: force the bucketed exchange (bucket A's asynchronous all-reduce under the CNN backward; with "
                          "--prefetch teacher that costs the one-graph structure); same as SED_DDP_OVERLAP=1")
     ap.add_argument("--gru-dw-side", action="store_true",
-                    help="A/B at N > 1: BiGRU weight-gradient GEMMs on the side stream as at N = 1 (default off at N > 1, see "
-                         "launcher.StepDriver); same as SED_GRU_DW_SIDE=1")
+                    help="A/B at N > 1: force the BiGRU / CNN weight-gradient GEMMs onto the side stream as at N = 1 (the default over RCCL "
+                         "with ONE all-reduce after backward; off with the bucketed overlap and over gloo, see launcher.StepDriver); same "
+                         "as SED_GRU_DW_SIDE=1")
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="N = 1 only: run the data-parallel step structure (graph split, bucketed RCCL all-reduces, eager Adam) on a "
                          "process group of ONE rank -- same bits as the plain step, times the exchange machinery without link time; "
