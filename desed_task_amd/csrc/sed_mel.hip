@@ -192,41 +192,32 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
 }
 
 
-// ---- round 5: one WAVE per frame --------------------------------------------------------------------------------------------------
-// The kernel above gives a frame to a 256-thread workgroup: five radix-4 passes, ten workgroup barriers per frame, and -- with a
-// grid-stride of 4 096 frames -- the eight frames that overlap a hop on eight different XCDs, so that every XCD's L2 fetched every clip
-// (rocprofv3 FETCH_SIZE: 262 MB for 46 MB of algorithmic traffic; 135 - 246 us, 2 - 4 % of the HBM roof).  Here a frame belongs to ONE
+// ---- rounds 5 / 6: one WAVE per frame, ONE frame per wave ------------------------------------------------------------------------------
+// mel_kernel above gives a frame to a 256-thread workgroup: five radix-4 passes, ten workgroup barriers per frame (141 - 150 us at
+// B = 48: wait_any 0.48, LDS conflict share 0.20 -- bound by its barrier-separated LDS passes, not by HBM).  Here a frame belongs to ONE
 // wave: the 1024-point packed transform is 16 x 16 x 4 -- lane l holds 16 complex values, does a radix-16 DFT in registers (two radix-4
 // stages), exchanges through a wave-private 8.5 KB LDS buffer, radix-16 again, exchanges, four radix-4 -- two exchanges instead of
-// four, and NO workgroup barrier in the frame loop: a wave's DS instructions execute in order, sed_wave_sync() only pins the compiler.
-// A workgroup (4 waves) walks runs of MEL_RUN consecutive frames of ONE clip, and the runs of a clip stay on one XCD (workgroup g is
-// dispatched to XCD g % 8; XCD x owns the clips c = x (mod 8)), so the 7/8 overlap of neighbouring frames is served by that XCD's L2 and
-// HBM sees every sample once.  LDS exchange layout (MI355X_MICROARCH.md, LDS: ds_write_b64 is banked per 16 contiguous lanes modulo
-// 16 slots of 8 B, ds_read_b64 per 32 lanes modulo 32): exchange 1 writes element 16 l + r at slot e + (e >> 4) (17 l + r: distinct
-// modulo 16 over 16 lanes) and reads l + 64 r there (contiguous; one 2-way pair); exchange 2 (writes 256 (l >> 4) + (l & 15) + 16 r,
-// reads l + 64 m + 256 r) and the conjugate-pair exchange of the real-FFT step are contiguous per lane group as they are.  All LDS
-// addresses are a per-lane base + an immediate.  Mel stage: lane l owns bands l and 127 - l (3 + 42 ... 13 + 13 taps: balanced), taps
-// in registers (MEL_WA + MEL_WB), magnitudes read from the wave's buffer; longer bands finish from memory (no recipe has any).
-// OPEN ISSUE (round 5): replayed as a hipGraph node while `gemm_bf16x3_kernel` (the BiGRU input projection) runs on another branch,
-// this kernel intermittently returns single frames with a handful of neighbouring bins k -- and their mirror bins 1024 - k -- wrong
-// (plausible magnitudes, not garbage), i.e. one register of a few neighbouring lanes between pass 3 and the real-FFT step; sometimes a
-// whole frame.  What is known (tools/mel_graph_race.py, profiles/r05_mel_graph_race.md):
-//   * never in eager launches (thousands, beside the same kernels on other streams);
-//   * never beside the convolutions, the BiGRU recurrence, the heads or a rocBLAS GEMM -- only beside the split-bf16 GEMM, and not when
-//     that GEMM's v_mfma_f32_32x32x16_bf16 are compiled out (its LDS traffic and global stores alone are harmless);
-//   * only in the SECOND and later frames a wave transforms, never its first: persistent walk with runs of 8 frames ~7 % of the replays,
-//     one run of 8 per workgroup (this build) 0.2 - 0.5 % beside the GEMM and 0 of 3 000 beside the full BiGRU + head tails, runs of 4
-//     (one frame per wave per run, persistent) 0 of 3 000 in the tool but 1 of 300 inside the full GPU test session;
-//   * still failing with: s_waitcnt vmcnt(0) / lgkmcnt(0) at every exchange (MORE often), drained stores before s_endpgm, no prefetch,
-//     plain (non-asm) arithmetic, -O1, a vector wave index, no s_setprio in the recurrences, 8 / 48 KB of LDS padding; the LDS tables stay
-//     intact (checksummed).
-// Cause not found.  The kernel is therefore OPT-IN (features.py: tuning key mel_wave = 1 or SED_MEL_WAVE=1); the default mel path stays
-// the kernel above, which passes the same graph test (tests/test_gpu_parity.py::test_mel_in_graph_beside_tails).  DESIGN.md section 12.
-#ifndef MEL_RUN
-#define MEL_RUN 8
+// four, and NO workgroup barrier after the tables are staged: a wave's DS instructions execute in order, sed_wave_sync() only pins the
+// compiler.  A workgroup = MEL_WAVES waves = MEL_WAVES consecutive frames of ONE clip ("a run"), and the runs of a clip stay on one XCD
+// (workgroup g is dispatched to XCD g % 8; XCD x owns the clips c = x (mod 8)), so the 7/8 overlap of neighbouring frames is served by
+// that XCD's L2 and HBM sees every sample once.  LDS exchange layout (MI355X_MICROARCH.md, LDS: ds_write_b64 is banked per 16
+// contiguous lanes modulo 16 slots of 8 B, ds_read_b64 per 32 lanes modulo 32): exchange 1 writes element 16 l + r at slot e + (e >> 4)
+// (17 l + r: distinct modulo 16 over 16 lanes) and reads l + 64 r there (contiguous; one 2-way pair); exchange 2 (writes
+// 256 (l >> 4) + (l & 15) + 16 r, reads l + 64 m + 256 r) and the conjugate-pair exchange of the real-FFT step are contiguous per lane
+// group as they are.  All LDS addresses are a per-lane base + an immediate.  Mel stage: lane l owns bands l and 127 - l (3 + 42 ...
+// 13 + 13 taps: balanced), taps as aligned 16-byte LDS reads (MEL_GA + MEL_GB groups), magnitudes read from the wave's buffer; longer
+// bands finish from memory (no recipe has any).
+// WHY ONE FRAME PER WAVE (profiles/r05_mel_graph_race.md, profiles/r06_mel_mechanism.md): round 5's form of this kernel walked runs of
+// 8 or 16 frames per workgroup, i.e. a wave transformed a SECOND frame in the same launch -- and replayed as a hipGraph node while
+// gemm_bf16x3_kernel ran on another branch that second frame came back with a few neighbouring bins k and their mirror bins 1024 - k
+// wrong in 0.2 - 7 % of the replays (never the first frame of a wave, never in eager launches, not cured by waits / fences / nop
+// padding / -O1 / plain arithmetic).  With exactly one frame per wave and launch the fault has never been seen (round 5: 0 of 32 000
+// replays beside the co-runners that break the multi-frame forms; this round: tests/test_gpu_parity.py::
+// test_mel_in_graph_beside_{tails,gemm}, 3 000 replays each in every GPU session).  The multi-frame form is NOT part of the library
+// any more; it lives on as a diagnostics-only reproducer (tools/mel_repro/).
+#ifndef MEL_WAVES
+#define MEL_WAVES 4            // waves = frames per workgroup; the 26 KB of tables are staged once per workgroup
 #endif
-// MEL_PERSISTENT: workgroups walk several runs (grid capped at two workgroups per CU) -- the form in which the open issue above shows.
-// Default: ONE run per workgroup (grid = all runs; the 26 KB of tables are re-read from L2 per run).
 #define MEL_XPAD 1088          // 1024 + 64 padding slots (exchange 1)
 
 // Complex arithmetic on the packed-fp32 pipe: a complex number is one 64-bit VGPR pair, and VOP3P's op_sel / neg modifiers pick and
@@ -298,14 +289,14 @@ __device__ __forceinline__ void dft16(float2* v) {
         for (int b = a + 1; b < 4; ++b) { const float2 t = v[4 * a + b]; v[4 * a + b] = v[4 * b + a]; v[4 * b + a] = t; }
 }
 
-// Workgroup = MEL_WAVES waves: the frame-invariant tables (window 8 KB, pass-2 twiddles 2 KB, the mel taps 16 KB) are shared by six
-// waves, 8.5 KB of exchange buffer each -> 78 KB: two workgroups = twelve waves per CU = three per SIMD, at <= 168 VGPRs.
+// Workgroup = MEL_WAVES waves: the frame-invariant tables (window 8 KB, pass-2 twiddles 2 KB, the mel taps 16 KB) are shared by its
+// waves, 8.5 KB of exchange buffer each -> 60 KB at four waves: two workgroups = eight waves per CU = two per SIMD at 184 VGPRs (three
+// per SIMD needs <= 168: every form that got there spilled and ran 2.3 x slower).
 // Mel taps in LDS: band `lane` as MEL_GA and band 127 - lane as MEL_GB groups of four taps, the first group starting at the band's
 // first bin rounded DOWN to a multiple of four (leading / trailing zeros), stored [group][lane] -- every lane reads its 16 bytes of group
 // g at the same offset (conflict-free), and the magnitudes as aligned 16-byte reads too: 32 ds_read_b128 per frame instead of 120 b32.
-#define MEL_WAVES 4
 #ifndef MEL_OCC
-#define MEL_OCC 2
+#define MEL_OCC (MEL_WAVES <= 6 ? 2 : 1)
 #endif
 #define MEL_GA 4
 #define MEL_GB 12
@@ -317,27 +308,71 @@ __global__ __launch_bounds__(64 * MEL_WAVES, MEL_OCC) void mel_wave_kernel(const
                                                        const float2* __restrict__ tw2048, const int* __restrict__ fb_start,
                                                        const int* __restrict__ fb_len, const float* __restrict__ fb_w, int fb_stride,
                                                        const float4* __restrict__ taps, int runs_per_clip, int segs_per_clip) {
+#ifndef MEL_WIN_GLOBAL
     __shared__ float2 s_win[MEL_M];                             // (w[2n], w[2n + 1])
+#endif
     __shared__ float2 s_tw16[15 * 16];                          // [r - 1][k]: e^{-2 pi i r k / 256}, r = 1..15, k < 16 (pass 2)
     __shared__ __attribute__((aligned(16))) float4 s_wa[MEL_GA][64];      // taps of band `lane`
     __shared__ __attribute__((aligned(16))) float4 s_wb[MEL_GB][64];      // taps of band 127 - lane
     __shared__ __attribute__((aligned(16))) float2 s_x[MEL_WAVES][MEL_XPAD];     // one exchange buffer per wave
     const int tid = threadIdx.x, wave = sed_wave_uniform(tid >> 6), lane = tid & 63;
+
+    // XCD-aware placement: workgroup g sits on XCD g & 7 and takes ONE run of the SEGMENTS s = (g & 7) (mod 8); a segment is a clip
+    // (segs_per_clip = 1 at the recipes' batch sizes) or, for small batches, one of several stretches of consecutive runs of a clip.
+    // (All three exits below are taken by whole workgroups: nobody is left waiting at the barrier.)
+    const int xcd = blockIdx.x & 7, run = blockIdx.x >> 3;
+    const int runs_per_seg = (runs_per_clip + segs_per_clip - 1) / segs_per_clip;
+    const int segs_here = (B * segs_per_clip - xcd + 7) >> 3;
+    if (run >= segs_here * runs_per_seg) return;
+    const int seg = xcd + 8 * (run / runs_per_seg);
+    const int b = seg / segs_per_clip;
+    const int run_in_clip = (seg - b * segs_per_clip) * runs_per_seg + run % runs_per_seg;
+    if (run_in_clip >= runs_per_clip) return;
+    const int t = run_in_clip * MEL_WAVES + wave;               // this wave's frame
+    const bool have = t < T;
+    const float* clip = audio + (size_t)b * N;
+
+    // ---- the frame's samples leave for the registers BEFORE the tables are staged: one memory latency for both ----
+    float2 v[16];
+    if (have) {
+        const int base = t * hop - MEL_NFFT / 2;
+        if (base >= 0 && base + MEL_NFFT <= N && ((reinterpret_cast<uintptr_t>(clip + base) & 7) == 0)) {   // interior frame: 8-byte loads
+            const float2* p = reinterpret_cast<const float2*>(clip + base);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = p[lane + 64 * j];
+        } else {                                // the first / last four frames of a clip: reflected indices, element by element
+            int le = lane;
+            sed_opaque(le);                     // (nothing of this cold path is worth a register outside it)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int s0 = base + 2 * (le + 64 * j), s1 = s0 + 1;
+                if (s0 < 0) s0 = -s0;
+                if (s1 < 0) s1 = -s1;
+                if (s0 >= N) s0 = 2 * (N - 1) - s0;
+                if (s1 >= N) s1 = 2 * (N - 1) - s1;
+                v[j] = make_float2(clip[s0], clip[s1]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = make_float2(0.f, 0.f);
+    }
+#ifdef MEL_WIN_GLOBAL
+    float2 wn[16];                              // every window tap is used once per wave: straight from L2 beside the samples
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wn[j] = reinterpret_cast<const float2*>(window)[lane + 64 * j];
+#else
     for (int i = tid; i < MEL_M; i += 64 * MEL_WAVES) s_win[i] = make_float2(window[2 * i], window[2 * i + 1]);
+#endif
     if (tid < 240) s_tw16[tid] = tw1024[(4 * ((tid >> 4) + 1) * (tid & 15)) & (MEL_M - 1)];
     // (the tap tables come ready-made from sed_mel_taps: built per workgroup from fb_start / fb_len / fb_w they were eleven rounds of
-    //  dependent gathers -- ~20 us in front of a workgroup's ~10 frames per wave)
+    //  dependent gathers -- ~20 us in front of a workgroup's frames)
     for (int i = tid; i < (MEL_GA + MEL_GB) * 64; i += 64 * MEL_WAVES) {
         if (i < MEL_GA * 64) s_wa[i >> 6][i & 63] = taps[i];
         else s_wb[(i >> 6) - MEL_GA][i & 63] = taps[i];
     }
-    __syncthreads();                            // the only workgroup barrier
-
-    float2* xb = s_x[wave];
-    float* magb = reinterpret_cast<float*>(xb);
     // The only per-lane twiddle kept in registers is w2048^lane: the real-FFT twiddles w2048^(lane + 64 q) = w2048^lane w32^q and
-    // the pass-3 twiddles w1024^(r (lane + 64 m)) = ((w2048^lane)^2 w16^m)^r are formed from it per frame (a dozen packed products
-    // against eight more registers that the frame loop does not have)
+    // the pass-3 twiddles w1024^(r (lane + 64 m)) = ((w2048^lane)^2 w16^m)^r are formed from it (a dozen packed products)
     const float2 wl = tw2048[lane];
     // mel bands of this lane: A = lane, Bd = 127 - lane
     const int bandA = lane, bandB = 127 - lane;
@@ -345,142 +380,100 @@ __global__ __launch_bounds__(64 * MEL_WAVES, MEL_OCC) void mel_wave_kernel(const
     if (bandA < n_mels) { sA = fb_start[bandA]; lA = fb_len[bandA]; }
     if (bandB < n_mels) { sB = fb_start[bandB]; lB = fb_len[bandB]; }
     const int gA0 = sA >> 2, gB0 = sB >> 2;     // first aligned group of four magnitudes of each band
+    __syncthreads();                            // the only workgroup barrier
+    if (!have) return;                          // (the last run of a clip: T is not a multiple of MEL_WAVES)
 
-    // XCD-aware walk: workgroup g sits on XCD g & 7 and takes the runs of the SEGMENTS s = (g & 7) (mod 8); a segment is a clip
-    // (segs_per_clip = 1 at the recipes' batch sizes) or, for small batches, one of several stretches of consecutive runs of a clip
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, n_slots = (gridDim.x + 7 - xcd) >> 3;
-    const int runs_per_seg = (runs_per_clip + segs_per_clip - 1) / segs_per_clip;
-    const int segs_here = (B * segs_per_clip - xcd + 7) >> 3;
-    const int total_runs = segs_here * runs_per_seg;
-    float2 v[16];
-    for (int run = slot; run < total_runs; run += n_slots) {
-        const int seg = xcd + 8 * (run / runs_per_seg);
-        const int b = seg / segs_per_clip;
-        const int run_in_clip = (seg - b * segs_per_clip) * runs_per_seg + run % runs_per_seg;
-        if (run_in_clip >= runs_per_clip) continue;
-        const int t0 = run_in_clip * MEL_RUN;
-        const float* clip = audio + (size_t)b * N;
-        const int t_end = t0 + MEL_RUN < T ? t0 + MEL_RUN : T;
-
-        auto load_frame = [&](int t_) {
-            const int base = t_ * hop - MEL_NFFT / 2;
-            if (base >= 0 && base + MEL_NFFT <= N && ((reinterpret_cast<uintptr_t>(clip + base) & 7) == 0)) {   // interior frame: 8-byte loads
-                const float2* p = reinterpret_cast<const float2*>(clip + base);
+    float2* xb = s_x[wave];
+    float* magb = reinterpret_cast<float*>(xb);
+    // ---- window; pass 1: radix 16, Ns = 1: in[lane + 64 r] -> out[16 lane + r] ----
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = p[lane + 64 * j];
-            } else {                                // the first / last four frames of a clip: reflected indices, element by element
-                int le = lane;
-                sed_opaque(le);                     // (nothing of this cold path is worth a register outside it)
+#ifdef MEL_WIN_GLOBAL
+    for (int j = 0; j < 16; ++j) v[j] = cscale(v[j], wn[j]);
+#else
+    for (int j = 0; j < 16; ++j) v[j] = cscale(v[j], s_win[lane + 64 * j]);
+#endif
+    dft16(v);
+    sed_sched_fence();
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    int s0 = base + 2 * (le + 64 * j), s1 = s0 + 1;
-                    if (s0 < 0) s0 = -s0;
-                    if (s1 < 0) s1 = -s1;
-                    if (s0 >= N) s0 = 2 * (N - 1) - s0;
-                    if (s1 >= N) s1 = 2 * (N - 1) - s1;
-                    v[j] = make_float2(clip[s0], clip[s1]);
-                }
-            }
-        };
-        int t = t0 + wave;
-        if (t < t_end) load_frame(t);
-        for (; t < t_end; t += MEL_WAVES) {
-            // (the table reads below are frame-invariant: without an opaque index LICM keeps all of them live across the frame loop
-            //  and the kernel spills)
-            int ln = lane;
-            sed_opaque(ln);
-            float2 wl_ = wl;                    // (same for what is derived from the per-lane twiddle)
-            sed_pin(wl_.x); sed_pin(wl_.y);
-            // ---- window; pass 1: radix 16, Ns = 1: in[lane + 64 r] -> out[16 lane + r] ----
+    for (int r = 0; r < 16; ++r) xb[17 * lane + r] = v[r];
+    sed_wave_sync(); sed_sched_fence();
+    // ---- pass 2: radix 16, Ns = 16: in[lane + 64 r] * w256^(r k), k = lane & 15 -> out[(lane - k) 16 + k + 16 r] ----
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = cscale(v[j], s_win[ln + 64 * j]);
-            dft16(v);
-            sed_wave_sync(); sed_sched_fence();                    // (the previous frame's mel stage has read its magnitudes from this buffer)
+    for (int r = 0; r < 16; ++r) v[r] = xb[lane + (lane >> 4) + 68 * r];        // e + (e >> 4), e = lane + 64 r
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xb[17 * lane + r] = v[r];
-            sed_wave_sync(); sed_sched_fence();
-            // ---- pass 2: radix 16, Ns = 16: in[lane + 64 r] * w256^(r k), k = lane & 15 -> out[(lane - k) 16 + k + 16 r] ----
+    for (int r = 1; r < 16; ++r) v[r] = cmulp(v[r], s_tw16[(r - 1) * 16 + (lane & 15)]);
+    dft16(v);
+    sed_wave_sync(); sed_sched_fence();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = xb[lane + (lane >> 4) + 68 * r];        // e + (e >> 4), e = lane + 64 r
+    for (int r = 0; r < 16; ++r) xb[((lane >> 4) << 8) + (lane & 15) + 16 * r] = v[r];
+    sed_wave_sync(); sed_sched_fence();
+    // ---- pass 3: radix 4, Ns = 256, four butterflies per lane: j = lane + 64 m, in[j + 256 r] * w1024^(r j) -> out[j + 256 r]
+    const float2 wl2 = cmulp(wl, wl);                                            // w1024^lane
 #pragma unroll
-            for (int r = 1; r < 16; ++r) v[r] = cmulp(v[r], s_tw16[(r - 1) * 16 + (ln & 15)]);
-            dft16(v);
-            sed_wave_sync(); sed_sched_fence();
+    for (int m = 0; m < 4; ++m) {
+        float2 a0 = xb[lane + 64 * m], a1 = xb[lane + 64 * m + 256], a2 = xb[lane + 64 * m + 512], a3 = xb[lane + 64 * m + 768];
+        const float a16 = 0.39269908169872414f * m;                              // w16^m = (cos, -sin)(2 pi m / 16): constants
+        const float2 w1m = m == 0 ? wl2 : cmulp(wl2, make_float2(__builtin_cosf(a16), -__builtin_sinf(a16)));
+        const float2 w2 = cmulp(w1m, w1m), w3 = cmulp(w2, w1m);
+        a1 = cmulp(a1, w1m); a2 = cmulp(a2, w2); a3 = cmulp(a3, w3);
+        dft4(a0, a1, a2, a3);
+        v[m] = a0; v[m + 4] = a1; v[m + 8] = a2; v[m + 12] = a3;                  // v[q] = Z[lane + 64 q]
+    }
+    // ---- real-FFT step: X[k] = Xe + w2048^k Xo needs Z[1024 - k]: conjugate-pair exchange through the buffer ----
+    sed_wave_sync(); sed_sched_fence();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xb[((lane >> 4) << 8) + (lane & 15) + 16 * r] = v[r];
-            sed_wave_sync(); sed_sched_fence();
-            // ---- pass 3: radix 4, Ns = 256, four butterflies per lane: j = lane + 64 m, in[j + 256 r] * w1024^(r j) -> out[j + 256 r]
-            const float2 wl2 = cmulp(wl_, wl_);                                          // w1024^lane
+    for (int q = 0; q < 16; ++q) xb[lane + 64 * q] = v[q];
+    if (lane == 0) xb[MEL_M] = v[0];                                             // Z[1024] = Z[0]
+    sed_wave_sync(); sed_sched_fence();
+    float mg[16], mag_nyq = 0.f;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                float2 a0 = xb[lane + 64 * m], a1 = xb[lane + 64 * m + 256], a2 = xb[lane + 64 * m + 512], a3 = xb[lane + 64 * m + 768];
-                const float a16 = 0.39269908169872414f * m;                              // w16^m = (cos, -sin)(2 pi m / 16): constants
-                const float2 w1m = m == 0 ? wl2 : cmulp(wl2, make_float2(__builtin_cosf(a16), -__builtin_sinf(a16)));
-                const float2 w2 = cmulp(w1m, w1m), w3 = cmulp(w2, w1m);
-                a1 = cmulp(a1, w1m); a2 = cmulp(a2, w2); a3 = cmulp(a3, w3);
-                dft4(a0, a1, a2, a3);
-                v[m] = a0; v[m + 4] = a1; v[m + 8] = a2; v[m + 12] = a3;                  // v[q] = Z[lane + 64 q]
-            }
-            // ---- real-FFT step: X[k] = Xe + w2048^k Xo needs Z[1024 - k]: conjugate-pair exchange through the buffer ----
-            sed_wave_sync(); sed_sched_fence();
-#pragma unroll
-            for (int q = 0; q < 16; ++q) xb[lane + 64 * q] = v[q];
-            if (lane == 0) xb[MEL_M] = v[0];                                             // Z[1024] = Z[0]
-            sed_wave_sync(); sed_sched_fence();
-            float mg[16], mag_nyq = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int k = ln + 64 * q;
-                const float2 zk = v[q], zm = xb[MEL_M - k];
-                const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-                const float dr = zk.x - zm.x, di = zk.y + zm.y;                          // zk - conj(zm)
-                const float2 xo = make_float2(0.5f * di, -0.5f * dr);                     // -i/2 (zk - conj(zm))
-                // w2048^(lane + 64 q) = w2048^lane * w32^q, w32^q = (cos, -sin)(2 pi q / 32)
-                const float ang = 0.19634954084936207f * q;                              // folded: q is a compile-time constant
-                const float2 wq = cmulp(wl_, make_float2(__builtin_cosf(ang), -__builtin_sinf(ang)));
-                const float2 wx = cmulp(wq, xo);
-                const float re = xe.x + wx.x, im = xe.y + wx.y;
-                mg[q] = fast_sqrt(re * re + im * im);
-                if (q == 0) {                                                            // k = 0 (lane 0): DC and Nyquist are real
-                    if (lane == 0) { mg[0] = fabsf(zk.x + zk.y); mag_nyq = fabsf(zk.x - zk.y); }
-                }
-            }
-            sed_wave_sync(); sed_sched_fence();
-#pragma unroll
-            for (int q = 0; q < 16; ++q) magb[lane + 64 * q] = mg[q];
-            if (lane == 0) magb[MEL_M] = mag_nyq;
-            sed_wave_sync(); sed_sched_fence();
-            // ---- the next frame's samples travel while the mel stage runs ----
-            const int t_cur = t;
-            if (t + MEL_WAVES < t_end) load_frame(t + MEL_WAVES);
-            // ---- sparse HTK mel: bands `lane` and `127 - lane`; four partial sums per band ----
-            const float4* mag4 = reinterpret_cast<const float4*>(magb);
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-#pragma unroll
-            for (int g = 0; g < MEL_GA; ++g) {
-                const float4 w = s_wa[g][ln], m = mag4[gA0 + g];
-                a0 = fmaf(w.x, m.x, a0); a1 = fmaf(w.y, m.y, a1); a2 = fmaf(w.z, m.z, a2); a3 = fmaf(w.w, m.w, a3);
-            }
-            sed_sched_fence();
-#pragma unroll
-            for (int g = 0; g < MEL_GB; ++g) {
-                const float4 w = s_wb[g][ln], m = mag4[gB0 + g];
-                b0 = fmaf(w.x, m.x, b0); b1 = fmaf(w.y, m.y, b1); b2 = fmaf(w.z, m.z, b2); b3 = fmaf(w.w, m.w, b3);
-                if ((g & 3) == 3) sed_sched_fence();        // at most four groups (32 VGPRs) of taps and magnitudes in flight
-            }
-            float accA = (a0 + a1) + (a2 + a3), accB = (b0 + b1) + (b2 + b3);
-            // bands longer than the tables (no recipe has any): the remaining taps from memory
-            for (int j = 4 * MEL_GA - (sA & 3); j < lA; ++j) accA = fmaf(fb_w[(size_t)bandA * fb_stride + j], magb[sA + j], accA);
-            for (int j = 4 * MEL_GB - (sB & 3); j < lB; ++j) accB = fmaf(fb_w[(size_t)bandB * fb_stride + j], magb[sB + j], accB);
-            if (LOG) {
-                accA = fminf(fmaxf(20.0f * log10f(fmaxf(accA, 1e-5f)), -50.0f), 80.0f);
-                accB = fminf(fmaxf(20.0f * log10f(fmaxf(accB, 1e-5f)), -50.0f), 80.0f);
-            }
-            float* o = out + ((size_t)b * T + t_cur) * n_mels;
-            if (bandA < n_mels) o[bandA] = accA;
-            if (bandB < n_mels) o[bandB] = accB;
+    for (int q = 0; q < 16; ++q) {
+        const int k = lane + 64 * q;
+        const float2 zk = v[q], zm = xb[MEL_M - k];
+        const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+        const float dr = zk.x - zm.x, di = zk.y + zm.y;                          // zk - conj(zm)
+        const float2 xo = make_float2(0.5f * di, -0.5f * dr);                     // -i/2 (zk - conj(zm))
+        // w2048^(lane + 64 q) = w2048^lane * w32^q, w32^q = (cos, -sin)(2 pi q / 32)
+        const float ang = 0.19634954084936207f * q;                              // folded: q is a compile-time constant
+        const float2 wq = cmulp(wl, make_float2(__builtin_cosf(ang), -__builtin_sinf(ang)));
+        const float2 wx = cmulp(wq, xo);
+        const float re = xe.x + wx.x, im = xe.y + wx.y;
+        mg[q] = fast_sqrt(re * re + im * im);
+        if (q == 0) {                                                            // k = 0 (lane 0): DC and Nyquist are real
+            if (lane == 0) { mg[0] = fabsf(zk.x + zk.y); mag_nyq = fabsf(zk.x - zk.y); }
         }
     }
+    sed_wave_sync(); sed_sched_fence();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) magb[lane + 64 * q] = mg[q];
+    if (lane == 0) magb[MEL_M] = mag_nyq;
+    sed_wave_sync(); sed_sched_fence();
+    // ---- sparse HTK mel: bands `lane` and `127 - lane`; four partial sums per band ----
+    const float4* mag4 = reinterpret_cast<const float4*>(magb);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+#pragma unroll
+    for (int g = 0; g < MEL_GA; ++g) {
+        const float4 w = s_wa[g][lane], m = mag4[gA0 + g];
+        a0 = fmaf(w.x, m.x, a0); a1 = fmaf(w.y, m.y, a1); a2 = fmaf(w.z, m.z, a2); a3 = fmaf(w.w, m.w, a3);
+    }
+    sed_sched_fence();
+#pragma unroll
+    for (int g = 0; g < MEL_GB; ++g) {
+        const float4 w = s_wb[g][lane], m = mag4[gB0 + g];
+        b0 = fmaf(w.x, m.x, b0); b1 = fmaf(w.y, m.y, b1); b2 = fmaf(w.z, m.z, b2); b3 = fmaf(w.w, m.w, b3);
+        if ((g & 3) == 3) sed_sched_fence();        // at most four groups (32 VGPRs) of taps and magnitudes in flight
+    }
+    float accA = (a0 + a1) + (a2 + a3), accB = (b0 + b1) + (b2 + b3);
+    // bands longer than the tables (no recipe has any): the remaining taps from memory
+    for (int j = 4 * MEL_GA - (sA & 3); j < lA; ++j) accA = fmaf(fb_w[(size_t)bandA * fb_stride + j], magb[sA + j], accA);
+    for (int j = 4 * MEL_GB - (sB & 3); j < lB; ++j) accB = fmaf(fb_w[(size_t)bandB * fb_stride + j], magb[sB + j], accB);
+    if (LOG) {
+        accA = fminf(fmaxf(20.0f * log10f(fmaxf(accA, 1e-5f)), -50.0f), 80.0f);
+        accB = fminf(fmaxf(20.0f * log10f(fmaxf(accB, 1e-5f)), -50.0f), 80.0f);
+    }
+    float* o = out + ((size_t)b * T + t) * n_mels;
+    if (bandA < n_mels) o[bandA] = accA;
+    if (bandB < n_mels) o[bandB] = accB;
 }
 
 // taps[(g * 64 + lane) * 4 + c]: groups g < MEL_GA = band `lane`, the others band 127 - lane; tap j = 4 g' + c - (start & 3) of the band
@@ -511,20 +504,16 @@ SED_API int sed_mel_fwd_wave(const float* audio, float* out, int B, int N, int T
                              const int* fb_len, const float* fb_w, int fb_stride, const float* taps, int apply_log, void* stream) {
     if (n_fft != MEL_NFFT || n_mels > 128 || n_mels < 1 || N < n_fft / 2 + 1 || T != 1 + N / hop || !taps) return SED_ERR_UNSUPPORTED;
     if (B <= 0) return SED_OK;
-    // one wave per frame, runs of MEL_RUN frames of one clip per workgroup, clips pinned to XCDs (see mel_wave_kernel)
-    const int runs_per_clip = (T + MEL_RUN - 1) / MEL_RUN;
+    // one wave per frame and one frame per wave: a workgroup takes a run of MEL_WAVES consecutive frames of one clip, clips pinned to
+    // XCDs (see mel_wave_kernel)
+    const int runs_per_clip = (T + MEL_WAVES - 1) / MEL_WAVES;
     int segs_per_clip = B >= 32 ? 1 : 32 / B;       // small batches: several stretches per clip, so that all eight XCDs work
     if (segs_per_clip > runs_per_clip) segs_per_clip = runs_per_clip;
-    long long runs = (long long)B * runs_per_clip;
-#ifdef MEL_PERSISTENT
-    int grid = runs < 512 ? (int)runs : 512;        // 2 resident workgroups on each of the 256 CUs
-    grid = (grid + 7) & ~7;                         // every XCD gets the same number of slots
-#else
-    // one run per workgroup: every XCD gets as many slots as it has runs (its segments x runs per segment)
+    // every XCD gets as many workgroups as it has runs (its segments x runs per segment)
     const int rps_ = (runs_per_clip + segs_per_clip - 1) / segs_per_clip;
-    const int grid = 8 * ((B * segs_per_clip + 7) / 8) * rps_;
-    (void)runs;
-#endif
+    const long long grid_ll = 8LL * ((B * (long long)segs_per_clip + 7) / 8) * rps_;
+    if (grid_ll > 0x7fffffffLL) return SED_ERR_UNSUPPORTED;
+    const int grid = (int)grid_ll;
 #define MELW_LAUNCH(LOG) SED_LAUNCH((mel_wave_kernel<LOG>), dim3(grid), dim3(64 * MEL_WAVES), 0, (hipStream_t)stream, audio, out, B, N, T, hop, \
                                     n_mels, window, (const float2*)tw1024, (const float2*)tw2048, fb_start, fb_len, fb_w, fb_stride,             \
                                     (const float4*)taps, runs_per_clip, segs_per_clip)

@@ -116,15 +116,17 @@ class MelSpectrogram(torch.nn.Module):
         elif tuple(out.shape) != (B, T, self.n_mels) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != audio.device:
             raise ValueError("frames_major: `out` must be a contiguous fp32 (B, T, n_mels) tensor on the audio's device")
         lib = _lib.get()
-        if (_lib.get_tuning("mel_wave") != 1 and os.environ.get("SED_MEL_WAVE") != "1") or _lib.get_tuning("mel_taps_mem"):
-            # DEFAULT: the round-1..4 kernel, one frame per 256-thread workgroup.  The round-5 wave-per-frame kernel below is 1.9 x
-            # faster alone (79 vs 147 us) and fetches every sample from HBM once instead of eight times, but replayed as a hipGraph node
-            # beside other kernels it intermittently returns a few wrong bins in single frames (never in eager launches; cause not
-            # found: DESIGN.md section 12, tools/mel_graph_race.py) -- parity first: it stays opt-in (`_lib.set_tuning("mel_wave", 1)`)
+        if _lib.get_tuning("mel_wave") == 2 or os.environ.get("SED_MEL_WAVE") == "0" or _lib.get_tuning("mel_taps_mem"):
+            # the round-1..4 kernel, one frame per 256-thread workgroup (141 - 150 us at B = 48): kept for A/B runs (`mel_wave` = 2 /
+            # SED_MEL_WAVE=0) and for filterbanks whose taps do not fit the wave kernel's tables (`mel_taps_mem`)
             lib.call("sed_mel_fwd", audio.data_ptr(), out.data_ptr(), B, N, T, self.n_fft, self.hop_length, self.n_mels,
                      self.window.data_ptr(), self.tw1024.data_ptr(), self.tw2048.data_ptr(), self.fb_start.data_ptr(),
                      self.fb_len.data_ptr(), self.fb_w.data_ptr(), self.fb_stride, int(apply_log), _lib.stream_ptr(audio))
             return out
+        # DEFAULT (round 6): one wave per frame and one frame per wave (`sed_mel_fwd_wave`).  Round 5's form of this kernel, in which a
+        # wave transformed several frames per launch, returned a few wrong bins in single frames when replayed as a hipGraph node beside
+        # the split-bf16 GEMM; with exactly one frame per wave the fault has never been seen (tests/test_gpu_parity.py::
+        # test_mel_in_graph_beside_{tails,gemm}: 3 000 replays each per GPU session; profiles/r06_mel_mechanism.md)
         taps = self._taps
         if taps is None or taps.device != audio.device:
             # the filterbank in the wave kernel's LDS layout: one tiny launch per device, outside any captured step

@@ -90,18 +90,27 @@ def case_mel_walk_batch_independent(dev, batch=48, n_samples=160000, probe=(0, 7
     return whole
 
 
-def case_mel_in_graph_beside_tails(dev, replays=300, beside="tails"):
-    """The wave-per-frame mel kernel as a hipGraph node on a side stream beside the student's and the teacher's BiGRU + head tails (the
-    "tails" fork of the pipelined step), replayed `replays` times on changing waveforms: every output bit-equal to the solo launch.
-    (Round 5: with runs of 8 frames per workgroup -- two frames per wave -- ~5 % of such replays had a few mirror-paired bins of a
-    wave's last frame wrong; never eager.  One frame per wave per run: clean.  tools/mel_graph_race.py is the same loop with a library
-    argument for variant builds.)"""
+def case_mel_in_graph_beside_tails(dev, replays=300, beside="tails", launch=None, after_replay=None):
+    """The mel kernel as a hipGraph node on a side stream beside the student's and the teacher's BiGRU + head tails (the "tails" fork of
+    the pipelined step; beside = "gemm": beside the BiGRU's split-bf16 input projection alone), replayed `replays` times on changing
+    waveforms: every output bit-equal to the solo launch.  (Round 5: a form of the wave-per-frame kernel in which a wave transformed two
+    or more frames per launch had a few mirror-paired bins of a wave's later frames wrong in 0.2 - 7 % of such replays, never eager;
+    the shipped kernel gives a wave exactly one frame.  tools/mel_graph_race.py is the same loop with a library argument for variant
+    builds; tools/mel_repro/race.py runs it on the diagnostics-only multi-frame reproducer: launch(audio, out) replaces the mel call,
+    after_replay(rep, i, n_bad_elements) is called after every replay.)"""
     task = build_task(dev, (1, 1, 2), O.make_state_dict(seed=7), dropout=0.5, specaug=True, rampup=5)
     mel = task.mel_spec
     B, N = 4, 16000 + 1024
     g = torch.Generator().manual_seed(1)
     audios = [to(dev, 0.1 * torch.randn(B, N, generator=g)) for _ in range(8)]
-    refs = [mel.frames_major(a).clone() for a in audios]
+    if launch is None:
+        def launch(audio_, out_):
+            mel.frames_major(audio_, out=out_)
+    refs = []
+    for a in audios:
+        r = torch.empty(B, 1 + N // mel.hop_length, mel.n_mels, device=a.device)
+        launch(a, r)
+        refs.append(r)
     static_audio = audios[0].clone()
     out = torch.empty_like(refs[0])
     x = task.scaled_logmel(mel(audios[0]))
@@ -133,7 +142,7 @@ def case_mel_in_graph_beside_tails(dev, replays=300, beside="tails"):
             cur = torch.cuda.current_stream()
             s_mel.wait_stream(cur)
             with torch.cuda.stream(s_mel):
-                mel.frames_major(static_audio, out=out)
+                launch(static_audio, out)
             s_t.wait_stream(cur)
             with torch.cuda.stream(s_t):
                 if beside == "tails":
@@ -174,8 +183,11 @@ def case_mel_in_graph_beside_tails(dev, replays=300, beside="tails"):
             graph.replay()
         torch.cuda.synchronize()
         ne = out != refs[i]
-        if ne.any():
-            bad.append((rep, int(ne.sum()), sorted({(int(b), int(t)) for b, t, m in ne.nonzero().tolist()})[:4]))
+        nbad = int(ne.sum())
+        if nbad:
+            bad.append((rep, nbad, sorted({(int(b), int(t)) for b, t, m in ne.nonzero().tolist()})[:4]))
+        if after_replay is not None:
+            after_replay(rep, i, nbad)
     assert not bad, (len(bad), bad[:5])
     return replays
 

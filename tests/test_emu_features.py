@@ -18,10 +18,10 @@ def test_mel_walk_batch_independent(emu):
     P.case_mel_walk_batch_independent("cpu", batch=13, n_samples=256 * 9 + 40, probe=(0, 5, 12))
 
 
-def test_mel_wave_kernel_matches_oracle(emu):
-    """The round-5 wave-per-frame kernel (`sed_mel_fwd_wave`, opt-in)."""
+def test_mel_workgroup_kernel_matches_oracle(emu):
+    """The round-1..4 kernel (`sed_mel_fwd`, one frame per workgroup; `mel_wave` = 2).  The default is the wave-per-frame kernel."""
     from desed_task_amd import _lib
-    _lib.set_tuning("mel_wave", 1)
+    _lib.set_tuning("mel_wave", 2)
     try:
         P.case_mel("cpu")
         P.case_mel("cpu", batch=3, n_samples=256 * 21 + 100)

@@ -33,18 +33,24 @@ def test_mel_walk_batch_independent_at_baseline_size():
     P.case_mel_walk_batch_independent("cuda")
 
 
-def test_mel_in_graph_beside_tails():
-    """The (default) mel kernel replayed as a hipGraph node next to the BiGRU tails gives the solo launch's bits, 300 replays.  (The
-    round-5 wave-per-frame kernel does NOT pass this reliably -- which is why it is opt-in; tools/mel_graph_race.py wave.)"""
-    P.case_mel_in_graph_beside_tails("cuda", replays=300)
+@pytest.mark.parametrize("beside", ["tails", "gemm"])
+def test_mel_in_graph_beside(beside):
+    """The default mel kernel (one wave per frame, one frame per wave) replayed as a hipGraph node next to the BiGRU + head tails / next to
+    the BiGRU's split-bf16 input-projection GEMM alone gives the solo launch's bits: 3 000 replays each.  These are the two co-runners
+    beside which round 5's multi-frame form of the kernel returned wrong bins in 0.2 - 7 % of the replays
+    (profiles/r05_mel_graph_race.md, profiles/r06_mel_mechanism.md; the reproducer lives in tools/mel_repro/)."""
+    assert _lib.get_tuning("mel_wave") == 0
+    P.case_mel_in_graph_beside_tails("cuda", replays=3000, beside=beside)
 
 
-def test_mel_wave_kernel_eager():
-    """The round-5 wave-per-frame kernel (`sed_mel_fwd_wave`, opt-in: `mel_wave` = 1) against the oracle in eager launches."""
-    _lib.set_tuning("mel_wave", 1)
+def test_mel_workgroup_kernel():
+    """The round-1..4 kernel (one frame per workgroup; `mel_wave` = 2): still exported (`sed_mel_fwd`), kept for A/B runs and as the
+    fall-back for filterbanks wider than the wave kernel's tap tables -- oracle parity and 300 graph replays beside the tails."""
+    _lib.set_tuning("mel_wave", 2)
     try:
         P.case_mel("cuda")
         P.case_mel("cuda", batch=5, n_samples=256 * 40 + 100)
+        P.case_mel_in_graph_beside_tails("cuda", replays=300)
     finally:
         _lib.set_tuning("mel_wave", 0)
 

@@ -1,14 +1,17 @@
-"""Mel kernel alone, B = 48 clips of 10 s: variants (tuning key mel_wave: 1 = the round-5 wave-per-frame kernel (opt-in), 0 = the default
-one-frame-per-workgroup kernel), HIP-event time per launch, agreement between the variants, and the error against an f64 FFT."""
-import sys, torch
+"""Mel kernel alone, B = 48 clips of 10 s: variants (tuning key mel_wave: 0 = the default wave-per-frame kernel, 2 = the round-1..4
+one-frame-per-workgroup kernel), HIP-event time per launch, agreement between the variants, and the error against an f64 FFT.
+SED_PROBE_LIB=<library.so>: a variant build (tools/build_variant.py) instead of the product library."""
+import os, sys, torch
 sys.path.insert(0, '.'); sys.path.insert(0, '..')
 from tests import parity_cases as P
 from desed_task_amd import _lib
+if os.environ.get("SED_PROBE_LIB"):
+    _lib.use_library(os.environ["SED_PROBE_LIB"], is_emulator=False)
 mel = P.make_mel()
 g = torch.Generator().manual_seed(3)
 audio = (0.1 * torch.randn(48, 160000, generator=g)).cuda()
 ref = None
-for v in [int(a) for a in sys.argv[1:]] or [1, 0]:
+for v in [int(a) for a in sys.argv[1:]] or [0, 2]:
     _lib.set_tuning("mel_wave", v)
     for _ in range(3): out = mel(audio)
     torch.cuda.synchronize()
