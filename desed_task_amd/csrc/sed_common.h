@@ -112,6 +112,40 @@ __device__ __forceinline__ void bf16_split(float x, unsigned short& hi, unsigned
     lo = f32_to_bf16(x - bf16_to_f32(hi));
 }
 
+// ---- gfx950 hazard: packed-fp32 VALU with OP_SEL on src1, beside v_mfma_f32_32x32x16_bf16 waves (found in round 6) ---------------------
+// A v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 whose LOW lane takes the HIGH dword of src1 (op_sel = [0,1] / [0,1,0]) intermittently
+// computes lanes 48-63 of its low result with that operand read as 0 while waves of ANOTHER kernel that issues the gfx950 double-K bf16
+// MFMA (v_mfma_f32_32x32x16_bf16: gemm_bf16x3_kernel, the split-bf16 convolutions) are resident on the same CU: 0.5 - 2.5 % of the
+// executions under a saturating co-runner, transient (the same instruction on the same registers is right the next time), in eager
+// launches as well as in hipGraph replays, not cured by s_nop / s_setprio / dependent or independent neighbours.  NOT affected: the
+// same selection on src0 (op_sel = [1,0]) or src2, op_sel = [1,1], op_sel_hi on any source, no op_sel; no fault beside an fp32-MFMA
+// GEMM, a rocBLAS GEMM or a VALU / LDS kernel.  (tools/mel_repro/pk_probe.{hip,py}: 1.3e8 executions per form; profiles/r06_mel_mechanism.md.
+// It is what round 5 saw as "wrong bins in single frames of the wave-per-frame mel kernel inside graph replays".)
+// RULE: no kernel of this library contains such an instruction -- hand-written packed arithmetic puts the operand whose halves are
+// swapped into src0 (the adds and products commute: same bits), compiler-generated pairs are broken up where the compiler picked the
+// form (sed_sadd, pinned scalars); tests/test_isa_audit.py::test_no_packed_f32_op_sel_on_src1 scans the ISA of every kernel.
+// scalar fp32 add that the compiler cannot merge into a packed instruction
+__device__ __forceinline__ float sed_sadd(float a, float b) {
+#ifdef SED_EMU
+    return a + b;
+#else
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
+
+// scalar fp32 FMA that the compiler cannot merge into a packed instruction (same note)
+__device__ __forceinline__ float sed_sfma(float a, float b, float c) {
+#ifdef SED_EMU
+    return fmaf(a, b, c);
+#else
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#endif
+}
+
 // compiler scheduling fence: nothing moves across it (bounds the live ranges of hoisted LDS reads in fully unrolled MFMA chains)
 __device__ __forceinline__ void sed_sched_fence() {
 #ifndef SED_EMU

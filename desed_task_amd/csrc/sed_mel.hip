@@ -21,9 +21,43 @@
 // under the gfx950 lane groups (modelled over all five passes: 992 -> 640 LDS cycles per frame for the data buffers).
 __device__ __forceinline__ int mel_sw(int i) { return i ^ ((i >> 2) & 15); }
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+// Complex arithmetic on the packed-fp32 pipe: a complex number is one 64-bit VGPR pair, and VOP3P's op_sel / neg modifiers pick and
+// negate the halves, so that a rotation by +-i folds into the add and a complex product is two instructions (the compiler's own
+// lowering of the float2 formulas spent 18 % of the frame loop on v_mov shuffles between scalar and packed forms).
+#if defined(SED_EMU) || defined(MEL_PLAIN_MATH)
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cadd_mi(float2 a, float2 b) { return make_float2(a.x + b.y, a.y - b.x); }     // a - i b
+__device__ __forceinline__ float2 cadd_pi(float2 a, float2 b) { return make_float2(a.x - b.y, a.y + b.x); }     // a + i b
+__device__ __forceinline__ float2 cmulp(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+__device__ __forceinline__ float2 cscale(float2 a, float2 w) { return make_float2(a.x * w.x, a.y * w.y); }      // elementwise
+__device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
+#else
+__device__ __forceinline__ f32x2 c_in(float2 a) { f32x2 r; r.x = a.x; r.y = a.y; return r; }
+__device__ __forceinline__ float2 c_out(f32x2 a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return c_out(c_in(a) + c_in(b)); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return c_out(c_in(a) - c_in(b)); }
+// (the operand whose halves are swapped is src0, never src1: sed_common.h, "gfx950 hazard".  Round 5's form -- b as src1 with
+//  op_sel:[0,1] -- is the instruction that returned a.x instead of a.x -+ b.y in lanes 48-63 beside the split-bf16 GEMM.)
+__device__ __forceinline__ float2 cadd_mi(float2 a, float2 b) {       // a - i b = (b.y + a.x, -b.x + a.y)
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(c_in(b)), "v"(c_in(a)));
+    return c_out(r);
 }
+__device__ __forceinline__ float2 cadd_pi(float2 a, float2 b) {       // a + i b = (-b.y + a.x, b.x + a.y)
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(r) : "v"(c_in(b)), "v"(c_in(a)));
+    return c_out(r);
+}
+__device__ __forceinline__ float2 cmulp(float2 a, float2 w) {         // a w = a.x (w.x, w.y) + a.y (-w.y, w.x)
+    f32x2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(c_in(a)), "v"(c_in(w)));         // (a.y w.y, a.y w.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(c_in(a)), "v"(c_in(w)), "v"(t));
+    return c_out(r);
+}
+__device__ __forceinline__ float2 cscale(float2 a, float2 w) { return c_out(c_in(a) * c_in(w)); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }      // v_sqrt_f32: 1 ulp, no denormal fix-up
+#endif
 
 // WPT > 0: the thread's filterbank taps (every second tap of its band, zero-padded to WPT) live in registers for all its frames.
 // With the weights read from memory inside the frame loop the mel stage was a chain of dependent loads -- start, length, then one
@@ -123,20 +157,18 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
             float2 v0 = src[mel_sw(tid)], v1 = src[mel_sw(tid + 256)], v2 = src[mel_sw(tid + 512)], v3 = src[mel_sw(tid + 768)];
             if (pass > 0) {                              // twiddles exp(-2 pi i j k / (4 Ns)), j = 1, 2, 3
                 const float2* tw = stw + (Ns - 4) + k;   // 3 * (4 + 16 + ... + Ns / 4) = Ns - 4
-                v1 = cmul(v1, tw[0]);
-                v2 = cmul(v2, tw[Ns]);
-                v3 = cmul(v3, tw[2 * Ns]);
+                v1 = cmulp(v1, tw[0]);
+                v2 = cmulp(v2, tw[Ns]);
+                v3 = cmulp(v3, tw[2 * Ns]);
             }
-            // DFT-4 (forward, e^{-i pi/2} = -i)
-            const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
-            const float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
-            const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
-            const float2 a3 = make_float2(v1.x - v3.x, v1.y - v3.y);   // (v1 - v3)
+            // DFT-4 (forward, e^{-i pi/2} = -i).  (Hand-picked packed instructions, as in the wave kernel below: left to itself the
+            // compiler paired these sums into v_pk_add_f32 ... op_sel:[0,1] -- the form sed_common.h's "gfx950 hazard" note forbids.)
+            const float2 a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3), a3 = csub(v1, v3);
             const int d = ((tid - k) << 2) + k;
-            dst[mel_sw(d)] = make_float2(a0.x + a2.x, a0.y + a2.y);
-            dst[mel_sw(d + Ns)] = make_float2(a1.x + a3.y, a1.y - a3.x);      // a1 - i a3
-            dst[mel_sw(d + 2 * Ns)] = make_float2(a0.x - a2.x, a0.y - a2.y);
-            dst[mel_sw(d + 3 * Ns)] = make_float2(a1.x - a3.y, a1.y + a3.x);  // a1 + i a3
+            dst[mel_sw(d)] = cadd(a0, a2);
+            dst[mel_sw(d + Ns)] = cadd_mi(a1, a3);            // a1 - i a3
+            dst[mel_sw(d + 2 * Ns)] = csub(a0, a2);
+            dst[mel_sw(d + 3 * Ns)] = cadd_pi(a1, a3);        // a1 + i a3
             __syncthreads();
             float2* tmp = src; src = dst; dst = tmp;
         }
@@ -152,11 +184,11 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
                 mag[MEL_M] = fabsf(z0.x - z0.y);
             } else {
                 const float2 zk = Z[mel_sw(k)], zm = Z[mel_sw(MEL_M - k)];
-                const float2 xe = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-                const float dr = zk.x - zm.x, di = zk.y + zm.y;            // zk - conj(zm)
-                const float2 xo = make_float2(0.5f * di, -0.5f * dr);       // -i/2 * (zk - conj(zm))
-                const float2 wx = cmul(tw2[q], xo);
-                const float re = xe.x + wx.x, im = xe.y + wx.y;
+                // Xe = (zk + conj(zm)) / 2, Xo = -i (zk - conj(zm)) / 2, X[k] = Xe + w2048^k Xo -- scalar halves, one packed product
+                const float ex = 0.5f * sed_sadd(zk.x, zm.x), ey = 0.5f * sed_sadd(zk.y, -zm.y);
+                const float dr = sed_sadd(zk.x, -zm.x), di = sed_sadd(zk.y, zm.y);            // zk - conj(zm)
+                const float2 wx = cmulp(tw2[q], make_float2(0.5f * di, -0.5f * dr));
+                const float re = sed_sadd(ex, wx.x), im = sed_sadd(ey, wx.y);
                 m = sqrtf(re * re + im * im);
             }
             mag[k] = m;
@@ -220,41 +252,6 @@ __global__ __launch_bounds__(256, 4) void mel_kernel(const float* __restrict__ a
 #endif
 #define MEL_XPAD 1088          // 1024 + 64 padding slots (exchange 1)
 
-// Complex arithmetic on the packed-fp32 pipe: a complex number is one 64-bit VGPR pair, and VOP3P's op_sel / neg modifiers pick and
-// negate the halves, so that a rotation by +-i folds into the add and a complex product is two instructions (the compiler's own
-// lowering of the float2 formulas spent 18 % of the frame loop on v_mov shuffles between scalar and packed forms).
-#if defined(SED_EMU) || defined(MEL_PLAIN_MATH)
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cadd_mi(float2 a, float2 b) { return make_float2(a.x + b.y, a.y - b.x); }     // a - i b
-__device__ __forceinline__ float2 cadd_pi(float2 a, float2 b) { return make_float2(a.x - b.y, a.y + b.x); }     // a + i b
-__device__ __forceinline__ float2 cmulp(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
-__device__ __forceinline__ float2 cscale(float2 a, float2 w) { return make_float2(a.x * w.x, a.y * w.y); }      // elementwise
-__device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
-#else
-__device__ __forceinline__ f32x2 c_in(float2 a) { f32x2 r; r.x = a.x; r.y = a.y; return r; }
-__device__ __forceinline__ float2 c_out(f32x2 a) { return make_float2(a.x, a.y); }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return c_out(c_in(a) + c_in(b)); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return c_out(c_in(a) - c_in(b)); }
-__device__ __forceinline__ float2 cadd_mi(float2 a, float2 b) {       // a - i b = (a.x + b.y, a.y - b.x)
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(c_in(a)), "v"(c_in(b)));
-    return c_out(r);
-}
-__device__ __forceinline__ float2 cadd_pi(float2 a, float2 b) {       // a + i b = (a.x - b.y, a.y + b.x)
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(c_in(a)), "v"(c_in(b)));
-    return c_out(r);
-}
-__device__ __forceinline__ float2 cmulp(float2 a, float2 w) {         // a w = a.x (w.x, w.y) + a.y (-w.y, w.x)
-    f32x2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(c_in(a)), "v"(c_in(w)));         // (a.y w.y, a.y w.x)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(c_in(a)), "v"(c_in(w)), "v"(t));
-    return c_out(r);
-}
-__device__ __forceinline__ float2 cscale(float2 a, float2 w) { return c_out(c_in(a) * c_in(w)); }
-__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }      // v_sqrt_f32: 1 ulp, no denormal fix-up
-#endif
 // forward DFT-4 in place: (v0, v1, v2, v3) -> (X0, X1, X2, X3), e^{-i pi / 2} = -i
 __device__ __forceinline__ void dft4(float2& v0, float2& v1, float2& v2, float2& v3) {
     const float2 a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3), a3 = csub(v1, v3);
@@ -289,14 +286,16 @@ __device__ __forceinline__ void dft16(float2* v) {
         for (int b = a + 1; b < 4; ++b) { const float2 t = v[4 * a + b]; v[4 * a + b] = v[4 * b + a]; v[4 * b + a] = t; }
 }
 
-// Workgroup = MEL_WAVES waves: the frame-invariant tables (window 8 KB, pass-2 twiddles 2 KB, the mel taps 16 KB) are shared by its
-// waves, 8.5 KB of exchange buffer each -> 60 KB at four waves: two workgroups = eight waves per CU = two per SIMD at 184 VGPRs (three
-// per SIMD needs <= 168: every form that got there spilled and ran 2.3 x slower).
+// Workgroup = MEL_WAVES waves: the frame-invariant LDS tables (pass-2 twiddles 2 KB, the mel taps 16 KB) are shared by its waves, 8.5 KB
+// of exchange buffer each -> 52 KB at four waves: THREE workgroups = twelve waves per CU = three per SIMD (142 VGPRs: with one frame per
+// wave there is no frame loop for LICM to hoist 47 table reads out of -- round 5's multi-frame form needed 184 and every attempt at
+// <= 168 spilled).  The window (8 KB) is not staged: every tap is used by exactly one lane of a wave, once -- it travels L2 -> registers
+// beside the samples (MEL_WIN_LDS: the staged form, 60 KB = two workgroups per CU; 104 vs 84 us at B = 48, profiles/r06_mel_variants.md).
 // Mel taps in LDS: band `lane` as MEL_GA and band 127 - lane as MEL_GB groups of four taps, the first group starting at the band's
 // first bin rounded DOWN to a multiple of four (leading / trailing zeros), stored [group][lane] -- every lane reads its 16 bytes of group
 // g at the same offset (conflict-free), and the magnitudes as aligned 16-byte reads too: 32 ds_read_b128 per frame instead of 120 b32.
 #ifndef MEL_OCC
-#define MEL_OCC (MEL_WAVES <= 6 ? 2 : 1)
+#define MEL_OCC (12 / MEL_WAVES)
 #endif
 #define MEL_GA 4
 #define MEL_GB 12
@@ -308,7 +307,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, MEL_OCC) void mel_wave_kernel(const
                                                        const float2* __restrict__ tw2048, const int* __restrict__ fb_start,
                                                        const int* __restrict__ fb_len, const float* __restrict__ fb_w, int fb_stride,
                                                        const float4* __restrict__ taps, int runs_per_clip, int segs_per_clip) {
-#ifndef MEL_WIN_GLOBAL
+#ifdef MEL_WIN_LDS
     __shared__ float2 s_win[MEL_M];                             // (w[2n], w[2n + 1])
 #endif
     __shared__ float2 s_tw16[15 * 16];                          // [r - 1][k]: e^{-2 pi i r k / 256}, r = 1..15, k < 16 (pass 2)
@@ -357,7 +356,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, MEL_OCC) void mel_wave_kernel(const
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = make_float2(0.f, 0.f);
     }
-#ifdef MEL_WIN_GLOBAL
+#ifndef MEL_WIN_LDS
     float2 wn[16];                              // every window tap is used once per wave: straight from L2 beside the samples
 #pragma unroll
     for (int j = 0; j < 16; ++j) wn[j] = reinterpret_cast<const float2*>(window)[lane + 64 * j];
@@ -387,7 +386,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, MEL_OCC) void mel_wave_kernel(const
     float* magb = reinterpret_cast<float*>(xb);
     // ---- window; pass 1: radix 16, Ns = 1: in[lane + 64 r] -> out[16 lane + r] ----
 #pragma unroll
-#ifdef MEL_WIN_GLOBAL
+#ifndef MEL_WIN_LDS
     for (int j = 0; j < 16; ++j) v[j] = cscale(v[j], wn[j]);
 #else
     for (int j = 0; j < 16; ++j) v[j] = cscale(v[j], s_win[lane + 64 * j]);

@@ -542,3 +542,302 @@ class RankShardedBatchSampler:
         for i, batch in enumerate(batches):
             if i % self.world == self.rank:
                 yield batch
+
+
+# ---- the one-command data-parallel run (SURVEY 8e "Launcher") ------------------------------------------------------------------------
+#     python -m desed_task_amd.launcher --conf_file confs/default.yaml --log_dir exp/run [--gpus N] [--strong_real]
+#                                       [--resume_from_checkpoint last.ckpt] [--test_from_checkpoint best.ckpt] [--fast_dev_run]
+# from the recipe directory (so that `local.*` and `desed_task.dataio` -- the reference's data sets, samplers and label encoder, which
+# are outside the hot path -- import as they do for train_sed.py).  It is what recipes/dcase2023_task4_baseline/train_sed.py:53-306 does,
+# minus the refusal of more than one GPU (:269-276) and minus Lightning: N processes, one per GPU (self-launched through
+# torch.distributed.run when the torchrun environment is absent), each building the SAME data sets, the recipe's
+# ConcatDatasetBatchSampler behind RankShardedBatchSampler, `CRNN(**config["net"])`, `torch.optim.Adam`, `ExponentialWarmup`,
+# `SEDTask4`; epochs of hipGraph-replayed steps (graph.GraphedStepDriver; launcher.StepDriver on a CPU device) with the next batch
+# announced and uploaded ahead; every `validation_interval` epochs the BatchNorm statistics are averaged over the ranks and rank 0
+# validates (same metrics, same objective), keeps `last.ckpt` / the best checkpoint in Lightning's layout (what --test_from_checkpoint
+# and the reference's own loaders read) and decides about early stopping; after the last epoch rank 0 tests the best weights.
+def _seed_all(seed, rank):
+    """pl.seed_everything(seed) on rank 0; the other ranks draw their mixup / dropout / SpecAugment from seed + rank (every rank trains
+    on its own clips with its own augmentation; the data split and the epoch's batch order are seeded separately, rank-independent)."""
+    import random
+    import numpy as np
+    random.seed(seed + rank)
+    np.random.seed(seed + rank)
+    torch.manual_seed(seed + rank)
+    _ops.reseed_dropout()
+
+
+def build_run(config, log_dir, rank=0, world=1, strong_real=False, fast_dev_run=False, test_only=False, evaluation=False):
+    """train_sed.py:79-246 -> the SEDTask4 of this package with the reference's data objects (imported from the reference checkout on
+    PYTHONPATH; nothing of them is re-implemented here).  The train sampler is the recipe's ConcatDatasetBatchSampler seen through
+    RankShardedBatchSampler: rank r trains on batches r, r + world, ... of every epoch."""
+    import pandas as pd
+    try:
+        from desed_task.dataio import ConcatDatasetBatchSampler
+        from desed_task.dataio.datasets import StronglyAnnotatedSet, UnlabeledSet, WeakSet
+        from desed_task.utils.encoder import ManyHotEncoder
+        from local.classes_dict import classes_labels
+    except ImportError as e:  # pragma: no cover
+        raise SystemExit("desed_task_amd.launcher needs the reference's data pipeline on PYTHONPATH (run it from the recipe directory, "
+                         "like train_sed.py; INTEGRATION.md): %s" % e)
+    from .nnet.CRNN import CRNN
+    from .sed_trainer import SEDTask4
+    from .utils.schedulers import ExponentialWarmup
+    config = dict(config)
+    config["log_dir"] = log_dir
+    data, tr = config["data"], config["training"]
+    encoder = ManyHotEncoder(list(classes_labels.keys()), audio_len=data["audio_max_len"], frame_len=config["feats"]["n_filters"],
+                             frame_hop=config["feats"]["hop_length"], net_pooling=data["net_subsample"], fs=data["fs"])
+    if not evaluation:
+        test_data = StronglyAnnotatedSet(data["test_folder"], pd.read_csv(data["test_tsv"], sep="\t"), encoder, return_filename=True,
+                                         pad_to=data["audio_max_len"])
+    else:
+        test_data = UnlabeledSet(data["eval_folder"], encoder, pad_to=None, return_filename=True)
+    student = CRNN(**config["net"])
+    if test_only:
+        return SEDTask4(config, encoder=encoder, sed_student=student, test_data=test_data, fast_dev_run=fast_dev_run, evaluation=evaluation)
+    synth = StronglyAnnotatedSet(data["synth_folder"], pd.read_csv(data["synth_tsv"], sep="\t"), encoder, pad_to=data["audio_max_len"])
+    weak_df = pd.read_csv(data["weak_tsv"], sep="\t")
+    train_weak_df = weak_df.sample(frac=tr["weak_split"], random_state=tr["seed"])
+    valid_weak_df = weak_df.drop(train_weak_df.index).reset_index(drop=True)
+    weak = WeakSet(data["weak_folder"], train_weak_df.reset_index(drop=True), encoder, pad_to=data["audio_max_len"])
+    unlabeled = UnlabeledSet(data["unlabeled_folder"], encoder, pad_to=data["audio_max_len"])
+    synth_val = StronglyAnnotatedSet(data["synth_val_folder"], pd.read_csv(data["synth_val_tsv"], sep="\t"), encoder, return_filename=True,
+                                     pad_to=data["audio_max_len"])
+    weak_val = WeakSet(data["weak_folder"], valid_weak_df, encoder, pad_to=data["audio_max_len"], return_filename=True)
+    if strong_real:
+        strong = StronglyAnnotatedSet(data["strong_folder"], pd.read_csv(data["strong_tsv"], sep="\t"), encoder, pad_to=data["audio_max_len"])
+        parts = [torch.utils.data.ConcatDataset([strong, synth]), weak, unlabeled]
+    else:
+        parts = [synth, weak, unlabeled]
+    sampler = RankShardedBatchSampler(ConcatDatasetBatchSampler([torch.utils.data.RandomSampler(x) for x in parts], tr["batch_size"]),
+                                      rank, world, seed=int(tr["seed"] or 0))
+    # The schedule counts optimizer steps: an epoch of N ranks has 1/N of the steps (N times the global batch), so the ramp of
+    # `n_epochs_warmup` epochs is that many steps shorter -- the reference's formula with the per-rank epoch length
+    steps_per_epoch = min(len(p) // (b * tr["accumulate_batches"]) for p, b in zip(parts, tr["batch_size"])) // world
+    opt = torch.optim.Adam(student.parameters(), config["opt"]["lr"], betas=(0.9, 0.999))
+    scheduler = {"scheduler": ExponentialWarmup(opt, config["opt"]["lr"], tr["n_epochs_warmup"] * max(steps_per_epoch, 1)), "interval": "step"}
+    return SEDTask4(config, encoder=encoder, sed_student=student, opt=opt, train_data=torch.utils.data.ConcatDataset(parts),
+                    valid_data=torch.utils.data.ConcatDataset([synth_val, weak_val]), test_data=test_data, train_sampler=sampler,
+                    scheduler=scheduler, fast_dev_run=fast_dev_run, evaluation=evaluation)
+
+
+def _run_eval(task, loader, device, step, limit):
+    from ._lightning_standin import move_to_device
+    task.eval()
+    n = len(loader)
+    n = n if limit is None else (int(n * limit) if isinstance(limit, float) else min(n, int(limit)))
+    with torch.no_grad():
+        for i, batch in enumerate(loader):
+            if i >= n:
+                break
+            step(move_to_device(batch, device), i)
+
+
+def fit(task, device, n_epochs, log_dir, world=1, rank=0, start_epoch=0, limit_train_batches=None, limit_val_batches=None,
+        use_graph=None, best=None, log=None):
+    """Epochs of data-parallel steps + validation on averaged BatchNorm statistics + checkpoints (what `trainer.fit` does for
+    train_sed.py:278-299).  -> (path of the best checkpoint, its objective).  Collective calls are made by every rank in the same order:
+    the per-step gradient exchange (inside the driver), the BN average, one broadcast of rank 0's decision per validation."""
+    import time
+    from ._lightning_standin import move_to_device
+    log = log or (lambda msg: print(msg, flush=True) if rank == 0 else None)
+    tr = task.hparams["training"]
+    os.makedirs(log_dir, exist_ok=True)
+    task.to(device)
+    if use_graph is None:
+        use_graph = device.type == "cuda"
+    if use_graph:
+        from .graph import GraphedStepDriver
+        driver = GraphedStepDriver(task, world_size=world, prefetch=os.environ.get("SED_PREFETCH", "teacher"))
+    else:
+        driver = StepDriver(task, world_size=world, prefetch=os.environ.get("SED_PREFETCH", "teacher"))
+    sampler = task.train_sampler
+    # a plain DataLoader over the rank's share (pinned host memory: the upload of batch k + 2 runs beside step k)
+    loader = torch.utils.data.DataLoader(task.train_data, batch_sampler=sampler, num_workers=task.num_workers, pin_memory=device.type == "cuda")
+    n_train = len(loader) if limit_train_batches is None else min(len(loader), int(limit_train_batches))
+    if n_train < 1:
+        raise SystemExit("no training batch per rank: %d batches of the sampler / %d ranks" % (len(sampler.batch_sampler), world))
+    best_metric, best_path = (best if best is not None else (None, None))
+    patience, bad_epochs = tr.get("early_stop_patience"), 0
+    val_every = int(tr.get("validation_interval", 1) or 1)
+    for epoch in range(start_epoch, n_epochs):
+        task.train()
+        try:
+            task.current_epoch = epoch
+        except AttributeError:                   # (real Lightning: a read-only property of the attached trainer)
+            pass
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
+        t0 = time.perf_counter()
+        it = iter(loader)
+        ahead = []                               # host batches k + 1, k + 2 (uploaded early: SEDTask4._stage)
+
+        def pull(k):
+            while len(ahead) < 2 and k + 1 + len(ahead) < n_train:
+                b = next(it, None)
+                if b is None:
+                    break
+                ahead.append(b)
+                task._stage((epoch, k + len(ahead)), b, device)
+
+        cur = move_to_device(next(it), device)
+        loss = None
+        for k in range(n_train):
+            pull(k)
+            nxt = None
+            if ahead:
+                ahead.pop(0)
+                nxt = task._take_staged((epoch, k + 1), device)
+            loss = driver.run_step(cur, k, next_batch=nxt)
+            cur = nxt
+            if cur is None:
+                break
+        del it
+        steps = k + 1
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        clips = steps * int(sum(tr["batch_size"])) * world
+        log("epoch %d: %d steps x %d ranks, loss %.4f, %.1f clips/s" % (epoch, steps, world, float(loss.detach()), clips / max(dt, 1e-9)))
+        if (epoch + 1) % val_every and epoch + 1 < n_epochs:
+            continue
+        # ---- validation on the rank-averaged BatchNorm statistics; rank 0 scores, everyone learns the verdict ----
+        average_bn_buffers(task, world)
+        verdict = torch.zeros(3, dtype=torch.float64)                    # (objective, is_best, stop)
+        if rank == 0:
+            _run_eval(task, task.val_dataloader(), device, task.validation_step, limit_val_batches)
+            obj = float(task.validation_epoch_end([]))
+            improved = best_metric is None or obj > best_metric
+            bad_epochs = 0 if improved else bad_epochs + 1
+            verdict[0], verdict[1] = obj, float(improved)
+            verdict[2] = float(patience is not None and bad_epochs >= int(patience))
+            ckpt = checkpoint_dict(task, epoch + 1)
+            ckpt["callbacks"] = {"launcher": {"best_metric": obj if improved else best_metric, "bad_epochs": bad_epochs}}
+            torch.save(ckpt, os.path.join(log_dir, "last.ckpt"))
+            if improved:
+                best_path = os.path.join(log_dir, "epoch=%d-step=%d.ckpt" % (epoch, ckpt["global_step"]))
+                if best_metric is not None:
+                    for f in os.listdir(log_dir):
+                        if f.startswith("epoch=") and f.endswith(".ckpt"):
+                            os.remove(os.path.join(log_dir, f))           # save_top_k = 1
+                torch.save(ckpt, best_path)
+            log("epoch %d: val/obj_metric %.4f%s" % (epoch, obj, " (best)" if improved else ""))
+        if world > 1:
+            v = verdict.to(device) if dist.get_backend() != "gloo" else verdict
+            dist.broadcast(v, src=0)
+            verdict = v.cpu()
+        if verdict[1] > 0:
+            best_metric = float(verdict[0])
+        task.reset_pipeline() if hasattr(task, "reset_pipeline") else None
+        if verdict[2] > 0:
+            log("early stopping after epoch %d" % epoch)
+            break
+    return best_path, best_metric
+
+
+def run_test(task, device, limit_test_batches=None):
+    """`trainer.test` (train_sed.py:305-306) on this rank."""
+    _run_eval(task, task.test_dataloader(), device, task.test_step, limit_test_batches)
+    return task.on_test_epoch_end()
+
+
+def _self_launch(n, argv):
+    """`--gpus N` from a plain shell: re-execute this command line under torch.distributed.run, one process per GPU of this node,
+    rendezvous on 127.0.0.1 at a free port (the contract bench.py follows)."""
+    import socket
+    import subprocess
+    import sys
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's intra-node transport needs it on these hosts
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "desed_task_amd.launcher"] + list(argv)
+    sys.stderr.write("desed_task_amd.launcher: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    import argparse
+    import sys
+    import yaml
+    ap = argparse.ArgumentParser("python -m desed_task_amd.launcher", description="Data-parallel training of the DESED CRNN mean-teacher baseline "
+                                 "on MI355X: train_sed.py's arguments, one process per GPU")
+    ap.add_argument("--conf_file", default="./confs/default.yaml")
+    ap.add_argument("--log_dir", default="./exp/2023_baseline")
+    ap.add_argument("--strong_real", action="store_true")
+    ap.add_argument("--resume_from_checkpoint", default=None)
+    ap.add_argument("--test_from_checkpoint", default=None)
+    ap.add_argument("--eval_from_checkpoint", default=None)
+    ap.add_argument("--gpus", default="1", help="number of GPUs of this node (one process each); 0 = a CPU device (needs --emulator)")
+    ap.add_argument("--fast_dev_run", action="store_true")
+    ap.add_argument("--emulator", action="store_true", help="TEST INFRASTRUCTURE: the CPU fiber emulator of the kernels (tests/emu) on a CPU "
+                    "device over gloo -- a plumbing check, no product path")
+    args = ap.parse_args(argv)
+    n = int(args.gpus)
+    if "RANK" not in os.environ and max(n, 1) > 1:
+        return _self_launch(n, sys.argv[1:] if argv is None else argv)
+    if args.emulator:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        from tests.emu_support import bind_emulator
+        bind_emulator()
+    elif not torch.cuda.is_available():
+        raise SystemExit("desed_task_amd.launcher needs the MI355X (no GPU visible); there is no CPU path")
+    rank, local, world = init_distributed(backend="gloo" if args.emulator else None)
+    device = torch.device("cpu") if args.emulator else torch.device("cuda", local)
+    with open(args.conf_file) as f:
+        config = yaml.safe_load(f)
+    evaluation = args.eval_from_checkpoint is not None
+    test_ckpt = args.eval_from_checkpoint or args.test_from_checkpoint
+    log_dir = os.path.join(args.log_dir, "version_0")
+    if evaluation:
+        config["training"]["batch_size_val"] = 1
+    seed = config["training"]["seed"]
+    if seed:
+        _seed_all(int(seed), rank)
+    if test_ckpt is not None:                                    # train_sed.py:367-380: no training, one rank scores
+        ckpt = torch.load(test_ckpt, map_location="cpu", weights_only=False)
+        hp = dict(ckpt["hyper_parameters"])
+        hp["data"] = config["data"]
+        task = build_run(hp, log_dir, test_only=True, evaluation=evaluation, fast_dev_run=args.fast_dev_run)
+        task.load_state_dict(ckpt["state_dict"])
+        task.to(device)
+        if rank == 0:
+            print("loaded model: %s\nat epoch: %s" % (test_ckpt, ckpt.get("epoch")))
+            run_test(task, device, 2 if args.fast_dev_run else None)
+        if world > 1:
+            dist.barrier()
+        return 0
+    task = build_run(config, log_dir, rank, world, strong_real=args.strong_real, fast_dev_run=args.fast_dev_run)
+    task.to(device)
+    start, best = 0, None
+    if args.resume_from_checkpoint:
+        ckpt = load_checkpoint(task, args.resume_from_checkpoint, resume=True)
+        start = int(ckpt.get("epoch", 0))
+        cb = (ckpt.get("callbacks") or {}).get("launcher") or {}
+        if cb.get("best_metric") is not None:
+            best = (float(cb["best_metric"]), None)
+    if args.fast_dev_run:
+        n_epochs, lim_train, lim_val, lim_test = 3, 2, 2, 2
+    else:
+        n_epochs, lim_train, lim_val, lim_test = config["training"]["n_epochs"], None, None, None
+    best_path, best_metric = fit(task, device, n_epochs, log_dir, world, rank, start, lim_train, lim_val, best=best)
+    if rank == 0:
+        print("best model: %s (val/obj_metric %s)" % (best_path, best_metric))
+        if best_path is not None:
+            task.load_state_dict(torch.load(best_path, map_location="cpu", weights_only=False)["state_dict"])
+        run_test(task, device, lim_test)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main())

@@ -330,6 +330,15 @@ class SEDTask4(_Base):
         cur = self._cur_batch
         key = cur[0] if (cur is not None and batch[0] is cur[1][0]) else loader.find(batch)
         self._cur_batch = None
+        announced = self._uploaded[0] if self._uploaded is not None else None
+        if announced is not None and key != announced:
+            # The previous step announced -- and prefetched the front half of -- a batch that is not the one we were given: the epoch
+            # was abandoned mid-way (a break / max_steps, then a new iter(loader)) or the caller skipped a batch.  What sits in the
+            # hand-over buffers (features, mixed labels, the teacher's CNN output) belongs to a batch nobody trains on now: forget it,
+            # this step runs its own front half inline (it used to be consumed silently -- the step trained on the old batch).
+            self.reset_pipeline()
+            self._uploaded = None
+            self._staged = None
         if key is None:
             return None
         loader.release(key)
@@ -354,6 +363,9 @@ class SEDTask4(_Base):
         nxt = self._next_from_loader(batch)
         drv = self._step_driver(pipelined=nxt is not None)
         self._served = None
+        # (a caller that runs training_step twice without an optimizer.step() in between -- a hand-written loop, a bench -- must not
+        #  leave the previous call's "update already applied" mark for the driver's OWN nested optimizer step to find: ADVICE r05)
+        self.opt.served = False
         graph_before = getattr(drv, "graph", None)
         rec = []
         object.__setattr__(self, "log", lambda name, value, **kw: rec.append((name, value, kw)))    # (no self.log inside a capture)

@@ -30,10 +30,11 @@ class Trainer:
     """The arguments of train_sed.py:278-296 that change what the loop calls; everything else is accepted and ignored."""
 
     def __init__(self, max_epochs=1, limit_train_batches=1.0, limit_val_batches=0, accumulate_grad_batches=1, device=None,
-                 check_val_every_n_epoch=1, on_step=None, **ignored):
+                 check_val_every_n_epoch=1, on_step=None, abandon=None, **ignored):
         self.max_epochs, self.limit_train, self.limit_val = max_epochs, limit_train_batches, limit_val_batches
         self.accumulate, self.device, self.val_every, self.on_step = accumulate_grad_batches, device, check_val_every_n_epoch, on_step
-        self.current_epoch = self.global_step = 0
+        self.abandon = abandon or {}     # {epoch: n}: leave that epoch's loop after n batches WITHOUT the module knowing beforehand (an
+        self.current_epoch = self.global_step = 0     # interrupted epoch / `max_steps`: `num_training_batches` stays what it was)
         self.num_training_batches = None
         self.losses = []
 
@@ -54,7 +55,7 @@ class Trainer:
             model.train()
             _hook(model, "on_train_epoch_start")
             for i, batch in enumerate(loader):
-                if i >= self.num_training_batches:
+                if i >= self.num_training_batches or i >= self.abandon.get(epoch, i + 1):
                     break
                 batch = model.transfer_batch_to_device(batch, device, 0)
                 _hook(model, "on_train_batch_start", batch, i)

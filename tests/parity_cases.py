@@ -131,6 +131,21 @@ def case_mel_in_graph_beside_tails(dev, replays=300, beside="tails", launch=None
                  rnn0.bias_ih_l0.data_ptr(), rnn0.bias_ih_l0_reverse.data_ptr(), gi_buf.data_ptr(), gi_buf.data_ptr() + 3 * Hq * 4,
                  Bq * Tq, 3 * Hq, Hq, Hq, Hq, 6 * Hq, 0, 1, 1, 0, stream.cuda_stream)
 
+    # beside = "storm": the split-bf16 GEMM at the production size of the BiGRU input projection (M = 48 x 156 rows: 708 workgroups), a
+    # dozen launches queued on the co-runner's stream BEFORE the mel node, so that MFMA waves are resident on every CU from the first to
+    # the last mel wave -- with the two small GEMMs of "gemm" the co-runner only arrives a few microseconds into the mel kernel, which
+    # is why round 5 saw the fault only in waves that lived long enough to transform a second frame (profiles/r06_mel_mechanism.md)
+    Ms = 48 * 156
+    h_big = torch.randn(Ms, Hq, device=out.device) if beside == "storm" else None
+    gi_big = torch.zeros(Ms, 2, 3 * Hq, device=out.device) if beside == "storm" else None
+
+    def gemm_storm(stream, n=12):
+        lib = _lib.get()
+        for _ in range(n):
+            lib.call("sed_gemm_pair_bf16x3", h_big.data_ptr(), h_big.data_ptr(), rnn0.weight_ih_l0.data_ptr(), rnn0.weight_ih_l0_reverse.data_ptr(),
+                     rnn0.bias_ih_l0.data_ptr(), rnn0.bias_ih_l0_reverse.data_ptr(), gi_big.data_ptr(), gi_big.data_ptr() + 3 * Hq * 4,
+                     Ms, 3 * Hq, Hq, Hq, Hq, 6 * Hq, 0, 1, 1, 0, stream.cuda_stream)
+
     def gru_only(stream):
         lib = _lib.get()
         lib.call("sed_gru_fwd", gi_buf.data_ptr(), rnn0.weight_hh_l0.data_ptr(), rnn0.weight_hh_l0_reverse.data_ptr(),
@@ -140,6 +155,10 @@ def case_mel_in_graph_beside_tails(dev, replays=300, beside="tails", launch=None
         with torch.no_grad():
             hs = task.sed_student.forward_cnn(x)
             cur = torch.cuda.current_stream()
+            if beside == "storm":
+                s_t.wait_stream(cur)
+                with torch.cuda.stream(s_t):
+                    gemm_storm(s_t)
             s_mel.wait_stream(cur)
             with torch.cuda.stream(s_mel):
                 launch(static_audio, out)
@@ -1212,6 +1231,95 @@ def case_lightning_surface(dev, epochs=3, per_epoch=3, n_samp=16000 + 1024, limi
             assert torch.equal(a, b), mode
         assert got[2] == ref[2], (mode, got[2], ref[2])
     return ref[0]
+
+
+def case_lightning_surface_abandoned_epoch(dev, n_samp=2048 + 1024, per_epoch=3, warmup=1):
+    """ADVICE r05 (medium, both): (1) an epoch that is ABANDONED while a successor is announced -- the loop leaves epoch 1 after its
+    second batch without the module knowing (`abandon`), then a new iter(loader) starts epoch 2 -- must not make the next step consume
+    the stale prefetched front half: whole-step mode == the hooks one by one, bit for bit (losses, weights, BatchNorm statistics,
+    Adam state); (2) training_step called twice with NO optimizer.step() in between (a hand-written loop) applies two Adam updates."""
+    import random
+    from desed_task_amd import ops as _ops
+    from desed_task_amd.lookahead import BatchList
+    from tests.lightning_order import Trainer
+    bs = (1, 1, 2)
+    B = sum(bs)
+    sd = O.make_state_dict(seed=7)
+    n_out = (1 + n_samp // 256) // 4
+    audios = [to(dev, O.synth_audio(B, n_samp, seed=900 + 7 * i)) for i in range(per_epoch)]
+    labelss = [to(dev, O.synth_labels(bs, 10, n_out, seed=60 + i)) for i in range(per_epoch)]
+
+    class Clips(BatchList):
+        def __getitem__(self, i):
+            return (audios[i], labelss[i].clone(), [1.0] * B)
+
+    def seed():
+        random.seed(43); np.random.seed(103); torch.manual_seed(103)
+        if dev != "cpu":
+            torch.cuda.manual_seed(103)
+        _ops.reseed_dropout()
+
+    def state(task):
+        out = [task.sed_student.arena.flat.detach().cpu().clone(), task.sed_teacher.arena.flat.detach().cpu().clone()]
+        for model in (task.sed_student, task.sed_teacher):
+            for i in range(7):
+                bn = getattr(model.cnn.cnn, "batchnorm%d" % i)
+                out += [bn.running_mean.detach().cpu().clone(), bn.running_var.detach().cpu().clone()]
+        osd = task.opt.state_dict()
+        out += [torch.cat([osd["state"][i]["exp_avg"].reshape(-1).cpu() for i in sorted(osd["state"])]),
+                torch.tensor([float(osd["state"][0]["step"]), float(task.scheduler["scheduler"].step_num)])]
+        return out
+
+    # Reference: the step driver by hand with the SAME announcements (the look-ahead draws the announced batch's mixup on the host one
+    # step early, so the hooks-one-by-one order cannot be the reference once an announced batch is dropped) and an explicit
+    # reset_pipeline() where the epoch is abandoned.
+    from desed_task_amd import graph as G
+    from desed_task_amd.launcher import StepDriver
+    results = {}
+    for mode in ("whole", "driver"):
+        task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=5, torch_adam=mode == "whole", whole_step=mode == "whole",
+                          train_data=Clips([None] * per_epoch))
+        task.whole_step_warmup = warmup
+        seed()
+        if mode == "whole":
+            tr = Trainer(max_epochs=4, abandon={1: 2}).fit(task)
+            assert tr.global_step == 3 * per_epoch + 2
+            losses = [float(l) for l in tr.losses]
+        else:
+            driver = (G.GraphedStepDriver(task, world_size=1, warmup=warmup, prefetch="teacher") if dev != "cpu"
+                      else StepDriver(task, world_size=1, prefetch="teacher"))
+            data, losses = Clips([None] * per_epoch), []
+            for epoch in range(4):
+                epoch_batches = list(torch.utils.data.DataLoader(data, batch_size=None))
+                used = 2 if epoch == 1 else per_epoch
+                for i in range(used):
+                    nxt = epoch_batches[i + 1] if i + 1 < per_epoch else None      # (epoch 1: batch 1 announces batch 2, which never comes)
+                    losses.append(float(driver.run_step(epoch_batches[i], i, next_batch=nxt).detach()))
+                if epoch == 1:
+                    task.reset_pipeline()
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        results[mode] = (losses, state(task))
+    assert results["whole"][0] == results["driver"][0], (results["whole"][0], results["driver"][0])
+    for a_, b_ in zip(results["whole"][1], results["driver"][1]):
+        assert torch.equal(a_, b_)
+
+    # (2) two training_step calls in a row, nobody calls optimizer.step(): each is a whole optimisation step
+    task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=5, torch_adam=True, whole_step=True, train_data=Clips([None] * per_epoch))
+    task.whole_step_warmup = warmup
+    seed()
+    task.train()
+    flats = [task.sed_student.arena.flat.detach().cpu().clone()]
+    step0 = task.scheduler["scheduler"].step_num
+    for i in range(3):
+        task.training_step((audios[i], labelss[i].clone(), [1.0] * B), i)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        flats.append(task.sed_student.arena.flat.detach().cpu().clone())
+    osd = task.opt.state_dict()
+    assert float(osd["state"][0]["step"]) == 3.0 and task.scheduler["scheduler"].step_num == step0 + 3
+    for i in range(3):
+        assert not torch.equal(flats[i], flats[i + 1]), "step %d left the weights where they were" % (i + 1)
 
 
 def case_step_bit_reproducible(dev, steps=3, n_samp=16000 + 1024):

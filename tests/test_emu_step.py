@@ -217,6 +217,11 @@ def test_lightning_hook_order_whole_step_equals_driver(emu):
     P.case_lightning_surface("cpu", epochs=2, per_epoch=3, n_samp=2048 + 1024)
 
 
+def test_lightning_abandoned_epoch_and_back_to_back_steps(emu):
+    """a stale announced successor is dropped, not consumed; training_step twice without optimizer.step() updates twice."""
+    P.case_lightning_surface_abandoned_epoch("cpu")
+
+
 def test_lightning_hook_order_limit_train_batches(emu):
     """`limit_train_batches` (train_sed.py:256): the batch before the cut announces no successor."""
     P.case_lightning_surface("cpu", epochs=2, per_epoch=3, n_samp=2048 + 1024, limit_train_batches=2)

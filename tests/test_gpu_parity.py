@@ -33,14 +33,37 @@ def test_mel_walk_batch_independent_at_baseline_size():
     P.case_mel_walk_batch_independent("cuda")
 
 
-@pytest.mark.parametrize("beside", ["tails", "gemm"])
+@pytest.mark.parametrize("beside", ["tails", "gemm", "storm"])
 def test_mel_in_graph_beside(beside):
     """The default mel kernel (one wave per frame, one frame per wave) replayed as a hipGraph node next to the BiGRU + head tails / next to
-    the BiGRU's split-bf16 input-projection GEMM alone gives the solo launch's bits: 3 000 replays each.  These are the two co-runners
-    beside which round 5's multi-frame form of the kernel returned wrong bins in 0.2 - 7 % of the replays
-    (profiles/r05_mel_graph_race.md, profiles/r06_mel_mechanism.md; the reproducer lives in tools/mel_repro/)."""
+    the BiGRU's split-bf16 input-projection GEMM alone / inside a storm of that GEMM at its production size (MFMA waves on every CU from
+    the first to the last mel wave) gives the solo launch's bits: 3 000 replays each.  Beside these co-runners round 5's form of the
+    kernel returned wrong bins in 0.2 - 29 % of the replays; cause (round 6): v_pk_add_f32 with op_sel on src1 beside
+    v_mfma_f32_32x32x16_bf16 waves -- sed_common.h "gfx950 hazard", profiles/r06_mel_mechanism.md, reproducer in tools/mel_repro/."""
     assert _lib.get_tuning("mel_wave") == 0
     P.case_mel_in_graph_beside_tails("cuda", replays=3000, beside=beside)
+
+
+def test_packed_f32_hazard_probe_is_clean_for_the_forms_we_use():
+    """The instruction-level reproducer of the same hazard (tools/mel_repro/pk_probe.hip, built on the box): the forms the library uses
+    (no op_sel; op_sel on src0; op_sel = [1,1]; op_sel_hi) never mismatch their scalar re-computation beside the GEMM storm.  (The
+    forbidden forms do, ~1 % of the time: not asserted -- the audit in tests/test_isa_audit.py keeps them out of the library.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "tools", "_pkprobe.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-DPROBE_LDS_FLOATS=8192",
+                               os.path.join(root, "tools", "mel_repro", "pk_probe.hip"), "-o", so])
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "mel_repro", "pk_probe.py"), so, "bf16x3"], capture_output=True, text=True,
+                         cwd=root, timeout=600).stdout
+    assert "hipGraph fork" in out, out[-2000:]
+    safe = ["pk_add (no op_sel)", "pk_add op_sel:[1,0] op_sel_hi:[0,1]", "pk_mul op_sel:[1,1] op_sel_hi:[1,0]",
+            "pk_fma op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]", "pk_fma op_sel:[1,0,0]", "pk_add op_sel_hi:[1,0]", "pk_mul (no op_sel)",
+            "pk_add SAME SUM, swapped operand as src0", "pk_fma op_sel:[0,0,1]"]
+    for line in out.split("\n"):
+        if "wrong lo / hi" in line:
+            assert not any(line.strip().startswith(f) for f in safe), line
 
 
 def test_mel_workgroup_kernel():

@@ -11,7 +11,7 @@ from tests import parity_cases as P
 if "wg" in sys.argv[3:]:
     _lib.set_tuning("mel_wave", 2)
 try:
-    beside = [a for a in sys.argv[3:] if a in ("tails", "matmul", "rnn", "cnn", "none", "gemm", "gru")]
+    beside = [a for a in sys.argv[3:] if a in ("tails", "matmul", "rnn", "cnn", "none", "gemm", "gru", "storm")]
     n = P.case_mel_in_graph_beside_tails("cuda", replays=int(sys.argv[2]) if len(sys.argv) > 2 else 400, beside=beside[0] if beside else "tails")
     print(sys.argv[1:], "replays", n, "bad 0")
 except AssertionError as e:

@@ -35,6 +35,64 @@ __device__ __forceinline__ f32x2 c_in(float2 a) { f32x2 r; r.x = a.x; r.y = a.y;
 __device__ __forceinline__ float2 c_out(f32x2 a) { return make_float2(a.x, a.y); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return c_out(c_in(a) + c_in(b)); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return c_out(c_in(a) - c_in(b)); }
+#ifdef MEL_SAFE_OPSEL
+// MEL_SAFE_OPSEL: the product's fix applied to this reproducer -- the operand whose halves are swapped is src0 (op_sel:[1,0]), not src1
+__device__ __forceinline__ float2 cadd_mi(float2 a, float2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(c_in(b)), "v"(c_in(a)));
+    return c_out(r);
+}
+__device__ __forceinline__ float2 cadd_pi(float2 a, float2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(r) : "v"(c_in(b)), "v"(c_in(a)));
+    return c_out(r);
+}
+#elif defined(MEL_CHECK)
+// MEL_CHECK: every +-i packed add (the instruction the MEL_DUMP runs pointed at) is re-computed with two scalar VALU instructions from
+// the SAME source registers and compared bitwise; a mismatch is logged: sources, the packed result, the scalar result, the packed
+// instruction executed once more on the same sources (transient or repeatable?), lane, HW_ID, which of the two forms.
+__device__ unsigned* mel_chk_buf;       // [0] = count, then 16 words per event
+__device__ __forceinline__ void mel_chk(f32x2 r, float2 a, float2 b, int form) {
+    float ex, ey;
+    if (form == 0) {        // a - i b = (a.x + b.y, a.y - b.x)
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(ex) : "v"(a.x), "v"(b.y));
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(ey) : "v"(a.y), "v"(b.x));
+    } else {                // a + i b = (a.x - b.y, a.y + b.x)
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(ex) : "v"(a.x), "v"(b.y));
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(ey) : "v"(a.y), "v"(b.x));
+    }
+    if (__float_as_uint(ex) != __float_as_uint(r.x) || __float_as_uint(ey) != __float_as_uint(r.y)) {
+        f32x2 r2, av, bv;
+        av.x = a.x; av.y = a.y; bv.x = b.x; bv.y = b.y;
+        if (form == 0) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r2) : "v"(av), "v"(bv));
+        else asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r2) : "v"(av), "v"(bv));
+        unsigned* cb = mel_chk_buf;
+        if (cb) {
+            const unsigned i = atomicAdd(cb, 1u);
+            if (i < 4000) {
+                unsigned* e = cb + 16 + 16 * i;
+                e[0] = __float_as_uint(a.x); e[1] = __float_as_uint(a.y); e[2] = __float_as_uint(b.x); e[3] = __float_as_uint(b.y);
+                e[4] = __float_as_uint(r.x); e[5] = __float_as_uint(r.y); e[6] = __float_as_uint(ex); e[7] = __float_as_uint(ey);
+                e[8] = __float_as_uint(r2.x); e[9] = __float_as_uint(r2.y); e[10] = threadIdx.x; e[11] = blockIdx.x;
+                e[12] = __builtin_amdgcn_s_getreg((31 << 11) | 4); e[13] = (unsigned)form;
+                e[14] = (unsigned)__builtin_amdgcn_s_memtime();
+            }
+        }
+    }
+}
+__device__ __forceinline__ float2 cadd_mi(float2 a, float2 b) {
+    f32x2 r;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(c_in(a)), "v"(c_in(b)));
+    mel_chk(r, a, b, 0);
+    return c_out(r);
+}
+__device__ __forceinline__ float2 cadd_pi(float2 a, float2 b) {
+    f32x2 r;
+    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(c_in(a)), "v"(c_in(b)));
+    mel_chk(r, a, b, 1);
+    return c_out(r);
+}
+#else
 __device__ __forceinline__ float2 cadd_mi(float2 a, float2 b) {       // a - i b = (a.x + b.y, a.y - b.x)
     f32x2 r;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(c_in(a)), "v"(c_in(b)));
@@ -45,6 +103,7 @@ __device__ __forceinline__ float2 cadd_pi(float2 a, float2 b) {       // a + i b
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(c_in(a)), "v"(c_in(b)));
     return c_out(r);
 }
+#endif
 __device__ __forceinline__ float2 cmulp(float2 a, float2 w) {         // a w = a.x (w.x, w.y) + a.y (-w.y, w.x)
     f32x2 t, r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(c_in(a)), "v"(c_in(w)));         // (a.y w.y, a.y w.x)
@@ -310,6 +369,14 @@ __global__ __launch_bounds__(64 * MEL_WAVES, MEL_OCC) void mel_wave_kernel(const
 }
 
 
+SED_API int melrepro_set_check(unsigned* buf) {
+#ifdef MEL_CHECK
+    return hipMemcpyToSymbol(HIP_SYMBOL(mel_chk_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -2;
+#else
+    (void)buf;
+    return -3;
+#endif
+}
 SED_API int melrepro_dump_floats() {
 #ifdef MEL_DUMP
     return MEL_DUMP_FLOATS;

@@ -21,6 +21,8 @@ _lib.get().call("sed_mel_taps", mel.fb_start.data_ptr(), mel.fb_len.data_ptr(), 
 torch.cuda.synchronize()
 state = {"dbg": None}
 P_ = ctypes.c_void_p
+chk = torch.zeros(16 + 16 * 4000, dtype=torch.int32, device="cuda")
+HAVE_CHK = rep_lib.melrepro_set_check(P_(chk.data_ptr())) == 0
 
 
 def launch(audio, out):
@@ -88,6 +90,40 @@ try:
 except AssertionError as e:
     verdict = "FAILED " + str(e)[:300]
 print(so, beside, "replays", replays, "bad replays", counts["bad"], "|", verdict[:200])
+if HAVE_CHK:
+    import struct
+    torch.cuda.synchronize()
+    c = chk.cpu().numpy().astype("uint32")
+    n = int(c[0])
+    f = lambda u: struct.unpack("f", struct.pack("I", int(u)))[0]
+    events = []
+    for i in range(min(n, 4000)):
+        e = c[16 + 16 * i: 32 + 16 * i]
+        ev = {"a": [f(e[0]), f(e[1])], "b": [f(e[2]), f(e[3])], "packed": [f(e[4]), f(e[5])], "scalar": [f(e[6]), f(e[7])],
+              "packed_again": [f(e[8]), f(e[9])], "lane": int(e[10]) & 63, "wave": int(e[10]) >> 6, "workgroup": int(e[11]), "hw": hw(int(e[12])),
+              "form": "a+ib (neg_lo)" if e[13] else "a-ib (neg_hi)", "t": int(e[14]),
+              "lo_wrong": bool(e[4] != e[6]), "hi_wrong": bool(e[5] != e[7]), "again_right": bool(e[8] == e[6] and e[9] == e[7])}
+        # what is the wrong half equal to?
+        cands = {"a.x+b.y": ev["a"][0] + ev["b"][1], "a.x-b.y": ev["a"][0] - ev["b"][1], "a.x+b.x": ev["a"][0] + ev["b"][0], "a.x-b.x": ev["a"][0] - ev["b"][0],
+                 "a.y+b.x": ev["a"][1] + ev["b"][0], "a.y-b.x": ev["a"][1] - ev["b"][0], "a.y+b.y": ev["a"][1] + ev["b"][1], "a.y-b.y": ev["a"][1] - ev["b"][1],
+                 "a.x": ev["a"][0], "a.y": ev["a"][1], "b.x": ev["b"][0], "b.y": ev["b"][1]}
+        import numpy as np
+        for half, idx in (("lo", 0), ("hi", 1)):
+            if ev[half + "_wrong"]:
+                ev[half + "_equals"] = [k for k, v_ in cands.items() if np.float32(v_) == np.float32(ev["packed"][idx])]
+        events.append(ev)
+    import collections
+    print("MEL_CHECK: %d mismatching +-i packed adds;" % n, "lanes", sorted(collections.Counter(e["lane"] // 16 for e in events).items()),
+          "forms", collections.Counter(e["form"] for e in events).most_common(), "lo/hi wrong", collections.Counter((e["lo_wrong"], e["hi_wrong"]) for e in events).most_common(),
+          "repeat right", collections.Counter(e["again_right"] for e in events).most_common(),
+          "lo equals", collections.Counter(tuple(e.get("lo_equals", ())) for e in events).most_common(5),
+          "hi equals", collections.Counter(tuple(e.get("hi_equals", ())) for e in events).most_common(5))
+    # events per (workgroup, wave, time): how many lanes per event group
+    groups = collections.Counter((e["workgroup"], e["wave"], e["t"] >> 8) for e in events)
+    print("events per (workgroup, wave, 256-cycle window):", collections.Counter(groups.values()).most_common(6))
+    for ev in events[:5]:
+        print(json.dumps(ev)[:700])
+    findings.append({"check_events": events[:400], "check_count": n})
 if report:
     json.dump({"library": so, "beside": beside, "replays": replays, "bad_replays": counts["bad"], "findings": findings}, open(report, "w"), indent=1)
 for ent in findings[:6]:
