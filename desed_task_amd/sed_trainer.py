@@ -221,10 +221,18 @@ class SEDTask4(_Base):
             return "accumulate_batches != 1 (one optimizer step per training_step is what a whole step is)"
         if (tr.get("gradient_clip") or 0) > 0:
             return "gradient_clip > 0 (clipping sits between backward and the optimizer step)"
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return "a process group with more than one rank is up: data-parallel runs go through desed_task_amd.launcher"
+        if self._ddp_world() > 1 and os.environ.get("SED_DDP_GRAPH_EXCHANGE") != "1":
+            # (with the exchange captured -- SED_DDP_GRAPH_EXCHANGE=1 -- the whole data-parallel step, all-reduce(s) and Adam included,
+            #  is the one graph behind training_step and the hooks that follow find their work done, exactly as at world size 1.  Without
+            #  it the exchange is host-driven between the replay and Adam, which belongs to desed_task_amd.launcher's own loop.)
+            return ("a process group with more than one rank is up: set SED_DDP_GRAPH_EXCHANGE=1 (the gradient exchange becomes part of "
+                    "the captured step) or run data-parallel through desed_task_amd.launcher")
         return None
+
+    @staticmethod
+    def _ddp_world():
+        import torch.distributed as dist
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
     def _whole_step_on(self):
         if self._whole_ok is None:
@@ -249,12 +257,13 @@ class SEDTask4(_Base):
             elif pf == "teacher" and not self.prefetch_teacher_ok:
                 pf = "backward"
             dev = next(self.sed_student.parameters()).device
-            if dev.type == "cuda":
-                self._driver = _graph.GraphedStepDriver(self, world_size=1, warmup=self.whole_step_warmup, prefetch=pf)
+            world = self._ddp_world()       # > 1: every rank's step exchanges its gradients (launcher.StepDriver: start-up broadcast,
+            if dev.type == "cuda":          # mean over the flat arena, 1 / world folded into Adam)
+                self._driver = _graph.GraphedStepDriver(self, world_size=world, warmup=self.whole_step_warmup, prefetch=pf)
                 self._driver.eager.check_announced = False
             else:
                 from .launcher import StepDriver
-                self._driver = StepDriver(self, world_size=1, prefetch=pf)
+                self._driver = StepDriver(self, world_size=world, prefetch=pf)
                 self._driver.check_announced = False    # this class tracks the identity of the batches itself (loader keys)
         return self._driver
 

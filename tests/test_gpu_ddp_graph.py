@@ -303,3 +303,42 @@ def test_bench_two_ranks_sharing_the_gpu(tmp_path):
     exposed = [k for k in tail if k.startswith("exposed_exchange")]
     assert exposed and tail[exposed[0]]["device_us"] is not None and tail[exposed[0]]["device_us"] > 0
     assert out["config"]["global_batch"] == 96 and out["roofline"] is not None
+
+
+def _whole_step_rehearsal_worker(rank, port, out_dir):
+    """SEDTask4's whole-step mode with the gradient exchange CAPTURED (SED_DDP_GRAPH_EXCHANGE=1), rehearsed on a one-rank RCCL group."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      SED_DDP_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SED_DDP_GRAPH_EXCHANGE="1")
+    os.environ.pop("SED_DIST_BACKEND", None)
+    os.environ.pop("SED_DDP_OVERLAP", None)
+    from tests import parity_cases as P
+    from desed_task_amd import graph as G
+    from desed_task_amd.launcher import init_distributed
+    init_distributed()
+    assert dist.is_initialized() and dist.get_backend() == "nccl"
+    seen = []
+    orig = G.GraphedStepDriver.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        seen.append((self.eager.exchange, self.capture_exchange))
+
+    G.GraphedStepDriver.__init__ = spy
+    # driver by hand == whole-step behind the Lightning-order loop == the hooks one by one (which exchange nothing: sums over one rank
+    # change no bit), 2 epochs x 3 batches, bit for bit
+    P.case_lightning_surface("cuda", epochs=2, per_epoch=3)
+    assert seen and all(s == (True, True) for s in seen), seen
+    torch.cuda.synchronize()
+    open(os.path.join(out_dir, "whole_rehearsal_ok"), "w").write(str(len(seen)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_whole_step_mode_with_the_exchange_captured_rccl_rehearsal(tmp_path):
+    """the whole-step (fast) mode is no longer blocked under a multi-rank process group when the exchange is part of
+    the captured step; here the same structure -- all-reduce and Adam as nodes of the ONE graph behind SEDTask4.training_step -- over RCCL
+    on one rank (tests/test_ddp_gloo.py::test_whole_step_mode_under_two_ranks runs it on two gloo ranks on the emulator)."""
+    mp.spawn(_whole_step_rehearsal_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "whole_rehearsal_ok"))
