@@ -1322,6 +1322,119 @@ def case_lightning_surface_abandoned_epoch(dev, n_samp=2048 + 1024, per_epoch=3,
         assert not torch.equal(flats[i], flats[i + 1]), "step %d left the weights where they were" % (i + 1)
 
 
+def _soak_state(task):
+    from desed_task_amd.launcher import bn_buffers
+    osd = task.opt.state_dict()
+    return [task.sed_student.arena.flat.detach().clone(), task.sed_teacher.arena.flat.detach().clone(),
+            torch.cat([b.detach().reshape(-1) for b in bn_buffers(task)]),
+            torch.cat([osd["state"][i]["exp_avg"].reshape(-1) for i in sorted(osd["state"])]),
+            torch.cat([osd["state"][i]["exp_avg_sq"].reshape(-1) for i in sorted(osd["state"])])]
+
+
+def case_corruption_soak(dev, steps=2000, K=8, bs=(12, 12, 24), n_samp=160000, marks=(1, 500, 2000), lr=2e-4):
+    """the B = 48 pipelined step captured once and replayed over the SAME sequence of `steps` batches (K different
+    batches in rotation) twice from the same state, plus once eagerly: student and teacher weights, all BatchNorm statistics and both Adam
+    moments must be BIT-equal between the two replayed runs and equal to the eager run at every mark.  A transient fault anywhere in
+    the ~120 kernels of the step -- like the packed-op_sel hazard of round 6, ~1e-5 per instruction -- shows up as a difference that
+    the later steps carry along."""
+    import random
+    from desed_task_amd import graph as G
+    from desed_task_amd import ops as _ops
+    from desed_task_amd.launcher import StepDriver
+    B = sum(bs)
+    sd = O.make_state_dict(seed=7)
+    n_out = (1 + n_samp // 256) // 4
+    g = torch.Generator().manual_seed(17)
+    audios = [to(dev, 0.1 * torch.randn(B, n_samp, generator=g)) for _ in range(K)]
+    labelss = [to(dev, O.synth_labels(bs, 10, n_out, seed=30 + i)) for i in range(K)]
+    marks = tuple(m for m in marks if m <= steps)
+
+    def run(kind):
+        task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=50, lr=lr)
+        random.seed(47); np.random.seed(107); torch.manual_seed(107)
+        if dev != "cpu":
+            torch.cuda.manual_seed(107)
+        _ops.reseed_dropout()
+        driver = (G.GraphedStepDriver(task, world_size=1, warmup=1, prefetch="teacher") if (kind == "graph" and dev != "cpu")
+                  else StepDriver(task, world_size=1, prefetch="teacher"))
+        snaps, cur = {}, labelss[0].clone()
+        for i in range(steps):
+            nl = labelss[(i + 1) % K].clone() if i + 1 < steps else None
+            nxt = (audios[(i + 1) % K], nl, None, None) if nl is not None else None
+            loss = driver.run_step((audios[i % K], cur, None, None), i, next_batch=nxt)
+            cur = nl
+            if i + 1 in marks:
+                if dev != "cpu":
+                    torch.cuda.synchronize()
+                snaps[i + 1] = _soak_state(task) + [loss.detach().clone().reshape(1)]
+        if kind == "graph" and steps > 3 and dev != "cpu":
+            assert driver.graph is not None and driver.eager_fallbacks == 1       # (only the last step -- no successor -- ran eagerly)
+        return snaps
+
+    first, second, eager = run("graph"), run("graph"), run("eager")
+    names = ("student", "teacher", "BatchNorm buffers", "Adam exp_avg", "Adam exp_avg_sq", "loss")
+    for m in marks:
+        assert all(bool(torch.isfinite(t).all()) for t in first[m]), "non-finite state at step %d" % m
+        for name, a_, b_, c_ in zip(names, first[m], second[m], eager[m]):
+            assert torch.equal(a_, b_), "step %d: %s differs between two replayed runs (%d elements, max %.3e)" % (
+                m, name, int((a_ != b_).sum()), float((a_ - b_).abs().max()))
+            assert torch.equal(a_, c_), "step %d: %s differs between the replayed and the eager run (%d elements, max %.3e)" % (
+                m, name, int((a_ != c_).sum()), float((a_ - c_).abs().max()))
+    return {m: float(first[m][-1]) for m in marks}
+
+
+def case_step_beside_gemm_storm(dev, reps=60, bs=(3, 3, 6), n_samp=160000, storm=260):
+    """The canary of the same item: two full training steps (every kernel of the step: the mel kernel, block 0, the GLU blocks, the
+    BiGRU recurrences, the heads, the losses, their backward twins, Adam, the EMA) launched while a storm of split-bf16 GEMMs
+    (v_mfma_f32_32x32x16_bf16 waves on every CU -- the co-runner of round 6's hazard) runs on another stream, `reps` times: weights of
+    both models, BatchNorm statistics and Adam moments after the two steps equal the solo run's BIT for BIT.  (The instruction-level
+    probe showed the hazard in eager launches on two streams as readily as in a replayed graph.)"""
+    import random
+    from desed_task_amd import ops as _ops
+    from desed_task_amd.launcher import StepDriver
+    B = sum(bs)
+    sd = O.make_state_dict(seed=7)
+    n_out = (1 + n_samp // 256) // 4
+    g = torch.Generator().manual_seed(19)
+    audios = [to(dev, 0.1 * torch.randn(B, n_samp, generator=g)) for _ in range(2)]
+    labelss = [to(dev, O.synth_labels(bs, 10, n_out, seed=70 + i)) for i in range(2)]
+    H, Ms = 128, 48 * 156
+    h_big = to(dev, torch.randn(Ms, H))
+    gi = torch.zeros(Ms, 2, 3 * H, device=h_big.device)
+    w0, w1, b0 = to(dev, 0.1 * torch.randn(3 * H, H)), to(dev, 0.1 * torch.randn(3 * H, H)), torch.zeros(3 * H, device=h_big.device)
+    side = torch.cuda.Stream() if dev != "cpu" else None
+
+    def two_steps(with_storm):
+        task = build_task(dev, bs, sd, dropout=0.5, specaug=True, rampup=5)
+        driver = StepDriver(task, world_size=1)
+        random.seed(49); np.random.seed(109); torch.manual_seed(109)
+        if dev != "cpu":
+            torch.cuda.manual_seed(109)
+        _ops.reseed_dropout()
+        if with_storm and side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            lib = _lib.get()
+            for _ in range(storm):
+                lib.call("sed_gemm_pair_bf16x3", h_big.data_ptr(), h_big.data_ptr(), w0.data_ptr(), w1.data_ptr(), b0.data_ptr(), b0.data_ptr(),
+                         gi.data_ptr(), gi.data_ptr() + 3 * H * 4, Ms, 3 * H, H, H, H, 6 * H, 0, 1, 1, 0, side.cuda_stream)
+        for i in range(2):
+            driver.run_step((audios[i], labelss[i].clone(), None, None), i)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        return _soak_state(task)
+
+    ref = two_steps(False)
+    again = two_steps(False)
+    for a_, b_ in zip(ref, again):
+        assert torch.equal(a_, b_)
+    names = ("student", "teacher", "BatchNorm buffers", "Adam exp_avg", "Adam exp_avg_sq")
+    for rep in range(reps):
+        got = two_steps(True)
+        for name, a_, b_ in zip(names, ref, got):
+            assert torch.equal(a_, b_), "repetition %d: %s differs from the solo run beside the GEMM storm (%d elements, max %.3e)" % (
+                rep, name, int((a_ != b_).sum()), float((a_ - b_).abs().max()))
+
+
 def case_step_bit_reproducible(dev, steps=3, n_samp=16000 + 1024):
     """Since round 3 no kernel of the default training step adds floats with atomics (loss sums, head and BiGRU bias gradients
     moved to per-workgroup records summed in a fixed order): the same seeded steps give the SAME BITS -- run twice eagerly, and once

@@ -455,3 +455,13 @@ def test_posconv_kernels():
     """BEATs position convolution at the extractor's size (496 tokens, k = 128, 16 groups of 48) on both kernels."""
     P.case_posconv("cuda", B=2, T=496, groups=16, K=128)
     P.case_posconv("cuda", B=1, T=100, groups=2, K=128)
+
+
+def test_corruption_soak_2000_steps():
+    """two replayed runs of 2 000 B = 48 pipelined steps and one eager run, bit-equal at steps 1 / 500 / 2 000."""
+    losses = P.case_corruption_soak("cuda")
+    print("soak losses at the marks:", losses)
+
+
+def test_training_step_bits_beside_a_gemm_storm():
+    P.case_step_beside_gemm_storm("cuda")
