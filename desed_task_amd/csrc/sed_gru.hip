@@ -327,6 +327,29 @@ SED_API int sed_colsum(const float* X, float* out, float* out1, int nsplit, int 
 #define GRU_NOTRANS ((GRU_VARIANT & 32) != 0)
 #define GRU_NOOBUF ((GRU_VARIANT & 64) != 0)
 #define GRU_NOBAR ((GRU_VARIANT & 128) != 0)
+// GRU_STAMP (diagnostics build only: ONLY=sed_gru.hip python tools/build_variant.py grustamp -DGRU_STAMP; tools/gru_stamps.py): s_memtime
+// at six points of a step -- top (behind the barrier), hidden state + gate inputs landed, FMAs done, quarters summed, gates done, results
+// stored -- for the first and the last wave of workgroup 0, steps 16 .. 47, collected in LDS and dumped after the loop.  Every stamp
+// waits for lgkmcnt(0) and fences the scheduler, so the phases it separates no longer overlap: an upper bound per phase, next to the
+// unstamped total.  (profiles/r06_gru_phase_stamps.md)
+#ifdef GRU_STAMP
+__device__ unsigned long long* gru_stamp_buf;
+SED_API int sed_gru_debug_set_stamps(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(gru_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? SED_OK : SED_ERR_LAUNCH;
+}
+#define GRU_TS(k)                                                                                      \
+    {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        if (stamp_on) {                                                                                \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                \
+            if ((tid & 63) == 0 && ts_step >= 0 && ts_step < 32) s_ts[ts_wave][ts_step][k] = t_;       \
+        }                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
+#else
+#define GRU_TS(k)
+#endif
 template <int H, int CH>
 __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ whh0,
                                                       const float* __restrict__ whh1, const float* __restrict__ bhh0,
@@ -349,6 +372,12 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
     // distinct banks (at a 128-byte pitch they would share four)
     constexpr int HP = GRU_HPAD ? KH + 4 : KH;
     __shared__ __attribute__((aligned(16))) float hbuf[2][4 * HP];
+#ifdef GRU_STAMP
+    __shared__ unsigned long long s_ts[2][32][8];
+    const bool stamp_on = blockIdx.x == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == (4 * H / 64 - 1));
+    const int ts_wave = (threadIdx.x >> 6) == 0 ? 0 : 1;
+    int ts_step = -16;
+#endif
     SED_DYN_SMEM(smem);
     float* gis = (float*)smem;                 // [2][CH][3H]
     float* obuf = gis + 2 * GI_F;              // [2][CH][5H] = h | r | z | n | hn
@@ -417,6 +446,7 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
         float* och = obuf + (c & 1) * OB_F;
         const int nsteps = min(CH, T - c * CH);
         for (int s = 0; s < nsteps; ++s) {
+            GRU_TS(0)
             const float gr = gch[s * 3 * H + j], gz = gch[s * 3 * H + H + j], gn = gch[s * 3 * H + 2 * H + j];
             // a block of this thread's h slice first (H = 128: all of it, one LDS latency, not one per read), then its FMAs
             f32x2 pr = {0.f, 0.f}, pz = {0.f, 0.f}, pn = {0.f, 0.f};
@@ -426,6 +456,9 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
                 float4 hq[HB];
 #pragma unroll
                 for (int k = 0; k < HB; ++k) hq[k] = GRU_NOREAD ? make_float4(gr, gz, gn, gr) : *(const float4*)(hbuf[cur] + half * HP + 4 * (kb + k));
+#ifdef GRU_STAMP
+                if (kb == 0) GRU_TS(1)
+#endif
 #pragma unroll
                 for (int k0 = 0; k0 < (GRU_NOFMA ? 1 : HB); ++k0) {
                     const int k = kb + k0;
@@ -440,13 +473,25 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
                 if (HB < KH / 4) sed_sched_fence();                       // keeps the later blocks' reads from being hoisted (VGPRs)
             }
             if (GRU_ACC6) { pr += qr; pz += qz; pn += qn; }
+#ifdef GRU_STAMP
+            sed_pin(pr); sed_pin(pz); sed_pin(pn);
+            GRU_TS(2)
+#endif
             float ar = pr.x + pr.y, az = pz.x + pz.y, an = pn.x + pn.y;
             ar = sed_quad_sum(ar); az = sed_quad_sum(az); an = sed_quad_sum(an);      // the four K-quarters (DPP, not ds_bpermute)
+#ifdef GRU_STAMP
+            sed_pin(ar); sed_pin(az); sed_pin(an);
+            GRU_TS(3)
+#endif
             const float r = GRU_NOTRANS ? (gr + ar + br) * 0.01f : sed_fast_sigmoid(gr + ar + br);
             const float z = GRU_NOTRANS ? (gz + az + bz) * 0.01f : sed_fast_sigmoid(gz + az + bz);
             const float hn = an + bn;
             const float n = GRU_NOTRANS ? (gn + r * hn) * 0.01f : sed_fast_tanh(gn + r * hn);
-            const float hnew = (1.0f - z) * n + z * hprev;
+            float hnew = (1.0f - z) * n + z * hprev;
+#ifdef GRU_STAMP
+            sed_pin(hnew);
+            GRU_TS(4)
+#endif
             hprev = hnew;
             if (GRU_QSTORE) {
                 // every lane of the quad stores one of the five results (all four hold them): two LDS stores on the chain, not five
@@ -463,12 +508,22 @@ __global__ __launch_bounds__(4 * H) void gru_fwd_kernel(const float* __restrict_
                 if (!GRU_NOOBUF) { o[j] = hnew; o[OBP + j] = r; o[2 * OBP + j] = z; o[3 * OBP + j] = n; o[4 * OBP + j] = hn; }
             }
             cur ^= 1;
+            GRU_TS(5)
             if (!GRU_NOBAR) __syncthreads();
+#ifdef GRU_STAMP
+            GRU_TS(6)
+            ++ts_step;
+#endif
         }
         if (c + 1 < nchunks) park_chunk(c + 1);
         __syncthreads();
     }
     flush_chunk(nchunks - 1);
+#ifdef GRU_STAMP
+    __syncthreads();
+    if (blockIdx.x == 0 && gru_stamp_buf)
+        for (int i = tid; i < 2 * 32 * 8; i += NT_) gru_stamp_buf[i] = (&s_ts[0][0][0])[i];
+#endif
 }
 // A recurrence workgroup claims (most of) its CU's LDS: a (clip, direction) is one latency-bound dependent chain, and any workgroup
 // of another stream that lands on the same CU (the prefetched mel front-end: 24 KB of LDS each, the other model's head, the
