@@ -48,7 +48,7 @@ static inline void sed_zero4(hipStream_t s, float* p0, int n0, float* p1, int n1
 // Tuning overrides (tests and sweep tools only; all 0 = built-in choices).  Set explicitly through sed_set_tuning(): the entry
 // points never read the process environment.
 enum { SED_TUNE_GLU_GRID_CAP = 0, SED_TUNE_GLU_BWD128_SPLIT = 1, SED_TUNE_CONVB_CK = 2, SED_TUNE_CONVB_MP = 3, SED_TUNE_B0_NOCENTER = 4, SED_TUNE_GLU_FWD128 = 5, SED_TUNE_WGRAD_NARROW = 6, SED_TUNE_WGRAD_CAP = 7,
-       SED_TUNE_ATTN_VALU = 8, SED_TUNE_WGRAD_WIDE = 9, SED_TUNE_GRU_LDS_KB = 10, SED_TUNE_MEL_TAPS_MEM = 11, SED_TUNE_CONVB_TPW = 12, SED_TUNE_MEL_WAVE = 13, SED_TUNE_GEMM_NTN = 14, SED_TUNE_COUNT = 16 };
+       SED_TUNE_ATTN_VALU = 8, SED_TUNE_WGRAD_WIDE = 9, SED_TUNE_GRU_LDS_KB = 10, SED_TUNE_MEL_TAPS_MEM = 11, SED_TUNE_CONVB_TPW = 12, SED_TUNE_MEL_WAVE = 13, SED_TUNE_GEMM_NTN = 14, SED_TUNE_LINEAR_P256 = 15, SED_TUNE_COUNT = 16 };
 extern int sed_tuning[SED_TUNE_COUNT];
 
 static inline int sed_check_launch() {
@@ -386,6 +386,52 @@ __device__ __forceinline__ float sed_fast_tanh(float x) { return 1.0f - 2.0f * s
 __device__ __forceinline__ void sed_wave_prio_high() {
 #if !defined(SED_EMU) && !defined(SED_NO_SETPRIO)
     __builtin_amdgcn_s_setprio(3);
+#endif
+}
+
+// s_setprio 1 / 0 around an MFMA cluster (cdna_hip_programming.md T5): the wave that owns the matrix pipe keeps it while its sibling on
+// the SIMD issues the loads and LDS traffic of the next phase
+__device__ __forceinline__ void sed_mfma_prio(int on) {
+#if !defined(SED_EMU) && !defined(SED_NO_SETPRIO)
+    if (on) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#else
+    (void)on;
+#endif
+}
+
+// LDS-DMA: every lane copies 16 bytes from its own global address to lds_wave_base + 16 * lane, without a register in between
+// (global_load_lds_dwordx4; the LDS base is wave-uniform, M0).  Counted on vmcnt; ordered for other waves' ds_reads only by the issuing
+// wave's s_waitcnt vmcnt + a barrier (MI355X_MICROARCH.md item 7).
+__device__ __forceinline__ void sed_dma16(const void* gptr, void* lds_wave_base) {
+#ifdef SED_EMU
+    memcpy((char*)lds_wave_base + 16 * emu_lane(), gptr, 16);
+#else
+    __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+// s_waitcnt vmcnt(N) lgkmcnt(0) by hand (N a literal): the compiler neither counts LDS-DMA nor knows which stage a ds_read belongs to
+#ifdef SED_EMU
+#define SED_WAIT_VM_LDS(N) do { } while (0)
+#else
+#define SED_WAIT_VM_LDS(N) do { asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
+
+// Raw workgroup barrier for hand-phased kernels (the two wave groups of linear_pp_kernel run one barrier apart): s_barrier with NO
+// implied waitcnt -- global loads in flight survive it; LDS traffic is ordered by the explicit sed_wait_lds() calls.  The scheduler
+// fences keep the compiler from moving LDS accesses or MFMAs across.
+__device__ __forceinline__ void sed_phase_barrier() {
+#ifdef SED_EMU
+    emu_block_barrier();
+#else
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+__device__ __forceinline__ void sed_wait_lds() {
+#ifndef SED_EMU
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #endif
 }
 

@@ -374,6 +374,16 @@ int sed_pack_weights_bf16x3(const float* W, unsigned short* Wp, int N, int K, vo
 int sed_linear_packed_bf16x3(const float* A, const unsigned short* Wp, const float* bias, float* C, int M, int N, int K, int act,
                              void* stream);
 
+/* Round 6: the same Linear with BOTH operands as pre-split bf16 hi / lo planes in a K-tiled image that a workgroup copies into LDS by
+ * LDS-DMA without touching a register (backbone.py:214-330 as above).  sed_split_tiles_bf16x3 turns a k-contiguous fp32 matrix
+ * X (R, K) -- an activation (R = M tokens) or a frozen weight (R = N) -- into ceil(R / 256) * (K / 16) blocks of 16 KB: block
+ * (r / 256, k / 16) = [hi | lo][256 rows][16 k], the 8-k octet o of row r stored at slot o ^ ((r >> 3) & 1); rows >= R are zero.
+ * Xt holds 2 * ceil(R / 256) * 256 * K bf16 bit patterns.  sed_linear_tiles_bf16x3: C (M, N) = act(A . W^T + bias) from two such
+ * images, 256 x 256 tiles, four LDS stages filled by DMA three K tiles ahead.  N % 256 == 0, K % 16 == 0, 16-byte aligned. */
+int sed_split_tiles_bf16x3(const float* X, unsigned short* Xt, int R, int K, void* stream);
+int sed_linear_tiles_bf16x3(const unsigned short* At, const unsigned short* Wt, const float* bias, float* C, int M, int N, int K,
+                            int act, void* stream);
+
 /* torchaudio.compliance.kaldi.fbank(waveform * 2^15, num_mel_bins, 16 kHz, 25 ms frames, 10 ms shift) with that function's
  * defaults (povey window, pre-emphasis 0.97, DC removal, snip_edges, 512-point FFT, power spectrum, log) followed by
  * (x - norm_mean) * norm_inv -- BEATs.preprocess, BEATs.py:109-133.  audio (B,N) -> out (B, 1 + (N - 400) / 160, n_mels).

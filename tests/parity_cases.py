@@ -602,6 +602,17 @@ def case_linear_n96_tile(dev, shapes=((300, 192, 64, 0), (513, 96, 96, 1), (130,
         _lib.set_tuning("gemm_ntn", 0)
 
 
+def case_linear_p256(dev, shapes=((300, 256, 64, 0), (513, 512, 96, 1), (256, 256, 32, 1), (700, 768, 160, 0))):
+    """The round-6 256 x 256 kernel behind sed_linear_packed_bf16x3 (forced with the tuning key `linear_p256` = 2; built-in choice: N >= 2048
+    and N % 256 == 0): ragged M, one and several K tiles, several N tiles, more row panels than XCDs would need, GELU epilogue."""
+    try:
+        for form in (2, 4):         # 2: the hand-phased two-group kernel (linear_pp_kernel, the shipped form); 4: the __syncthreads() form
+            _lib.set_tuning("linear_p256", form)
+            case_linear_packed(dev, shapes=shapes)
+    finally:
+        _lib.set_tuning("linear_p256", 0)
+
+
 def case_linear_packed(dev, shapes=((300, 128, 64, 0), (513, 256, 96, 1), (256, 128, 32, 1))):
     """sed_pack_weights_bf16x3 + sed_linear_packed_bf16x3 (the BEATs encoder's large Linear layers: frozen weight split into bf16
     hi / lo planes once, 256 x 128 tiles, A fragments straight from HBM, optional exact-GELU epilogue) vs float64: ragged M (rows
@@ -630,6 +641,62 @@ def case_linear_packed(dev, shapes=((300, 128, 64, 0), (513, 256, 96, 1), (256, 
     try:
         lib.call("sed_linear_packed_bf16x3", Ad.data_ptr(), Wp.data_ptr(), None, C.data_ptr(), M, 100, K, 0, _lib.stream_ptr(Ad))
         raise AssertionError("N % 128 != 0 must be refused")
+    except RuntimeError:
+        pass
+
+
+def tile_image(X, bk=16):
+    """Independent host restatement of the image sed_split_tiles_bf16x3 documents in include/sed_hip.h (X: (R, K) float32 on the CPU ->
+    int16 tensor of 2 * ceil(R / 256) * 256 * K bf16 bit patterns): block (r // 256, k // bk) = [hi | lo][256][bk], octet o of row r at
+    slot o ^ ((r >> 3) & 1); rows >= R zero."""
+    R, K = X.shape
+    P = (R + 255) // 256
+    Xp = torch.zeros(P * 256, K)
+    Xp[:R] = X
+    hi = Xp.to(torch.bfloat16)
+    lo = (Xp - hi.float()).to(torch.bfloat16)
+    out = []
+    rows = torch.arange(256)
+    for plane in (hi, lo):
+        v = plane.view(torch.int16).view(P, 256, K // bk, bk // 8, 8)             # (panel, row, ktile, octet, 8)
+        sw = ((rows >> 3) & 1).view(1, 256, 1, 1, 1)
+        octs = torch.arange(bk // 8).view(1, 1, 1, bk // 8, 1)
+        src = (octs ^ sw).expand(P, 256, K // bk, bk // 8, 8)                       # slot s holds octet s ^ sw
+        out.append(torch.gather(v, 3, src.contiguous()))
+    img = torch.stack(out, 0)                                                       # (plane, panel, row, ktile, slot, 8)
+    return img.permute(1, 3, 0, 2, 4, 5).contiguous().view(-1)                      # (panel, ktile, plane, row, slot, 8)
+
+
+def case_linear_tiles(dev, shapes=((300, 256, 64, 0), (513, 512, 96, 1), (256, 256, 16, 1), (700, 768, 160, 0), (2100, 256, 48, 0))):
+    """sed_split_tiles_bf16x3 + sed_linear_tiles_bf16x3 (round 6: both operands as K-tiled bf16 hi / lo images, four LDS stages filled by
+    LDS-DMA three K tiles ahead, two wave groups one barrier apart): the image bit for bit against the host restatement above, the
+    product vs float64 -- ragged M (zero rows in the image, never stored), one to ten K tiles (fewer than the pipeline's depth
+    included), several N tiles and more row panels than XCDs, GELU epilogue, no bias."""
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(12)
+    for (M, N, K, act) in shapes:
+        A, W, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+        ref = A.double() @ W.double().t() + bias.double()
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        Ad, Wd, bd = to(dev, A, W, bias)
+        st = _lib.stream_ptr(Ad)
+        At = torch.full((2 * ((M + 255) // 256) * 256 * K,), 77, dtype=torch.int16, device=Ad.device)
+        Wt = torch.full((2 * N * K,), 77, dtype=torch.int16, device=Ad.device)
+        lib.call("sed_split_tiles_bf16x3", Ad.data_ptr(), At.data_ptr(), M, K, st)
+        lib.call("sed_split_tiles_bf16x3", Wd.data_ptr(), Wt.data_ptr(), N, K, st)
+        assert torch.equal(At.cpu(), tile_image(A)), (M, K, "A image")
+        assert torch.equal(Wt.cpu(), tile_image(W)), (N, K, "W image")
+        C = torch.full((M, N), 7.0, device=Ad.device)
+        lib.call("sed_linear_tiles_bf16x3", At.data_ptr(), Wt.data_ptr(), bd.data_ptr(), C.data_ptr(), M, N, K, act, st)
+        err = (C.cpu().double() - ref).abs().max().item()
+        assert err < 3e-5 * max(1.0, ref.abs().max().item()), (M, N, K, act, err)
+        lib.call("sed_linear_tiles_bf16x3", At.data_ptr(), Wt.data_ptr(), None, C.data_ptr(), M, N, K, 0, st)
+        err = (C.cpu().double() - A.double() @ W.double().t()).abs().max().item()
+        assert err < 3e-5 * max(1.0, ref.abs().max().item()), (M, N, K, "nobias", err)
+    try:
+        lib.call("sed_linear_tiles_bf16x3", At.data_ptr(), Wt.data_ptr(), None, C.data_ptr(), M, 128, K, 0, st)
+        raise AssertionError("N % 256 != 0 must be refused")
     except RuntimeError:
         pass
 

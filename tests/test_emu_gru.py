@@ -11,6 +11,12 @@ def test_gemm(emu):
 def test_linear_packed(emu):
     """The BEATs encoder's packed-weight Linear (round 5)."""
     P.case_linear_packed("cpu", shapes=((300, 128, 64, 0), (257, 256, 32, 1)))
+    P.case_linear_p256("cpu", shapes=((300, 256, 64, 0), (257, 512, 32, 1)))
+
+
+def test_linear_tiles(emu):
+    """Round 6: K-tiled plane images + the all-DMA 256 x 256 kernel."""
+    P.case_linear_tiles("cpu", shapes=((300, 256, 64, 0), (257, 512, 16, 1), (520, 256, 48, 0)))
 
 
 def test_linear_n96_tile(emu):

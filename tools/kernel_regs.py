@@ -12,7 +12,7 @@ filt = subprocess.run(["c++filt"], input="\n".join(re.findall(r"\.name:\s+(\S+)"
 names = dict(zip(re.findall(r"\.name:\s+(\S+)", txt), filt))
 for b in re.findall(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", txt, flags=re.S):
     g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, b).group(1))
-    name = re.sub(r"\(.*", "", names.get(re.search(r"\.name:\s+(\S+)", b).group(1), "?")).replace("void ", "")
+    name = re.sub(r"\(.*", "", names.get(re.search(r"\.name:\s+(\S+)", b).group(1), "?").replace("(anonymous namespace)::", "")).replace("void ", "")
     if flt in name:
         print("%-90s vgpr %3d agpr %3d spill %3d scratch %4d lds %6d" % (name[:90], g("vgpr_count"), g("agpr_count"), g("vgpr_spill_count"),
                                                                           g("private_segment_fixed_size"), g("group_segment_fixed_size")))
