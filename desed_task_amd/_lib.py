@@ -83,7 +83,7 @@ def use_library(path, is_emulator=True):
     return _lib
 
 
-TUNING_KEYS = {"glu_grid_cap": 0, "glu_bwd128_split": 1, "convb_ck": 2, "convb_mp": 3, "block0_nocenter": 4, "glu_fwd128": 5, "wgrad_narrow": 6, "wgrad_cap": 7, "attn_valu": 8, "wgrad_wide": 9, "gru_lds_kb": 10, "mel_taps_mem": 11, "convb_tpw": 12, "mel_wave": 13, "gemm_ntn": 14, "linear_p256": 15}
+TUNING_KEYS = {"glu_grid_cap": 0, "glu_bwd128_split": 1, "convb_ck": 2, "convb_mp": 3, "block0_nocenter": 4, "glu_fwd128": 5, "wgrad_narrow": 6, "wgrad_cap": 7, "attn_valu": 8, "wgrad_wide": 9, "gru_lds_kb": 10, "mel_taps_mem": 11, "convb_tpw": 12, "mel_wave": 13, "gemm_ntn": 14, "linear_tiles": 15}
 
 
 _tuning = {}

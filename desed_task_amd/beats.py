@@ -22,6 +22,9 @@ from . import _lib
 
 
 POSCONV_MFMA = True             # position convolution on the split-bf16 MFMA (False: the f32 vector-pipe kernel, A/B and tests)
+LINEAR_TILES = True             # round 6: the q / k / v projection through the LDS-DMA kernel on K-tiled bf16 plane images (sed_linear_tiles_bf16x3); the
+                                # LayerNorm in front of it writes the activation's image beside its fp32 output (False: the round-5 path, A/B and tests)
+LINEAR_TILES_FFN = True         # ... and fc1 -> GELU -> fc2 the same way (fc1 writes its output as fc2's image, no fp32 copy of the 3072-wide hidden state)
 LINEAR_PACKED = True            # the large Linear layers through the packed-weight 256 x 128-tile kernel (False: sed_linear_bf16x3, A/B and tests)
 
 
@@ -280,10 +283,40 @@ class BEATs(nn.Module):
                      x.shape[0], n, k, act, st)
             return y
 
-        def layernorm(x, res, alpha, ln, d):
+        def layernorm(x, res, alpha, ln, d, image=None):
             y = torch.empty_like(x)
+            if image is not None:
+                lib.call("sed_layernorm_tiles", x.data_ptr(), res.data_ptr() if res is not None else None, float(alpha), ln.weight.data_ptr(),
+                         ln.bias.data_ptr(), y.data_ptr(), image.data_ptr(), x.shape[0], d, float(ln.eps), st)
+                return y
             lib.call("sed_layernorm", x.data_ptr(), res.data_ptr() if res is not None else None, float(alpha), ln.weight.data_ptr(),
                      ln.bias.data_ptr(), y.data_ptr(), x.shape[0], d, float(ln.eps), st)
+            return y
+
+        # round 6: the q / k / v projection reads its activation as a K-tiled bf16 hi / lo image (written by the LayerNorm that produces
+        # it) and its frozen weight as the same kind of image (built once); ONE image buffer, re-written by every layer's last LayerNorm
+        tiles = LINEAR_TILES and D % 256 == 0 and R >= 256
+        ximg = torch.empty(2 * ((R + 255) // 256) * 256 * D, device=fb.device, dtype=torch.int16) if tiles else None
+
+        Fd = cfg.encoder_ffn_embed_dim
+        ffn_tiles = tiles and LINEAR_TILES_FFN and Fd % 256 == 0
+        ximg2 = torch.empty_like(ximg) if ffn_tiles else None                      # the attention block's LayerNorm output -> fc1
+        himg = torch.empty(2 * ((R + 255) // 256) * 256 * Fd, device=fb.device, dtype=torch.int16) if ffn_tiles else None   # GELU(fc1) -> fc2
+
+        def linear_tiles(img, w, b, n, k, act=0, out_image=None):
+            key = ("tiles", w.data_ptr(), n, k)
+            wt_ = packed.get(key)
+            if wt_ is None or wt_.device != fb.device:
+                wt_ = torch.empty(2 * ((n + 255) // 256) * 256 * k, device=fb.device, dtype=torch.int16)
+                wsrc = w.detach().float().contiguous()
+                lib.call("sed_split_tiles_bf16x3", wsrc.data_ptr(), wt_.data_ptr(), n, k, st)
+                packed[key] = wt_
+            bp = b.data_ptr() if b is not None else None
+            if out_image is not None:           # the product leaves as the next Linear's image (fc1's GELU output is only read by fc2)
+                lib.call("sed_linear_tiles_out_bf16x3", img.data_ptr(), wt_.data_ptr(), bp, out_image.data_ptr(), R, n, k, act, st)
+                return None
+            y = torch.empty(R, n, **f32)
+            lib.call("sed_linear_tiles_bf16x3", img.data_ptr(), wt_.data_ptr(), bp, y.data_ptr(), R, n, k, act, st)
             return y
 
         patches = torch.empty(R, P * P, **f32)
@@ -300,24 +333,28 @@ class BEATs(nn.Module):
         else:
             lib.call("sed_posconv", x.data_ptr(), pk["wt"].data_ptr(), enc.pos_conv[0].bias.data_ptr(), y.data_ptr(), B, T, D, cfg.conv_pos,
                      cfg.conv_pos_groups, st)
-        x = layernorm(y, None, 1.0, enc.layer_norm, D)
+        x = layernorm(y, None, 1.0, enc.layer_norm, D, image=ximg)
         if taps is not None:
             taps["enc_in"] = x.view(B, T, D)
         alpha = math.pow(2 * cfg.encoder_layers, 0.25) if cfg.deep_norm else 1.0
         relb = self._rel_bias(T, fb.device)
         for lyr, lp in zip(enc.layers, pk["layers"]):
             a = lyr.self_attn
-            qkv = linear(x, lp["wqkv"], lp["bqkv"], 3 * D, D)
+            qkv = linear_tiles(ximg, lp["wqkv"], lp["bqkv"], 3 * D, D) if tiles else linear(x, lp["wqkv"], lp["bqkv"], 3 * D, D)
             att = torch.empty(R, D, **f32)
             gated = cfg.gru_rel_pos and relb is not None
             lib.call("sed_attention_relpos", qkv.data_ptr(), relb.data_ptr() if relb is not None else None,
                      a.grep_linear.weight.data_ptr() if gated else None, a.grep_linear.bias.data_ptr() if gated else None,
                      lp["grep_a"].data_ptr() if gated else None, att.data_ptr(), B, T, H, D // H, st)
             o = linear(att, a.out_proj.weight, a.out_proj.bias, D, D)
-            x = layernorm(o, x, alpha, lyr.self_attn_layer_norm, D)
-            h = linear(x, lyr.fc1.weight, lyr.fc1.bias, cfg.encoder_ffn_embed_dim, D, act=1)
-            h = linear(h, lyr.fc2.weight, lyr.fc2.bias, D, cfg.encoder_ffn_embed_dim)
-            x = layernorm(h, x, alpha, lyr.final_layer_norm, D)
+            x = layernorm(o, x, alpha, lyr.self_attn_layer_norm, D, image=ximg2)
+            if ffn_tiles:
+                linear_tiles(ximg2, lyr.fc1.weight, lyr.fc1.bias, Fd, D, act=1, out_image=himg)
+                h = linear_tiles(himg, lyr.fc2.weight, lyr.fc2.bias, D, Fd)
+            else:
+                h = linear(x, lyr.fc1.weight, lyr.fc1.bias, Fd, D, act=1)
+                h = linear(h, lyr.fc2.weight, lyr.fc2.bias, D, Fd)
+            x = layernorm(h, x, alpha, lyr.final_layer_norm, D, image=ximg)     # (the last layer's image is written and not read)
             if taps is not None:
                 taps["layer%d" % len([k for k in taps if k.startswith("layer")])] = x.view(B, T, D)
         return x.view(B, T, D), None

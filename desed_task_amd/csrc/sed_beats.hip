@@ -164,6 +164,69 @@ SED_API int sed_layernorm(const float* x, const float* res, float alpha, const f
     return SED_ERR_UNSUPPORTED;
 }
 
+// Round 6: the same LayerNorm that ALSO writes y as the K-tiled bf16 hi / lo image the next Linear's LDS-DMA kernel reads
+// (sed_gemm_bf16.hip, sed_linear_tiles_bf16x3: block (row / 256, c / 16) = [hi | lo][256][16], octet o of row r at slot o ^ ((r >> 3) & 1)).
+// A lane owns 4 consecutive channels (float4 in, float4 out, one 8-byte piece per plane); D % 256 == 0.  The sums run in a different
+// order than layernorm_kernel's (4 channels per lane instead of every 64th), so y agrees with it to rounding, not bit for bit.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_tiles_kernel(const float* __restrict__ x, const float* __restrict__ res, float alpha,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ y, unsigned short* __restrict__ yt, int Mrows, float eps) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Mrows) return;
+    float4 v[NV];
+    const size_t i0 = (size_t)row * D + 4 * lane;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) v[u] = *(const float4*)(x + i0 + 256 * u);
+    if (res) {                                          // (uniform)
+        float4 r[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) r[u] = *(const float4*)(res + i0 + 256 * u);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) { v[u].x = fmaf(alpha, r[u].x, v[u].x); v[u].y = fmaf(alpha, r[u].y, v[u].y);
+                                       v[u].z = fmaf(alpha, r[u].z, v[u].z); v[u].w = fmaf(alpha, r[u].w, v[u].w); }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const float a = v[u].x - mean, b = v[u].y - mean, c = v[u].z - mean, d = v[u].w - mean;
+        q = fmaf(a, a, q); q = fmaf(b, b, q); q = fmaf(c, c, q); q = fmaf(d, d, q);
+    }
+    const float inv = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    const int panel = row >> 8, r8 = row & 255;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = 4 * lane + 256 * u;
+        const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+        const float4 o = make_float4((v[u].x - mean) * inv * g.x + b.x, (v[u].y - mean) * inv * g.y + b.y, (v[u].z - mean) * inv * g.z + b.z,
+                                     (v[u].w - mean) * inv * g.w + b.w);
+        *(float4*)(y + (size_t)row * D + c) = o;
+        unsigned h0, l0, h1, l1;
+        bf16_split2(o.x, o.y, h0, l0);
+        bf16_split2(o.z, o.w, h1, l1);
+        unsigned short* d = yt + ((size_t)panel * (D / 16) + (c >> 4)) * 8192 + r8 * 16 + ((((c >> 3) & 1) ^ ((r8 >> 3) & 1)) << 3) + (c & 7);
+        *(uint2*)d = make_uint2(h0, h1);
+        *(uint2*)(d + 4096) = make_uint2(l0, l1);
+    }
+}
+SED_API int sed_layernorm_tiles(const float* x, const float* res, float alpha, const float* gamma, const float* beta, float* y,
+                                unsigned short* yt, int M, int D, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y || !yt || M < 0) return SED_ERR_ARG;
+    if (M == 0) return SED_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((M + 3) / 4);
+#define LN_CASE(d) \
+    if (D == d) { SED_LAUNCH((layernorm_tiles_kernel<d / 256>), grid, dim3(256), 0, s, x, res, alpha, gamma, beta, y, yt, M, eps); return sed_check_launch(); }
+    LN_CASE(256) LN_CASE(512) LN_CASE(768) LN_CASE(1024)
+#undef LN_CASE
+    return SED_ERR_UNSUPPORTED;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K-B4: y = x + GELU(bias + grouped Conv1d(x)), kernel K (even: the reference drops the last output, SamePad), padding K / 2,
 // CG channels per group (backbone.py:30-43,118-120).  x, y (B, T, D); wt (D / CG groups, K, CG co, CG ci): the weight-normalised

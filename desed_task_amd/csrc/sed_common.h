@@ -48,7 +48,7 @@ static inline void sed_zero4(hipStream_t s, float* p0, int n0, float* p1, int n1
 // Tuning overrides (tests and sweep tools only; all 0 = built-in choices).  Set explicitly through sed_set_tuning(): the entry
 // points never read the process environment.
 enum { SED_TUNE_GLU_GRID_CAP = 0, SED_TUNE_GLU_BWD128_SPLIT = 1, SED_TUNE_CONVB_CK = 2, SED_TUNE_CONVB_MP = 3, SED_TUNE_B0_NOCENTER = 4, SED_TUNE_GLU_FWD128 = 5, SED_TUNE_WGRAD_NARROW = 6, SED_TUNE_WGRAD_CAP = 7,
-       SED_TUNE_ATTN_VALU = 8, SED_TUNE_WGRAD_WIDE = 9, SED_TUNE_GRU_LDS_KB = 10, SED_TUNE_MEL_TAPS_MEM = 11, SED_TUNE_CONVB_TPW = 12, SED_TUNE_MEL_WAVE = 13, SED_TUNE_GEMM_NTN = 14, SED_TUNE_LINEAR_P256 = 15, SED_TUNE_COUNT = 16 };
+       SED_TUNE_ATTN_VALU = 8, SED_TUNE_WGRAD_WIDE = 9, SED_TUNE_GRU_LDS_KB = 10, SED_TUNE_MEL_TAPS_MEM = 11, SED_TUNE_CONVB_TPW = 12, SED_TUNE_MEL_WAVE = 13, SED_TUNE_GEMM_NTN = 14, SED_TUNE_LINEAR_TILES = 15, SED_TUNE_COUNT = 16 };
 extern int sed_tuning[SED_TUNE_COUNT];
 
 static inline int sed_check_launch() {

@@ -436,319 +436,10 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(const float* __restr
 }
 
 }  // namespace
-// ---- round 6: 256 x 256 tiles, eight waves, both operands through double-buffered LDS, one K tile of register prefetch ----------------
-// Where linear_big_kernel stood (profiles/r05j_pmc_beats_wait.md, r05a_pmc_linear.md): MFMA-busy 0.29 - 0.36 with the LDS pipe only ~30 %
-// busy -- each wave waits for its OWN fragment-shaped A loads (fp32 rows straight from L2 / HBM, one row block = 24 MFMAs = ~0.3 us of
-// cover per load) and the 256 x 128 tile asks L2 for 1.5 KB per k (43 flop / B: ~10 TB/s at the target rate, 5.4 x the algorithmic
-// bytes from HBM).  Here:
-//   * tile 256 x 256 x 32: 2 KB per k for twice the products (64 flop / B); a wave owns 128 x 64 of it (4 x 2 MFMA blocks: 12 fragment
-//     reads per 24 MFMAs);
-//   * A (fp32 in HBM) and W (packed hi / lo planes) both travel global -> registers -> LDS as whole 128-byte / 64-byte row pieces, one K
-//     tile AHEAD: the loads of tile k + 2 are issued during the MFMAs of tile k, their registers are split (A) and parked in the other
-//     LDS buffer during tile k + 1 -- a full K tile (48 MFMAs per wave, two waves per SIMD: ~1.3 us) of memory latency is covered;
-//   * LDS planes are unpadded [row][32 k] bf16 (64-byte rows), the 16-byte octet o of row r stored at slot o ^ ((r >> 2) & 3): every
-//     ds_read_b128 lane group of an MFMA fragment read ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and their upper twins) then covers the
-//     64 banks exactly once, and the 8-lane row pieces of the staging stores alternate between the two bank halves;
-//   * 2 buffers x (A hi | lo + W hi | lo) x 16 KB = 128 KB: one workgroup per CU, 8 waves, <= 256 VGPRs (128 of them accumulators);
-//   * XCD-aware walk: the N tiles of a 256-row panel of A are consecutive workgroups of ONE XCD.
-namespace {
-constexpr int P_BM = 256, P_BN = 256, P_BK = 32, P_PLANE = 256 * 32;        // one plane of one operand: 256 rows x 32 k (ushorts)
-__device__ __forceinline__ int p_off(int row, int oct) { return row * P_BK + ((oct ^ ((row >> 2) & 3)) << 3); }
 
-template <int ACT>
-__global__ __launch_bounds__(512, 1) void linear_p256_kernel(const float* __restrict__ A, const unsigned short* __restrict__ Wp,
-                                                            const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K,
-                                                            int tiles_m, int tiles_n) {
-    SED_DYN_SMEM(smem);                               // [2 buffers][A hi | A lo | W hi | W lo][256][32] bf16
-    unsigned short* lds = (unsigned short*)smem;
-    const int tid = threadIdx.x, lane = tid & 63, w = sed_wave_uniform(tid >> 6), lo = lane & 31, hi = lane >> 5;
-    const int wr = w >> 2, wc = w & 3;                // wave: rows 128 wr .. + 127, columns 64 wc .. + 63 of the tile
-    // tile walk: workgroup g runs on XCD g & 7; XCD x owns the row panels tm = x (mod 8) and sweeps their N tiles back to back
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tm = xcd + 8 * (slot / tiles_n), tn = slot % tiles_n;
-    if (tm >= tiles_m) return;
-    const int m0 = tm * P_BM, n0 = tn * P_BN;
-    // staging maps.  A: thread -> rows (tid >> 3) + 64 u, float4 q = tid & 7 of the row's 32 floats (8 lanes = one 128-byte line).
-    // W: thread -> 16-byte pieces p = tid + 512 u: plane p >> 10, row (p >> 2) & 255, octet p & 3 (4 lanes = one 64-byte row piece).
-    const int arow = tid >> 3, aq = tid & 7;
-    // (named registers, not arrays: an indexed array of prefetch registers captured by a lambda ends up in scratch memory)
-    auto arow_ptr = [&](int u) {
-        int r = m0 + arow + 64 * u;
-        r = r < M ? r : M - 1;                        // rows past M: computed on a clamped row, never stored
-        return A + (size_t)r * K + 4 * aq;
-    };
-    const float* const asrc0 = arow_ptr(0);
-    const float* const asrc1 = arow_ptr(1);
-    const float* const asrc2 = arow_ptr(2);
-    const float* const asrc3 = arow_ptr(3);
-    const int wrow = (tid >> 2) & 127, woct = tid & 3;          // piece u: plane = u >> 1, row = wrow + 128 (u & 1)
-    const unsigned short* wsrc = Wp + (size_t)(n0 + wrow) * K + 8 * woct;
-    const size_t wplane = (size_t)N * K, wrow128 = (size_t)128 * K;
-    float4 ra0, ra1, ra2, ra3;
-    uint4 rw0, rw1, rw2, rw3;
-#define P256_LOAD_TILE(k0)                                                   \
-    do {                                                                     \
-        ra0 = *(const float4*)(asrc0 + (k0));                                \
-        ra1 = *(const float4*)(asrc1 + (k0));                                \
-        ra2 = *(const float4*)(asrc2 + (k0));                                \
-        ra3 = *(const float4*)(asrc3 + (k0));                                \
-        rw0 = *(const uint4*)(wsrc + (k0));                                  \
-        rw1 = *(const uint4*)(wsrc + wrow128 + (k0));                        \
-        rw2 = *(const uint4*)(wsrc + wplane + (k0));                         \
-        rw3 = *(const uint4*)(wsrc + wplane + wrow128 + (k0));               \
-    } while (0)
-    const int aoff0 = p_off(arow, aq >> 1) + 4 * (aq & 1);      // rows arow + 64 u: (row >> 2) & 3 is the same for all four
-    const int woff0 = p_off(wrow, woct);                        // rows wrow, wrow + 128: likewise
-#define P256_PARK_A(base, u, r)                                              \
-    do {                                                                     \
-        uint2 h_, l_;                                                        \
-        split4(r, h_, l_);                                                   \
-        *(uint2*)((base) + aoff0 + 64 * (u) * P_BK) = h_;                    \
-        *(uint2*)((base) + P_PLANE + aoff0 + 64 * (u) * P_BK) = l_;          \
-    } while (0)
-#define P256_PARK_TILE(buf)                                                  \
-    do {                                                                     \
-        unsigned short* pb_ = lds + (buf) * 4 * P_PLANE;                     \
-        P256_PARK_A(pb_, 0, ra0);                                            \
-        P256_PARK_A(pb_, 1, ra1);                                            \
-        P256_PARK_A(pb_, 2, ra2);                                            \
-        P256_PARK_A(pb_, 3, ra3);                                            \
-        *(uint4*)(pb_ + 2 * P_PLANE + woff0) = rw0;                          \
-        *(uint4*)(pb_ + 2 * P_PLANE + woff0 + 128 * P_BK) = rw1;             \
-        *(uint4*)(pb_ + 3 * P_PLANE + woff0) = rw2;                          \
-        *(uint4*)(pb_ + 3 * P_PLANE + woff0 + 128 * P_BK) = rw3;             \
-    } while (0)
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16_zero();
-    const int nk = K / P_BK;
-    P256_LOAD_TILE(0);
-    P256_PARK_TILE(0);
-    if (nk > 1) P256_LOAD_TILE(P_BK);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned short* base = lds + (kt & 1) * 4 * P_PLANE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            s16x8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int off = p_off(64 * wc + 32 * j + lo, 2 * ks + hi);
-                bh[j] = *(const s16x8*)(base + 2 * P_PLANE + off);
-                bl[j] = *(const s16x8*)(base + 3 * P_PLANE + off);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int off = p_off(128 * wr + 32 * i + lo, 2 * ks + hi);
-                ah[i] = *(const s16x8*)(base + off);
-                al[i] = *(const s16x8*)(base + P_PLANE + off);
-            }
-            if (ks == 1 && kt + 1 < nk) {
-                // tile kt + 1 (in registers since the previous iteration) -> the other buffer: its last readers passed the barrier
-                // at the end of iteration kt - 1; then the loads of tile kt + 2 go out under the second half of this tile's MFMAs
-                P256_PARK_TILE((kt + 1) & 1);
-                if (kt + 2 < nk) P256_LOAD_TILE((kt + 2) * P_BK);
-            }
-            sed_mfma_prio(1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32_bf16(al[i], bh[j], acc[i][j]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32_bf16(ah[i], bl[j], acc[i][j]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32_bf16(ah[i], bh[j], acc[i][j]);
-            sed_mfma_prio(0);
-        }
-        __syncthreads();                    // buffer (kt + 1) & 1 is complete; everybody is done reading buffer kt & 1
-    }
-    // epilogue: bias (+ exact GELU); lane holds column n0 + 64 wc + 32 j + lo, rows mfma32_row(r, lane) of each 32-row block
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int gn = n0 + 64 * wc + 32 * j + lo;
-        const float bv = bias != nullptr ? bias[gn] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + 128 * wr + 32 * i + mfma32_row(r, lane);
-                float v = acc[i][j][r] + bv;
-                if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                if (gm < M) Cm[(size_t)gm * N + gn] = v;
-            }
-    }
-#undef P256_LOAD_TILE
-#undef P256_PARK_A
-#undef P256_PARK_TILE
-}
-}  // namespace
-
-// ---- round 6, second form: the same 256 x 256 x 32 tile and LDS layout, hand-phased ("ping-pong") ---------------------------------------
-// linear_p256_kernel measured 0.27 - 0.30 of the split-bf16 ceiling, like every kernel of the family (profiles/r06b_linear_shapes.txt):
-// __syncthreads() phase-locks the two waves of a SIMD, so both read their fragments at once (matrix pipe idle) and then queue for the
-// pipe together.  Here the eight waves are two GROUPS of four (one wave per SIMD each: waves 0-3 own tile rows 0-127, waves 4-7 rows
-// 128-255) running ONE BARRIER APART: a K tile is four phases (k16 step ks x row half h), each "LDS reads (+ a share of the staging) |
-// barrier | 12 MFMAs | barrier"; while group 0 issues its 12 MFMAs (384 matrix-pipe cycles) group 1 reads the fragments of its next
-// phase, parks its share of the next K tile and issues its global loads, and vice versa (cdna_hip_programming.md, the 8-phase
-// template; s_setprio 1 around the MFMA cluster).  Barriers are raw s_barrier (no vmcnt drain: the global loads of tile kt + 2 stay in
-// flight across twelve of them).  Hazards, in intervals between barriers (eight per K tile; group 1 runs one interval late):
-//   * every phase q = 0 .. 3 parks quarter q of tile kt + 1 into the other buffer (and re-loads its registers with tile kt + 2: two global
-//     loads per phase -- four in one phase made that phase longer than the 12 MFMAs beside it); phases 0 - 2 are followed by "barrier,
-//     s_waitcnt lgkmcnt(0), MFMAs, barrier", phase 3 waits for lgkmcnt(0) BEFORE its barrier, so group 1's last store (interval 7) is
-//     published by the barrier that ends interval 7; the first read of tile kt + 1 is group 0's in interval 8;
-//   * the other buffer's last readers (tile kt - 1) are group 1's reads of phase 3 in interval -1, retired by that same early wait
-//     before the barrier that ends interval -1; the first store is group 0's in interval 0;
-//   * the prefetch registers of a quarter are loaded one whole K tile (eight intervals, ~3 000 matrix-pipe cycles) before they are parked.
-#ifndef PP_DIAG
-#define PP_DIAG 0           // tools/build_variant.py -DPP_DIAG=<bits>: timing-only builds with a part of the loop removed (wrong results)
-#endif
-namespace {
-template <int ACT>
-__global__ __launch_bounds__(512, 1) void linear_pp_kernel(const float* __restrict__ A, const unsigned short* __restrict__ Wp,
-                                                          const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K,
-                                                          int tiles_m, int tiles_n) {
-    SED_DYN_SMEM(smem);                               // [2 buffers][A hi | A lo | W hi | W lo][256][32] bf16
-    unsigned short* lds = (unsigned short*)smem;
-    const int tid = threadIdx.x, lane = tid & 63, w = sed_wave_uniform(tid >> 6), lo = lane & 31, hi = lane >> 5;
-    const int wr = w >> 2, wc = w & 3;                // wave: rows 128 wr .. + 127, columns 64 wc .. + 63 of the tile; group = wr
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tm = xcd + 8 * (slot / tiles_n), tn = slot % tiles_n;
-    if (tm >= tiles_m) return;
-    const int m0 = tm * P_BM, n0 = tn * P_BN;
-    const int arow = tid >> 3, aq = tid & 7;
-    auto arow_ptr = [&](int u) {
-        int r = m0 + arow + 64 * u;
-        r = r < M ? r : M - 1;
-        return A + (size_t)r * ((PP_DIAG & 128) ? K + 64 : K) + 4 * aq;       // diag 128: padded row pitch (timing only)
-    };
-    const float* const asrc0 = arow_ptr(0);
-    const float* const asrc1 = arow_ptr(1);
-    const float* const asrc2 = arow_ptr(2);
-    const float* const asrc3 = arow_ptr(3);
-    const int wrow = (tid >> 2) & 127, woct = tid & 3;
-    const int ldw = (PP_DIAG & 256) ? K + 128 : K;                           // diag 256: padded row pitch of the weight planes
-    const unsigned short* wsrc = Wp + (size_t)(n0 + wrow) * ldw + 8 * woct;
-    const size_t wplane = (size_t)N * ldw, wrow128 = (size_t)128 * ldw;
-    float4 ra0, ra1, ra2, ra3;                        // half 0 of a K tile: ra0, ra1 (rows arow, + 64), rw0, rw1 (hi plane, rows wrow, + 128)
-    uint4 rw0, rw1, rw2, rw3;                         // half 1: ra2, ra3 (rows + 128, + 192), rw2, rw3 (lo plane)
-    // quarter q of a K tile = A rows arow + 64 q (ra_q) + W piece q (rw_q: plane q >> 1, rows wrow + 128 (q & 1))
-#define PP_LOAD_Q(ra, rw, asrc, woff, k0) do { if (!(PP_DIAG & 32)) ra = *(const float4*)((asrc) + (k0));                      \
-                                              if (!(PP_DIAG & 64)) rw = *(const uint4*)(wsrc + (woff) + (k0)); } while (0)
-#define PP_LOAD_Q0(k0) PP_LOAD_Q(ra0, rw0, asrc0, (size_t)0, k0)
-#define PP_LOAD_Q1(k0) PP_LOAD_Q(ra1, rw1, asrc1, wrow128, k0)
-#define PP_LOAD_Q2(k0) PP_LOAD_Q(ra2, rw2, asrc2, wplane, k0)
-#define PP_LOAD_Q3(k0) PP_LOAD_Q(ra3, rw3, asrc3, wplane + wrow128, k0)
-    const int aoff0 = p_off(arow, aq >> 1) + 4 * (aq & 1);
-    const int woff0 = p_off(wrow, woct);
-#define PP_PARK_Q(pb_, q, ra, rw) do { uint2 h_, l_; split4(ra, h_, l_);                                                        \
-                                       *(uint2*)((pb_) + aoff0 + 64 * (q) * P_BK) = h_;                                         \
-                                       *(uint2*)((pb_) + P_PLANE + aoff0 + 64 * (q) * P_BK) = l_;                               \
-                                       *(uint4*)((pb_) + (2 + ((q) >> 1)) * P_PLANE + woff0 + 128 * ((q) & 1) * P_BK) = rw; } while (0)
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16_zero();
-    const int nk = K / P_BK, klast = K - P_BK;
-    PP_LOAD_Q0(0); PP_LOAD_Q1(0); PP_LOAD_Q2(0); PP_LOAD_Q3(0);
-    PP_PARK_Q(lds, 0, ra0, rw0); PP_PARK_Q(lds, 1, ra1, rw1); PP_PARK_Q(lds, 2, ra2, rw2); PP_PARK_Q(lds, 3, ra3, rw3);
-    { const int k1 = nk > 1 ? P_BK : 0; PP_LOAD_Q0(k1); PP_LOAD_Q1(k1); PP_LOAD_Q2(k1); PP_LOAD_Q3(k1); }
-    __syncthreads();
-    if (wr == 1) sed_phase_barrier();               // group 1 runs one interval behind group 0
-    // fragment addresses: row 128 wr + 32 i + lo (A) / 64 wc + 32 j + lo (W), octet 2 ks + hi, swizzled by (row >> 2) & 3 = (lo >> 2) & 3
-    const int sw = (lo >> 2) & 3;
-    const int fa0 = (128 * wr + lo) * P_BK + ((hi ^ sw) << 3), fa1 = (128 * wr + lo) * P_BK + (((2 + hi) ^ sw) << 3);
-    const int fb0 = 2 * P_PLANE + (64 * wc + lo) * P_BK + ((hi ^ sw) << 3), fb1 = 2 * P_PLANE + (64 * wc + lo) * P_BK + (((2 + hi) ^ sw) << 3);
-    s16x8 ah0, ah1, al0, al1, bh0, bh1, bl0, bl1;
-#if defined(PP_DIAG) && (PP_DIAG & 8)
-#define PP_BAR() sed_sched_fence()
-#else
-#define PP_BAR() sed_phase_barrier()
-#endif
-#define PP_READ_B(base, fb) do { bh0 = *(const s16x8*)((base) + (fb)); bh1 = *(const s16x8*)((base) + (fb) + 32 * P_BK);       \
-                                 bl0 = *(const s16x8*)((base) + P_PLANE + (fb)); bl1 = *(const s16x8*)((base) + P_PLANE + (fb) + 32 * P_BK); } while (0)
-#define PP_READ_A(base, fa, h) do { ah0 = *(const s16x8*)((base) + (fa) + (2 * (h)) * 32 * P_BK); ah1 = *(const s16x8*)((base) + (fa) + (2 * (h) + 1) * 32 * P_BK); \
-                                    al0 = *(const s16x8*)((base) + P_PLANE + (fa) + (2 * (h)) * 32 * P_BK);                    \
-                                    al1 = *(const s16x8*)((base) + P_PLANE + (fa) + (2 * (h) + 1) * 32 * P_BK); } while (0)
-#define PP_MFMA(h, pre) do { if (pre) sed_wait_lds(); PP_BAR(); sed_wait_lds(); sed_mfma_prio(1); if (!(PP_DIAG & 1024)) {                                                             \
-        acc[2 * (h)][0] = mfma32_bf16(al0, bh0, acc[2 * (h)][0]); acc[2 * (h)][1] = mfma32_bf16(al0, bh1, acc[2 * (h)][1]);     \
-        acc[2 * (h) + 1][0] = mfma32_bf16(al1, bh0, acc[2 * (h) + 1][0]); acc[2 * (h) + 1][1] = mfma32_bf16(al1, bh1, acc[2 * (h) + 1][1]); \
-        acc[2 * (h)][0] = mfma32_bf16(ah0, bl0, acc[2 * (h)][0]); acc[2 * (h)][1] = mfma32_bf16(ah0, bl1, acc[2 * (h)][1]);     \
-        acc[2 * (h) + 1][0] = mfma32_bf16(ah1, bl0, acc[2 * (h) + 1][0]); acc[2 * (h) + 1][1] = mfma32_bf16(ah1, bl1, acc[2 * (h) + 1][1]); \
-        acc[2 * (h)][0] = mfma32_bf16(ah0, bh0, acc[2 * (h)][0]); acc[2 * (h)][1] = mfma32_bf16(ah0, bh1, acc[2 * (h)][1]);     \
-        acc[2 * (h) + 1][0] = mfma32_bf16(ah1, bh0, acc[2 * (h) + 1][0]); acc[2 * (h) + 1][1] = mfma32_bf16(ah1, bh1, acc[2 * (h) + 1][1]); \
-        } sed_mfma_prio(0); PP_BAR(); } while (0)
-    // one loop body for both buffers (a runtime buffer offset costs a handful of address adds per K tile; two specialised copies behind
-    // a branch made the register allocator copy and spill the accumulators)
-#define PP_IF(bit, stmt) do { if (!(PP_DIAG & (bit))) { stmt; } } while (0)
-    if (PP_DIAG & 4) { PP_READ_B(lds, fb0); PP_READ_A(lds, fa0, 0); }
-#if PP_DIAG & 2048
-    // diag: TWO K tiles of prefetch registers in flight (only possible without the accumulators: use with bit 1024)
-    float4 sa0 = ra0, sa1 = ra1, sa2 = ra2, sa3 = ra3; uint4 sw0 = rw0, sw1 = rw1, sw2 = rw2, sw3 = rw3;
-    for (int kt = 0; kt < nk; ++kt) {
-        unsigned short* other = lds + ((kt & 1) ^ 1) * 4 * P_PLANE;
-        const int k3 = min((kt + 3) * P_BK, klast);
-        if (kt & 1) {
-            PP_PARK_Q(other, 0, ra0, rw0); PP_LOAD_Q0(k3); PP_MFMA(0, 0); PP_PARK_Q(other, 1, ra1, rw1); PP_LOAD_Q1(k3); PP_MFMA(1, 0);
-            PP_PARK_Q(other, 2, ra2, rw2); PP_LOAD_Q2(k3); PP_MFMA(0, 0); PP_PARK_Q(other, 3, ra3, rw3); PP_LOAD_Q3(k3); PP_MFMA(1, 1);
-        } else {
-            PP_PARK_Q(other, 0, sa0, sw0); PP_LOAD_Q(sa0, sw0, asrc0, (size_t)0, k3); PP_MFMA(0, 0);
-            PP_PARK_Q(other, 1, sa1, sw1); PP_LOAD_Q(sa1, sw1, asrc1, wrow128, k3); PP_MFMA(1, 0);
-            PP_PARK_Q(other, 2, sa2, sw2); PP_LOAD_Q(sa2, sw2, asrc2, wplane, k3); PP_MFMA(0, 0);
-            PP_PARK_Q(other, 3, sa3, sw3); PP_LOAD_Q(sa3, sw3, asrc3, wplane + wrow128, k3); PP_MFMA(1, 1);
-        }
-    }
-#else
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned short* base = lds + (kt & 1) * 4 * P_PLANE;
-        unsigned short* other = lds + ((kt & 1) ^ 1) * 4 * P_PLANE;
-        const int k2 = (PP_DIAG & 16) ? (kt & 1) * P_BK : min((kt + 2) * P_BK, klast);      // past the end: a valid tile nobody uses
-        // phase q parks quarter q of tile kt + 1 (loaded one K tile ago) and re-loads its registers with quarter q of tile kt + 2:
-        // two global loads, one split and three LDS stores per phase beside the 4 - 8 fragment reads
-        PP_IF(4, PP_READ_B(base, fb0)); PP_IF(4, PP_READ_A(base, fa0, 0)); PP_IF(2, PP_PARK_Q(other, 0, ra0, rw0)); PP_IF(1, PP_LOAD_Q0(k2)); PP_MFMA(0, 0);
-        PP_IF(4, PP_READ_A(base, fa0, 1));                                 PP_IF(2, PP_PARK_Q(other, 1, ra1, rw1)); PP_IF(1, PP_LOAD_Q1(k2)); PP_MFMA(1, 0);
-        PP_IF(4, PP_READ_B(base, fb1)); PP_IF(4, PP_READ_A(base, fa1, 0)); PP_IF(2, PP_PARK_Q(other, 2, ra2, rw2)); PP_IF(1, PP_LOAD_Q2(k2)); PP_MFMA(0, 0);
-        PP_IF(4, PP_READ_A(base, fa1, 1));                                 PP_IF(2, PP_PARK_Q(other, 3, ra3, rw3)); PP_IF(1, PP_LOAD_Q3(k2)); PP_MFMA(1, 1);
-    }
-#endif
-#undef PP_IF
-    if (wr == 0) sed_phase_barrier();               // the barrier group 1 took at the top
-    // epilogue: bias (+ exact GELU); lane holds column n0 + 64 wc + 32 j + lo, rows mfma32_row(r, lane) of each 32-row block
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int gn = n0 + 64 * wc + 32 * j + lo;
-        const float bv = bias != nullptr ? bias[gn] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + 128 * wr + 32 * i + mfma32_row(r, lane);
-                float v = acc[i][j][r] + bv;
-                if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                if ((PP_DIAG & 4096) ? (v == 1.2345e-30f) : (gm < M)) Cm[(size_t)gm * N + gn] = v;      // diag 4096: no C stores
-            }
-    }
-#undef PP_LOAD_Q
-#undef PP_LOAD_Q0
-#undef PP_LOAD_Q1
-#undef PP_LOAD_Q2
-#undef PP_LOAD_Q3
-#undef PP_PARK_Q
-#undef PP_READ_A
-#undef PP_READ_B
-#undef PP_MFMA
-#undef PP_BAR
-}
-}  // namespace
-
-// ---- round 6, third form: both operands as pre-split planes in a K-tiled LDS image, every byte moved by LDS-DMA -------------------------
-// What the two kernels above taught (profiles/r06_linear_diag.md): with the loads removed the hand-phased loop runs at the matrix pipe's
+// ---- round 6: both operands as pre-split planes in a K-tiled LDS image, every byte moved by LDS-DMA --------------------------------------
+// Two 256 x 256 kernels with register staging came first (a __syncthreads() form and a hand-phased two-group form; commit 43bb868,
+// timing-only builds and stamps in profiles/r06_linear_diag.md).  What they taught: with the loads removed the hand-phased loop runs at the matrix pipe's
 // pace (1.57 us per 32-deep K tile); the loads alone -- global_load_dwordx4 into VGPRs, 64 KB per K tile and CU -- take 0.7 (L2-hot) to
 // 1.4 us per K tile; and together they ADD (2.67 us): load data returning into the VGPR file and the MFMAs do not overlap, whatever the
 // schedule.  So here nothing returns into a register: activations and weights arrive as bf16 hi / lo planes already cut into the blocks
@@ -761,6 +452,7 @@ __global__ __launch_bounds__(512, 1) void linear_pp_kernel(const float* __restri
 // The stage refilled during tile kt is tile kt - 1's, whose last reads (group 1, second phase) were retired by the lgkmcnt(0) of that
 // same wait.  LDS: 4 x 32 KB.
 namespace {
+constexpr int P_BM = 256, P_BN = 256;                    // output tile
 constexpr int T_BK = 16, T_PLANE = 256 * T_BK, T_BLOCK = 2 * T_PLANE, T_STAGE = 2 * T_BLOCK;      // ushorts: 4096, 8192 (16 KB), 16384 (32 KB)
 __device__ __forceinline__ int t_off(int row, int oct) { return row * T_BK + ((oct ^ ((row >> 3) & 1)) << 3); }
 
@@ -794,44 +486,75 @@ SED_API int sed_linear_debug_set_stamps(unsigned long long* buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(t_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? SED_OK : SED_ERR_LAUNCH;
 }
 #define T_TS(k) do { __builtin_amdgcn_sched_barrier(0);                                                                          \
-                     if (stamp_on && kt >= 8 && kt < 24) { const unsigned long long t_ = __builtin_amdgcn_s_memtime();           \
-                                                           if (lane == 0) s_ts[((w >> 2) * 16 + kt - 8) * 16 + (k)] = t_; }      \
+                     if (stamp_on && step >= 8 && step < 24) { const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
+                                                           if (lane == 0) s_ts[((w >> 2) * 16 + step - 8) * 16 + (k)] = t_; }      \
                      __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define T_TS(k) do { } while (0)
 #endif
 
-template <int ACT>
+// Persistent form: one workgroup per CU walks its output tiles (virtual block g, g + gridDim, ...; the XCD of a tile's row panel is
+// g & 7 as before) as ONE stream of K steps -- the DMA cursor runs three steps ahead of the MFMAs across tile boundaries, so a tile's first
+// blocks are in flight while the previous tile's accumulators are written.  The product is accumulated transposed (MFMA a = W fragment, b
+// = A fragment: a lane then holds one row m and 4 consecutive columns n per register quad): C leaves as 16-byte stores, or (OUT = 1) as
+// 8-byte hi / lo pieces straight into the K-tiled image the NEXT Linear reads (fc1's GELU output -> fc2), rows of the padded last panel
+// included.
+template <int ACT, int OUT>
 __global__ __launch_bounds__(512, 1) void linear_dma_kernel(const unsigned short* __restrict__ At, const unsigned short* __restrict__ Wt,
-                                                           const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K,
-                                                           int tiles_m, int tiles_n) {
+                                                           const float* __restrict__ bias, void* __restrict__ Cout, int M, int N, int K,
+                                                           int tiles_m, int tiles_n, int nvb, int skew) {
     SED_DYN_SMEM(smem);                               // [4 stages][A hi | A lo | W hi | W lo][256][16] bf16
     unsigned short* lds = (unsigned short*)smem;
     const int tid = threadIdx.x, lane = tid & 63, w = sed_wave_uniform(tid >> 6), lo = lane & 31, hi = lane >> 5;
     const int wr = w >> 2, wc = w & 3;                // wave: rows 128 wr .. + 127, columns 64 wc .. + 63 of the tile; group = wr
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tm = xcd + 8 * (slot / tiles_n), tn = slot % tiles_n;
-    if (tm >= tiles_m) return;
-    const int m0 = tm * P_BM, n0 = tn * P_BN, nk = K / T_BK;
+    const int nk = K / T_BK, gstride = gridDim.x;
+    // virtual block -> tile: XCD x = vb & 7 owns the row panels tm = x (mod 8) and sweeps their N tiles back to back
+    auto valid = [&](int vb) { return (vb & 7) + 8 * ((vb >> 3) / tiles_n) < tiles_m; };
+    auto next_vb = [&](int vb) { do vb += gstride; while (vb < nvb && !valid(vb)); return vb; };
+    int cvb = (int)blockIdx.x;                        // compute cursor
+    if (!valid(cvb)) cvb = next_vb(cvb);
+    if (cvb >= nvb) return;
+#ifndef SED_EMU
+    if (skew > 0) {
+        // Every tile takes the same time, so the CUs would all reach their epilogues together and write 64 MB of C in one burst (17 us at
+        // HBM's write rate, matrix pipes idle: a quarter of the QKV launch).  The workgroups that walk one tile FEWER than the longest
+        // walk have a tile's time to spare: they start late, by a fraction of a tile's time that depends on their row panel (the
+        // workgroups sharing an A panel stay together, for its L2), and their epilogues then fall into the others' K loops.
+        int mine = 0, vb0 = (int)blockIdx.x;
+        for (int vb = valid(vb0) ? vb0 : next_vb(vb0); vb < nvb; vb = next_vb(vb)) ++mine;
+        if (mine < skew) {
+            const int grp = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) / tiles_n);
+            const long long wait = (long long)nk * 2800 * (((grp * 5) & 31) + 1) / 36;
+            const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+            while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+#endif
     // DMA pieces of a stage: 32 pieces of 1 KB (0 - 15: the A block, 16 - 31: the W block); wave w moves pieces w, w + 8 (first phase) and
-    // w + 16, w + 24 (second phase)
-    const unsigned short* asrc = At + (size_t)tm * nk * T_BLOCK + w * 512 + lane * 8;
-    const unsigned short* wsrc = Wt + (size_t)tn * nk * T_BLOCK + w * 512 + lane * 8;
-#define T_DMA_A(kt_, stage_) do { const unsigned short* g_ = asrc + (size_t)(kt_) * T_BLOCK; unsigned short* l_ = lds + (stage_) * T_STAGE + w * 512; \
-                                  sed_dma16(g_, l_); sed_dma16(g_ + 8 * 512, l_ + 8 * 512); } while (0)
-#define T_DMA_W(kt_, stage_) do { const unsigned short* g_ = wsrc + (size_t)(kt_) * T_BLOCK; unsigned short* l_ = lds + (stage_) * T_STAGE + T_BLOCK + w * 512; \
-                                  sed_dma16(g_, l_); sed_dma16(g_ + 8 * 512, l_ + 8 * 512); } while (0)
+    // w + 16, w + 24 (second phase).  Uniform block pointer + one 32-bit lane offset: no vector arithmetic in the read phases.
+    const unsigned voff = (unsigned)(w * 512 + lane * 8), voff2 = voff + 8 * 512;
+    int dvb = cvb, dkt = 0;                           // DMA cursor (tile, K step); past the last tile it stays on the last block (never read)
+    bool dlive = true;
+    const unsigned short* da = At + (size_t)((dvb & 7) + 8 * ((dvb >> 3) / tiles_n)) * nk * T_BLOCK;
+    const unsigned short* dw = Wt + (size_t)((dvb >> 3) % tiles_n) * nk * T_BLOCK;
+#define T_DMA_A(stage_) do { const unsigned short* g_ = da + (size_t)dkt * T_BLOCK; unsigned short* l_ = lds + (stage_) * T_STAGE + w * 512; \
+                             sed_dma16(g_ + voff, l_); sed_dma16(g_ + voff2, l_ + 8 * 512); } while (0)
+#define T_DMA_W(stage_) do { const unsigned short* g_ = dw + (size_t)dkt * T_BLOCK; unsigned short* l_ = lds + (stage_) * T_STAGE + T_BLOCK + w * 512; \
+                             sed_dma16(g_ + voff, l_); sed_dma16(g_ + voff2, l_ + 8 * 512); } while (0)
+#define T_DMA_NEXT() do { if (dlive && ++dkt == nk) { const int nv_ = next_vb(dvb);                                              \
+                              if (nv_ < nvb) { dvb = nv_; dkt = 0; da = At + (size_t)((dvb & 7) + 8 * ((dvb >> 3) / tiles_n)) * nk * T_BLOCK; \
+                                               dw = Wt + (size_t)((dvb >> 3) % tiles_n) * nk * T_BLOCK; }                      \
+                              else { dkt = nk - 1; dlive = false; } } } while (0)
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x16_zero();
-    // prologue: tiles 0, 1, 2 (past the end: the last tile again -- a valid block nobody reads -- so that the DMA count per tile is fixed)
-    {
-        const int k1 = min(1, nk - 1), k2 = min(2, nk - 1);
-        T_DMA_A(0, 0); T_DMA_W(0, 0); T_DMA_A(k1, 1); T_DMA_W(k1, 1); T_DMA_A(k2, 2); T_DMA_W(k2, 2);
-    }
-    SED_WAIT_VM_LDS(8);                               // tile 0 has landed (this wave's share)
+    // prologue: the first three K steps of the stream (a fixed DMA count per step keeps the vmcnt arithmetic below valid)
+    T_DMA_A(0); T_DMA_W(0); T_DMA_NEXT();
+    T_DMA_A(1); T_DMA_W(1); T_DMA_NEXT();
+    T_DMA_A(2); T_DMA_W(2); T_DMA_NEXT();
+    SED_WAIT_VM_LDS(8);                               // step 0 has landed (this wave's share)
     __syncthreads();
     if (wr == 1) sed_phase_barrier();                 // group 1 runs one interval behind group 0
     const int sw = (lo >> 3) & 1;
@@ -842,26 +565,35 @@ __global__ __launch_bounds__(512, 1) void linear_dma_kernel(const unsigned short
 #define T_READ_A(base, h) do { ah0 = *(const s16x8*)((base) + fa + (2 * (h)) * 32 * T_BK); ah1 = *(const s16x8*)((base) + fa + (2 * (h) + 1) * 32 * T_BK); \
                                al0 = *(const s16x8*)((base) + T_PLANE + fa + (2 * (h)) * 32 * T_BK);                            \
                                al1 = *(const s16x8*)((base) + T_PLANE + fa + (2 * (h) + 1) * 32 * T_BK); } while (0)
-#define T_MFMA(h) do { sed_mfma_prio(1);                                                                                        \
-        acc[2 * (h)][0] = mfma32_bf16(al0, bh0, acc[2 * (h)][0]); acc[2 * (h)][1] = mfma32_bf16(al0, bh1, acc[2 * (h)][1]);     \
-        acc[2 * (h) + 1][0] = mfma32_bf16(al1, bh0, acc[2 * (h) + 1][0]); acc[2 * (h) + 1][1] = mfma32_bf16(al1, bh1, acc[2 * (h) + 1][1]); \
-        acc[2 * (h)][0] = mfma32_bf16(ah0, bl0, acc[2 * (h)][0]); acc[2 * (h)][1] = mfma32_bf16(ah0, bl1, acc[2 * (h)][1]);     \
-        acc[2 * (h) + 1][0] = mfma32_bf16(ah1, bl0, acc[2 * (h) + 1][0]); acc[2 * (h) + 1][1] = mfma32_bf16(ah1, bl1, acc[2 * (h) + 1][1]); \
-        acc[2 * (h)][0] = mfma32_bf16(ah0, bh0, acc[2 * (h)][0]); acc[2 * (h)][1] = mfma32_bf16(ah0, bh1, acc[2 * (h)][1]);     \
-        acc[2 * (h) + 1][0] = mfma32_bf16(ah1, bh0, acc[2 * (h) + 1][0]); acc[2 * (h) + 1][1] = mfma32_bf16(ah1, bh1, acc[2 * (h) + 1][1]); \
+    // acc[im][jn] = (W rows 32 jn ..) x (A rows 32 im ..)^T: lane -> A row lo of block im, W rows (r & 3) + 8 (r >> 2) + 4 hi of block jn
+#ifndef T_DIAG
+#define T_DIAG 0            // timing-only builds: 1 no MFMAs, 2 no fragment reads, 4 no DMA (wrong results)
+#endif
+#define T_MFMA(h) do { sed_mfma_prio(1); if (!(T_DIAG & 1)) {                                                                    \
+        acc[2 * (h)][0] = mfma32_bf16(bh0, al0, acc[2 * (h)][0]); acc[2 * (h)][1] = mfma32_bf16(bh1, al0, acc[2 * (h)][1]);     \
+        acc[2 * (h) + 1][0] = mfma32_bf16(bh0, al1, acc[2 * (h) + 1][0]); acc[2 * (h) + 1][1] = mfma32_bf16(bh1, al1, acc[2 * (h) + 1][1]); \
+        acc[2 * (h)][0] = mfma32_bf16(bl0, ah0, acc[2 * (h)][0]); acc[2 * (h)][1] = mfma32_bf16(bl1, ah0, acc[2 * (h)][1]);     \
+        acc[2 * (h) + 1][0] = mfma32_bf16(bl0, ah1, acc[2 * (h) + 1][0]); acc[2 * (h) + 1][1] = mfma32_bf16(bl1, ah1, acc[2 * (h) + 1][1]); \
+        acc[2 * (h)][0] = mfma32_bf16(bh0, ah0, acc[2 * (h)][0]); acc[2 * (h)][1] = mfma32_bf16(bh1, ah0, acc[2 * (h)][1]);     \
+        acc[2 * (h) + 1][0] = mfma32_bf16(bh0, ah1, acc[2 * (h) + 1][0]); acc[2 * (h) + 1][1] = mfma32_bf16(bh1, ah1, acc[2 * (h) + 1][1]); } \
         sed_mfma_prio(0); } while (0)
 #ifdef T_STAMP
     unsigned long long* s_ts = (unsigned long long*)(lds + 4 * T_STAGE);
     const bool stamp_on = blockIdx.x == 64 && (w & 3) == 0;
 #endif
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned short* base = lds + (kt & 3) * T_STAGE;
-        const int k3 = min(kt + 3, nk - 1), s3 = (kt + 3) & 3;
-        // first phase: A pieces of tile kt + 3, W fragments + A fragments of the upper 64 rows
+    int step = 0;
+    for (;;) {                                        // tiles of this workgroup
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt, ++step) {
+        const unsigned short* base = lds + (step & 3) * T_STAGE;
+        const int s3 = (step + 3) & 3;
+        // first phase: W fragments + A fragments of the upper 64 rows, then the A pieces of step + 3 (fragment reads FIRST: the four waves
+        // of a group issue their DMA pieces at the same moment and queue for the CU's one address pipe, profiles/r06g_linear_stamps_qkv.log)
         T_TS(0);
-        T_READ_B(base); T_READ_A(base, 0);          // fragment reads FIRST: the four waves of a group issue their DMA pieces at the same moment and
-        sed_sched_fence();                          // queue for the CU's one address pipe (~25 - 60 cycles a piece, r06g_linear_stamps)
-        T_DMA_A(k3, s3);
+        if (!(T_DIAG & 2) || step == 0) { T_READ_B(base); T_READ_A(base, 0); }
+        sed_sched_fence();
+        T_TS(10);
+        if (!(T_DIAG & 4)) T_DMA_A(s3);
         T_TS(1);
         sed_phase_barrier(); sed_wait_lds();
         T_TS(2);
@@ -869,10 +601,13 @@ __global__ __launch_bounds__(512, 1) void linear_dma_kernel(const unsigned short
         T_TS(3);
         sed_phase_barrier();
         T_TS(4);
-        // second phase: W pieces of tile kt + 3, A fragments of the lower 64 rows; then this wave's share of tile kt + 1 must have landed
-        T_READ_A(base, 1);
+        // second phase: A fragments of the lower 64 rows, the W pieces of step + 3; then this wave's share of step + 1 must have landed
+        if (!(T_DIAG & 2)) T_READ_A(base, 1);
         sed_sched_fence();
-        T_DMA_W(k3, s3);
+        T_TS(11);
+        if (!(T_DIAG & 4)) T_DMA_W(s3);
+        T_TS(12);
+        T_DMA_NEXT();
         T_TS(5);
         SED_WAIT_VM_LDS(8);
         T_TS(6);
@@ -883,29 +618,54 @@ __global__ __launch_bounds__(512, 1) void linear_dma_kernel(const unsigned short
         sed_phase_barrier();
         T_TS(9);
     }
+        // ---- a tile is complete: bias (+ exact GELU), store, next tile ------------------------------------------------------------------
+        const int tm = (cvb & 7) + 8 * ((cvb >> 3) / tiles_n), tn = (cvb >> 3) % tiles_n;
+        const int m0 = tm * P_BM, n0 = tn * P_BN;
+        int elo = lo, ehi = hi;                       // opaque copies: the epilogue's address arithmetic stays HERE (hoisted out of the K loop it
+        sed_pin(elo); sed_pin(ehi);                   // occupied ~30 registers across it and spilled into the loop)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gn = n0 + 64 * wc + 32 * jn + 8 * q + 4 * ehi;                // 4 consecutive columns
+                const float4 bv = bias != nullptr ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int im = 0; im < 4; ++im) {
+                    const int mrow = 128 * wr + 32 * im + elo;
+                    float4 v = make_float4(acc[im][jn][4 * q] + bv.x, acc[im][jn][4 * q + 1] + bv.y, acc[im][jn][4 * q + 2] + bv.z,
+                                           acc[im][jn][4 * q + 3] + bv.w);
+                    if (ACT == 1) {
+                        v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752f)); v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752f));
+                        v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752f)); v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752f));
+                    }
+                    if (OUT == 0) {
+                        if ((T_DIAG & 8) ? (v.x == 1.2345e-30f) : (m0 + mrow < M)) *(float4*)((float*)Cout + (size_t)(m0 + mrow) * N + gn) = v;
+                    } else {
+                        uint2 h_, l_;
+                        split4(v, h_, l_);
+                        unsigned short* d_ = (unsigned short*)Cout + ((size_t)tm * (N / T_BK) + (gn >> 4)) * T_BLOCK + t_off(mrow, q & 1) + 4 * ehi;
+                        *(uint2*)d_ = h_;
+                        *(uint2*)(d_ + T_PLANE) = l_;
+                    }
+                }
+            }
+        cvb = next_vb(cvb);
+        if (cvb >= nvb) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x16_zero();
+    }
+    if (wr == 0) sed_phase_barrier();                 // the barrier group 1 took at the top
+    SED_WAIT_VM_LDS(0);                               // the tail's dummy DMAs: nothing may be in flight when the workgroup's LDS is released
 #ifdef T_STAMP
     __syncthreads();
     if (stamp_on && lane < 16 && t_stamp_buf != nullptr)
         for (int q = 0; q < 16; ++q) t_stamp_buf[((w >> 2) * 16 + q) * 16 + lane] = s_ts[((w >> 2) * 16 + q) * 16 + lane];
 #endif
-    if (wr == 0) sed_phase_barrier();                 // the barrier group 1 took at the top
-    SED_WAIT_VM_LDS(0);                               // the clamped tail DMAs: nothing may be in flight when the workgroup's LDS is released
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int gn = n0 + 64 * wc + 32 * j + lo;
-        const float bv = bias != nullptr ? bias[gn] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + 128 * wr + 32 * i + mfma32_row(r, lane);
-                float v = acc[i][j][r] + bv;
-                if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                if (gm < M) Cm[(size_t)gm * N + gn] = v;
-            }
-    }
 #undef T_DMA_A
 #undef T_DMA_W
+#undef T_DMA_NEXT
 #undef T_READ_A
 #undef T_READ_B
 #undef T_MFMA
@@ -922,23 +682,45 @@ SED_API int sed_split_tiles_bf16x3(const float* X, unsigned short* Xt, int R, in
     return sed_check_launch();
 }
 
-SED_API int sed_linear_tiles_bf16x3(const unsigned short* At, const unsigned short* Wt, const float* bias, float* Cm, int M, int N, int K,
-                                    int act, void* stream) {
-    if (!At || !Wt || !Cm || M < 0 || N < 0 || K < 0) return SED_ERR_ARG;
+static int linear_tiles_launch(const unsigned short* At, const unsigned short* Wt, const float* bias, void* Cout, int M, int N, int K, int act,
+                               int out_tiles, void* stream) {
+    if (!At || !Wt || !Cout || M < 0 || N < 0 || K < 0) return SED_ERR_ARG;
     if (act < 0 || act > 1) return SED_ERR_ARG;
     if (M <= 0 || N <= 0) return SED_OK;
-    if (N % P_BN != 0 || K % T_BK != 0 || K <= 0 || ((uintptr_t)At & 15) || ((uintptr_t)Wt & 15)) return SED_ERR_UNSUPPORTED;
+    if (N % P_BN != 0 || K % T_BK != 0 || K <= 0 || ((uintptr_t)At & 15) || ((uintptr_t)Wt & 15) || ((uintptr_t)Cout & 15) || ((uintptr_t)bias & 15))
+        return SED_ERR_UNSUPPORTED;
     const int tm = (M + P_BM - 1) / P_BM, tn = N / P_BN;
-    const long long grid_ll = 8LL * ((tm + 7) / 8) * tn;
-    if (grid_ll > 0x7fffffffLL) return SED_ERR_UNSUPPORTED;
+    const long long nvb_ll = 8LL * ((tm + 7) / 8) * tn;
+    if (nvb_ll > 0x7fffffffLL) return SED_ERR_UNSUPPORTED;
+    const int nvb = (int)nvb_ll;
+    // one persistent workgroup per CU (128 KB of LDS each); a multiple of 8 so that a workgroup stays on one XCD's row panels
+    int grid = sed_tuning[SED_TUNE_LINEAR_TILES] > 8 ? sed_tuning[SED_TUNE_LINEAR_TILES] & ~7 : 256;
+    if (grid > nvb) grid = nvb;
+    // skew = the longest walk's tile count when some workgroups walk fewer (0: none do, or switched off with the tuning key = 3)
+    const long long ntiles = (long long)tm * tn;
+    int skew = (ntiles > grid && ntiles % grid != 0) ? (int)((ntiles + grid - 1) / grid) : 0;
+    if (sed_tuning[SED_TUNE_LINEAR_TILES] == 3) skew = 0;
 #ifdef T_STAMP
     constexpr int SMEM_T = 4 * T_STAGE * 2 + 4096;
 #else
     constexpr int SMEM_T = 4 * T_STAGE * 2;
 #endif
-    if (act) { SED_MAX_SMEM((linear_dma_kernel<1>), SMEM_T); SED_LAUNCH((linear_dma_kernel<1>), dim3((unsigned)grid_ll), dim3(512), SMEM_T, (hipStream_t)stream, At, Wt, bias, Cm, M, N, K, tm, tn); }
-    else { SED_MAX_SMEM((linear_dma_kernel<0>), SMEM_T); SED_LAUNCH((linear_dma_kernel<0>), dim3((unsigned)grid_ll), dim3(512), SMEM_T, (hipStream_t)stream, At, Wt, bias, Cm, M, N, K, tm, tn); }
+#define T_LAUNCH(A_, O_) do { SED_MAX_SMEM((linear_dma_kernel<A_, O_>), SMEM_T);                                                 \
+        SED_LAUNCH((linear_dma_kernel<A_, O_>), dim3((unsigned)grid), dim3(512), SMEM_T, (hipStream_t)stream, At, Wt, bias, Cout, M, N, K, tm, tn, nvb, skew); } while (0)
+    if (out_tiles) { if (act) T_LAUNCH(1, 1); else T_LAUNCH(0, 1); }
+    else { if (act) T_LAUNCH(1, 0); else T_LAUNCH(0, 0); }
+#undef T_LAUNCH
     return sed_check_launch();
+}
+
+SED_API int sed_linear_tiles_bf16x3(const unsigned short* At, const unsigned short* Wt, const float* bias, float* Cm, int M, int N, int K,
+                                    int act, void* stream) {
+    return linear_tiles_launch(At, Wt, bias, Cm, M, N, K, act, 0, stream);
+}
+
+SED_API int sed_linear_tiles_out_bf16x3(const unsigned short* At, const unsigned short* Wt, const float* bias, unsigned short* Ct, int M, int N,
+                                        int K, int act, void* stream) {
+    return linear_tiles_launch(At, Wt, bias, Ct, M, N, K, act, 1, stream);
 }
 
 namespace {
@@ -968,21 +750,6 @@ SED_API int sed_linear_packed_bf16x3(const float* A, const unsigned short* Wp, c
     if (act < 0 || act > 1) return SED_ERR_ARG;
     if (M <= 0 || N <= 0) return SED_OK;
     if (N % LB_BN != 0 || K % LB_BK != 0 || K <= 0 || ((uintptr_t)A & 15) || ((uintptr_t)Wp & 15)) return SED_ERR_UNSUPPORTED;
-    if (N % P_BN == 0 && sed_tuning[SED_TUNE_LINEAR_P256] != 1 && (sed_tuning[SED_TUNE_LINEAR_P256] >= 2 || N >= 2048)) {
-        // the 256 x 256 kernel (round 6): one workgroup per tile, 128 KB of LDS
-        const int tm = (M + P_BM - 1) / P_BM, tn = N / P_BN;
-        const long long grid_ll = 8LL * ((tm + 7) / 8) * tn;
-        if (grid_ll > 0x7fffffffLL) return SED_ERR_UNSUPPORTED;
-        constexpr int SMEM_P = 2 * 4 * P_PLANE * 2;
-        if (sed_tuning[SED_TUNE_LINEAR_P256] != 4) {       // the hand-phased form (4: the __syncthreads() form, kept for A/B runs)
-            if (act) { SED_MAX_SMEM((linear_pp_kernel<1>), SMEM_P); SED_LAUNCH((linear_pp_kernel<1>), dim3((unsigned)grid_ll), dim3(512), SMEM_P, (hipStream_t)stream, A, Wp, bias, Cm, M, N, K, tm, tn); }
-            else { SED_MAX_SMEM((linear_pp_kernel<0>), SMEM_P); SED_LAUNCH((linear_pp_kernel<0>), dim3((unsigned)grid_ll), dim3(512), SMEM_P, (hipStream_t)stream, A, Wp, bias, Cm, M, N, K, tm, tn); }
-            return sed_check_launch();
-        }
-        if (act) { SED_MAX_SMEM((linear_p256_kernel<1>), SMEM_P); SED_LAUNCH((linear_p256_kernel<1>), dim3((unsigned)grid_ll), dim3(512), SMEM_P, (hipStream_t)stream, A, Wp, bias, Cm, M, N, K, tm, tn); }
-        else { SED_MAX_SMEM((linear_p256_kernel<0>), SMEM_P); SED_LAUNCH((linear_p256_kernel<0>), dim3((unsigned)grid_ll), dim3(512), SMEM_P, (hipStream_t)stream, A, Wp, bias, Cm, M, N, K, tm, tn); }
-        return sed_check_launch();
-    }
     const int tiles_m = (M + LB_BM - 1) / LB_BM, tiles_n = N / LB_BN;
     long long tiles = (long long)tiles_m * tiles_n;
     int grid = tiles < 512 ? (int)tiles : 512;          // two resident workgroups per CU

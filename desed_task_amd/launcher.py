@@ -742,7 +742,7 @@ def run_test(task, device, limit_test_batches=None):
     return task.on_test_epoch_end()
 
 
-def _self_launch(n, argv):
+def _self_launch(n, argv, module="desed_task_amd.launcher"):
     """`--gpus N` from a plain shell: re-execute this command line under torch.distributed.run, one process per GPU of this node,
     rendezvous on 127.0.0.1 at a free port (the contract bench.py follows)."""
     import socket
@@ -756,12 +756,14 @@ def _self_launch(n, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's intra-node transport needs it on these hosts
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "-m", "desed_task_amd.launcher"] + list(argv)
+           "--master-port", str(port), "-m", module] + list(argv)
     sys.stderr.write("desed_task_amd.launcher: starting %d ranks: %s\n" % (n, " ".join(cmd)))
     return subprocess.call(cmd, env=env)
 
 
-def main(argv=None):
+def main(argv=None, cpu_test_device=False, entry_module="desed_task_amd.launcher"):
+    """cpu_test_device / entry_module: how tests/launcher_emu.py (the CPU plumbing check: a gloo group on a CPU device, the caller having
+    bound its own build of the C-ABI) re-enters this function in every rank; the product command line never sets them."""
     import argparse
     import sys
     import yaml
@@ -773,23 +775,16 @@ def main(argv=None):
     ap.add_argument("--resume_from_checkpoint", default=None)
     ap.add_argument("--test_from_checkpoint", default=None)
     ap.add_argument("--eval_from_checkpoint", default=None)
-    ap.add_argument("--gpus", default="1", help="number of GPUs of this node (one process each); 0 = a CPU device (needs --emulator)")
+    ap.add_argument("--gpus", default="1", help="number of GPUs of this node (one process each)")
     ap.add_argument("--fast_dev_run", action="store_true")
-    ap.add_argument("--emulator", action="store_true", help="TEST INFRASTRUCTURE: the CPU fiber emulator of the kernels (tests/emu) on a CPU "
-                    "device over gloo -- a plumbing check, no product path")
     args = ap.parse_args(argv)
     n = int(args.gpus)
     if "RANK" not in os.environ and max(n, 1) > 1:
-        return _self_launch(n, sys.argv[1:] if argv is None else argv)
-    if args.emulator:
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        sys.path.insert(0, root)
-        from tests.emu_support import bind_emulator
-        bind_emulator()
-    elif not torch.cuda.is_available():
+        return _self_launch(n, sys.argv[1:] if argv is None else argv, entry_module)
+    if not cpu_test_device and not torch.cuda.is_available():
         raise SystemExit("desed_task_amd.launcher needs the MI355X (no GPU visible); there is no CPU path")
-    rank, local, world = init_distributed(backend="gloo" if args.emulator else None)
-    device = torch.device("cpu") if args.emulator else torch.device("cuda", local)
+    rank, local, world = init_distributed(backend="gloo" if cpu_test_device else None)
+    device = torch.device("cpu") if cpu_test_device else torch.device("cuda", local)
     with open(args.conf_file) as f:
         config = yaml.safe_load(f)
     evaluation = args.eval_from_checkpoint is not None

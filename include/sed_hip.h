@@ -379,10 +379,16 @@ int sed_linear_packed_bf16x3(const float* A, const unsigned short* Wp, const flo
  * X (R, K) -- an activation (R = M tokens) or a frozen weight (R = N) -- into ceil(R / 256) * (K / 16) blocks of 16 KB: block
  * (r / 256, k / 16) = [hi | lo][256 rows][16 k], the 8-k octet o of row r stored at slot o ^ ((r >> 3) & 1); rows >= R are zero.
  * Xt holds 2 * ceil(R / 256) * 256 * K bf16 bit patterns.  sed_linear_tiles_bf16x3: C (M, N) = act(A . W^T + bias) from two such
- * images, 256 x 256 tiles, four LDS stages filled by DMA three K tiles ahead.  N % 256 == 0, K % 16 == 0, 16-byte aligned. */
+ * images, 256 x 256 tiles, one persistent workgroup per CU, four LDS stages filled by DMA three K steps ahead.  N % 256 == 0,
+ * K % 16 == 0, 16-byte aligned. */
 int sed_split_tiles_bf16x3(const float* X, unsigned short* Xt, int R, int K, void* stream);
 int sed_linear_tiles_bf16x3(const unsigned short* At, const unsigned short* Wt, const float* bias, float* C, int M, int N, int K,
                             int act, void* stream);
+/* The same product written as the K-tiled image of C (M, N) -- what the NEXT Linear takes as its activation (backbone.py:279-283: fc1's
+ * GELU output is only ever read by fc2).  Ct holds 2 * ceil(M / 256) * 256 * N bf16 bit patterns; every row of the padded last panel
+ * is written. */
+int sed_linear_tiles_out_bf16x3(const unsigned short* At, const unsigned short* Wt, const float* bias, unsigned short* Ct, int M, int N,
+                                int K, int act, void* stream);
 
 /* torchaudio.compliance.kaldi.fbank(waveform * 2^15, num_mel_bins, 16 kHz, 25 ms frames, 10 ms shift) with that function's
  * defaults (povey window, pre-emphasis 0.97, DC removal, snip_edges, 512-point FFT, power spectrum, log) followed by
@@ -400,6 +406,12 @@ int sed_patchify(const float* fbank, float* patches, int B, int M, int F, int P,
  * deep-norm residual of the encoder layers (backbone.py:268-294) and the plain LayerNorms of BEATs.py:157, backbone.py:122. */
 int sed_layernorm(const float* x, const float* res, float alpha, const float* gamma, const float* beta, float* y, int M, int D,
                   float eps, void* stream);
+/* Round 6: the same LayerNorm, y written twice: fp32 (M, D) (the next sub-layer's residual) and as the K-tiled bf16 hi / lo image of
+ * sed_split_tiles_bf16x3 (yt: 2 * ceil(M / 256) * 256 * D bf16 bit patterns; rows >= M are left as they are -- the Linear never stores
+ * their products) that sed_linear_tiles_bf16x3 takes as its activation: the post-LN encoder's q / k / v projection reads the image
+ * (backbone.py:286-330), the residual path the fp32 copy.  256 | D, D <= 1024. */
+int sed_layernorm_tiles(const float* x, const float* res, float alpha, const float* gamma, const float* beta, float* y,
+                        unsigned short* yt, int M, int D, float eps, void* stream);
 
 /* y = x + GELU(bias + grouped Conv1d(x)): the convolutional position embedding (backbone.py:30-43,118-120; even kernel, padding
  * K/2, last output dropped).  x, y (B,T,D); wt (groups, K, D/groups co, D/groups ci) = the weight-normalised filter transposed

@@ -31,6 +31,7 @@ struct uint4 { unsigned x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return {x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
 
 typedef void* hipStream_t;

@@ -602,17 +602,6 @@ def case_linear_n96_tile(dev, shapes=((300, 192, 64, 0), (513, 96, 96, 1), (130,
         _lib.set_tuning("gemm_ntn", 0)
 
 
-def case_linear_p256(dev, shapes=((300, 256, 64, 0), (513, 512, 96, 1), (256, 256, 32, 1), (700, 768, 160, 0))):
-    """The round-6 256 x 256 kernel behind sed_linear_packed_bf16x3 (forced with the tuning key `linear_p256` = 2; built-in choice: N >= 2048
-    and N % 256 == 0): ragged M, one and several K tiles, several N tiles, more row panels than XCDs would need, GELU epilogue."""
-    try:
-        for form in (2, 4):         # 2: the hand-phased two-group kernel (linear_pp_kernel, the shipped form); 4: the __syncthreads() form
-            _lib.set_tuning("linear_p256", form)
-            case_linear_packed(dev, shapes=shapes)
-    finally:
-        _lib.set_tuning("linear_p256", 0)
-
-
 def case_linear_packed(dev, shapes=((300, 128, 64, 0), (513, 256, 96, 1), (256, 128, 32, 1))):
     """sed_pack_weights_bf16x3 + sed_linear_packed_bf16x3 (the BEATs encoder's large Linear layers: frozen weight split into bf16
     hi / lo planes once, 256 x 128 tiles, A fragments straight from HBM, optional exact-GELU epilogue) vs float64: ragged M (rows
@@ -667,6 +656,19 @@ def tile_image(X, bk=16):
     return img.permute(1, 3, 0, 2, 4, 5).contiguous().view(-1)                      # (panel, ktile, plane, row, slot, 8)
 
 
+def tile_unimage(img, R, K, bk=16):
+    """Inverse of tile_image: int16 image -> (R, K) float32 = hi + lo."""
+    P = (R + 255) // 256
+    v = img.view(P, K // bk, 2, 256, bk // 8, 8)                                    # (panel, ktile, plane, row, slot, 8)
+    rows = torch.arange(256)
+    sw = ((rows >> 3) & 1).view(1, 1, 1, 256, 1, 1)
+    octs = torch.arange(bk // 8).view(1, 1, 1, 1, bk // 8, 1)
+    src = (octs ^ sw).expand(P, K // bk, 2, 256, bk // 8, 8)                       # octet o sits in slot o ^ sw
+    planes = torch.gather(v, 4, src.contiguous()).view(torch.bfloat16).float()      # (panel, ktile, plane, row, octet, 8)
+    full = planes.permute(2, 0, 3, 1, 4, 5).contiguous().view(2, P * 256, K)
+    return (full[0] + full[1])[:R]
+
+
 def case_linear_tiles(dev, shapes=((300, 256, 64, 0), (513, 512, 96, 1), (256, 256, 16, 1), (700, 768, 160, 0), (2100, 256, 48, 0))):
     """sed_split_tiles_bf16x3 + sed_linear_tiles_bf16x3 (round 6: both operands as K-tiled bf16 hi / lo images, four LDS stages filled by
     LDS-DMA three K tiles ahead, two wave groups one barrier apart): the image bit for bit against the host restatement above, the
@@ -694,6 +696,21 @@ def case_linear_tiles(dev, shapes=((300, 256, 64, 0), (513, 512, 96, 1), (256, 2
         lib.call("sed_linear_tiles_bf16x3", At.data_ptr(), Wt.data_ptr(), None, C.data_ptr(), M, N, K, 0, st)
         err = (C.cpu().double() - A.double() @ W.double().t()).abs().max().item()
         assert err < 3e-5 * max(1.0, ref.abs().max().item()), (M, N, K, "nobias", err)
+        # the product written as the next Linear's image (fc1 -> fc2): hi + lo of every element within 2^-16 relative of the fp32 result
+        Ct = torch.full((2 * ((M + 255) // 256) * 256 * N,), 77, dtype=torch.int16, device=Ad.device)
+        lib.call("sed_linear_tiles_out_bf16x3", At.data_ptr(), Wt.data_ptr(), bd.data_ptr(), Ct.data_ptr(), M, N, K, act, st)
+        got = tile_unimage(Ct.cpu(), M, N)
+        err = (got.double() - ref).abs().max().item()
+        assert err < 3e-5 * max(1.0, ref.abs().max().item()), (M, N, K, act, "image out", err)
+        # a few workgroups only: every workgroup walks several tiles (the persistent loop's tile hand-over and its DMA cursor)
+        _lib.set_tuning("linear_tiles", 16)
+        try:
+            C.fill_(7.0)
+            lib.call("sed_linear_tiles_bf16x3", At.data_ptr(), Wt.data_ptr(), bd.data_ptr(), C.data_ptr(), M, N, K, act, st)
+        finally:
+            _lib.set_tuning("linear_tiles", 0)
+        err = (C.cpu().double() - ref).abs().max().item()
+        assert err < 3e-5 * max(1.0, ref.abs().max().item()), (M, N, K, act, "16 workgroups", err)
     try:
         lib.call("sed_linear_tiles_bf16x3", At.data_ptr(), Wt.data_ptr(), None, C.data_ptr(), M, 128, K, 0, st)
         raise AssertionError("N % 256 != 0 must be refused")

@@ -437,7 +437,7 @@ RECIPE = os.path.join(REF, "recipes", "dcase2023_task4_baseline")
 @pytest.mark.skipif(not os.path.isdir(RECIPE), reason="needs the reference's data pipeline (build container only)")
 def test_launcher_cli_trains_two_ranks_and_resumes(tmp_path):
     """SURVEY 8e "Launcher" / VERDICT r05 item 5: `python -m desed_task_amd.launcher --conf_file ... --gpus 2` from a plain shell (no
-    torchrun environment) -- here with --emulator: two gloo ranks on the CPU emulator of the kernels -- builds the REFERENCE's data sets /
+    torchrun environment) -- here through tests/launcher_emu.py: the same main() on two gloo ranks with the CPU emulator of the kernels bound -- builds the REFERENCE's data sets /
     ConcatDatasetBatchSampler (a miniature DESED; torchaudio.load stubbed) behind RankShardedBatchSampler, trains two epochs, validates on
     the rank-averaged BatchNorm statistics, writes Lightning-shaped checkpoints from rank 0 and tests the best one; the checkpoint loads
     strictly into a fresh reference-shaped SEDTask4 and into torch.optim.Adam; a second command resumes it for one more epoch."""
@@ -452,7 +452,7 @@ def test_launcher_cli_trains_two_ranks_and_resumes(tmp_path):
     env["PYTHONPATH"] = os.pathsep.join([RECIPE, os.path.join(ROOT, "desed_task_amd", "drop_in"), ROOT, REF, stubs])
     env["SED_EMU_THREADS"] = "3"
     log_dir = os.path.join(tmp, "exp")
-    cmd = [sys.executable, "-W", "ignore", "-m", "desed_task_amd.launcher", "--conf_file", conf, "--log_dir", log_dir, "--gpus", "2", "--emulator"]
+    cmd = [sys.executable, "-W", "ignore", "-m", "tests.launcher_emu", "--conf_file", conf, "--log_dir", log_dir, "--gpus", "2"]
     r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = r.stdout
@@ -482,7 +482,7 @@ def test_launcher_cli_trains_two_ranks_and_resumes(tmp_path):
     conf3 = os.path.join(tmp, "conf3.yaml")
     yaml.safe_dump(cfg, open(conf3, "w"))
     log2 = os.path.join(tmp, "exp_resumed")
-    r2 = subprocess.run(cmd[:5] + ["--conf_file", conf3, "--log_dir", log2, "--gpus", "2", "--emulator", "--resume_from_checkpoint",
+    r2 = subprocess.run(cmd[:5] + ["--conf_file", conf3, "--log_dir", log2, "--gpus", "2", "--resume_from_checkpoint",
                                    os.path.join(vdir, "last.ckpt")], cwd=tmp, env=env, capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
     assert "epoch 2: 2 steps x 2 ranks" in r2.stdout and "epoch 0:" not in r2.stdout and "epoch 1:" not in r2.stdout

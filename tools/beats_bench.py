@@ -4,7 +4,13 @@ import json, sys, time
 sys.path.insert(0, ".")
 import torch
 from desed_task_amd import _lib
+from desed_task_amd import beats as _beats
 from desed_task_amd.beats import BEATs, BEATsConfig
+import os
+if os.environ.get("LINEAR_TILES") == "0":       # A/B: the round-5 path of the q / k / v projection
+    _beats.LINEAR_TILES = False
+if os.environ.get("LINEAR_TILES_FFN") == "0":   # A/B: only the q / k / v projection on the tile path
+    _beats.LINEAR_TILES_FFN = False
 CFG = dict(input_patch_size=16, embed_dim=512, conv_bias=False, encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072,
            encoder_attention_heads=12, activation_fn="gelu", layer_norm_first=False, deep_norm=True, conv_pos=128, conv_pos_groups=16,
            relative_position_embedding=True, num_buckets=320, max_distance=800, gru_rel_pos=True, dropout=0.0, attention_dropout=0.0,
@@ -36,6 +42,9 @@ def entry_work(name, a):
     if name == "sed_layernorm":
         M, D = a[6:8]
         return "hbm", 4.0 * M * D * (3 if a[1] else 2)
+    if name == "sed_layernorm_tiles":
+        M, D = a[7:9]
+        return "hbm", 4.0 * M * D * (4 if a[1] else 3)
     if name == "sed_kaldi_fbank":
         B_, N = a[2:4]
         return "hbm", 4.0 * B_ * (N + (1 + (N - 400) // 160) * a[4])

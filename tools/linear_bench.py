@@ -7,7 +7,7 @@ import os
 if os.environ.get('SED_LIB'): _lib.use_library(os.environ['SED_LIB'], is_emulator=False)       # a tools/build_variant.py build
 lib = _lib.get()
 shape_only = os.environ.get("SHAPE")                # SHAPE=qkv: one layer only (PMC runs)
-which = sys.argv[1:] or ["tiles", "pp", "p256", "packed", "generic"]
+which = sys.argv[1:] or ["tiles", "tiles+split", "packed", "generic"]
 M = 23808
 g = torch.Generator(device="cuda").manual_seed(1)
 for (N, K, act, name) in ((2304, 768, 0, "qkv"), (768, 768, 0, "out"), (3072, 768, 1, "fc1+gelu"), (768, 3072, 0, "fc2")):
@@ -26,18 +26,18 @@ for (N, K, act, name) in ((2304, 768, 0, "qkv"), (768, 768, 0, "out"), (3072, 76
     lib.call("sed_split_tiles_bf16x3", A.data_ptr(), At.data_ptr(), M, K, st)
     for kind in which:
         def run():
-            if kind == "tiles":         # the GEMM alone on pre-split images (the producers write them); "tiles+split" adds the activation's split pass
+            if kind in ("tiles", "tiles-noskew"):         # the GEMM alone on pre-split images (the producers write them); "tiles+split" adds the activation's split pass
                 lib.call("sed_linear_tiles_bf16x3", At.data_ptr(), Wt.data_ptr(), b.data_ptr(), C.data_ptr(), M, N, K, act, st)
                 return
             if kind == "tiles+split":
                 lib.call("sed_split_tiles_bf16x3", A.data_ptr(), At.data_ptr(), M, K, st)
                 lib.call("sed_linear_tiles_bf16x3", At.data_ptr(), Wt.data_ptr(), b.data_ptr(), C.data_ptr(), M, N, K, act, st)
                 return
-            if kind in ("packed", "p256", "pp"):
+            if kind == "packed":
                 lib.call("sed_linear_packed_bf16x3", A.data_ptr(), Wp.data_ptr(), b.data_ptr(), C.data_ptr(), M, N, K, act, st)
             else:
                 lib.call("sed_linear_bf16x3", A.data_ptr(), W.data_ptr(), b.data_ptr(), C.data_ptr(), M, N, K, act, st)
-        _lib.set_tuning("linear_p256", {"pp": 2, "p256": 4}.get(kind, 1))      # 2: hand-phased 256 x 256 kernel, 4: its __syncthreads() form, 1: round-5 kernels
+        _lib.set_tuning("linear_tiles", 3 if kind == "tiles-noskew" else 0)      # 3: no start skew
         for _ in range(2): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -46,5 +46,5 @@ for (N, K, act, name) in ((2304, 768, 0, "qkv"), (768, 768, 0, "out"), (3072, 76
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         tf = 2.0 * M * N * K / ms / 1e9
-        _lib.set_tuning("linear_p256", 0)
+        _lib.set_tuning("linear_tiles", 0)
         print("%-9s %-8s N %4d K %4d: %7.1f us  %6.1f TFLOP/s  = %.3f of 833" % (name, kind, N, K, ms * 1e3, tf, tf / 833.3))

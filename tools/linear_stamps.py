@@ -47,4 +47,9 @@ for grp in (0, 1):
     for i, nme in enumerate(names):
         print("   %-50s median %5d   min %5d   max %5d" % (nme, np.median(d[:, i]), d[:, i].min(), d[:, i].max()))
     print("   sum of medians %d" % np.median(d, axis=0).sum())
+full = buf.cpu().numpy().reshape(2, 16, 16).astype(np.int64)
+for grp in (0, 1):
+    print("group %d: phase 0 start -> reads landed %d, -> DMA A issued %d | phase 1 start -> reads landed %d, -> DMA W issued %d, -> cursor advanced %d" % (
+        grp, np.median(full[grp, :, 10] - full[grp, :, 0]), np.median(full[grp, :, 1] - full[grp, :, 10]), np.median(full[grp, :, 11] - full[grp, :, 4]),
+        np.median(full[grp, :, 12] - full[grp, :, 11]), np.median(full[grp, :, 5] - full[grp, :, 12])))
 print("group 1 minus group 0 at the phase-0 start: median %d ticks" % np.median(ts[1, :, 0] - ts[0, :, 0]))
