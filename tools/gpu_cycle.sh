@@ -34,6 +34,8 @@ surf) # the four launch paths of the same step, same box: Lightning-order whole-
         n=$(echo $v | tr -d ' -'); timeout 300 python bench.py --surface $v --steps 50 --warmup 10 --no-cpu-baseline 2>gpurun_out/surf_${tag}_$n.err | tail -1 > gpurun_out/surf_${tag}_$n.json
         python -c "import json;d=json.load(open('gpurun_out/surf_${tag}_$n.json'));print('$v', d['ms_per_step'], d['config']['surface'].get('driver_surface_ms_per_step'), d['config']['launch'][:40])" 2>&1 | tail -1
       done ;;
+tsprobe) timeout 300 python bench.py --ts-probe --steps 50 --warmup 10 --no-cpu-baseline 2>gpurun_out/tsprobe_$tag.err | tail -1 > gpurun_out/tsprobe_$tag.json
+         python -c "import json;d=json.load(open('gpurun_out/tsprobe_$tag.json'));print('ts-probe run', d['ms_per_step']);[print('  %-40s %8.1f us' % (t, u)) for t, u in d.get('ts_probe_us', [])]" ;;
 beats) timeout 300 python tools/beats_bench.py 2>/dev/null | tail -1 > gpurun_out/beats_$tag.json; cut -c1-400 gpurun_out/beats_$tag.json ;;
 host) timeout 300 python bench.py --host-batches --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/host_$tag.json; python -c "import json;d=json.load(open('gpurun_out/host_$tag.json'));print('host batches (PCIe-inclusive)', d['ms_per_step'], d['value'])" ;;
 beatspmc) timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/pmcbeats_$tag -o b -- python tools/beats_bench.py > gpurun_out/pmcbeats_$tag.log 2>&1

@@ -30,6 +30,9 @@ def main(path, min_us=0.0, back=8):
     lo, hi = adam[-back - 1] + 1, adam[-back] + 1
     step = rows[lo:hi]
     t0 = rows[adam[-back - 1]][2]
+    print("NOTE: a KERNEL INVENTORY under the tracer, not the timeline of the untraced replay -- rocprofv3 re-maps the branches of the replayed "
+          "graph onto hardware queues (DESIGN.md 12.6: `head_bwd` starts 500 us after the loss here, 4 us in the untraced step).  The in-graph "
+          "wall-clock stamps the step-level decisions were taken from: `bench.py --ts-probe` -> profiles/*_ts_probe.json.\n")
     print("step = %d kernels, %.1f us from the previous Adam's end to this Adam's end" % (len(step), (step[-1][2] - t0) / 1e3))
     print("| start us | dur us | stream/queue | kernel |"); print("|---|---|---|---|")
     for name, s, e, st, q in step:
