@@ -197,6 +197,12 @@ class BEATs(nn.Module):
         self._packed, self._relb = None, {}
         return super()._apply(fn, *a, **k)
 
+    def _load_from_state_dict(self, *a, **k):
+        # a PARENT's load_state_dict (BEATsModel, a LightningModule) reaches this module through its recursive `load`, not through
+        # load_state_dict above: the derived weight copies (fused q / k / v, position-convolution planes, packed images) are stale then
+        self._packed, self._relb = None, {}
+        return super()._load_from_state_dict(*a, **k)
+
     @torch.no_grad()
     def _pack(self):
         if self._packed is not None:
@@ -269,7 +275,7 @@ class BEATs(nn.Module):
             if LINEAR_PACKED and n >= 2048 and n % 128 == 0 and k % 32 == 0 and x.shape[0] >= 256:
                 # frozen weight: split into bf16 hi / lo planes once, then the 256 x 128-tile kernel (sed_gemm_bf16.hip, round 5).  Wide
                 # outputs only: at N = 768 its 558 tiles on 512 resident workgroups lose to the 128-row tiles (gpurun_out/linear_r05a.txt)
-                key = (w.data_ptr(), n, k)
+                key = (w.data_ptr(), w._version, n, k)      # _version: an in-place weight load keeps the pointer
                 wp = packed.get(key)
                 if wp is None or wp.device != x.device:
                     wp = torch.empty(2 * n * k, device=x.device, dtype=torch.int16)
@@ -304,7 +310,7 @@ class BEATs(nn.Module):
         himg = torch.empty(2 * ((R + 255) // 256) * 256 * Fd, device=fb.device, dtype=torch.int16) if ffn_tiles else None   # GELU(fc1) -> fc2
 
         def linear_tiles(img, w, b, n, k, act=0, out_image=None):
-            key = ("tiles", w.data_ptr(), n, k)
+            key = ("tiles", w.data_ptr(), w._version, n, k)
             wt_ = packed.get(key)
             if wt_ is None or wt_.device != fb.device:
                 wt_ = torch.empty(2 * ((n + 255) // 256) * 256 * k, device=fb.device, dtype=torch.int16)

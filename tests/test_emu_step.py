@@ -174,6 +174,33 @@ def test_beats_fbank_and_extractor_vs_reference_golden(emu):
     P.case_beats_vs_reference_golden("cpu", G)
 
 
+def test_beats_derived_weights_are_dropped_by_a_parents_load_state_dict():
+    """loading through a PARENT module (BEATsModel / a LightningModule) reaches BEATs via `_load_from_state_dict`, not via its
+    own load_state_dict: the fused q / k / v copy, the position-convolution planes and the packed weight images must not survive it; the
+    per-weight caches are keyed by the tensor's version as well as its pointer (an in-place copy keeps the pointer)."""
+    from desed_task_amd.beats import BEATs, BEATsConfig
+    cfg = dict(input_patch_size=16, embed_dim=64, conv_bias=False, encoder_layers=1, encoder_embed_dim=128, encoder_ffn_embed_dim=128,
+               encoder_attention_heads=2, activation_fn="gelu", layer_norm_first=False, deep_norm=True, conv_pos=16, conv_pos_groups=4,
+               relative_position_embedding=True, num_buckets=32, max_distance=80, gru_rel_pos=True, dropout=0.0, attention_dropout=0.0,
+               encoder_layerdrop=0.0)
+    m = BEATs(BEATsConfig(cfg))
+    m._packed = {"stale": 1}
+
+    class Parent(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.child = m
+
+    p = Parent()
+    p.load_state_dict(p.state_dict())
+    assert m._packed is None
+    w = m.encoder.layers[0].fc1.weight
+    v0 = w._version
+    with torch.no_grad():
+        w.copy_(torch.zeros_like(w))
+    assert w._version != v0
+
+
 def test_beats_12_layers_vs_reference_golden(emu):
     """12 layers x 496 tokens (one 10 s clip) against the reference module's own output."""
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_beats12.npz"))
