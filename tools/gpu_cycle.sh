@@ -41,6 +41,9 @@ host) timeout 300 python bench.py --host-batches --steps 50 --warmup 10 --no-cpu
 beatspmc) timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/pmcbeats_$tag -o b -- python tools/beats_bench.py > gpurun_out/pmcbeats_$tag.log 2>&1
           python tools/pmc_ratio_summary.py gpurun_out/pmcbeats_$tag/b_results.db > gpurun_out/pmcbeats_$tag.md 2>&1; head -12 gpurun_out/pmcbeats_$tag.md | cut -c1-200; rm -rf gpurun_out/pmcbeats_$tag ;;
 beatswait) bash tools/pmc_beats.sh $tag 2>&1 | tail -8 | cut -c1-300 ;;
+beatsfetch) for c in FETCH_SIZE WRITE_SIZE; do timeout 300 rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmcbf_${tag}_$c -o b -- python tools/beats_bench.py > gpurun_out/pmcbf_${tag}_$c.log 2>&1; done
+            python tools/pmc_summary.py gpurun_out/pmcbf_${tag}_FETCH_SIZE/b_results.db > gpurun_out/pmcbeats_fetch_$tag.md 2>&1; python tools/pmc_summary.py gpurun_out/pmcbf_${tag}_WRITE_SIZE/b_results.db > gpurun_out/pmcbeats_write_$tag.md 2>&1
+            head -12 gpurun_out/pmcbeats_fetch_$tag.md | cut -c1-200; rm -rf gpurun_out/pmcbf_${tag}_FETCH_SIZE gpurun_out/pmcbf_${tag}_WRITE_SIZE ;;
 melpmc) bash tools/pmc_mel.sh $tag 2>&1 | tail -3 | cut -c1-300; rm -rf gpurun_out/pmcmel_${tag}_[abcfw] ;;
 smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
 second) timeout 300 python tools/bench_2024.py --graph --prefetch 2>/dev/null | tail -1 > gpurun_out/bench2024_$tag.json; cut -c1-80,330- gpurun_out/bench2024_$tag.json
