@@ -718,6 +718,43 @@ def case_linear_tiles(dev, shapes=((300, 256, 64, 0), (513, 512, 96, 1), (256, 2
         pass
 
 
+def case_linear_tiles_race_screen(dev, reps=600):
+    """The LDS-DMA Linear orders its stages by counted vmcnt waits and raw barriers only (sed_gemm_bf16.hip): a hazard there would show as a
+    rare wrong tile that comes and goes with timing.  `reps` launches of the two production shapes with the deepest pipelines (QKV: K = 768,
+    837 tiles; fc2: K = 3072) must return the bits of the first launch every time -- alone, and while a second stream keeps the CUs busy with
+    the generic split-bf16 GEMM (other workgroups' LDS and VMEM traffic beside the persistent ones)."""
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(13)
+    M = 23808
+    side = torch.cuda.Stream()
+    Xs = torch.randn(4096, 768, generator=g).to(dev); Ws = torch.randn(768, 768, generator=g).to(dev); Ys = torch.empty(4096, 768, device=dev)
+    for (N, K, act) in ((2304, 768, 0), (768, 3072, 1)):
+        A, W, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+        Ad, Wd, bd = to(dev, A, W, bias)
+        st = _lib.stream_ptr(Ad)
+        At = torch.empty(2 * ((M + 255) // 256) * 256 * K, dtype=torch.int16, device=Ad.device)
+        Wt = torch.empty(2 * N * K, dtype=torch.int16, device=Ad.device)
+        lib.call("sed_split_tiles_bf16x3", Ad.data_ptr(), At.data_ptr(), M, K, st)
+        lib.call("sed_split_tiles_bf16x3", Wd.data_ptr(), Wt.data_ptr(), N, K, st)
+        C0 = torch.empty(M, N, device=Ad.device)
+        lib.call("sed_linear_tiles_bf16x3", At.data_ptr(), Wt.data_ptr(), bd.data_ptr(), C0.data_ptr(), M, N, K, act, st)
+        ref = A[:512].double() @ W.double().t() + bias.double()
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        assert (C0[:512].cpu().double() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+        C = torch.empty_like(C0)
+        bad = 0
+        for rep in range(reps):
+            if rep >= reps // 2:            # second half: a co-runner on another stream
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        lib.call("sed_linear_bf16x3", Xs.data_ptr(), Ws.data_ptr(), None, Ys.data_ptr(), 4096, 768, 768, 0, side.cuda_stream)
+            lib.call("sed_linear_tiles_bf16x3", At.data_ptr(), Wt.data_ptr(), bd.data_ptr(), C.data_ptr(), M, N, K, act, st)
+            bad += int(not torch.equal(C, C0))
+        torch.cuda.synchronize()
+        assert bad == 0, (N, K, "launches that differ from the first", bad, "of", reps)
+
+
 # ------------------------------------------------------------------------------------------------
 # whole mean-teacher step (a16): SEDTask4.training_step + EMA + backward + Adam + scheduler
 # ------------------------------------------------------------------------------------------------

@@ -126,6 +126,11 @@ def test_linear_tiles():
     P.case_linear_tiles("cuda", shapes=((1000, 768, 3072, 0), (2100, 3072, 768, 1), (23808, 2304, 768, 0)))
 
 
+def test_linear_tiles_race_screen():
+    """600 launches of the QKV and fc2 production shapes, alone and beside a co-runner: the bits of the first launch every time."""
+    P.case_linear_tiles_race_screen("cuda")
+
+
 def test_linear_n96_tile():
     """The 128 x 96 tile of the split-bf16 GEMM, forced at small sizes and picked by the dispatch at BEATs' out-proj / FC2 shapes."""
     P.case_linear_n96_tile("cuda")
