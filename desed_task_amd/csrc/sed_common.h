@@ -409,6 +409,25 @@ __device__ __forceinline__ void sed_dma16(const void* gptr, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 #endif
 }
+// The same copy with NO vector register at all: `buffer_load_dwordx4 off, s[rsrc], soffset lds` on a buffer resource with ADD_TID_ENABLE and
+// a stride of 16 -- lane l reads base + soffset + 16 l.  (word3: the DATA_FORMAT bits are the stride's high bits under ADD_TID_ENABLE and must
+// be 0; tools/dma_probe/addtid_probe.hip is the hardware check.)  An MFMA-heavy CU takes ~90 cycles to issue a piece that reads a VGPR
+// offset beside running MFMAs (profiles/r06_linear_diag.md); this form reads none.
+#ifdef SED_EMU
+struct sed_rsrc { const char* base; };
+static inline sed_rsrc sed_make_rsrc_tid16(const void* p, unsigned) { return sed_rsrc{(const char*)p}; }
+static inline void sed_dma16_tid(sed_rsrc r, unsigned soffset_bytes, void* lds_wave_base) {
+    memcpy((char*)lds_wave_base + 16 * emu_lane(), r.base + soffset_bytes + 16 * emu_lane(), 16);
+}
+#else
+typedef __amdgpu_buffer_rsrc_t sed_rsrc;
+__device__ __forceinline__ sed_rsrc sed_make_rsrc_tid16(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, (short)16, (int)bytes, 0x00007000 | (1 << 23));
+}
+__device__ __forceinline__ void sed_dma16_tid(sed_rsrc r, unsigned soffset_bytes, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, (int)soffset_bytes, 0, 0);
+}
+#endif
 // s_waitcnt vmcnt(N) lgkmcnt(0) by hand (N a literal): the compiler neither counts LDS-DMA nor knows which stage a ds_read belongs to
 #ifdef SED_EMU
 #define SED_WAIT_VM_LDS(N) do { } while (0)

@@ -682,6 +682,190 @@ SED_API int sed_split_tiles_bf16x3(const float* X, unsigned short* Xt, int R, in
     return sed_check_launch();
 }
 
+// ---- loader-wave form (round 6, last step) -----------------------------------------------------------------------------------------------------
+// linear_dma_kernel's remaining costs were both VMEM side effects on the waves that own the matrix pipe (profiles/r06_linear_diag.md): a DMA
+// piece stalls its issuing wave in the CU's address pipe (the wave is late at its barrier, the other group's MFMAs wait), and the C
+// stores share the wave's one vmcnt with the DMA pieces, so the first "has step + 1 landed" wait of the next tile drains the stores'
+// acknowledgements (~ 10 us per tile).  Here TWO MORE waves (8, 9) do nothing but move data: each issues 16 of a K step's 32 DMA pieces,
+// four per interval, and performs the counted wait; the eight MFMA waves issue no vector-memory load at all -- their read phases are
+// 4 - 8 ds_read_b128, and their C stores are never waited for.  Same stages, same barrier sequence (the loaders keep group 0's clock),
+// same hazards: the loaders' wait for step + 1 sits before the barrier that ends the step's fourth interval, the first read of step + 1 is
+// one barrier later; the stage refilled during a step was last read in group 1's second read phase of the step before, retired by
+// that wave's lgkmcnt(0) before its barrier.  640 threads: three waves on two of the SIMDs, so <= 168 VGPRs.
+namespace {
+template <int ACT, int OUT>
+__global__ __launch_bounds__(640, 1) void linear_ldr_kernel(const unsigned short* __restrict__ At, const unsigned short* __restrict__ Wt,
+                                                           const float* __restrict__ bias, void* __restrict__ Cout, int M, int N, int K,
+                                                           int tiles_m, int tiles_n, int nvb) {
+    SED_DYN_SMEM(smem);                               // [4 stages][A hi | A lo | W hi | W lo][256][16] bf16
+    unsigned short* lds = (unsigned short*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, w = sed_wave_uniform(tid >> 6), lo = lane & 31, hi = lane >> 5;
+    const int nk = K / T_BK, gstride = gridDim.x;
+    auto valid = [&](int vb) { return (vb & 7) + 8 * ((vb >> 3) / tiles_n) < tiles_m; };
+    auto next_vb = [&](int vb) { do vb += gstride; while (vb < nvb && !valid(vb)); return vb; };
+    int cvb = (int)blockIdx.x;
+    if (!valid(cvb)) cvb = next_vb(cvb);
+    if (cvb >= nvb) return;
+    if (w >= 8) {
+        // ---------------- loader waves ----------------
+        int ntl = 0;
+        for (int vb = cvb; vb < nvb; vb = next_vb(vb)) ++ntl;
+        const int total = ntl * nk, L = w - 8;
+        // pieces addressed by SGPRs alone (sed_dma16_tid): one resource per operand, the piece's byte offset in soffset
+        const sed_rsrc ra = sed_make_rsrc_tid16(At, (unsigned)((size_t)tiles_m * nk * T_BLOCK * 2));
+        const sed_rsrc rw = sed_make_rsrc_tid16(Wt, (unsigned)((size_t)tiles_n * nk * T_BLOCK * 2));
+        int dvb = cvb, dkt = 0;                       // DMA cursor (tile, K step); past the last tile it stays on the last block (never read)
+        bool dlive = true;
+        unsigned da = (unsigned)((dvb & 7) + 8 * ((dvb >> 3) / tiles_n)) * (unsigned)nk, dw = (unsigned)((dvb >> 3) % tiles_n) * (unsigned)nk;   // first block of the tile
+        // interval q of a step: pieces 8 q + 4 L .. + 3 of the stage (0 - 15: the A block, 16 - 31: the W block)
+#define L_ISSUE(stage_, q_) do { const unsigned o_ = ((((q_) < 2 ? da : dw) + (unsigned)dkt) * T_BLOCK + (8 * ((q_) & 1) + 4 * L) * 512) * 2;             \
+                                 unsigned short* l_ = lds + (stage_) * T_STAGE + (8 * (q_) + 4 * L) * 512;                                                 \
+                                 if ((q_) < 2) { sed_dma16_tid(ra, o_, l_); sed_dma16_tid(ra, o_ + 1024, l_ + 512);                                        \
+                                                 sed_dma16_tid(ra, o_ + 2048, l_ + 1024); sed_dma16_tid(ra, o_ + 3072, l_ + 1536); }                       \
+                                 else { sed_dma16_tid(rw, o_, l_); sed_dma16_tid(rw, o_ + 1024, l_ + 512);                                                 \
+                                        sed_dma16_tid(rw, o_ + 2048, l_ + 1024); sed_dma16_tid(rw, o_ + 3072, l_ + 1536); } } while (0)
+#define L_NEXT() do { if (dlive && ++dkt == nk) { const int nv_ = next_vb(dvb);                                                    \
+                          if (nv_ < nvb) { dvb = nv_; dkt = 0; da = (unsigned)((dvb & 7) + 8 * ((dvb >> 3) / tiles_n)) * (unsigned)nk; \
+                                           dw = (unsigned)((dvb >> 3) % tiles_n) * (unsigned)nk; }                               \
+                          else { dkt = nk - 1; dlive = false; } } } while (0)
+#ifdef T_STAMP
+        unsigned long long* s_ts = (unsigned long long*)(lds + 4 * T_STAGE);
+#define L_TS(k) do { __builtin_amdgcn_sched_barrier(0);                                                                          \
+                     if (blockIdx.x == 64 && w == 8 && step >= 8 && step < 24) { const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+                                                                      if (lane == 0) s_ts[(2 * 16 + step - 8) * 16 + (k)] = t_; }   \
+                     __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define L_TS(k) do { } while (0)
+#endif
+        for (int p = 0; p < 3; ++p) { L_ISSUE(p, 0); L_ISSUE(p, 1); L_ISSUE(p, 2); L_ISSUE(p, 3); L_NEXT(); }
+        SED_WAIT_VM_LDS(32);                          // step 0 has landed (this wave's half)
+        sed_phase_barrier();                          // (start) everybody
+#pragma unroll 1
+        for (int step = 0; step < total; ++step) {
+            const int s3 = (step + 3) & 3;
+            L_TS(0); L_ISSUE(s3, 0); L_TS(1); sed_phase_barrier();
+            L_TS(2); L_ISSUE(s3, 1); L_TS(3); sed_phase_barrier();
+            L_TS(4); L_ISSUE(s3, 2); L_TS(5); sed_phase_barrier();
+            L_TS(6); L_ISSUE(s3, 3); L_NEXT(); L_TS(7);
+            SED_WAIT_VM_LDS(32);                      // at most the 32 youngest pieces (steps + 2, + 3) outstanding: step + 1 has landed
+            L_TS(8);
+            sed_phase_barrier();
+            L_TS(9);
+        }
+        sed_phase_barrier();                          // the barrier group 1 took at the top
+        SED_WAIT_VM_LDS(0);
+#ifdef T_STAMP
+        sed_phase_barrier();                          // (stamped build: the MFMA waves' dump barrier)
+        if (blockIdx.x == 64 && w == 8 && lane < 16 && t_stamp_buf != nullptr)
+            for (int q = 0; q < 16; ++q) t_stamp_buf[(2 * 16 + q) * 16 + lane] = s_ts[(2 * 16 + q) * 16 + lane];
+#endif
+#undef L_TS
+#undef L_ISSUE
+#undef L_NEXT
+        return;
+    }
+    // ---------------- MFMA waves ----------------
+    const int wr = w >> 2, wc = w & 3;                // wave: rows 128 wr .. + 127, columns 64 wc .. + 63 of the tile; group = wr
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16_zero();
+    sed_phase_barrier();                              // (start)
+    if (wr == 1) sed_phase_barrier();                 // group 1 runs one interval behind group 0
+    const int sw = (lo >> 3) & 1;
+    const int fa = (128 * wr + lo) * T_BK + ((hi ^ sw) << 3), fb = T_BLOCK + (64 * wc + lo) * T_BK + ((hi ^ sw) << 3);
+    s16x8 ah0, ah1, al0, al1, bh0, bh1, bl0, bl1;
+#define T_READ_B(base) do { bh0 = *(const s16x8*)((base) + fb); bh1 = *(const s16x8*)((base) + fb + 32 * T_BK);                 \
+                            bl0 = *(const s16x8*)((base) + T_PLANE + fb); bl1 = *(const s16x8*)((base) + T_PLANE + fb + 32 * T_BK); } while (0)
+#define T_READ_A(base, h) do { ah0 = *(const s16x8*)((base) + fa + (2 * (h)) * 32 * T_BK); ah1 = *(const s16x8*)((base) + fa + (2 * (h) + 1) * 32 * T_BK); \
+                               al0 = *(const s16x8*)((base) + T_PLANE + fa + (2 * (h)) * 32 * T_BK);                            \
+                               al1 = *(const s16x8*)((base) + T_PLANE + fa + (2 * (h) + 1) * 32 * T_BK); } while (0)
+#define T_MFMA(h) do { sed_mfma_prio(1);                                                                                        \
+        acc[2 * (h)][0] = mfma32_bf16(bh0, al0, acc[2 * (h)][0]); acc[2 * (h)][1] = mfma32_bf16(bh1, al0, acc[2 * (h)][1]);     \
+        acc[2 * (h) + 1][0] = mfma32_bf16(bh0, al1, acc[2 * (h) + 1][0]); acc[2 * (h) + 1][1] = mfma32_bf16(bh1, al1, acc[2 * (h) + 1][1]); \
+        acc[2 * (h)][0] = mfma32_bf16(bl0, ah0, acc[2 * (h)][0]); acc[2 * (h)][1] = mfma32_bf16(bl1, ah0, acc[2 * (h)][1]);     \
+        acc[2 * (h) + 1][0] = mfma32_bf16(bl0, ah1, acc[2 * (h) + 1][0]); acc[2 * (h) + 1][1] = mfma32_bf16(bl1, ah1, acc[2 * (h) + 1][1]); \
+        acc[2 * (h)][0] = mfma32_bf16(bh0, ah0, acc[2 * (h)][0]); acc[2 * (h)][1] = mfma32_bf16(bh1, ah0, acc[2 * (h)][1]);     \
+        acc[2 * (h) + 1][0] = mfma32_bf16(bh0, ah1, acc[2 * (h) + 1][0]); acc[2 * (h) + 1][1] = mfma32_bf16(bh1, ah1, acc[2 * (h) + 1][1]); \
+        sed_mfma_prio(0); } while (0)
+#ifdef T_STAMP
+    unsigned long long* s_ts = (unsigned long long*)(lds + 4 * T_STAGE);
+    const bool stamp_on = blockIdx.x == 64 && (w & 3) == 0;
+#endif
+    int step = 0;
+    for (;;) {                                        // tiles of this workgroup
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt, ++step) {
+        const unsigned short* base = lds + (step & 3) * T_STAGE;
+        T_TS(0);
+        T_READ_B(base); T_READ_A(base, 0);
+        T_TS(1);
+        sed_phase_barrier(); sed_wait_lds();
+        T_TS(2);
+        T_MFMA(0);
+        T_TS(3);
+        sed_phase_barrier();
+        T_TS(4);
+        T_READ_A(base, 1);
+        sed_wait_lds();                               // before the barrier: the stage is refilled once every reader has passed it
+        T_TS(5);
+        sed_phase_barrier();
+        T_TS(6);
+        T_MFMA(1);
+        T_TS(7);
+        sed_phase_barrier();
+        T_TS(8);
+    }
+        const int tm = (cvb & 7) + 8 * ((cvb >> 3) / tiles_n), tn = (cvb >> 3) % tiles_n;
+        const int m0 = tm * P_BM, n0 = tn * P_BN;
+        int elo = lo, ehi = hi;
+        sed_pin(elo); sed_pin(ehi);
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gn = n0 + 64 * wc + 32 * jn + 8 * q + 4 * ehi;                // 4 consecutive columns
+                const float4 bv = bias != nullptr ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int im = 0; im < 4; ++im) {
+                    const int mrow = 128 * wr + 32 * im + elo;
+                    float4 v = make_float4(acc[im][jn][4 * q] + bv.x, acc[im][jn][4 * q + 1] + bv.y, acc[im][jn][4 * q + 2] + bv.z,
+                                           acc[im][jn][4 * q + 3] + bv.w);
+                    if (ACT == 1) {
+                        v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752f)); v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752f));
+                        v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752f)); v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752f));
+                    }
+                    if (OUT == 0) {
+                        if (m0 + mrow < M) *(float4*)((float*)Cout + (size_t)(m0 + mrow) * N + gn) = v;
+                    } else {
+                        uint2 h_, l_;
+                        split4(v, h_, l_);
+                        unsigned short* d_ = (unsigned short*)Cout + ((size_t)tm * (N / T_BK) + (gn >> 4)) * T_BLOCK + t_off(mrow, q & 1) + 4 * ehi;
+                        *(uint2*)d_ = h_;
+                        *(uint2*)(d_ + T_PLANE) = l_;
+                    }
+                }
+            }
+        cvb = next_vb(cvb);
+        if (cvb >= nvb) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x16_zero();
+    }
+    if (wr == 0) sed_phase_barrier();                 // the barrier group 1 took at the top
+#ifdef T_STAMP
+    sed_phase_barrier();
+    if (stamp_on && lane < 16 && t_stamp_buf != nullptr)
+        for (int q = 0; q < 16; ++q) t_stamp_buf[((w >> 2) * 16 + q) * 16 + lane] = s_ts[((w >> 2) * 16 + q) * 16 + lane];
+#endif
+#undef T_READ_A
+#undef T_READ_B
+#undef T_MFMA
+}
+}  // namespace
+
 static int linear_tiles_launch(const unsigned short* At, const unsigned short* Wt, const float* bias, void* Cout, int M, int N, int K, int act,
                                int out_tiles, void* stream) {
     if (!At || !Wt || !Cout || M < 0 || N < 0 || K < 0) return SED_ERR_ARG;
@@ -694,19 +878,30 @@ static int linear_tiles_launch(const unsigned short* At, const unsigned short* W
     if (nvb_ll > 0x7fffffffLL) return SED_ERR_UNSUPPORTED;
     const int nvb = (int)nvb_ll;
     // one persistent workgroup per CU (128 KB of LDS each); a multiple of 8 so that a workgroup stays on one XCD's row panels
-    int grid = sed_tuning[SED_TUNE_LINEAR_TILES] > 8 ? sed_tuning[SED_TUNE_LINEAR_TILES] & ~7 : 256;
+    // Which kernel: the eight-wave form.  The loader-wave form is faster where it was measured alone (one long-K tile per CU: 1 451 vs 1 615 -
+    // 1 748 ns per K step; the QKV shape 270 vs 295 - 329 us on the same boxes) and NOT in the extractor: with it the q / k / v + fc2 launches take
+    // 7.1 - 7.3 instead of 7.45 - 7.5 ms per 48 clips and the launches after them run slower by as much (fc1 4.04 -> 4.2 - 4.3 ms, the layer
+    // norms + 3 %): 17.82 - 17.86 vs 17.55 - 17.60 ms in every alternation (profiles/r06s_beats_ab_forms.txt, r06t_beats_ab_forms.txt) -- the
+    // extractor runs at the chip's power budget (all-zero operands: the same loop 1.5 x faster, profiles/r06t_linear_period.txt).  Tuning key
+    // "linear_tiles" (tests, A/B): 3 = no start skew, 5 = the loader-wave form, n > 8 = n & ~7 workgroups (odd n: loader-wave form).
+    const int tune = sed_tuning[SED_TUNE_LINEAR_TILES];
+    bool ldr = tune == 5 || (tune > 8 && (tune & 1));
+    if ((long long)tm * (K / T_BK) * T_BLOCK * 2 > 0x7fffffffLL || (long long)tn * (K / T_BK) * T_BLOCK * 2 > 0x7fffffffLL) ldr = false;   // (its buffer resources count bytes in 31 bits)
+    int grid = tune > 8 ? tune & ~7 : 256;
     if (grid > nvb) grid = nvb;
     // skew = the longest walk's tile count when some workgroups walk fewer (0: none do, or switched off with the tuning key = 3)
     const long long ntiles = (long long)tm * tn;
     int skew = (ntiles > grid && ntiles % grid != 0) ? (int)((ntiles + grid - 1) / grid) : 0;
     if (sed_tuning[SED_TUNE_LINEAR_TILES] == 3) skew = 0;
 #ifdef T_STAMP
-    constexpr int SMEM_T = 4 * T_STAGE * 2 + 4096;
+    constexpr int SMEM_T = 4 * T_STAGE * 2 + 8192;
 #else
     constexpr int SMEM_T = 4 * T_STAGE * 2;
 #endif
-#define T_LAUNCH(A_, O_) do { SED_MAX_SMEM((linear_dma_kernel<A_, O_>), SMEM_T);                                                 \
-        SED_LAUNCH((linear_dma_kernel<A_, O_>), dim3((unsigned)grid), dim3(512), SMEM_T, (hipStream_t)stream, At, Wt, bias, Cout, M, N, K, tm, tn, nvb, skew); } while (0)
+#define T_LAUNCH(A_, O_) do { if (ldr) { SED_MAX_SMEM((linear_ldr_kernel<A_, O_>), SMEM_T);   \
+        SED_LAUNCH((linear_ldr_kernel<A_, O_>), dim3((unsigned)grid), dim3(640), SMEM_T, (hipStream_t)stream, At, Wt, bias, Cout, M, N, K, tm, tn, nvb); } \
+        else { SED_MAX_SMEM((linear_dma_kernel<A_, O_>), SMEM_T);                                                               \
+        SED_LAUNCH((linear_dma_kernel<A_, O_>), dim3((unsigned)grid), dim3(512), SMEM_T, (hipStream_t)stream, At, Wt, bias, Cout, M, N, K, tm, tn, nvb, skew); } } while (0)
     if (out_tiles) { if (act) T_LAUNCH(1, 1); else T_LAUNCH(0, 1); }
     else { if (act) T_LAUNCH(1, 0); else T_LAUNCH(0, 0); }
 #undef T_LAUNCH

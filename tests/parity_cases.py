@@ -669,13 +669,15 @@ def tile_unimage(img, R, K, bk=16):
     return (full[0] + full[1])[:R]
 
 
-def case_linear_tiles(dev, shapes=((300, 256, 64, 0), (513, 512, 96, 1), (256, 256, 16, 1), (700, 768, 160, 0), (2100, 256, 48, 0))):
+def case_linear_tiles(dev, shapes=((300, 256, 64, 0), (513, 512, 96, 1), (256, 256, 16, 1), (700, 768, 160, 0), (2100, 256, 48, 0)), form=0):
     """sed_split_tiles_bf16x3 + sed_linear_tiles_bf16x3 (round 6: both operands as K-tiled bf16 hi / lo images, four LDS stages filled by
     LDS-DMA three K tiles ahead, two wave groups one barrier apart): the image bit for bit against the host restatement above, the
     product vs float64 -- ragged M (zero rows in the image, never stored), one to ten K tiles (fewer than the pipeline's depth
     included), several N tiles and more row panels than XCDs, GELU epilogue, no bias."""
     lib = _lib.get()
     g = torch.Generator().manual_seed(12)
+    FORM = form          # sed_set_tuning("linear_tiles"): 0 = the shipped eight-wave form, 5 = the loader-wave form
+    _lib.set_tuning("linear_tiles", FORM)
     for (M, N, K, act) in shapes:
         A, W, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
         ref = A.double() @ W.double().t() + bias.double()
@@ -703,12 +705,12 @@ def case_linear_tiles(dev, shapes=((300, 256, 64, 0), (513, 512, 96, 1), (256, 2
         err = (got.double() - ref).abs().max().item()
         assert err < 3e-5 * max(1.0, ref.abs().max().item()), (M, N, K, act, "image out", err)
         # a few workgroups only: every workgroup walks several tiles (the persistent loop's tile hand-over and its DMA cursor)
-        _lib.set_tuning("linear_tiles", 16)
+        _lib.set_tuning("linear_tiles", 16 if FORM == 0 else 16 + 1)     # (odd grid requests: the loader-wave form, even: the eight-wave form)
         try:
             C.fill_(7.0)
             lib.call("sed_linear_tiles_bf16x3", At.data_ptr(), Wt.data_ptr(), bd.data_ptr(), C.data_ptr(), M, N, K, act, st)
         finally:
-            _lib.set_tuning("linear_tiles", 0)
+            _lib.set_tuning("linear_tiles", FORM)
         err = (C.cpu().double() - ref).abs().max().item()
         assert err < 3e-5 * max(1.0, ref.abs().max().item()), (M, N, K, act, "16 workgroups", err)
     try:
@@ -716,6 +718,8 @@ def case_linear_tiles(dev, shapes=((300, 256, 64, 0), (513, 512, 96, 1), (256, 2
         raise AssertionError("N % 256 != 0 must be refused")
     except RuntimeError:
         pass
+    finally:
+        _lib.set_tuning("linear_tiles", 0)
 
 
 def case_linear_tiles_race_screen(dev, reps=600):

@@ -16,6 +16,7 @@ def test_linear_packed(emu):
 def test_linear_tiles(emu):
     """Round 6: K-tiled plane images + the all-DMA 256 x 256 kernel."""
     P.case_linear_tiles("cpu", shapes=((300, 256, 64, 0), (257, 512, 16, 1), (520, 256, 48, 0)))
+    P.case_linear_tiles("cpu", shapes=((300, 256, 64, 0), (257, 512, 16, 1), (520, 256, 48, 0)), form=5)
 
 
 def test_linear_n96_tile(emu):

@@ -124,6 +124,7 @@ def test_linear_tiles():
     """Round 6: K-tiled plane images + the all-DMA 256 x 256 kernel, incl. the BEATs production widths."""
     P.case_linear_tiles("cuda")
     P.case_linear_tiles("cuda", shapes=((1000, 768, 3072, 0), (2100, 3072, 768, 1), (23808, 2304, 768, 0)))
+    P.case_linear_tiles("cuda", shapes=((300, 256, 64, 0), (700, 768, 160, 1), (2100, 3072, 768, 1), (23808, 2304, 768, 0)), form=5)     # the loader-wave form
 
 
 def test_linear_tiles_race_screen():

@@ -9,6 +9,8 @@ from desed_task_amd.beats import BEATs, BEATsConfig
 import os
 if os.environ.get("LINEAR_TILES") == "0":       # A/B: the round-5 path of the q / k / v projection
     _beats.LINEAR_TILES = False
+if os.environ.get("LINEAR_FORM"):                 # A/B: 5 = the loader-wave form of the tile Linear (sed_set_tuning linear_tiles)
+    _lib.set_tuning("linear_tiles", int(os.environ["LINEAR_FORM"]))
 if os.environ.get("LINEAR_TILES_FFN") == "0":   # A/B: only the q / k / v projection on the tile path
     _beats.LINEAR_TILES_FFN = False
 CFG = dict(input_patch_size=16, embed_dim=512, conv_bias=False, encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072,

@@ -26,7 +26,7 @@ for (N, K, act, name) in ((2304, 768, 0, "qkv"), (768, 768, 0, "out"), (3072, 76
     lib.call("sed_split_tiles_bf16x3", A.data_ptr(), At.data_ptr(), M, K, st)
     for kind in which:
         def run():
-            if kind in ("tiles", "tiles-noskew"):         # the GEMM alone on pre-split images (the producers write them); "tiles+split" adds the activation's split pass
+            if kind in ("tiles", "tiles-noskew", "tiles-ldr"):         # the GEMM alone on pre-split images (the producers write them); "tiles+split" adds the activation's split pass
                 lib.call("sed_linear_tiles_bf16x3", At.data_ptr(), Wt.data_ptr(), b.data_ptr(), C.data_ptr(), M, N, K, act, st)
                 return
             if kind == "tiles+split":
@@ -37,7 +37,7 @@ for (N, K, act, name) in ((2304, 768, 0, "qkv"), (768, 768, 0, "out"), (3072, 76
                 lib.call("sed_linear_packed_bf16x3", A.data_ptr(), Wp.data_ptr(), b.data_ptr(), C.data_ptr(), M, N, K, act, st)
             else:
                 lib.call("sed_linear_bf16x3", A.data_ptr(), W.data_ptr(), b.data_ptr(), C.data_ptr(), M, N, K, act, st)
-        _lib.set_tuning("linear_tiles", 3 if kind == "tiles-noskew" else 0)      # 3: no start skew
+        _lib.set_tuning("linear_tiles", {"tiles-noskew": 3, "tiles-ldr": 5}.get(kind, 0))      # 3: no start skew
         for _ in range(2): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -29,15 +29,17 @@ def timed(lib, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+if os.environ.get("FORM"): _lib.set_tuning("linear_tiles", int(os.environ["FORM"]))
 us = timed(_lib.get())
 print("%s: product kernel %.1f us per launch" % (shape, us))
 so = os.environ.get("STAMP_LIB", "tools/_libsed_tstamp.so")
 _lib.use_library(so, is_emulator=False)
-buf = torch.zeros(2 * 16 * 16, dtype=torch.int64, device="cuda")
+buf = torch.zeros(3 * 16 * 16, dtype=torch.int64, device="cuda")
+if os.environ.get("FORM"): _lib.set_tuning("linear_tiles", int(os.environ["FORM"]))      # FORM=5: the loader-wave kernel
 assert ctypes.CDLL(so).sed_linear_debug_set_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
 us_s = timed(_lib.get(), 3)
 print("stamped kernel %.1f us per launch" % us_s)
-ts = buf.cpu().numpy().reshape(2, 16, 16)[:, :, :10].astype(np.int64)
+ts = buf.cpu().numpy().reshape(3, 16, 16)[:2, :, :10].astype(np.int64)
 names = ["phase 0: DMA A issued, B + A fragments landed", "first barrier passed", "12 MFMAs issued", "second barrier passed",
          "phase 1: DMA W issued, A fragments landed", "vmcnt(8): tile kt + 1 landed", "first barrier passed", "12 MFMAs issued", "second barrier passed"]
 for grp in (0, 1):
@@ -47,9 +49,17 @@ for grp in (0, 1):
     for i, nme in enumerate(names):
         print("   %-50s median %5d   min %5d   max %5d" % (nme, np.median(d[:, i]), d[:, i].min(), d[:, i].max()))
     print("   sum of medians %d" % np.median(d, axis=0).sum())
-full = buf.cpu().numpy().reshape(2, 16, 16).astype(np.int64)
+full = buf.cpu().numpy().reshape(3, 16, 16).astype(np.int64)
 for grp in (0, 1):
     print("group %d: phase 0 start -> reads landed %d, -> DMA A issued %d | phase 1 start -> reads landed %d, -> DMA W issued %d, -> cursor advanced %d" % (
         grp, np.median(full[grp, :, 10] - full[grp, :, 0]), np.median(full[grp, :, 1] - full[grp, :, 10]), np.median(full[grp, :, 11] - full[grp, :, 4]),
         np.median(full[grp, :, 12] - full[grp, :, 11]), np.median(full[grp, :, 5] - full[grp, :, 12])))
 print("group 1 minus group 0 at the phase-0 start: median %d ticks" % np.median(ts[1, :, 0] - ts[0, :, 0]))
+
+if os.environ.get("FORM") == "5":
+    ld = full[2, :, :10]
+    d = np.diff(ld, axis=1)
+    print("== loader wave 8: ticks between its stamps (issue 4 pieces | barrier) x 4, the 4th incl. the vmcnt wait")
+    for i, nme in enumerate(["issue q0", "barrier", "issue q1", "barrier", "issue q2", "barrier", "issue q3 + cursor", "vmcnt(32)", "barrier"]):
+        print("   %-22s median %5d  min %5d  max %5d" % (nme, np.median(d[:, i]), d[:, i].min(), d[:, i].max()))
+    print("   step period median %d" % np.median(np.diff(ld[:, 0])))
