@@ -302,11 +302,15 @@ class BEATs(nn.Module):
         # round 6: the q / k / v projection reads its activation as a K-tiled bf16 hi / lo image (written by the LayerNorm that produces
         # it) and its frozen weight as the same kind of image (built once); ONE image buffer, re-written by every layer's last LayerNorm
         tiles = LINEAR_TILES and D % 256 == 0 and R >= 256
-        ximg = torch.empty(2 * ((R + 255) // 256) * 256 * D, device=fb.device, dtype=torch.int16) if tiles else None
+        # (zeros: the LayerNorm writes rows < R only; the rows of the padded last panel then stay finite all the way through fc1 -> fc2)
+        imgs = self._relb.get(("images", R, D, fb.device))                      # (kept across calls: 2 x 73 MB at 48 clips; dropped with the other caches)
+        if tiles and imgs is None:
+            imgs = self._relb[("images", R, D, fb.device)] = [torch.zeros(2 * ((R + 255) // 256) * 256 * D, device=fb.device, dtype=torch.int16) for _ in range(2)]
+        ximg = imgs[0] if tiles else None
 
         Fd = cfg.encoder_ffn_embed_dim
         ffn_tiles = tiles and LINEAR_TILES_FFN and Fd % 256 == 0
-        ximg2 = torch.empty_like(ximg) if ffn_tiles else None                      # the attention block's LayerNorm output -> fc1
+        ximg2 = imgs[1] if ffn_tiles else None                      # the attention block's LayerNorm output -> fc1
         himg = torch.empty(2 * ((R + 255) // 256) * 256 * Fd, device=fb.device, dtype=torch.int16) if ffn_tiles else None   # GELU(fc1) -> fc2
 
         def linear_tiles(img, w, b, n, k, act=0, out_image=None):
