@@ -4,6 +4,7 @@ sys.path.insert(0, '.')
 import torch
 from desed_task_amd import _lib
 from desed_task_amd.ops import pack_conv_weights
+if os.environ.get("SED_LIB"): _lib.use_library(os.environ["SED_LIB"], is_emulator=False)       # a tools/build_variant.py build
 lib = _lib.get()
 B, T, F, CIN, COUT = 48, 156, int(os.environ.get("F", "8")), int(os.environ.get("CIN", "128")), int(os.environ.get("COUT", "128"))
 x = torch.randn(B, T, F, CIN, device="cuda")
