@@ -441,8 +441,9 @@ __global__ __launch_bounds__(256, 2) void linear_big_kernel(const float* __restr
 // Two 256 x 256 kernels with register staging came first (a __syncthreads() form and a hand-phased two-group form; commit 43bb868,
 // timing-only builds and stamps in profiles/r06_linear_diag.md).  What they taught: with the loads removed the hand-phased loop runs at the matrix pipe's
 // pace (1.57 us per 32-deep K tile); the loads alone -- global_load_dwordx4 into VGPRs, 64 KB per K tile and CU -- take 0.7 (L2-hot) to
-// 1.4 us per K tile; and together they ADD (2.67 us): load data returning into the VGPR file and the MFMAs do not overlap, whatever the
-// schedule.  So here nothing returns into a register: activations and weights arrive as bf16 hi / lo planes already cut into the blocks
+// 1.4 us per K tile; and together they ADD (2.67 us), whatever the schedule.  (The explanation found last: the kernel runs at the board's
+// 1 400 W power cap with the clock throttled to 2.0 GHz -- profiles/r06_linear_diag.md section 5 -- so work that overlaps in time is paid back as
+// clock.)  What this kernel removes is work: nothing returns into a register -- activations and weights arrive as bf16 hi / lo planes already cut into the blocks
 // a workgroup needs (sed_split_tiles_bf16x3: block (row panel, 16-deep K tile) = [hi | lo][256][16], 16 KB, swizzled for the fragment
 // reads), and a K tile's two blocks are copied into one of FOUR 32 KB LDS stages by eight wave-instructions of LDS-DMA per wave pair
 // -- contiguous 1 KB pieces, full cache lines, no staging registers, no ds_write, no VALU.  Same 256 x 256 tile, eight waves as two
