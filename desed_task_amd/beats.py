@@ -25,6 +25,7 @@ POSCONV_MFMA = True             # position convolution on the split-bf16 MFMA (F
 LINEAR_TILES = True             # round 6: the q / k / v projection through the LDS-DMA kernel on K-tiled bf16 plane images (sed_linear_tiles_bf16x3); the
                                 # LayerNorm in front of it writes the activation's image beside its fp32 output (False: the round-5 path, A/B and tests)
 LINEAR_TILES_FFN = True         # ... and fc1 -> GELU -> fc2 the same way (fc1 writes its output as fc2's image, no fp32 copy of the 3072-wide hidden state)
+LINEAR_TILES_KSPLIT = True      # ... fc2 (N = 768) as two K halves whose partial sums the final LayerNorm adds (round quantisation: 2 rounds -> 1.5)
 LINEAR_PACKED = True            # the large Linear layers through the packed-weight 256 x 128-tile kernel (False: sed_linear_bf16x3, A/B and tests)
 
 
@@ -289,10 +290,10 @@ class BEATs(nn.Module):
                      x.shape[0], n, k, act, st)
             return y
 
-        def layernorm(x, res, alpha, ln, d, image=None):
+        def layernorm(x, res, alpha, ln, d, image=None, x2=None):
             y = torch.empty_like(x)
             if image is not None:
-                lib.call("sed_layernorm_tiles", x.data_ptr(), res.data_ptr() if res is not None else None, float(alpha), ln.weight.data_ptr(),
+                lib.call("sed_layernorm_tiles", x.data_ptr(), x2.data_ptr() if x2 is not None else None, res.data_ptr() if res is not None else None, float(alpha), ln.weight.data_ptr(),
                          ln.bias.data_ptr(), y.data_ptr(), image.data_ptr(), x.shape[0], d, float(ln.eps), st)
                 return y
             lib.call("sed_layernorm", x.data_ptr(), res.data_ptr() if res is not None else None, float(alpha), ln.weight.data_ptr(),
@@ -313,7 +314,7 @@ class BEATs(nn.Module):
         ximg2 = imgs[1] if ffn_tiles else None                      # the attention block's LayerNorm output -> fc1
         himg = torch.empty(2 * ((R + 255) // 256) * 256 * Fd, device=fb.device, dtype=torch.int16) if ffn_tiles else None   # GELU(fc1) -> fc2
 
-        def linear_tiles(img, w, b, n, k, act=0, out_image=None):
+        def linear_tiles(img, w, b, n, k, act=0, out_image=None, split2=False):
             key = ("tiles", w.data_ptr(), w._version, n, k)
             wt_ = packed.get(key)
             if wt_ is None or wt_.device != fb.device:
@@ -325,6 +326,10 @@ class BEATs(nn.Module):
             if out_image is not None:           # the product leaves as the next Linear's image (fc1's GELU output is only read by fc2)
                 lib.call("sed_linear_tiles_out_bf16x3", img.data_ptr(), wt_.data_ptr(), bp, out_image.data_ptr(), R, n, k, act, st)
                 return None
+            if split2:                           # two partial sums over the halves of K: (2, R, n)
+                y = torch.empty(2, R, n, **f32)
+                lib.call("sed_linear_tiles_split2_bf16x3", img.data_ptr(), wt_.data_ptr(), bp, y.data_ptr(), R, n, k, st)
+                return y
             y = torch.empty(R, n, **f32)
             lib.call("sed_linear_tiles_bf16x3", img.data_ptr(), wt_.data_ptr(), bp, y.data_ptr(), R, n, k, act, st)
             return y
@@ -358,13 +363,20 @@ class BEATs(nn.Module):
                      lp["grep_a"].data_ptr() if gated else None, att.data_ptr(), B, T, H, D // H, st)
             o = linear(att, a.out_proj.weight, a.out_proj.bias, D, D)
             x = layernorm(o, x, alpha, lyr.self_attn_layer_norm, D, image=ximg2)
+            h2 = None
             if ffn_tiles:
                 linear_tiles(ximg2, lyr.fc1.weight, lyr.fc1.bias, Fd, D, act=1, out_image=himg)
-                h = linear_tiles(himg, lyr.fc2.weight, lyr.fc2.bias, D, Fd)
+                if LINEAR_TILES_KSPLIT and (Fd // 16) % 2 == 0:
+                    # N = 768: 279 tiles on 256 CUs would be two rounds; two K halves = 558 items = three half-rounds, the partial sums
+                    # added by the LayerNorm that follows
+                    hh = linear_tiles(himg, lyr.fc2.weight, lyr.fc2.bias, D, Fd, split2=True)
+                    h, h2 = hh[0], hh[1]
+                else:
+                    h = linear_tiles(himg, lyr.fc2.weight, lyr.fc2.bias, D, Fd)
             else:
                 h = linear(x, lyr.fc1.weight, lyr.fc1.bias, Fd, D, act=1)
                 h = linear(h, lyr.fc2.weight, lyr.fc2.bias, D, Fd)
-            x = layernorm(h, x, alpha, lyr.final_layer_norm, D, image=ximg)     # (the last layer's image is written and not read)
+            x = layernorm(h, x, alpha, lyr.final_layer_norm, D, image=ximg, x2=h2)     # (the last layer's image is written and not read)
             if taps is not None:
                 taps["layer%d" % len([k for k in taps if k.startswith("layer")])] = x.view(B, T, D)
         return x.view(B, T, D), None

@@ -169,7 +169,7 @@ SED_API int sed_layernorm(const float* x, const float* res, float alpha, const f
 // A lane owns 4 consecutive channels (float4 in, float4 out, one 8-byte piece per plane); D % 256 == 0.  The sums run in a different
 // order than layernorm_kernel's (4 channels per lane instead of every 64th), so y agrees with it to rounding, not bit for bit.
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_tiles_kernel(const float* __restrict__ x, const float* __restrict__ res, float alpha,
+__global__ __launch_bounds__(256) void layernorm_tiles_kernel(const float* __restrict__ x, const float* __restrict__ x2, const float* __restrict__ res, float alpha,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ y, unsigned short* __restrict__ yt, int Mrows, float eps) {
     constexpr int D = NV * 256;
@@ -179,6 +179,14 @@ __global__ __launch_bounds__(256) void layernorm_tiles_kernel(const float* __res
     const size_t i0 = (size_t)row * D + 4 * lane;
 #pragma unroll
     for (int u = 0; u < NV; ++u) v[u] = *(const float4*)(x + i0 + 256 * u);
+    if (x2) {                                           // (uniform) the second K half's partial sum of a split Linear
+        float4 r[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) r[u] = *(const float4*)(x2 + i0 + 256 * u);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) { v[u].x = sed_sadd(v[u].x, r[u].x); v[u].y = sed_sadd(v[u].y, r[u].y);
+                                       v[u].z = sed_sadd(v[u].z, r[u].z); v[u].w = sed_sadd(v[u].w, r[u].w); }
+    }
     if (res) {                                          // (uniform)
         float4 r[NV];
 #pragma unroll
@@ -215,14 +223,14 @@ __global__ __launch_bounds__(256) void layernorm_tiles_kernel(const float* __res
         *(uint2*)(d + 4096) = make_uint2(l0, l1);
     }
 }
-SED_API int sed_layernorm_tiles(const float* x, const float* res, float alpha, const float* gamma, const float* beta, float* y,
+SED_API int sed_layernorm_tiles(const float* x, const float* x2, const float* res, float alpha, const float* gamma, const float* beta, float* y,
                                 unsigned short* yt, int M, int D, float eps, void* stream) {
     if (!x || !gamma || !beta || !y || !yt || M < 0) return SED_ERR_ARG;
     if (M == 0) return SED_OK;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((M + 3) / 4);
 #define LN_CASE(d) \
-    if (D == d) { SED_LAUNCH((layernorm_tiles_kernel<d / 256>), grid, dim3(256), 0, s, x, res, alpha, gamma, beta, y, yt, M, eps); return sed_check_launch(); }
+    if (D == d) { SED_LAUNCH((layernorm_tiles_kernel<d / 256>), grid, dim3(256), 0, s, x, x2, res, alpha, gamma, beta, y, yt, M, eps); return sed_check_launch(); }
     LN_CASE(256) LN_CASE(512) LN_CASE(768) LN_CASE(1024)
 #undef LN_CASE
     return SED_ERR_UNSUPPORTED;

@@ -503,18 +503,21 @@ SED_API int sed_linear_debug_set_stamps(unsigned long long* buf) {
 template <int ACT, int OUT>
 __global__ __launch_bounds__(512, 1) void linear_dma_kernel(const unsigned short* __restrict__ At, const unsigned short* __restrict__ Wt,
                                                            const float* __restrict__ bias, void* __restrict__ Cout, int M, int N, int K,
-                                                           int tiles_m, int tiles_n, int nvb, int skew) {
+                                                           int tiles_m, int tiles_n, int nvb, int skew, int ksplit) {
     SED_DYN_SMEM(smem);                               // [4 stages][A hi | A lo | W hi | W lo][256][16] bf16
     unsigned short* lds = (unsigned short*)smem;
     const int tid = threadIdx.x, lane = tid & 63, w = sed_wave_uniform(tid >> 6), lo = lane & 31, hi = lane >> 5;
     const int wr = w >> 2, wc = w & 3;                // wave: rows 128 wr .. + 127, columns 64 wc .. + 63 of the tile; group = wr
-    const int nk = K / T_BK, gstride = gridDim.x;
-    // virtual block -> tile: XCD x = vb & 7 owns the row panels tm = x (mod 8) and sweeps their N tiles back to back
-    auto valid = [&](int vb) { return (vb & 7) + 8 * ((vb >> 3) / tiles_n) < tiles_m; };
-    auto next_vb = [&](int vb) { do vb += gstride; while (vb < nvb && !valid(vb)); return vb; };
+    const int gstride = gridDim.x;
+    // virtual block -> tile: XCD x = vb & 7 owns the row panels tm = x (mod 8) and sweeps their N tiles back to back.  With ksplit = 2 a
+    // work item is (tile, K half): items [0, nvb) are the first halves, [nvb, 2 nvb) the second (nvb is a multiple of 8: same XCD), each
+    // writing its own partial C -- 279 tiles on 256 CUs are two rounds, 558 half-items three half-rounds (the N = 768 layers).
+    const int nk = K / T_BK / ksplit, nwi = nvb * ksplit;          // K steps per work item
+    auto valid = [&](int wi) { const int vb = wi >= nvb ? wi - nvb : wi; return (vb & 7) + 8 * ((vb >> 3) / tiles_n) < tiles_m; };
+    auto next_vb = [&](int wi) { do wi += gstride; while (wi < nwi && !valid(wi)); return wi; };
     int cvb = (int)blockIdx.x;                        // compute cursor
     if (!valid(cvb)) cvb = next_vb(cvb);
-    if (cvb >= nvb) return;
+    if (cvb >= nwi) return;
 #ifndef SED_EMU
     if (skew > 0) {
         // Every tile takes the same time, so the CUs would all reach their epilogues together and write 64 MB of C in one burst (17 us at
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(512, 1) void linear_dma_kernel(const unsigned short
         // walk have a tile's time to spare: they start late, by a fraction of a tile's time that depends on their row panel (the
         // workgroups sharing an A panel stay together, for its L2), and their epilogues then fall into the others' K loops.
         int mine = 0, vb0 = (int)blockIdx.x;
-        for (int vb = valid(vb0) ? vb0 : next_vb(vb0); vb < nvb; vb = next_vb(vb)) ++mine;
+        for (int vb = valid(vb0) ? vb0 : next_vb(vb0); vb < nwi; vb = next_vb(vb)) ++mine;
         if (mine < skew) {
             const int grp = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) / tiles_n);
             const long long wait = (long long)nk * 2800 * (((grp * 5) & 31) + 1) / 36;
@@ -536,15 +539,19 @@ __global__ __launch_bounds__(512, 1) void linear_dma_kernel(const unsigned short
     const unsigned voff = (unsigned)(w * 512 + lane * 8), voff2 = voff + 8 * 512;
     int dvb = cvb, dkt = 0;                           // DMA cursor (tile, K step); past the last tile it stays on the last block (never read)
     bool dlive = true;
-    const unsigned short* da = At + (size_t)((dvb & 7) + 8 * ((dvb >> 3) / tiles_n)) * nk * T_BLOCK;
-    const unsigned short* dw = Wt + (size_t)((dvb >> 3) % tiles_n) * nk * T_BLOCK;
+    // first block of a work item's K range: row panel (or N tile) x all K steps of the matrix, + the item's half
+    auto a_blocks = [&](int wi) { const int ks = wi >= nvb ? 1 : 0, vb = wi - ks * nvb;
+                                  return At + ((size_t)((vb & 7) + 8 * ((vb >> 3) / tiles_n)) * ksplit + ks) * nk * T_BLOCK; };
+    auto w_blocks = [&](int wi) { const int ks = wi >= nvb ? 1 : 0, vb = wi - ks * nvb;
+                                  return Wt + ((size_t)((vb >> 3) % tiles_n) * ksplit + ks) * nk * T_BLOCK; };
+    const unsigned short* da = a_blocks(dvb);
+    const unsigned short* dw = w_blocks(dvb);
 #define T_DMA_A(stage_) do { const unsigned short* g_ = da + (size_t)dkt * T_BLOCK; unsigned short* l_ = lds + (stage_) * T_STAGE + w * 512; \
                              sed_dma16(g_ + voff, l_); sed_dma16(g_ + voff2, l_ + 8 * 512); } while (0)
 #define T_DMA_W(stage_) do { const unsigned short* g_ = dw + (size_t)dkt * T_BLOCK; unsigned short* l_ = lds + (stage_) * T_STAGE + T_BLOCK + w * 512; \
                              sed_dma16(g_ + voff, l_); sed_dma16(g_ + voff2, l_ + 8 * 512); } while (0)
 #define T_DMA_NEXT() do { if (dlive && ++dkt == nk) { const int nv_ = next_vb(dvb);                                              \
-                              if (nv_ < nvb) { dvb = nv_; dkt = 0; da = At + (size_t)((dvb & 7) + 8 * ((dvb >> 3) / tiles_n)) * nk * T_BLOCK; \
-                                               dw = Wt + (size_t)((dvb >> 3) % tiles_n) * nk * T_BLOCK; }                      \
+                              if (nv_ < nwi) { dvb = nv_; dkt = 0; da = a_blocks(dvb); dw = w_blocks(dvb); }                  \
                               else { dkt = nk - 1; dlive = false; } } } while (0)
     f32x16 acc[4][2];
 #pragma unroll
@@ -620,8 +627,10 @@ __global__ __launch_bounds__(512, 1) void linear_dma_kernel(const unsigned short
         T_TS(9);
     }
         // ---- a tile is complete: bias (+ exact GELU), store, next tile ------------------------------------------------------------------
-        const int tm = (cvb & 7) + 8 * ((cvb >> 3) / tiles_n), tn = (cvb >> 3) % tiles_n;
+        const int eks = cvb >= nvb ? 1 : 0, evb = cvb - eks * nvb;
+        const int tm = (evb & 7) + 8 * ((evb >> 3) / tiles_n), tn = (evb >> 3) % tiles_n;
         const int m0 = tm * P_BM, n0 = tn * P_BN;
+        float* Cpart = (float*)Cout + (size_t)eks * M * N;              // (ksplit = 2: the second K half's partial sums; its bias is zero)
         int elo = lo, ehi = hi;                       // opaque copies: the epilogue's address arithmetic stays HERE (hoisted out of the K loop it
         sed_pin(elo); sed_pin(ehi);                   // occupied ~30 registers across it and spilled into the loop)
 #pragma unroll
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(512, 1) void linear_dma_kernel(const unsigned short
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int gn = n0 + 64 * wc + 32 * jn + 8 * q + 4 * ehi;                // 4 consecutive columns
-                const float4 bv = bias != nullptr ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 bv = (bias != nullptr && eks == 0) ? *(const float4*)(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int im = 0; im < 4; ++im) {
                     const int mrow = 128 * wr + 32 * im + elo;
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(512, 1) void linear_dma_kernel(const unsigned short
                         v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752f)); v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752f));
                     }
                     if (OUT == 0) {
-                        if ((T_DIAG & 8) ? (v.x == 1.2345e-30f) : (m0 + mrow < M)) *(float4*)((float*)Cout + (size_t)(m0 + mrow) * N + gn) = v;
+                        if ((T_DIAG & 8) ? (v.x == 1.2345e-30f) : (m0 + mrow < M)) *(float4*)(Cpart + (size_t)(m0 + mrow) * N + gn) = v;
                     } else {
                         uint2 h_, l_;
                         split4(v, h_, l_);
@@ -651,7 +660,7 @@ __global__ __launch_bounds__(512, 1) void linear_dma_kernel(const unsigned short
                 }
             }
         cvb = next_vb(cvb);
-        if (cvb >= nvb) break;
+        if (cvb >= nwi) break;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -868,10 +877,11 @@ __global__ __launch_bounds__(640, 1) void linear_ldr_kernel(const unsigned short
 }  // namespace
 
 static int linear_tiles_launch(const unsigned short* At, const unsigned short* Wt, const float* bias, void* Cout, int M, int N, int K, int act,
-                               int out_tiles, void* stream) {
+                               int out_tiles, void* stream, int ksplit = 1) {
     if (!At || !Wt || !Cout || M < 0 || N < 0 || K < 0) return SED_ERR_ARG;
     if (act < 0 || act > 1) return SED_ERR_ARG;
     if (M <= 0 || N <= 0) return SED_OK;
+    if (ksplit == 2 && (act != 0 || out_tiles || (K / T_BK) % 2 != 0)) return SED_ERR_UNSUPPORTED;
     if (N % P_BN != 0 || K % T_BK != 0 || K <= 0 || ((uintptr_t)At & 15) || ((uintptr_t)Wt & 15) || ((uintptr_t)Cout & 15) || ((uintptr_t)bias & 15))
         return SED_ERR_UNSUPPORTED;
     const int tm = (M + P_BM - 1) / P_BM, tn = N / P_BN;
@@ -889,9 +899,9 @@ static int linear_tiles_launch(const unsigned short* At, const unsigned short* W
     bool ldr = tune == 5 || (tune > 8 && (tune & 1));
     if ((long long)tm * (K / T_BK) * T_BLOCK * 2 > 0x7fffffffLL || (long long)tn * (K / T_BK) * T_BLOCK * 2 > 0x7fffffffLL) ldr = false;   // (its buffer resources count bytes in 31 bits)
     int grid = tune > 8 ? tune & ~7 : 256;
-    if (grid > nvb) grid = nvb;
+    if (grid > nvb * ksplit) grid = nvb * ksplit;
     // skew = the longest walk's tile count when some workgroups walk fewer (0: none do, or switched off with the tuning key = 3)
-    const long long ntiles = (long long)tm * tn;
+    const long long ntiles = (long long)tm * tn * ksplit;
     int skew = (ntiles > grid && ntiles % grid != 0) ? (int)((ntiles + grid - 1) / grid) : 0;
     if (sed_tuning[SED_TUNE_LINEAR_TILES] == 3) skew = 0;
 #ifdef T_STAMP
@@ -899,10 +909,10 @@ static int linear_tiles_launch(const unsigned short* At, const unsigned short* W
 #else
     constexpr int SMEM_T = 4 * T_STAGE * 2;
 #endif
-#define T_LAUNCH(A_, O_) do { if (ldr) { SED_MAX_SMEM((linear_ldr_kernel<A_, O_>), SMEM_T);   \
+#define T_LAUNCH(A_, O_) do { if (ldr && ksplit == 1) { SED_MAX_SMEM((linear_ldr_kernel<A_, O_>), SMEM_T);   \
         SED_LAUNCH((linear_ldr_kernel<A_, O_>), dim3((unsigned)grid), dim3(640), SMEM_T, (hipStream_t)stream, At, Wt, bias, Cout, M, N, K, tm, tn, nvb); } \
         else { SED_MAX_SMEM((linear_dma_kernel<A_, O_>), SMEM_T);                                                               \
-        SED_LAUNCH((linear_dma_kernel<A_, O_>), dim3((unsigned)grid), dim3(512), SMEM_T, (hipStream_t)stream, At, Wt, bias, Cout, M, N, K, tm, tn, nvb, skew); } } while (0)
+        SED_LAUNCH((linear_dma_kernel<A_, O_>), dim3((unsigned)grid), dim3(512), SMEM_T, (hipStream_t)stream, At, Wt, bias, Cout, M, N, K, tm, tn, nvb, skew, ksplit); } } while (0)
     if (out_tiles) { if (act) T_LAUNCH(1, 1); else T_LAUNCH(0, 1); }
     else { if (act) T_LAUNCH(1, 0); else T_LAUNCH(0, 0); }
 #undef T_LAUNCH
@@ -912,6 +922,11 @@ static int linear_tiles_launch(const unsigned short* At, const unsigned short* W
 SED_API int sed_linear_tiles_bf16x3(const unsigned short* At, const unsigned short* Wt, const float* bias, float* Cm, int M, int N, int K,
                                     int act, void* stream) {
     return linear_tiles_launch(At, Wt, bias, Cm, M, N, K, act, 0, stream);
+}
+
+SED_API int sed_linear_tiles_split2_bf16x3(const unsigned short* At, const unsigned short* Wt, const float* bias, float* C2, int M, int N, int K,
+                                           void* stream) {
+    return linear_tiles_launch(At, Wt, bias, C2, M, N, K, 0, 0, stream, 2);
 }
 
 SED_API int sed_linear_tiles_out_bf16x3(const unsigned short* At, const unsigned short* Wt, const float* bias, unsigned short* Ct, int M, int N,

@@ -384,6 +384,11 @@ int sed_linear_packed_bf16x3(const float* A, const unsigned short* Wp, const flo
 int sed_split_tiles_bf16x3(const float* X, unsigned short* Xt, int R, int K, void* stream);
 int sed_linear_tiles_bf16x3(const unsigned short* At, const unsigned short* Wt, const float* bias, float* C, int M, int N, int K,
                             int act, void* stream);
+/* The same product as TWO partial sums over the two halves of K: C2 = [2][M][N], C2[0] = A[:, :K/2] . W[:, :K/2]^T + bias, C2[1] = the
+ * other half; their sum is taken by the consumer (sed_layernorm_tiles' x2).  For the N = 768 layers of the encoder (backbone.py:279-283 fc2):
+ * 279 output tiles on 256 CUs are two rounds, 558 half-K items three half-rounds.  (K / 16) even; no activation. */
+int sed_linear_tiles_split2_bf16x3(const unsigned short* At, const unsigned short* Wt, const float* bias, float* C2, int M, int N, int K,
+                                   void* stream);
 /* The same product written as the K-tiled image of C (M, N) -- what the NEXT Linear takes as its activation (backbone.py:279-283: fc1's
  * GELU output is only ever read by fc2).  Ct holds 2 * ceil(M / 256) * 256 * N bf16 bit patterns; every row of the padded last panel
  * is written. */
@@ -409,8 +414,9 @@ int sed_layernorm(const float* x, const float* res, float alpha, const float* ga
 /* Round 6: the same LayerNorm, y written twice: fp32 (M, D) (the next sub-layer's residual) and as the K-tiled bf16 hi / lo image of
  * sed_split_tiles_bf16x3 (yt: 2 * ceil(M / 256) * 256 * D bf16 bit patterns; rows >= M are left as they are -- the Linear never stores
  * their products) that sed_linear_tiles_bf16x3 takes as its activation: the post-LN encoder's q / k / v projection reads the image
- * (backbone.py:286-330), the residual path the fp32 copy.  256 | D, D <= 1024. */
-int sed_layernorm_tiles(const float* x, const float* res, float alpha, const float* gamma, const float* beta, float* y,
+ * (backbone.py:286-330), the residual path the fp32 copy.  x2 (may be null) is added to x first: the second partial sum of
+ * sed_linear_tiles_split2_bf16x3.  256 | D, D <= 1024. */
+int sed_layernorm_tiles(const float* x, const float* x2, const float* res, float alpha, const float* gamma, const float* beta, float* y,
                         unsigned short* yt, int M, int D, float eps, void* stream);
 
 /* y = x + GELU(bias + grouped Conv1d(x)): the convolutional position embedding (backbone.py:30-43,118-120; even kernel, padding

@@ -704,6 +704,14 @@ def case_linear_tiles(dev, shapes=((300, 256, 64, 0), (513, 512, 96, 1), (256, 2
         got = tile_unimage(Ct.cpu(), M, N)
         err = (got.double() - ref).abs().max().item()
         assert err < 3e-5 * max(1.0, ref.abs().max().item()), (M, N, K, act, "image out", err)
+        # two K halves as two partial sums (sed_linear_tiles_split2_bf16x3): C2[0] + C2[1] = the product, the bias in the first
+        if (K // 16) % 2 == 0 and not act:
+            C2 = torch.full((2, M, N), 7.0, device=Ad.device)
+            lib.call("sed_linear_tiles_split2_bf16x3", At.data_ptr(), Wt.data_ptr(), bd.data_ptr(), C2.data_ptr(), M, N, K, st)
+            err = ((C2[0] + C2[1]).cpu().double() - ref).abs().max().item()
+            assert err < 3e-5 * max(1.0, ref.abs().max().item()), (M, N, K, "split2", err)
+            half = A[:, :K // 2].double() @ W[:, :K // 2].double().t() + bias.double()
+            assert (C2[0].cpu().double() - half).abs().max().item() < 3e-5 * max(1.0, half.abs().max().item()), (M, N, K, "split2 first half")
         # a few workgroups only: every workgroup walks several tiles (the persistent loop's tile hand-over and its DMA cursor)
         _lib.set_tuning("linear_tiles", 16 if FORM == 0 else 16 + 1)     # (odd grid requests: the loader-wave form, even: the eight-wave form)
         try:
@@ -720,6 +728,29 @@ def case_linear_tiles(dev, shapes=((300, 256, 64, 0), (513, 512, 96, 1), (256, 2
         pass
     finally:
         _lib.set_tuning("linear_tiles", 0)
+
+
+def case_layernorm_tiles(dev, shapes=((300, 256), (513, 768), (70, 1024))):
+    """sed_layernorm_tiles: y = LayerNorm(x (+ x2) + alpha * res) as fp32 AND as the K-tiled bf16 hi / lo image (rows < M), against
+    torch.nn.functional.layer_norm in float64 and against the host restatement of the image (hi + lo of y within 2^-16 relative)."""
+    lib = _lib.get()
+    g = torch.Generator().manual_seed(14)
+    for (M, D) in shapes:
+        x, x2, res = torch.randn(M, D, generator=g), torch.randn(M, D, generator=g), torch.randn(M, D, generator=g)
+        gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+        xd, x2d, rd, gd, bd = to(dev, x, x2, res, gamma, beta)
+        st = _lib.stream_ptr(xd)
+        for (use2, user, alpha) in ((False, False, 1.0), (True, True, 1.7), (False, True, 0.5)):
+            pre = x.double() + (x2.double() if use2 else 0) + (alpha * res.double() if user else 0)
+            ref = torch.nn.functional.layer_norm(pre, (D,), gamma.double(), beta.double(), 1e-5)
+            y = torch.full((M, D), 7.0, device=xd.device)
+            yt = torch.zeros(2 * ((M + 255) // 256) * 256 * D, dtype=torch.int16, device=xd.device)
+            lib.call("sed_layernorm_tiles", xd.data_ptr(), x2d.data_ptr() if use2 else None, rd.data_ptr() if user else None, float(alpha), gd.data_ptr(),
+                     bd.data_ptr(), y.data_ptr(), yt.data_ptr(), M, D, 1e-5, st)
+            tol = 2e-5 * max(1.0, ref.abs().max().item())
+            assert (y.cpu().double() - ref).abs().max().item() < tol, (M, D, use2, user)
+            got = tile_unimage(yt.cpu(), M, D)
+            assert (got.double() - y.cpu().double()).abs().max().item() <= 2.0 ** -15 * max(1.0, ref.abs().max().item()), (M, D, "image")
 
 
 def case_linear_tiles_race_screen(dev, reps=600):

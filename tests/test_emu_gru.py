@@ -19,6 +19,10 @@ def test_linear_tiles(emu):
     P.case_linear_tiles("cpu", shapes=((300, 256, 64, 0), (257, 512, 16, 1), (520, 256, 48, 0)), form=5)
 
 
+def test_layernorm_tiles(emu):
+    P.case_layernorm_tiles("cpu", shapes=((300, 256), (70, 768)))
+
+
 def test_linear_n96_tile(emu):
     """The 128 x 96 tile of the split-bf16 GEMM (BEATs N = 768 layers)."""
     P.case_linear_n96_tile("cpu", shapes=((300, 192, 64, 0), (130, 96, 96, 1), (2100, 192, 32, 0)))     # last: 17 row panels -> the XCD-aware walk

@@ -127,6 +127,11 @@ def test_linear_tiles():
     P.case_linear_tiles("cuda", shapes=((300, 256, 64, 0), (700, 768, 160, 1), (2100, 3072, 768, 1), (23808, 2304, 768, 0)), form=5)     # the loader-wave form
 
 
+def test_layernorm_tiles():
+    P.case_layernorm_tiles("cuda")
+    P.case_layernorm_tiles("cuda", shapes=((23808, 768),))
+
+
 def test_linear_tiles_race_screen():
     """600 launches of the QKV and fc2 production shapes, alone and beside a co-runner: the bits of the first launch every time."""
     P.case_linear_tiles_race_screen("cuda")

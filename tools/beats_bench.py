@@ -11,6 +11,8 @@ if os.environ.get("LINEAR_TILES") == "0":       # A/B: the round-5 path of the q
     _beats.LINEAR_TILES = False
 if os.environ.get("LINEAR_FORM"):                 # A/B: 5 = the loader-wave form of the tile Linear (sed_set_tuning linear_tiles)
     _lib.set_tuning("linear_tiles", int(os.environ["LINEAR_FORM"]))
+if os.environ.get("LINEAR_TILES_KSPLIT") == "0":   # A/B: fc2 as one product per tile (two rounds of tiles)
+    _beats.LINEAR_TILES_KSPLIT = False
 if os.environ.get("LINEAR_TILES_FFN") == "0":   # A/B: only the q / k / v projection on the tile path
     _beats.LINEAR_TILES_FFN = False
 CFG = dict(input_patch_size=16, embed_dim=512, conv_bias=False, encoder_layers=12, encoder_embed_dim=768, encoder_ffn_embed_dim=3072,
@@ -45,8 +47,8 @@ def entry_work(name, a):
         M, D = a[6:8]
         return "hbm", 4.0 * M * D * (3 if a[1] else 2)
     if name == "sed_layernorm_tiles":
-        M, D = a[7:9]
-        return "hbm", 4.0 * M * D * (4 if a[1] else 3)
+        M, D = a[8:10]
+        return "hbm", 4.0 * M * D * (3 + (1 if a[1] else 0) + (1 if a[2] else 0))
     if name == "sed_kaldi_fbank":
         B_, N = a[2:4]
         return "hbm", 4.0 * B_ * (N + (1 + (N - 400) // 160) * a[4])
